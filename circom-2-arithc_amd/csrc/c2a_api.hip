@@ -1,0 +1,740 @@
+// c2a_api.hip — host runtime behind include/c2a.h: context, HBM workspace, kernel orchestration.
+// Built by hipcc for gfx950 into libc2a_hip.so (the product) and, for the CPU test-suite only, by g++
+// against tests/emul/hip_emul.h into tests/emul/libc2a_emul.so.
+#include "../../include/c2a.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "c2a_kernels.h"
+#include "c2a_templates.h"
+
+using namespace c2a;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+enum Stage { ST_EMPTY = 0, ST_LOADED, ST_SORTED, ST_WIRED, ST_EMITTED, ST_BOOLIFIED };
+
+enum Ev { EV_PREP0, EV_PREP1, EV_PEEL1, EV_ORDER1, EV_WIRES0, EV_WIRES1, EV_EMIT0, EV_EMIT1, EV_BPREP0, EV_BPREP1,
+          EV_BMAP1, EV_BUILD0, EV_BUILD1, EV_COUNT };
+
+}  // namespace
+
+struct c2a_ctx {
+    int device = 0;
+    hipStream_t stream{};
+    hipEvent_t ev[EV_COUNT]{};
+    bool ev_valid[EV_COUNT]{};
+    std::string err;
+    Stage stage = ST_EMPTY;
+    int n_cu = 256;
+
+    // problem
+    u32 n = 0, n_nodes = 0, n_in = 0, n_out = 0;
+    u32 planes = 0;
+    // results (host copies of scalars)
+    u32 wire_count = 0, n_mid = 0;
+    c2a_stats stats{};
+    c2a_bool_info binfo{};
+    u32 bool_width = 0;
+
+    // device buffers
+    DevBuf lh, rh, out, op, in_nodes, out_nodes;
+    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, fill, cons, pending, order, posof, meta, anc, fbase, fcount;
+    DevBuf child0, child1, rflag, ridx, rlist, next, owner, local, slist, snext, ssum, jnxt, jval, sorted;
+    DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op;
+    DevBuf scan_tmp, scalars, dfs_state, dfs_stack;
+    DevBuf tsz, asz, goff, aoff, tmpl, tables, b_in0, b_in1, b_out, b_op;
+    std::vector<DevBuf*> all;
+
+    c2a_ctx() {
+        all = {&lh, &rh, &out, &op, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &fill, &cons,
+               &pending, &order, &posof, &meta, &anc, &fbase, &fcount, &child0, &child1, &rflag, &ridx, &rlist, &next,
+               &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
+               &node_wire, &e_in0, &e_in1, &e_out, &e_op, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &tsz, &asz, &goff,
+               &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op};
+    }
+};
+
+namespace {
+
+// scalars block layout (u32 words unless noted)
+enum Scalar { SC_MAXDEPTH = 0, SC_SCOUNT = 1, SC_ERR = 2, SC_NMID = 3, SC_NROOTS = 4, SC_LEVELS = 5, SC_DFS = 8 /*3 words*/,
+              SC_TOTAL64 = 16 /* u64 slots from here: 16..31 */, SC_WORDS = 64 };
+
+int fail(c2a_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess)                                                                           \
+            return fail(c, C2A_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));             \
+    } while (0)
+
+int ensure(c2a_ctx* c, DevBuf& b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return C2A_OK;
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(c, C2A_ERR_NOMEM, "hipMalloc(" + std::to_string(bytes) + " bytes): " + hipGetErrorString(e));
+    }
+    b.cap = bytes;
+    return C2A_OK;
+}
+#define ENSURE(buf, bytes)                                   \
+    do {                                                     \
+        int _r = ensure(c, (buf), (size_t)(bytes));          \
+        if (_r) return _r;                                   \
+    } while (0)
+
+inline u32 grid_for(u64 items, u32 cap_blocks) {
+    u64 b = (items + kThreads - 1) / kThreads;
+    if (b < 1) b = 1;
+    if (b > cap_blocks) b = cap_blocks;
+    return (u32)b;
+}
+
+void rec(c2a_ctx* c, Ev e) {
+    if (hipEventRecord(c->ev[e], c->stream) == hipSuccess) c->ev_valid[e] = true;
+}
+
+// exclusive scan of `in` (n entries, u32) into `out` (n+1 entries; out[n] = total).
+template <typename TOut>
+int scan_exclusive(c2a_ctx* c, const u32* in, TOut* out, u64 n) {
+    if (n == 0) {
+        HIP_TRY(hipMemsetAsync(out, 0, sizeof(TOut), c->stream));
+        return C2A_OK;
+    }
+    // level sizes
+    std::vector<u64> sizes;
+    u64 m = n;
+    while (true) {
+        m = (m + kScanTile - 1) / kScanTile;
+        sizes.push_back(m);
+        if (m == 1) break;
+    }
+    size_t total = 0;
+    for (u64 s : sizes) total += (size_t)s + 1;
+    ENSURE(c->scan_tmp, total * sizeof(TOut));
+    std::vector<TOut*> part(sizes.size());
+    {
+        TOut* base = c->scan_tmp.as<TOut>();
+        for (size_t l = 0; l < sizes.size(); ++l) { part[l] = base; base += sizes[l] + 1; }
+    }
+    // up-sweep
+    C2A_LAUNCH((k_scan_tile<u32, TOut>), (u32)sizes[0], kThreads, c->stream, in, out, part[0], n);
+    for (size_t l = 1; l < sizes.size(); ++l)
+        C2A_LAUNCH((k_scan_tile<TOut, TOut>), (u32)sizes[l], kThreads, c->stream, (const TOut*)part[l - 1], part[l - 1],
+                   part[l], sizes[l - 1]);
+    // part[last][0] = grand total (single tile at the top level; its tile-exclusive prefix is 0)
+    C2A_LAUNCH_NOSYNC((k_scan_total<TOut>), 1, 64, c->stream, out + n, (const TOut*)part.back());
+    // down-sweep: part[L-1] is already a full exclusive scan (the top level is a single tile)
+    for (int l = (int)sizes.size() - 2; l >= 1; --l)
+        C2A_LAUNCH_NOSYNC((k_scan_add<TOut>), grid_for(sizes[l - 1], 2048), kThreads, c->stream, part[l - 1],
+                          (const TOut*)part[l], sizes[l - 1]);
+    if (sizes[0] > 1)
+        C2A_LAUNCH_NOSYNC((k_scan_add<TOut>), grid_for(n, 4096), kThreads, c->stream, out, (const TOut*)part[0], n);
+    return C2A_OK;
+}
+
+int read_scalars(c2a_ctx* c, u32* host, int first, int count) {
+    HIP_TRY(hipMemcpyAsync(host, c->scalars.as<u32>() + first, sizeof(u32) * count, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return C2A_OK;
+}
+
+u32 planes_for(u64 n) {
+    // tree depth < n, so 16^planes > n-1 is always enough
+    u32 p = 1;
+    u64 reach = 16;
+    while (reach < n) { reach <<= 4; ++p; }
+    return p;
+}
+
+int do_prep(c2a_ctx* c) {
+    const u32 n = c->n;
+    hipStream_t s = c->stream;
+    const u32 G = grid_for(n, 4096);
+    HIP_TRY(hipMemsetAsync(c->prod1.p, 0, (size_t)c->n_nodes * 4, s));
+    HIP_TRY(hipMemsetAsync(c->cons_cnt.p, 0, (size_t)n * 4, s));
+    HIP_TRY(hipMemsetAsync(c->fill.p, 0, (size_t)n * 4, s));
+    HIP_TRY(hipMemsetAsync(c->fcount.p, 0, ((size_t)n + 2) * 4, s));
+    HIP_TRY(hipMemsetAsync(c->fbase.p, 0, 8, s));
+    HIP_TRY(hipMemsetAsync(c->scalars.p, 0, SC_WORDS * 4, s));
+    C2A_LAUNCH_NOSYNC(k_producer, G, kThreads, s, n, c->out.as<u32>(), c->prod1.as<u32>());
+    C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->prod1.as<u32>(), c->dep0.as<u32>(),
+                      c->dep1.as<u32>(), c->cons_cnt.as<u32>());
+    int r = scan_exclusive<u32>(c, c->cons_cnt.as<u32>(), c->cons_off.as<u32>(), n);
+    if (r) return r;
+    C2A_LAUNCH_NOSYNC(k_fill_csr, G, kThreads, s, n, c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_off.as<u32>(),
+                      c->fill.as<u32>(), c->cons.as<u32>());
+    C2A_LAUNCH_NOSYNC(k_init_frontier, G, kThreads, s, n, c->cons_cnt.as<u32>(), c->pending.as<u32>(), c->order.as<u32>(),
+                      c->posof.as<u32>(), c->fcount.as<u32>());
+    return C2A_OK;
+}
+
+// Reverse Kahn peel: one launch per level, queued in batches; the host only looks at the frontier
+// counters between batches (to stop, and to size the next batch's grid).
+int do_peel(c2a_ctx* c, u32* peeled_out) {
+    const u32 n = c->n;
+    hipStream_t s = c->stream;
+    PeelArgs A;
+    A.n = n; A.dep0 = c->dep0.as<u32>(); A.dep1 = c->dep1.as<u32>(); A.cons_off = c->cons_off.as<u32>();
+    A.cons = c->cons.as<u32>(); A.pending = c->pending.as<u32>(); A.order = c->order.as<u32>();
+    A.posof = c->posof.as<u32>(); A.meta = c->meta.as<uint4>(); A.anc = c->anc.as<u32>();
+    A.fbase = c->fbase.as<u32>(); A.fcount = c->fcount.as<u32>(); A.maxdepth = c->scalars.as<u32>() + SC_MAXDEPTH;
+    A.levels = c->scalars.as<u32>() + SC_LEVELS;
+
+    u32 level = 0, launches = 0;
+    u32 f0 = 0;
+    HIP_TRY(hipMemcpyAsync(&f0, c->fcount.as<u32>(), 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    u32 est = f0;                    // frontier size estimate for grid sizing
+    u32 batch = 8;
+    const u32 max_blocks = (u32)c->n_cu * 8;
+    u32 peeled = 0;
+    while (true) {
+        const u32 blocks = std::max<u32>(8u, std::min<u32>(max_blocks, (u32)(((u64)est * 2 + kThreads - 1) / kThreads)));
+        for (u32 i = 0; i < batch; ++i) {
+            // the first launch of the very first batch sees the (possibly huge) level-0 frontier
+            const u32 b = (level == 0) ? std::max<u32>(blocks, grid_for(f0, max_blocks)) : blocks;
+            C2A_LAUNCH_NOSYNC(k_peel_level, b, kThreads, s, A, level);
+            ++level; ++launches;
+            if (level > n) break;
+        }
+        // look at the last few frontier counters of the batch
+        u32 tail[9] = {0};
+        const u32 look = std::min<u32>(8u, level);
+        HIP_TRY(hipMemcpyAsync(tail, c->fcount.as<u32>() + (level - look), (look + 1) * 4, hipMemcpyDeviceToHost, s));
+        u32 base_next = 0;
+        HIP_TRY(hipMemcpyAsync(&base_next, c->fbase.as<u32>() + level, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        const u32 next_cnt = tail[look];
+        peeled = base_next + next_cnt;
+        if (next_cnt == 0 || level > n) break;
+        u32 mx = next_cnt;
+        for (u32 k = 0; k <= look; ++k) mx = std::max(mx, tail[k]);
+        est = mx;
+        batch = std::min<u32>(batch * 2, 512u);
+    }
+    c->stats.level_launches = launches;
+    *peeled_out = peeled;
+    return C2A_OK;
+}
+
+int do_order(c2a_ctx* c) {
+    const u32 n = c->n;
+    hipStream_t s = c->stream;
+    const u32 G = grid_for(n, 4096);
+    HIP_TRY(hipMemsetAsync(c->child0.p, 0xFF, (size_t)n * 4, s));
+    HIP_TRY(hipMemsetAsync(c->child1.p, 0xFF, (size_t)n * 4, s));
+    C2A_LAUNCH_NOSYNC(k_children, G, kThreads, s, n, c->meta.as<uint4>(), c->child0.as<u32>(), c->child1.as<u32>());
+    C2A_LAUNCH_NOSYNC(k_rootflag, G, kThreads, s, n, c->meta.as<uint4>(), c->posof.as<u32>(), c->rflag.as<u32>());
+    int r = scan_exclusive<u32>(c, c->rflag.as<u32>(), c->ridx.as<u32>(), n);
+    if (r) return r;
+    C2A_LAUNCH_NOSYNC(k_rootlist, G, kThreads, s, n, c->rflag.as<u32>(), c->ridx.as<u32>(), c->posof.as<u32>(),
+                      c->rlist.as<u32>());
+    u32 n_roots = 0;
+    HIP_TRY(hipMemcpyAsync(&n_roots, c->ridx.as<u32>() + n, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    c->stats.n_roots = n_roots;
+    C2A_LAUNCH_NOSYNC(k_euler_next, G, kThreads, s, n, c->meta.as<uint4>(), c->order.as<u32>(), c->child0.as<u32>(),
+                      c->child1.as<u32>(), c->ridx.as<u32>(), c->rlist.as<u32>(), n_roots, c->next.as<u32>());
+    const u32 m = 2 * n;
+    u32* scount = c->scalars.as<u32>() + SC_SCOUNT;
+    C2A_LAUNCH_NOSYNC(k_rank_mark, grid_for(m, 4096), kThreads, s, m, c->rlist.as<u32>(), scount, c->slist.as<u32>(),
+                      c->owner.as<u32>());
+    u32 S = 0;
+    r = read_scalars(c, &S, SC_SCOUNT, 1);
+    if (r) return r;
+    c->stats.n_splitters = S;
+    C2A_LAUNCH_NOSYNC(k_rank_walk, grid_for(S, 8192), kThreads, s, (const u32*)scount, c->rlist.as<u32>(), c->slist.as<u32>(),
+                      c->next.as<u32>(), c->owner.as<u32>(), c->local.as<u32>(), c->snext.as<u32>(), c->ssum.as<u32>());
+    // pointer jumping, ping-pong between (snext,ssum) and (jnxt,jval)
+    u32 rounds = 0;
+    while ((1ull << rounds) < S) ++rounds;
+    u32 *nx_a = c->snext.as<u32>(), *vl_a = c->ssum.as<u32>(), *nx_b = c->jnxt.as<u32>(), *vl_b = c->jval.as<u32>();
+    for (u32 k = 0; k < rounds; ++k) {
+        C2A_LAUNCH_NOSYNC(k_rank_jump, grid_for(S, 4096), kThreads, s, (const u32*)scount, (const u32*)nx_a, (const u32*)vl_a,
+                          nx_b, vl_b);
+        std::swap(nx_a, nx_b);
+        std::swap(vl_a, vl_b);
+    }
+    C2A_LAUNCH_NOSYNC(k_rank_final, G, kThreads, s, n, c->order.as<u32>(), c->owner.as<u32>(), c->local.as<u32>(),
+                      (const u32*)vl_a, c->sorted.as<u32>());
+    return C2A_OK;
+}
+
+int run_serial_dfs(c2a_ctx* c, u32* status, u64* cycle_at) {
+    const u32 n = c->n;
+    hipStream_t s = c->stream;
+    ENSURE(c->dfs_state, (size_t)n);
+    ENSURE(c->dfs_stack, (size_t)n * 4);
+    HIP_TRY(hipMemsetAsync(c->dfs_state.p, 0, (size_t)n, s));
+    C2A_LAUNCH_NOSYNC(k_serial_dfs, 1, 64, s, n, c->dep0.as<u32>(), c->dep1.as<u32>(), c->dfs_state.as<u8>(),
+                      c->dfs_stack.as<u32>(), c->sorted.as<u32>(), c->scalars.as<u32>() + SC_DFS);
+    u32 res[3] = {0, 0, 0};
+    int r = read_scalars(c, res, SC_DFS, 3);
+    if (r) return r;
+    *status = res[0];
+    *cycle_at = res[1];
+    return C2A_OK;
+}
+
+int do_topo_sort(c2a_ctx* c, u64* cycle_at) {
+    if (c->stage < ST_LOADED) return fail(c, C2A_ERR_STATE, "c2a_topo_sort: no gates loaded");
+    c->stage = ST_LOADED;
+    const u32 n = c->n;
+    std::memset(c->ev_valid, 0, sizeof(c->ev_valid));
+    c->stats = c2a_stats{};
+    c->stats.n_gates = n;
+    c->stats.anc_planes = c->planes;
+    if (cycle_at) *cycle_at = 0;
+    if (n == 0) { c->stage = ST_SORTED; return C2A_OK; }
+    rec(c, EV_PREP0);
+    int r = do_prep(c);
+    if (r) return r;
+    rec(c, EV_PREP1);
+    u32 peeled = 0;
+    r = do_peel(c, &peeled);
+    if (r) return r;
+    rec(c, EV_PEEL1);
+    {
+        u32 edges = 0, md = 0, lv = 0;
+        HIP_TRY(hipMemcpyAsync(&edges, c->cons_off.as<u32>() + n, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(&md, c->scalars.as<u32>() + SC_MAXDEPTH, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(&lv, c->scalars.as<u32>() + SC_LEVELS, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->stats.n_edges = edges;
+        c->stats.max_depth = md;
+        c->stats.levels = lv;
+    }
+    if (peeled != n) {
+        // leftover gates sit on or above a dependency cycle: replay the reference's DFS for its message
+        u32 status = 0;
+        u64 at = 0;
+        r = run_serial_dfs(c, &status, &at);
+        if (r) return r;
+        if (cycle_at) *cycle_at = at;
+        if (status == 1) return fail(c, C2A_ERR_CYCLIC, "Cyclic dependency: detected at i=" + std::to_string(at));
+        return fail(c, C2A_ERR_HIP, "internal: peel left gates behind but the serial DFS found no cycle");
+    }
+    r = do_order(c);
+    if (r) return r;
+    rec(c, EV_ORDER1);
+    c->stage = ST_SORTED;
+    return C2A_OK;
+}
+
+int do_assign_wires(c2a_ctx* c) {
+    if (c->stage < ST_SORTED) return fail(c, C2A_ERR_STATE, "c2a_assign_wires: call c2a_topo_sort first");
+    const u32 n = c->n;
+    hipStream_t s = c->stream;
+    const u64 m = (u64)n * 3;
+    rec(c, EV_WIRES0);
+    HIP_TRY(hipMemsetAsync(c->node_wire1.p, 0, (size_t)c->n_nodes * 4, s));
+    HIP_TRY(hipMemsetAsync(c->nflag.p, 0, (size_t)c->n_nodes, s));
+    HIP_TRY(hipMemsetAsync(c->first.p, 0xFF, (size_t)c->n_nodes * 4, s));
+    HIP_TRY(hipMemsetAsync(c->scalars.as<u32>() + SC_ERR, 0, 4, s));
+    if (c->n_in)
+        C2A_LAUNCH_NOSYNC(k_mark_inputs, grid_for(c->n_in, 1024), kThreads, s, c->n_in, c->in_nodes.as<u32>(),
+                          c->node_wire1.as<u32>(), c->nflag.as<u8>());
+    if (c->n_out)
+        C2A_LAUNCH_NOSYNC(k_mark_outputs, grid_for(c->n_out, 1024), kThreads, s, c->n_out, c->out_nodes.as<u32>(),
+                          c->nflag.as<u8>(), c->scalars.as<u32>() + SC_ERR);
+    if (n) {
+        const u32 G = grid_for(m, 4096);
+        C2A_LAUNCH_NOSYNC(k_first_seen, G, kThreads, s, m, c->sorted.as<u32>(), c->lh.as<u32>(), c->rh.as<u32>(),
+                          c->out.as<u32>(), c->first.as<u32>());
+        C2A_LAUNCH_NOSYNC(k_new_wire_flags, G, kThreads, s, m, c->sorted.as<u32>(), c->lh.as<u32>(), c->rh.as<u32>(),
+                          c->out.as<u32>(), c->first.as<u32>(), c->nflag.as<u8>(), c->wflag.as<u32>());
+    }
+    int r = scan_exclusive<u32>(c, c->wflag.as<u32>(), c->widx.as<u32>(), m);
+    if (r) return r;
+    if (n) {
+        C2A_LAUNCH_NOSYNC(k_assign_wires, grid_for(m, 4096), kThreads, s, m, c->sorted.as<u32>(), c->lh.as<u32>(),
+                          c->rh.as<u32>(), c->out.as<u32>(), c->wflag.as<u32>(), c->widx.as<u32>(), c->n_in,
+                          c->node_wire1.as<u32>());
+    }
+    if (c->n_out)
+        C2A_LAUNCH_NOSYNC(k_assign_outputs, grid_for(c->n_out, 1024), kThreads, s, c->n_out, c->out_nodes.as<u32>(), c->n_in,
+                          (const u32*)(c->widx.as<u32>() + m), c->node_wire1.as<u32>());
+    rec(c, EV_WIRES1);
+    u32 n_mid = 0, err = 0;
+    HIP_TRY(hipMemcpyAsync(&n_mid, c->widx.as<u32>() + m, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&err, c->scalars.as<u32>() + SC_ERR, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (err) return fail(c, C2A_ERR_INCONSISTENCY, "Inconsistency: a node is used for both input and output");
+    c->n_mid = n_mid;
+    c->wire_count = c->n_in + n_mid + c->n_out;
+    c->stage = ST_WIRED;
+    return C2A_OK;
+}
+
+int do_emit(c2a_ctx* c) {
+    if (c->stage < ST_WIRED) return fail(c, C2A_ERR_STATE, "c2a_emit_gates: call c2a_assign_wires first");
+    rec(c, EV_EMIT0);
+    if (c->n)
+        C2A_LAUNCH_NOSYNC(k_emit, grid_for(c->n, 4096), kThreads, c->stream, c->n, c->sorted.as<u32>(), c->lh.as<u32>(),
+                          c->rh.as<u32>(), c->out.as<u32>(), c->op.as<u8>(), c->node_wire1.as<u32>(), c->e_in0.as<u32>(),
+                          c->e_in1.as<u32>(), c->e_out.as<u32>(), c->e_op.as<u8>());
+    rec(c, EV_EMIT1);
+    c->stage = ST_EMITTED;
+    return C2A_OK;
+}
+
+float elapsed(c2a_ctx* c, Ev a, Ev b) {
+    if (!c->ev_valid[a] || !c->ev_valid[b]) return 0.f;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev[a], c->ev[b]) != hipSuccess) return 0.f;
+    return ms;
+}
+
+int copy_out(c2a_ctx* c, void* host, const void* dev, size_t bytes) {
+    if (!host || !bytes) return C2A_OK;
+    HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    return C2A_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* c2a_version(void) {
+#ifdef C2A_EMULATE
+    return "c2a 0.1 (host emulation build — tests only)";
+#else
+    return "c2a 0.1 (hip gfx950)";
+#endif
+}
+
+int c2a_create(int device_id, c2a_ctx** out) {
+    if (!out || device_id < 0) return C2A_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return C2A_ERR_HIP;
+    if (device_id >= count) return C2A_ERR_ARG;
+    if (hipSetDevice(device_id) != hipSuccess) return C2A_ERR_HIP;
+    c2a_ctx* c = new (std::nothrow) c2a_ctx();
+    if (!c) return C2A_ERR_NOMEM;
+    c->device = device_id;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+        c->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return C2A_ERR_HIP; }
+    for (int i = 0; i < EV_COUNT; ++i)
+        if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return C2A_ERR_HIP; }
+    *out = c;
+    return C2A_OK;
+}
+
+void c2a_destroy(c2a_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf* b : c->all) if (b->p) (void)hipFree(b->p);
+    for (int i = 0; i < EV_COUNT; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* c2a_last_error(const c2a_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t* rh, const uint32_t* out,
+                   const uint8_t* op, uint32_t n_nodes, uint32_t n_in, const uint32_t* input_nodes, uint32_t n_out,
+                   const uint32_t* output_nodes) {
+    if (!c) return C2A_ERR_ARG;
+    c->stage = ST_EMPTY;
+    if (n64 >= (1ull << 31)) return fail(c, C2A_ERR_ARG, "c2a_load_gates: n must be < 2^31");
+    if (n64 && (!lh || !rh || !out || !op)) return fail(c, C2A_ERR_ARG, "c2a_load_gates: null gate arrays");
+    if ((n_in && !input_nodes) || (n_out && !output_nodes)) return fail(c, C2A_ERR_ARG, "c2a_load_gates: null IO lists");
+    const u32 n = (u32)n64;
+    // argument validation on the host copy (ids must address the node table; op must be an AGateType)
+    for (u64 g = 0; g < n; ++g) {
+        if (lh[g] >= n_nodes || rh[g] >= n_nodes || out[g] >= n_nodes)
+            return fail(c, C2A_ERR_ARG, "c2a_load_gates: node id >= n_nodes at gate " + std::to_string(g));
+        if (op[g] >= C2A_NUM_GATE_TYPES)
+            return fail(c, C2A_ERR_ARG, "c2a_load_gates: unknown gate type at gate " + std::to_string(g));
+    }
+    for (u32 i = 0; i < n_in; ++i)
+        if (input_nodes[i] >= n_nodes) return fail(c, C2A_ERR_ARG, "c2a_load_gates: input node id >= n_nodes");
+    for (u32 i = 0; i < n_out; ++i)
+        if (output_nodes[i] >= n_nodes) return fail(c, C2A_ERR_ARG, "c2a_load_gates: output node id >= n_nodes");
+    HIP_TRY(hipSetDevice(c->device));
+    c->n = n; c->n_nodes = n_nodes; c->n_in = n_in; c->n_out = n_out;
+    c->planes = planes_for(n);
+    const size_t n4 = (size_t)n * 4, nn4 = (size_t)n_nodes * 4;
+    ENSURE(c->lh, n4); ENSURE(c->rh, n4); ENSURE(c->out, n4); ENSURE(c->op, n);
+    ENSURE(c->in_nodes, (size_t)n_in * 4); ENSURE(c->out_nodes, (size_t)n_out * 4);
+    ENSURE(c->prod1, nn4); ENSURE(c->dep0, n4); ENSURE(c->dep1, n4); ENSURE(c->cons_cnt, n4);
+    ENSURE(c->cons_off, n4 + 4); ENSURE(c->fill, n4); ENSURE(c->cons, 2 * n4); ENSURE(c->pending, n4);
+    ENSURE(c->order, n4); ENSURE(c->posof, n4); ENSURE(c->meta, (size_t)n * 16);
+    ENSURE(c->anc, (size_t)c->planes * n * 64);
+    ENSURE(c->fbase, n4 + 8); ENSURE(c->fcount, n4 + 8);
+    ENSURE(c->child0, n4); ENSURE(c->child1, n4); ENSURE(c->rflag, n4); ENSURE(c->ridx, n4 + 4); ENSURE(c->rlist, n4);
+    ENSURE(c->next, 2 * n4); ENSURE(c->owner, 2 * n4); ENSURE(c->local, 2 * n4); ENSURE(c->slist, 2 * n4);
+    ENSURE(c->snext, 2 * n4); ENSURE(c->ssum, 2 * n4); ENSURE(c->jnxt, 2 * n4); ENSURE(c->jval, 2 * n4);
+    ENSURE(c->sorted, n4);
+    ENSURE(c->first, nn4); ENSURE(c->nflag, n_nodes); ENSURE(c->wflag, 3 * n4); ENSURE(c->widx, 3 * n4 + 4);
+    ENSURE(c->node_wire1, nn4); ENSURE(c->node_wire, nn4);
+    ENSURE(c->e_in0, n4); ENSURE(c->e_in1, n4); ENSURE(c->e_out, n4); ENSURE(c->e_op, n);
+    ENSURE(c->scalars, SC_WORDS * 4);
+    hipStream_t s = c->stream;
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(c->lh.p, lh, n4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->rh.p, rh, n4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->out.p, out, n4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->op.p, op, n, hipMemcpyHostToDevice, s));
+    }
+    if (n_in) HIP_TRY(hipMemcpyAsync(c->in_nodes.p, input_nodes, (size_t)n_in * 4, hipMemcpyHostToDevice, s));
+    if (n_out) HIP_TRY(hipMemcpyAsync(c->out_nodes.p, output_nodes, (size_t)n_out * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    c->stage = ST_LOADED;
+    return C2A_OK;
+}
+
+int c2a_topo_sort(c2a_ctx* c, uint32_t* sorted, uint64_t* cycle_at) {
+    if (!c) return C2A_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    int r = do_topo_sort(c, cycle_at);
+    if (r) return r;
+    r = copy_out(c, sorted, c->sorted.p, (size_t)c->n * 4);
+    if (r) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return C2A_OK;
+}
+
+int c2a_topo_sort_serial(c2a_ctx* c, uint32_t* sorted, uint64_t* cycle_at) {
+    if (!c) return C2A_ERR_ARG;
+    if (c->stage < ST_LOADED) return fail(c, C2A_ERR_STATE, "c2a_topo_sort_serial: no gates loaded");
+    HIP_TRY(hipSetDevice(c->device));
+    c->stage = ST_LOADED;
+    if (cycle_at) *cycle_at = 0;
+    if (c->n == 0) { c->stage = ST_SORTED; return C2A_OK; }
+    // the deps closure only (no peel)
+    HIP_TRY(hipMemsetAsync(c->prod1.p, 0, (size_t)c->n_nodes * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(c->cons_cnt.p, 0, (size_t)c->n * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(c->scalars.p, 0, SC_WORDS * 4, c->stream));
+    const u32 G = grid_for(c->n, 4096);
+    C2A_LAUNCH_NOSYNC(k_producer, G, kThreads, c->stream, c->n, c->out.as<u32>(), c->prod1.as<u32>());
+    C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, c->stream, c->n, c->lh.as<u32>(), c->rh.as<u32>(), c->prod1.as<u32>(),
+                      c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_cnt.as<u32>());
+    u32 status = 0;
+    u64 at = 0;
+    int r = run_serial_dfs(c, &status, &at);
+    if (r) return r;
+    if (status == 1) {
+        if (cycle_at) *cycle_at = at;
+        return fail(c, C2A_ERR_CYCLIC, "Cyclic dependency: detected at i=" + std::to_string(at));
+    }
+    r = copy_out(c, sorted, c->sorted.p, (size_t)c->n * 4);
+    if (r) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stage = ST_SORTED;
+    return C2A_OK;
+}
+
+int c2a_assign_wires(c2a_ctx* c, uint32_t* node_to_wire, uint32_t* wire_count) {
+    if (!c) return C2A_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    int r = do_assign_wires(c);
+    if (r) return r;
+    if (wire_count) *wire_count = c->wire_count;
+    if (node_to_wire && c->n_nodes) {
+        C2A_LAUNCH_NOSYNC(k_unbias, grid_for(c->n_nodes, 4096), kThreads, c->stream, (u64)c->n_nodes,
+                          (const u32*)c->node_wire1.as<u32>(), c->node_wire.as<u32>());
+        r = copy_out(c, node_to_wire, c->node_wire.p, (size_t)c->n_nodes * 4);
+        if (r) return r;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return C2A_OK;
+}
+
+int c2a_emit_gates(c2a_ctx* c, uint32_t* in0, uint32_t* in1, uint32_t* out, uint8_t* op) {
+    if (!c) return C2A_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    int r = do_emit(c);
+    if (r) return r;
+    const size_t n4 = (size_t)c->n * 4;
+    if ((r = copy_out(c, in0, c->e_in0.p, n4)) || (r = copy_out(c, in1, c->e_in1.p, n4)) ||
+        (r = copy_out(c, out, c->e_out.p, n4)) || (r = copy_out(c, op, c->e_op.p, c->n)))
+        return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return C2A_OK;
+}
+
+int c2a_build_circuit(c2a_ctx* c, uint64_t* cycle_at, uint32_t* wire_count) {
+    if (!c) return C2A_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->stage < ST_LOADED) return fail(c, C2A_ERR_STATE, "c2a_build_circuit: no gates loaded");
+    hipEvent_t b0 = c->ev[EV_BUILD0];
+    HIP_TRY(hipEventRecord(b0, c->stream));
+    int r = do_topo_sort(c, cycle_at);
+    if (r) return r;
+    c->ev_valid[EV_BUILD0] = true;
+    if ((r = do_assign_wires(c))) return r;
+    if ((r = do_emit(c))) return r;
+    rec(c, EV_BUILD1);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (wire_count) *wire_count = c->wire_count;
+    return C2A_OK;
+}
+
+int c2a_template_size(uint32_t op, uint32_t width, uint64_t* n_gates, uint64_t* n_aux) {
+    if (op >= C2A_NUM_GATE_TYPES || width == 0 || width > 64) return C2A_ERR_ARG;
+    TemplateBuilder tb(width);
+    tb.build(op);
+    if (n_gates) *n_gates = tb.gates.size();
+    if (n_aux) *n_aux = tb.aux;
+    return C2A_OK;
+}
+
+int c2a_boolify(c2a_ctx* c, uint32_t width, c2a_bool_info* info) {
+    if (!c) return C2A_ERR_ARG;
+    if (c->stage < ST_EMITTED) return fail(c, C2A_ERR_STATE, "c2a_boolify: call c2a_emit_gates / c2a_build_circuit first");
+    if (width == 0 || width > 64) return fail(c, C2A_ERR_ARG, "c2a_boolify: width must be in 1..64");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const u32 n = c->n;
+    // templates for this width (host-generated once per width, cached in HBM)
+    if (c->bool_width != width) {
+        std::vector<TemplateEntry> all;
+        BoolTables T;
+        for (u32 op = 0; op < 20; ++op) {
+            TemplateBuilder tb(width);
+            tb.build(op);
+            T.toff[op] = (u32)all.size();
+            T.tsize[op] = (u32)tb.gates.size();
+            T.taux[op] = tb.aux;
+            all.insert(all.end(), tb.gates.begin(), tb.gates.end());
+        }
+        ENSURE(c->tmpl, all.size() * sizeof(TemplateEntry));
+        ENSURE(c->tables, sizeof(BoolTables));
+        HIP_TRY(hipMemcpyAsync(c->tmpl.p, all.data(), all.size() * sizeof(TemplateEntry), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->tables.p, &T, sizeof(T), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        c->bool_width = width;
+    }
+    rec(c, EV_BPREP0);
+    ENSURE(c->tsz, (size_t)n * 4); ENSURE(c->asz, (size_t)n * 4);
+    ENSURE(c->goff, ((size_t)n + 1) * 8); ENSURE(c->aoff, ((size_t)n + 1) * 8);
+    if (n)
+        C2A_LAUNCH_NOSYNC(k_bool_sizes, grid_for(n, 4096), kThreads, s, n, c->e_op.as<u8>(),
+                          (const BoolTables*)c->tables.as<BoolTables>(), c->tsz.as<u32>(), c->asz.as<u32>());
+    int r = scan_exclusive<u64>(c, c->tsz.as<u32>(), c->goff.as<u64>(), n);
+    if (r) return r;
+    r = scan_exclusive<u64>(c, c->asz.as<u32>(), c->aoff.as<u64>(), n);
+    if (r) return r;
+    u64 totals[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(&totals[0], c->goff.as<u64>() + n, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&totals[1], c->aoff.as<u64>() + n, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const u64 G = totals[0], AUX = totals[1];
+    const u64 wires = (u64)c->wire_count * width + AUX;
+    if (wires >= 0xFFFFFFFFull) return fail(c, C2A_ERR_OVERFLOW, "c2a_boolify: boolean wire ids exceed u32");
+    ENSURE(c->b_in0, G * 4); ENSURE(c->b_in1, G * 4); ENSURE(c->b_out, G * 4); ENSURE(c->b_op, G);
+    rec(c, EV_BPREP1);
+    const u32 M = c->wire_count - c->n_out;
+    if (n) {
+        BoolArgs A;
+        A.n = n; A.width = width; A.M = M; A.aux_base = (u64)M * width; A.out_base = (u64)M * width + AUX;
+        A.e_in0 = c->e_in0.as<u32>(); A.e_in1 = c->e_in1.as<u32>(); A.e_out = c->e_out.as<u32>(); A.e_op = c->e_op.as<u8>();
+        A.goff = c->goff.as<u64>(); A.aoff = c->aoff.as<u64>(); A.tmpl = c->tmpl.as<uint4>();
+        A.b_in0 = c->b_in0.as<u32>(); A.b_in1 = c->b_in1.as<u32>(); A.b_out = c->b_out.as<u32>(); A.b_op = c->b_op.as<u8>();
+        const u32 blocks = (n + kBoolChunk - 1) / kBoolChunk;
+        C2A_LAUNCH(k_boolify, blocks, kThreads, s, A, (const BoolTables*)c->tables.as<BoolTables>());
+    }
+    rec(c, EV_BMAP1);
+    HIP_TRY(hipStreamSynchronize(s));
+    c->binfo.n_gates = G; c->binfo.wire_count = wires; c->binfo.aux_total = AUX; c->binfo.width = width;
+    c->binfo.n_in = c->n_in; c->binfo.n_out = c->n_out; c->binfo.m_wires = M;
+    if (info) *info = c->binfo;
+    c->stage = ST_BOOLIFIED;
+    return C2A_OK;
+}
+
+int c2a_bool_read(c2a_ctx* c, uint64_t first, uint64_t count, uint32_t* in0, uint32_t* in1, uint32_t* out, uint8_t* op) {
+    if (!c) return C2A_ERR_ARG;
+    if (c->stage < ST_BOOLIFIED) return fail(c, C2A_ERR_STATE, "c2a_bool_read: call c2a_boolify first");
+    if (first + count > c->binfo.n_gates) return fail(c, C2A_ERR_ARG, "c2a_bool_read: range out of bounds");
+    HIP_TRY(hipSetDevice(c->device));
+    int r;
+    if ((r = copy_out(c, in0, c->b_in0.as<u32>() + first, count * 4)) || (r = copy_out(c, in1, c->b_in1.as<u32>() + first, count * 4)) ||
+        (r = copy_out(c, out, c->b_out.as<u32>() + first, count * 4)) || (r = copy_out(c, op, c->b_op.as<u8>() + first, count)))
+        return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return C2A_OK;
+}
+
+int c2a_checksum(c2a_ctx* c, int which, uint64_t* value) {
+    if (!c || !value) return C2A_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    const void* p = nullptr;
+    u64 cnt = 0;
+    bool bytes = false;
+    Stage need = ST_SORTED;
+    switch (which) {
+    case 0: p = c->sorted.p; cnt = c->n; need = ST_SORTED; break;
+    case 1: p = c->e_in0.p; cnt = c->n; need = ST_EMITTED; break;
+    case 2: p = c->e_in1.p; cnt = c->n; need = ST_EMITTED; break;
+    case 3: p = c->e_out.p; cnt = c->n; need = ST_EMITTED; break;
+    case 4: p = c->e_op.p; cnt = c->n; need = ST_EMITTED; bytes = true; break;
+    case 5: p = c->b_in0.p; cnt = c->binfo.n_gates; need = ST_BOOLIFIED; break;
+    case 6: p = c->b_in1.p; cnt = c->binfo.n_gates; need = ST_BOOLIFIED; break;
+    case 7: p = c->b_out.p; cnt = c->binfo.n_gates; need = ST_BOOLIFIED; break;
+    case 8: p = c->b_op.p; cnt = c->binfo.n_gates; need = ST_BOOLIFIED; bytes = true; break;
+    case 9: p = c->node_wire1.p; cnt = c->n_nodes; need = ST_WIRED; break;
+    default: return fail(c, C2A_ERR_ARG, "c2a_checksum: unknown stream id");
+    }
+    if (c->stage < need) return fail(c, C2A_ERR_STATE, "c2a_checksum: result not computed yet");
+    ull* acc = reinterpret_cast<ull*>(c->scalars.as<u32>() + SC_TOTAL64);
+    HIP_TRY(hipMemsetAsync(acc, 0, 8, c->stream));
+    if (cnt) {
+        if (bytes) C2A_LAUNCH_NOSYNC(k_checksum_u8, grid_for(cnt, 2048), kThreads, c->stream, cnt, (const u8*)p, acc);
+        else C2A_LAUNCH_NOSYNC(k_checksum_u32, grid_for(cnt, 2048), kThreads, c->stream, cnt, (const u32*)p, acc);
+    }
+    u64 v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, acc, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *value = v;
+    return C2A_OK;
+}
+
+int c2a_get_timings(c2a_ctx* c, c2a_timings* t) {
+    if (!c || !t) return C2A_ERR_ARG;
+    (void)hipStreamSynchronize(c->stream);
+    t->prep = elapsed(c, EV_PREP0, EV_PREP1);
+    t->peel = elapsed(c, EV_PREP1, EV_PEEL1);
+    t->order = elapsed(c, EV_PEEL1, EV_ORDER1);
+    t->wires = elapsed(c, EV_WIRES0, EV_WIRES1);
+    t->emit = elapsed(c, EV_EMIT0, EV_EMIT1);
+    t->bool_prep = elapsed(c, EV_BPREP0, EV_BPREP1);
+    t->bool_map = elapsed(c, EV_BPREP1, EV_BMAP1);
+    t->build_total = elapsed(c, EV_BUILD0, EV_BUILD1);
+    t->boolify_total = elapsed(c, EV_BPREP0, EV_BMAP1);
+    return C2A_OK;
+}
+
+int c2a_get_stats(c2a_ctx* c, c2a_stats* s) {
+    if (!c || !s) return C2A_ERR_ARG;
+    *s = c->stats;
+    return C2A_OK;
+}
+
+}  // extern "C"
