@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -38,6 +39,7 @@ struct c2a_ctx {
     std::string err;
     Stage stage = ST_EMPTY;
     int n_cu = 256;
+    u32 peel_wave_max = 8192;      // frontier size up to which a level gets one wave per gate
 
     // problem
     u32 n = 0, n_nodes = 0, n_in = 0, n_out = 0;
@@ -50,18 +52,18 @@ struct c2a_ctx {
 
     // device buffers
     DevBuf lh, rh, out, op, in_nodes, out_nodes;
-    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, fill, cons, pending, order, posof, meta, anc, fbase, fcount;
-    DevBuf child0, child1, rflag, ridx, rlist, next, owner, local, slist, snext, ssum, jnxt, jval, sorted;
+    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, fill, cand, order, posof, meta, anc, fbase, fcount;
+    DevBuf rflag, ridx, rlist, next, owner, local, slist, snext, ssum, jnxt, jval, sorted;
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op;
-    DevBuf scan_tmp, scalars, dfs_state, dfs_stack;
+    DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof;
     DevBuf tsz, asz, goff, aoff, tmpl, tables, b_in0, b_in1, b_out, b_op;
     std::vector<DevBuf*> all;
 
     c2a_ctx() {
-        all = {&lh, &rh, &out, &op, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &fill, &cons,
-               &pending, &order, &posof, &meta, &anc, &fbase, &fcount, &child0, &child1, &rflag, &ridx, &rlist, &next,
+        all = {&lh, &rh, &out, &op, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &fill, &cand,
+               &order, &posof, &meta, &anc, &fbase, &fcount, &rflag, &ridx, &rlist, &next,
                &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
-               &node_wire, &e_in0, &e_in1, &e_out, &e_op, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &tsz, &asz, &goff,
+               &node_wire, &e_in0, &e_in1, &e_out, &e_op, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &tsz, &asz, &goff,
                &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op};
     }
 };
@@ -181,10 +183,8 @@ int do_prep(c2a_ctx* c) {
                       c->dep1.as<u32>(), c->cons_cnt.as<u32>());
     int r = scan_exclusive<u32>(c, c->cons_cnt.as<u32>(), c->cons_off.as<u32>(), n);
     if (r) return r;
-    C2A_LAUNCH_NOSYNC(k_fill_csr, G, kThreads, s, n, c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_off.as<u32>(),
-                      c->fill.as<u32>(), c->cons.as<u32>());
-    C2A_LAUNCH_NOSYNC(k_init_frontier, G, kThreads, s, n, c->cons_cnt.as<u32>(), c->pending.as<u32>(), c->order.as<u32>(),
-                      c->posof.as<u32>(), c->fcount.as<u32>());
+    C2A_LAUNCH(k_init_frontier, G, kThreads, s, n, c->cons_cnt.as<u32>(), c->order.as<u32>(), c->posof.as<u32>(),
+               c->fcount.as<u32>());
     return C2A_OK;
 }
 
@@ -195,10 +195,17 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
     hipStream_t s = c->stream;
     PeelArgs A;
     A.n = n; A.dep0 = c->dep0.as<u32>(); A.dep1 = c->dep1.as<u32>(); A.cons_off = c->cons_off.as<u32>();
-    A.cons = c->cons.as<u32>(); A.pending = c->pending.as<u32>(); A.order = c->order.as<u32>();
-    A.posof = c->posof.as<u32>(); A.meta = c->meta.as<uint4>(); A.anc = c->anc.as<u32>();
-    A.fbase = c->fbase.as<u32>(); A.fcount = c->fcount.as<u32>(); A.maxdepth = c->scalars.as<u32>() + SC_MAXDEPTH;
+    A.cons_cnt = c->cons_cnt.as<u32>(); A.cand = c->cand.as<u32>(); A.fill = c->fill.as<u32>();
+    A.order = c->order.as<u32>(); A.posof = c->posof.as<u32>(); A.meta = c->meta.as<uint4>(); A.anc = c->anc.as<u32>();
+    A.fbase = c->fbase.as<u32>(); A.fcount = c->fcount.as<u32>();
     A.levels = c->scalars.as<u32>() + SC_LEVELS;
+    A.prof = nullptr;
+    const bool profiling = std::getenv("C2A_PEEL_PROFILE") != nullptr;
+    if (profiling) {
+        ENSURE(c->peel_prof, (size_t)kProfLevels * kProfWaves * 8 * sizeof(ull));
+        HIP_TRY(hipMemsetAsync(c->peel_prof.p, 0, (size_t)kProfLevels * kProfWaves * 8 * sizeof(ull), s));
+        A.prof = c->peel_prof.as<ull>();
+    }
 
     u32 level = 0, launches = 0;
     u32 f0 = 0;
@@ -209,11 +216,21 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
     const u32 max_blocks = (u32)c->n_cu * 8;
     u32 peeled = 0;
     while (true) {
-        const u32 blocks = std::max<u32>(8u, std::min<u32>(max_blocks, (u32)(((u64)est * 2 + kThreads - 1) / kThreads)));
+        // narrow frontier -> one wave per gate (latency ~ one path comparison per level);
+        // wide frontier   -> one lane per gate (throughput)
+        const bool wave_mode = est <= c->peel_wave_max;
+        const u32 want = wave_mode ? (u32)(((u64)est * 2 + kWavesPerBlock - 1) / kWavesPerBlock)
+                                   : (u32)(((u64)est * 2 + kThreads - 1) / kThreads);
+        const u32 blocks = std::max<u32>(8u, std::min<u32>(max_blocks, want));
         for (u32 i = 0; i < batch; ++i) {
-            // the first launch of the very first batch sees the (possibly huge) level-0 frontier
-            const u32 b = (level == 0) ? std::max<u32>(blocks, grid_for(f0, max_blocks)) : blocks;
-            C2A_LAUNCH_NOSYNC(k_peel_level, b, kThreads, s, A, level);
+            if (level == 0) {
+                // the very first launch sees the (possibly huge) level-0 frontier: sinks have no consumers
+                C2A_LAUNCH_NOSYNC(k_peel_level, grid_for(f0, max_blocks), kThreads, s, A, level);
+            } else if (wave_mode) {
+                C2A_LAUNCH(k_peel_level_wave, blocks, kPeelWaveThreads, s, A, level);
+            } else {
+                C2A_LAUNCH_NOSYNC(k_peel_level, blocks, kThreads, s, A, level);
+            }
             ++level; ++launches;
             if (level > n) break;
         }
@@ -233,6 +250,31 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
         batch = std::min<u32>(batch * 2, 512u);
     }
     c->stats.level_launches = launches;
+    if (profiling) {   // diagnostics: mean over levels of the slowest wave's phase timestamps (ns since kernel entry)
+        std::vector<ull> hp((size_t)kProfLevels * kProfWaves * 8);
+        HIP_TRY(hipMemcpy(hp.data(), c->peel_prof.p, hp.size() * sizeof(ull), hipMemcpyDeviceToHost));
+        for (u32 L = 0; L < kProfLevels; L += 8) {
+            // per level: number of active waves, mean/max of each phase, and the slowest wave's record
+            double mean[6] = {0}; ull mx[6] = {0}; u32 act = 0, slow = 0; ull slow_end = 0; u32 last_active = 0; ull tmin = ~0ull, tmax = 0, fin = 0;
+            for (u32 w = 0; w < kProfWaves; ++w) {
+                const ull* r = &hp[((size_t)L * kProfWaves + w) * 8];
+                if (!r[5]) continue;
+                last_active = w;
+                if (!r[7]) continue;
+                ++act;
+                for (int k = 0; k < 6; ++k) { mean[k] += (double)r[k] * 10; mx[k] = std::max(mx[k], r[k] * 10); }
+                if (r[5] > slow_end) { slow_end = r[5]; slow = w; }
+                tmin = std::min(tmin, r[6]); tmax = std::max(tmax, r[6]); fin = std::max(fin, r[6] + r[5]);
+            }
+            if (!act) continue;
+            const ull* r = &hp[((size_t)L * kProfWaves + slow) * 8];
+            std::fprintf(stderr, "[c2a peel profile] level %u: %u gate-waves (last wave id with a record %u); mean ns loaded=%.0f cand=%.0f tourn=%.0f rows=%.0f sync=%.0f end=%.0f | "
+                         "max end=%llu start-skew=%llu first-start->last-finish=%llu | slowest wave %u: %llu %llu %llu %llu %llu %llu cands=%llu\n", L + kProfLevel0, act, last_active,
+                         mean[0] / act, mean[1] / act, mean[2] / act, mean[3] / act, mean[4] / act, mean[5] / act, (unsigned long long)mx[5], (unsigned long long)(tmax - tmin) * 10, (unsigned long long)(fin - tmin) * 10, slow,
+                         (unsigned long long)r[0] * 10, (unsigned long long)r[1] * 10, (unsigned long long)r[2] * 10, (unsigned long long)r[3] * 10,
+                         (unsigned long long)r[4] * 10, (unsigned long long)r[5] * 10, (unsigned long long)(r[7] - 1000));
+        }
+    }
     *peeled_out = peeled;
     return C2A_OK;
 }
@@ -241,10 +283,8 @@ int do_order(c2a_ctx* c) {
     const u32 n = c->n;
     hipStream_t s = c->stream;
     const u32 G = grid_for(n, 4096);
-    HIP_TRY(hipMemsetAsync(c->child0.p, 0xFF, (size_t)n * 4, s));
-    HIP_TRY(hipMemsetAsync(c->child1.p, 0xFF, (size_t)n * 4, s));
-    C2A_LAUNCH_NOSYNC(k_children, G, kThreads, s, n, c->meta.as<uint4>(), c->child0.as<u32>(), c->child1.as<u32>());
-    C2A_LAUNCH_NOSYNC(k_rootflag, G, kThreads, s, n, c->meta.as<uint4>(), c->posof.as<u32>(), c->rflag.as<u32>());
+    C2A_LAUNCH(k_rootflag, grid_for(n, 1024), kThreads, s, n, c->meta.as<uint4>(), c->posof.as<u32>(), c->rflag.as<u32>(),
+               c->scalars.as<u32>() + SC_MAXDEPTH);
     int r = scan_exclusive<u32>(c, c->rflag.as<u32>(), c->ridx.as<u32>(), n);
     if (r) return r;
     C2A_LAUNCH_NOSYNC(k_rootlist, G, kThreads, s, n, c->rflag.as<u32>(), c->ridx.as<u32>(), c->posof.as<u32>(),
@@ -253,15 +293,18 @@ int do_order(c2a_ctx* c) {
     HIP_TRY(hipMemcpyAsync(&n_roots, c->ridx.as<u32>() + n, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     c->stats.n_roots = n_roots;
-    C2A_LAUNCH_NOSYNC(k_euler_next, G, kThreads, s, n, c->meta.as<uint4>(), c->order.as<u32>(), c->child0.as<u32>(),
-                      c->child1.as<u32>(), c->ridx.as<u32>(), c->rlist.as<u32>(), n_roots, c->next.as<u32>());
+    C2A_LAUNCH_NOSYNC(k_euler_next, G, kThreads, s, n, c->meta.as<uint4>(), c->order.as<u32>(), c->posof.as<u32>(),
+                      c->dep0.as<u32>(), c->dep1.as<u32>(), c->ridx.as<u32>(), c->rlist.as<u32>(), n_roots,
+                      c->next.as<u32>());
     const u32 m = 2 * n;
     u32* scount = c->scalars.as<u32>() + SC_SCOUNT;
-    C2A_LAUNCH_NOSYNC(k_rank_mark, grid_for(m, 4096), kThreads, s, m, c->rlist.as<u32>(), scount, c->slist.as<u32>(),
+    C2A_LAUNCH(k_rank_mark, grid_for(m, 2048), kThreads, s, m, c->rlist.as<u32>(), scount, c->slist.as<u32>(),
                       c->owner.as<u32>());
-    u32 S = 0;
-    r = read_scalars(c, &S, SC_SCOUNT, 1);
+    u32 sc[2] = {0, 0};                       // SC_MAXDEPTH, SC_SCOUNT are adjacent
+    r = read_scalars(c, sc, SC_MAXDEPTH, 2);
     if (r) return r;
+    const u32 S = sc[1];
+    c->stats.max_depth = sc[0];
     c->stats.n_splitters = S;
     C2A_LAUNCH_NOSYNC(k_rank_walk, grid_for(S, 8192), kThreads, s, (const u32*)scount, c->rlist.as<u32>(), c->slist.as<u32>(),
                       c->next.as<u32>(), c->owner.as<u32>(), c->local.as<u32>(), c->snext.as<u32>(), c->ssum.as<u32>());
@@ -315,13 +358,11 @@ int do_topo_sort(c2a_ctx* c, u64* cycle_at) {
     if (r) return r;
     rec(c, EV_PEEL1);
     {
-        u32 edges = 0, md = 0, lv = 0;
+        u32 edges = 0, lv = 0;
         HIP_TRY(hipMemcpyAsync(&edges, c->cons_off.as<u32>() + n, 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(&md, c->scalars.as<u32>() + SC_MAXDEPTH, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(&lv, c->scalars.as<u32>() + SC_LEVELS, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->stats.n_edges = edges;
-        c->stats.max_depth = md;
         c->stats.levels = lv;
     }
     if (peeled != n) {
@@ -437,6 +478,7 @@ int c2a_create(int device_id, c2a_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
         c->n_cu = prop.multiProcessorCount;
+    if (const char* e = std::getenv("C2A_PEEL_WAVE_MAX")) c->peel_wave_max = (u32)std::strtoul(e, nullptr, 10);   // tuning / test knob
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return C2A_ERR_HIP; }
     for (int i = 0; i < EV_COUNT; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return C2A_ERR_HIP; }
@@ -483,11 +525,11 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     ENSURE(c->lh, n4); ENSURE(c->rh, n4); ENSURE(c->out, n4); ENSURE(c->op, n);
     ENSURE(c->in_nodes, (size_t)n_in * 4); ENSURE(c->out_nodes, (size_t)n_out * 4);
     ENSURE(c->prod1, nn4); ENSURE(c->dep0, n4); ENSURE(c->dep1, n4); ENSURE(c->cons_cnt, n4);
-    ENSURE(c->cons_off, n4 + 4); ENSURE(c->fill, n4); ENSURE(c->cons, 2 * n4); ENSURE(c->pending, n4);
+    ENSURE(c->cons_off, n4 + 4); ENSURE(c->fill, n4); ENSURE(c->cand, 2 * n4);
     ENSURE(c->order, n4); ENSURE(c->posof, n4); ENSURE(c->meta, (size_t)n * 16);
     ENSURE(c->anc, (size_t)c->planes * n * 64);
     ENSURE(c->fbase, n4 + 8); ENSURE(c->fcount, n4 + 8);
-    ENSURE(c->child0, n4); ENSURE(c->child1, n4); ENSURE(c->rflag, n4); ENSURE(c->ridx, n4 + 4); ENSURE(c->rlist, n4);
+    ENSURE(c->rflag, n4); ENSURE(c->ridx, n4 + 4); ENSURE(c->rlist, n4);
     ENSURE(c->next, 2 * n4); ENSURE(c->owner, 2 * n4); ENSURE(c->local, 2 * n4); ENSURE(c->slist, 2 * n4);
     ENSURE(c->snext, 2 * n4); ENSURE(c->ssum, 2 * n4); ENSURE(c->jnxt, 2 * n4); ENSURE(c->jval, 2 * n4);
     ENSURE(c->sorted, n4);

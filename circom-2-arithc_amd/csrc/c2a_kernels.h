@@ -97,50 +97,62 @@ __global__ void k_deps(u32 n, const u32* __restrict__ lh, const u32* __restrict_
     }
 }
 
-// CSR of consumers: cons[cons_off[d] ..] = (consumer gate << 1) | label
-__global__ void k_fill_csr(u32 n, const u32* __restrict__ dep0, const u32* __restrict__ dep1,
-                           const u32* __restrict__ cons_off, u32* fill, u32* cons) {
-    for (u64 g = gtid(); g < n; g += gstride()) {
-        const u32 d0 = dep0[g], d1 = dep1[g];
-        if (d0 != C2A_NONE) cons[cons_off[d0] + atomicAdd(&fill[d0], 1u)] = ((u32)g << 1);
-        if (d1 != C2A_NONE) cons[cons_off[d1] + atomicAdd(&fill[d1], 1u)] = ((u32)g << 1) | 1u;
+// One atomic per workgroup instead of one per wave on a hot append counter (a single address takes
+// ~12 ns per atomic: MI355X_MICROARCH.md price list, row "fanin").  Must be called by every thread of a
+// 256-thread workgroup the same number of times; returns the slot of the threads that `want` one.
+__device__ __forceinline__ u32 block_append_slot(bool want, u32* counter) {
+    __shared__ u32 s_cnt[kThreads / 64];
+    __shared__ u32 s_base;
+    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const u64 mask = __ballot(want);
+    if (lane == 0) s_cnt[wv] = (u32)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 run = 0;
+        for (int w = 0; w < kThreads / 64; ++w) { const u32 t = s_cnt[w]; s_cnt[w] = run; run += t; }
+        s_base = run ? atomicAdd(counter, run) : 0u;
     }
+    __syncthreads();
+    const u32 slot = s_base + s_cnt[wv] + (u32)__popcll(mask & ((1ull << lane) - 1ull));
+    __syncthreads();
+    return slot;
 }
 
 // level 0 of the reverse Kahn peel: gates nobody consumes.  fcount[0] must be zero.
-__global__ void k_init_frontier(u32 n, const u32* __restrict__ cons_cnt, u32* pending, u32* order, u32* posof,
-                                u32* fcount) {
-    for (u64 g = gtid(); g < n; g += gstride()) {
-        const u32 c = cons_cnt[g];
-        pending[g] = c;
-        if (c == 0) {
-            const u32 p = atomicAdd(&fcount[0], 1u);
-            order[p] = (u32)g;
-            posof[g] = p;
-        }
+__global__ void __launch_bounds__(kThreads) k_init_frontier(u32 n, const u32* __restrict__ cons_cnt, u32* order,
+                                                            u32* posof, u32* fcount) {
+    for (u64 base = (u64)blockIdx.x * kThreads; base < n; base += (u64)gridDim.x * kThreads) {
+        const u64 g = base + threadIdx.x;
+        const bool sink = g < n && cons_cnt[g] == 0;
+        const u32 p = block_append_slot(sink, &fcount[0]);
+        if (sink) { order[p] = (u32)g; posof[g] = p; }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // peel one level + pick DFS-tree parents
 // ------------------------------------------------------------------------------------------------
-// tree node == peel position `pos` (index into order[]).  meta[pos] = {parent pos | NONE, depth, root
+// tree node == peel position (index into order[]): nodes of recent levels are contiguous, so the hops of a
+// path comparison that stay near the frontier stay in cache.  meta[pos] = {parent pos | NONE, depth, root
 // gate id, label}.  anc plane j, row pos: 16 ancestors at distances (d+1)*16^j, valid while <= depth.
+// Candidate lists are filled as consumers are peeled: cand[cons_off[d] + k] = (consumer pos << 1) | label;
+// the gate whose push completes d's list (k + 1 == cons_cnt[d]) appends d to the next frontier.
 struct PeelArgs {
     u32 n;
     const u32* dep0;
     const u32* dep1;
     const u32* cons_off;
-    const u32* cons;
-    u32* pending;
-    u32* order;
-    u32* posof;
+    const u32* cons_cnt;
+    u32* cand;
+    u32* fill;       // pushes so far per gate (zeroed)
+    u32* order;      // peel order (frontier lists back to back)
+    u32* posof;      // gate -> peel position
     uint4* meta;
     u32* anc;        // [planes][n][16]
     u32* fbase;      // [levels+2]
     u32* fcount;     // [levels+2]
-    u32* maxdepth;   // running max tree depth (stat)
     u32* levels;     // number of non-empty levels (stat)
+    ull* prof;       // optional [levels][64 sampled waves][8] phase timestamps (diagnostics; nullptr normally)
 };
 
 __device__ __forceinline__ u32 anc_entry(const u32* anc, u64 plane, int j, u32 x, u32 d) {
@@ -210,6 +222,15 @@ __device__ __forceinline__ bool path_less(const u32* anc, u64 plane, const uint4
     return meta[a].w < meta[b].w;
 }
 
+// gate at position p pushes itself into producer d's candidate list; returns true when that completes it
+__device__ __forceinline__ bool push_cand(const PeelArgs& A, u32 d, u32 p, u32 label) {
+    const u32 k = atomicAdd(&A.fill[d], 1u);
+    A.cand[A.cons_off[d] + k] = (p << 1) | label;
+    return k + 1 == A.cons_cnt[d];
+}
+
+// Variant 1: one lane per frontier gate, candidates compared one after the other.  Used while the frontier
+// is wide (the first levels); its latency per level is (largest fan-out) x (one path comparison).
 __global__ void __launch_bounds__(kThreads) k_peel_level(PeelArgs A, u32 level) {
     const u32 lo = A.fbase[level];
     const u32 cnt = A.fcount[level];
@@ -219,17 +240,15 @@ __global__ void __launch_bounds__(kThreads) k_peel_level(PeelArgs A, u32 level) 
         if (cnt) atomicMax(A.levels, level + 1);
     }
     const u64 plane = (u64)A.n * 16;
-    u32 local_maxdepth = 0;
     for (u64 i = gtid(); i < cnt; i += gstride()) {
         const u32 pos = lo + (u32)i;
         const u32 g = A.order[pos];
         // ---- tournament over the candidate paths: [g] (child of the virtual root) and P(c).l per consumer
         u32 best = C2A_NONE, best_label = 0, best_root = g, best_depth = 0;
-        const u32 e0 = A.cons_off[g], e1 = A.cons_off[g + 1];
+        const u32 e0 = A.cons_off[g], e1 = e0 + A.cons_cnt[g];
         for (u32 e = e0; e < e1; ++e) {
-            const u32 ce = A.cons[e];
-            const u32 c = ce >> 1, l = ce & 1u;
-            const u32 pc = A.posof[c];
+            const u32 ce = A.cand[e];
+            const u32 pc = ce >> 1, l = ce & 1u;
             const uint4 mc = A.meta[pc];
             bool take;
             if (best == C2A_NONE) take = mc.z < g;
@@ -240,7 +259,6 @@ __global__ void __launch_bounds__(kThreads) k_peel_level(PeelArgs A, u32 level) 
         }
         const u32 depth = best == C2A_NONE ? 0u : best_depth + 1;
         A.meta[pos] = make_uint4(best, depth, best_root, best == C2A_NONE ? 0u : best_label);
-        if (depth > local_maxdepth) local_maxdepth = depth;
         // ---- ancestor rows: row j = [q_j, row_j(q_j)[0..14]], q_0 = parent, q_{j+1} = my ancestor at 16^(j+1)
         if (depth) {
             u32 q = best;
@@ -258,72 +276,266 @@ __global__ void __launch_bounds__(kThreads) k_peel_level(PeelArgs A, u32 level) 
                 need <<= 4;
             }
         }
-        // ---- release producers: a gate joins the next frontier when its last consumer is peeled
+        // ---- tell the producers; a producer joins the next frontier when its last consumer has been peeled
         const u32 d0 = A.dep0[g], d1 = A.dep1[g];
-        if (d0 != C2A_NONE && atomicSub(&A.pending[d0], 1u) == 1u) {
+        if (d0 != C2A_NONE && push_cand(A, d0, pos, 0)) {
             const u32 p = next_base + atomicAdd(&A.fcount[level + 1], 1u);
-            A.order[p] = d0;
-            A.posof[d0] = p;
+            A.order[p] = d0; A.posof[d0] = p;
         }
-        if (d1 != C2A_NONE && atomicSub(&A.pending[d1], 1u) == 1u) {
+        if (d1 != C2A_NONE && push_cand(A, d1, pos, 1)) {
             const u32 p = next_base + atomicAdd(&A.fcount[level + 1], 1u);
-            A.order[p] = d1;
-            A.posof[d1] = p;
+            A.order[p] = d1; A.posof[d1] = p;
         }
     }
-    if (local_maxdepth) atomicMax(A.maxdepth, local_maxdepth);
+}
+
+// Variant 2: one WAVE per frontier gate.  Lanes load the consumers in parallel, candidates with a larger
+// DFS root are dropped by a wave-wide min, and the survivors play a one-round all-pairs tournament (one path
+// comparison per lane, <= 11 candidates = 55 pairs per round) — so the latency per level is about ONE path
+// comparison whatever the fan-out.  Ancestor rows are written 16 lanes wide (one 64-byte line per plane).
+constexpr int kPeelWaveThreads = 1024;
+constexpr int kWavesPerBlock = kPeelWaveThreads / 64;     // 16 gates per workgroup pass
+constexpr int kGroup = 11;                                // 11*10/2 = 55 pairs <= 64 lanes
+
+__device__ __forceinline__ u32 wave_min_u32(u32 v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const u32 o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// lanes of one wave exchange data through LDS: the hardware runs a wave's DS ops in order, the barrier
+// only has to stop the compiler (and gives the host emulation its rendezvous point)
+__device__ __forceinline__ void wave_lds_sync() {
+#ifdef C2A_EMULATE
+    (void)__ballot(1);
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
+__device__ __forceinline__ ull c2a_now() {
+#ifdef C2A_EMULATE
+    return 0;
+#else
+    return wall_clock64();      // constant 100 MHz
+#endif
+}
+// diagnostics: every wave of levels [256, 288) stores its phase timestamps (slot 7 = candidates of its gate)
+constexpr u32 kProfLevel0 = 256, kProfLevels = 32, kProfWaves = 32768;
+#define C2A_PROF(slot)                                                                                          \
+    do {                                                                                                        \
+        if (A.prof && lane == 0 && level >= kProfLevel0 && level < kProfLevel0 + kProfLevels) {                 \
+            const u32 wg_ = blockIdx.x * kWavesPerBlock + wv;                                                   \
+            if (wg_ < kProfWaves) A.prof[((u64)(level - kProfLevel0) * kProfWaves + wg_) * 8 + (slot)] = c2a_now() - t_begin; \
+        }                                                                                                       \
+    } while (0)
+
+__global__ void __launch_bounds__(kPeelWaveThreads) k_peel_level_wave(PeelArgs A, u32 level) {
+    const ull t_begin = A.prof ? c2a_now() : 0;
+    __shared__ u32 s_c[kWavesPerBlock][72], s_l[kWavesPerBlock][72], s_d[kWavesPerBlock][72];
+    __shared__ u32 s_ready[2 * kWavesPerBlock];
+    __shared__ u32 s_base;
+    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const u32 lo = A.fbase[level];
+    const u32 cnt = A.fcount[level];
+    const u32 next_base = lo + cnt;
+    if (gtid() == 0) {
+        A.fbase[level + 1] = next_base;
+        if (cnt) atomicMax(A.levels, level + 1);
+    }
+    const u64 plane = (u64)A.n * 16;
+    const u64 lt_mask = (1ull << lane) - 1ull;
+    for (u32 chunk = blockIdx.x; (u64)chunk * kWavesPerBlock < cnt; chunk += gridDim.x) {
+        const u32 i = chunk * kWavesPerBlock + wv;
+        u32 r0 = C2A_NONE, r1 = C2A_NONE;               // producers released by this wave's gate (lane 0 / lane 1)
+        if (i < cnt) {
+            const u32 pos = lo + i;
+            const u32 g = A.order[pos];
+            const u32 d0 = A.dep0[g], d1 = A.dep1[g];
+            const u32 e0 = A.cons_off[g], e1 = e0 + A.cons_cnt[g];
+            C2A_PROF(0);
+            if (A.prof && lane == 0 && level >= kProfLevel0 && level < kProfLevel0 + kProfLevels && blockIdx.x * kWavesPerBlock + wv < kProfWaves)
+            {
+                A.prof[((u64)(level - kProfLevel0) * kProfWaves + blockIdx.x * kWavesPerBlock + wv) * 8 + 7] = e1 - e0 + 1000;
+                A.prof[((u64)(level - kProfLevel0) * kProfWaves + blockIdx.x * kWavesPerBlock + wv) * 8 + 6] = t_begin;
+            }
+            // the pushes only need `pos`: issue them first so their round trips hide under the tournament
+            if (lane == 0 && d0 != C2A_NONE && push_cand(A, d0, pos, 0)) r0 = d0;
+            if (lane == 1 && d1 != C2A_NONE && push_cand(A, d1, pos, 1)) r1 = d1;
+            // champion so far (wave-uniform); NONE = the virtual-root candidate [g]
+            u32 ch = C2A_NONE, ch_label = 0, ch_root = g, ch_depth = 0;
+            for (u32 eb = e0; eb < e1; eb += 64) {
+                const u32 e = eb + lane;
+                const bool valid = e < e1;
+                u32 c = 0, l = 0, cdepth = 0, croot = 0xFFFFFFFFu;
+                if (valid) {
+                    const u32 ce = A.cand[e];
+                    c = ce >> 1; l = ce & 1u;
+                    const uint4 mc = A.meta[c];
+                    cdepth = mc.y; croot = mc.z;
+                }
+                const u32 rmin = wave_min_u32(croot);
+                C2A_PROF(1);
+                if (rmin > ch_root) continue;                       // the whole chunk starts from a later DFS root
+                const bool keep_ch = (ch != C2A_NONE) && (ch_root == rmin);
+                const bool surv = valid && croot == rmin;
+                const u64 smask = __ballot(surv);
+                u32 m = (u32)__popcll(smask);
+                if (surv) {
+                    const u32 k = (u32)__popcll(smask & lt_mask);
+                    s_c[wv][k] = c; s_l[wv][k] = l; s_d[wv][k] = cdepth;
+                }
+                if (keep_ch && lane == 0) { s_c[wv][m] = ch; s_l[wv][m] = ch_label; s_d[wv][m] = ch_depth; }
+                m += keep_ch ? 1u : 0u;
+                wave_lds_sync();
+                // all-pairs rounds over groups of <= kGroup candidates: [winner so far] + next candidates
+                u32 win = 0;        // index (in s_*) of the current winner
+                u32 next = 1;       // next unplayed candidate
+                while (next < m) {
+                    const u32 take = (m - next) < (u32)(kGroup - 1) ? (m - next) : (u32)(kGroup - 1);
+                    const u32 q = take + 1;                         // group: member 0 = win, member t = next+t-1
+                    const u32 P = q * (q - 1) / 2;
+                    u32 pi = 0, pj = 1;                             // lane -> pair (i<j), triangular enumeration
+                    {
+                        u32 rem = lane, row = 0, len = q - 1;
+                        while (len && rem >= len) { rem -= len; ++row; --len; }
+                        pi = row; pj = row + 1 + rem;
+                    }
+                    u32 loser = 0xFFFFFFFFu;
+                    if (lane < P) {
+                        const u32 xi = pi == 0 ? win : next + pi - 1, xj = next + pj - 1;
+                        const u32 ci = s_c[wv][xi], cj = s_c[wv][xj];
+                        const u32 li = s_l[wv][xi], lj = s_l[wv][xj];
+                        bool less;
+                        if (ci == cj) less = li < lj;
+                        else less = path_less(A.anc, plane, A.meta, ci, li, s_d[wv][xi], cj, lj, s_d[wv][xj]);
+                        loser = less ? pj : pi;
+                    }
+                    u32 w = 0;
+                    for (u32 t = 0; t < q; ++t) {
+                        const u64 lost = __ballot(loser == t);
+                        if (lost == 0) w = t;
+                    }
+                    win = w == 0 ? win : next + w - 1;
+                    next += take;
+                }
+                ch = s_c[wv][win]; ch_label = s_l[wv][win]; ch_depth = s_d[wv][win]; ch_root = rmin;
+                wave_lds_sync();
+            }
+            C2A_PROF(2);
+            const u32 depth = ch == C2A_NONE ? 0u : ch_depth + 1;
+            if (lane == 0) A.meta[pos] = make_uint4(ch, depth, ch_root, ch == C2A_NONE ? 0u : ch_label);
+            if (depth) {
+                u32 q = ch;
+                u32 need = 1;
+                for (int j = 0; need <= depth; ++j) {
+                    u32 v = q;
+                    if (lane >= 1 && lane < 16) v = anc_entry(A.anc, plane, j, q, lane - 1);
+                    if (lane < 16) A.anc[(u64)j * plane + (u64)pos * 16 + lane] = v;
+                    q = __shfl(v, 15, 64);
+                    if (need > (0xFFFFFFFFu >> 4)) break;
+                    need <<= 4;
+                }
+            }
+            C2A_PROF(3);
+        }
+        // ---- one append per workgroup: a single counter takes ~12 ns per atomic, so per-gate appends would
+        // cost more than the whole level (MI355X_MICROARCH.md price list, row "fanin")
+        if (lane == 0) s_ready[2 * wv] = r0;
+        if (lane == 1) s_ready[2 * wv + 1] = r1;
+        __syncthreads();
+        C2A_PROF(4);
+        if (wv == 0) {
+            const u32 d = lane < 2 * kWavesPerBlock ? s_ready[lane] : C2A_NONE;
+            const u64 mask = __ballot(d != C2A_NONE);
+            if (mask) {
+                if (lane == 0) s_base = atomicAdd(&A.fcount[level + 1], (u32)__popcll(mask));
+                wave_lds_sync();
+                if (d != C2A_NONE) {
+                    const u32 p = next_base + s_base + (u32)__popcll(mask & lt_mask);
+                    A.order[p] = d; A.posof[d] = p;
+                }
+            }
+        }
+        __syncthreads();
+        C2A_PROF(5);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // post-order numbering: Euler tour of the DFS tree + list ranking (random splitters)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_children(u32 n, const uint4* __restrict__ meta, u32* child0, u32* child1) {
-    for (u64 x = gtid(); x < n; x += gstride()) {
-        const uint4 m = meta[x];
-        if (m.x != C2A_NONE) (m.w ? child1 : child0)[m.x] = (u32)x;
+// also collects the DFS-tree depth (stat) with one atomic per workgroup — never one per gate on a single word
+__global__ void __launch_bounds__(kThreads) k_rootflag(u32 n, const uint4* __restrict__ meta,
+                                                       const u32* __restrict__ posof, u32* rflag, u32* maxdepth) {
+    __shared__ u32 s_max[kThreads];
+    u32 md = 0;
+    for (u64 g = gtid(); g < n; g += gstride()) {
+        const uint4 m = meta[posof[g]];
+        rflag[g] = m.x == C2A_NONE ? 1u : 0u;
+        md = m.y > md ? m.y : md;
     }
+    s_max[threadIdx.x] = md;
+    __syncthreads();
+    for (u32 off = kThreads / 2; off; off >>= 1) {
+        if (threadIdx.x < off) { const u32 o = s_max[threadIdx.x + off]; if (o > s_max[threadIdx.x]) s_max[threadIdx.x] = o; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && s_max[0]) atomicMax(maxdepth, s_max[0]);
 }
 
-__global__ void k_rootflag(u32 n, const uint4* __restrict__ meta, const u32* __restrict__ posof, u32* rflag) {
-    for (u64 g = gtid(); g < n; g += gstride()) rflag[g] = meta[posof[g]].x == C2A_NONE ? 1u : 0u;
-}
-
+// DFS roots in ascending gate id (topological_sort.rs:11-13), as tree positions
 __global__ void k_rootlist(u32 n, const u32* __restrict__ rflag, const u32* __restrict__ ridx,
                            const u32* __restrict__ posof, u32* rlist) {
     for (u64 g = gtid(); g < n; g += gstride())
         if (rflag[g]) rlist[ridx[g]] = posof[g];
 }
 
+// tree child of the node at position p along label l: p's dep_l, when that gate chose (p,l) as its parent
+__device__ __forceinline__ u32 tree_child(const uint4* meta, const u32* posof, u32 p, u32 dep, u32 label) {
+    if (dep == C2A_NONE) return C2A_NONE;
+    const u32 pd = posof[dep];
+    const uint4 m = meta[pd];
+    return (m.x == p && m.w == label) ? pd : C2A_NONE;
+}
+
 // element 2x = enter(x), 2x+1 = exit(x); the tour visits label-0 child, label-1 child, then exits.
 __global__ void k_euler_next(u32 n, const uint4* __restrict__ meta, const u32* __restrict__ order,
-                             const u32* __restrict__ child0, const u32* __restrict__ child1,
+                             const u32* __restrict__ posof, const u32* __restrict__ dep0, const u32* __restrict__ dep1,
                              const u32* __restrict__ ridx, const u32* __restrict__ rlist, u32 n_roots, u32* next) {
-    for (u64 x = gtid(); x < n; x += gstride()) {
-        const u32 c0 = child0[x], c1 = child1[x];
-        next[2 * x] = c0 != C2A_NONE ? 2 * c0 : (c1 != C2A_NONE ? 2 * c1 : (u32)(2 * x + 1));
+    for (u64 i = gtid(); i < n; i += gstride()) {
+        const u32 x = (u32)i;
+        const u32 g = order[x];
+        const u32 c0 = tree_child(meta, posof, x, dep0[g], 0), c1 = tree_child(meta, posof, x, dep1[g], 1);
+        next[2 * i] = c0 != C2A_NONE ? 2 * c0 : (c1 != C2A_NONE ? 2 * c1 : 2 * x + 1);
         const uint4 m = meta[x];
         u32 nx;
         if (m.x == C2A_NONE) {
-            const u32 k = ridx[order[x]];
+            const u32 k = ridx[g];
             nx = k + 1 < n_roots ? 2 * rlist[k + 1] : C2A_NONE;
         } else {
-            const u32 s1 = child1[m.x];
-            nx = (m.w == 0 && s1 != C2A_NONE) ? 2 * s1 : 2 * m.x + 1;
+            const u32 s1 = m.w == 0 ? tree_child(meta, posof, m.x, dep1[order[m.x]], 1) : C2A_NONE;
+            nx = s1 != C2A_NONE ? 2 * s1 : 2 * m.x + 1;
         }
-        next[2 * x + 1] = nx;
+        next[2 * i + 1] = nx;
     }
 }
 
 __device__ __forceinline__ bool is_splitter(u32 e, u32 head) { return e == head || ((e * 0x9E3779B1u) >> 26) == 0u; }
 
-__global__ void k_rank_mark(u32 m, const u32* __restrict__ rlist, u32* scount, u32* slist, u32* owner) {
+__global__ void __launch_bounds__(kThreads) k_rank_mark(u32 m, const u32* __restrict__ rlist, u32* scount, u32* slist,
+                                                        u32* owner) {
     const u32 head = 2 * rlist[0];
-    for (u64 e = gtid(); e < m; e += gstride()) {
-        if (is_splitter((u32)e, head)) {
-            const u32 k = atomicAdd(scount, 1u);
-            slist[k] = (u32)e;
-            owner[e] = k;
-        }
+    for (u64 base = (u64)blockIdx.x * kThreads; base < m; base += (u64)gridDim.x * kThreads) {
+        const u64 e = base + threadIdx.x;
+        const bool sp = e < m && is_splitter((u32)e, head);
+        const u32 k = block_append_slot(sp, scount);
+        if (sp) { slist[k] = (u32)e; owner[e] = k; }
     }
 }
 
