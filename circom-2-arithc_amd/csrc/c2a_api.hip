@@ -40,6 +40,7 @@ struct c2a_ctx {
     Stage stage = ST_EMPTY;
     int n_cu = 256;
     u32 peel_wave_max = 8192;      // frontier size up to which a level gets one wave per gate
+    u32 peel_wpb = 16;             // gates (waves) per workgroup in wave mode: 4, 8 or 16
 
     // problem
     u32 n = 0, n_nodes = 0, n_in = 0, n_out = 0;
@@ -52,7 +53,7 @@ struct c2a_ctx {
 
     // device buffers
     DevBuf lh, rh, out, op, in_nodes, out_nodes;
-    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, fill, cand, order, posof, meta, anc, fbase, fcount;
+    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, fill, cand, order, posof, meta, anc, fbase, fcount, ginfo, frec;
     DevBuf rflag, ridx, rlist, next, owner, local, slist, snext, ssum, jnxt, jval, sorted;
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op;
     DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof;
@@ -61,7 +62,7 @@ struct c2a_ctx {
 
     c2a_ctx() {
         all = {&lh, &rh, &out, &op, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &fill, &cand,
-               &order, &posof, &meta, &anc, &fbase, &fcount, &rflag, &ridx, &rlist, &next,
+               &order, &posof, &ginfo, &frec, &meta, &anc, &fbase, &fcount, &rflag, &ridx, &rlist, &next,
                &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
                &node_wire, &e_in0, &e_in1, &e_out, &e_op, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &tsz, &asz, &goff,
                &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op};
@@ -183,8 +184,10 @@ int do_prep(c2a_ctx* c) {
                       c->dep1.as<u32>(), c->cons_cnt.as<u32>());
     int r = scan_exclusive<u32>(c, c->cons_cnt.as<u32>(), c->cons_off.as<u32>(), n);
     if (r) return r;
-    C2A_LAUNCH(k_init_frontier, G, kThreads, s, n, c->cons_cnt.as<u32>(), c->order.as<u32>(), c->posof.as<u32>(),
-               c->fcount.as<u32>());
+    C2A_LAUNCH_NOSYNC(k_ginfo, G, kThreads, s, n, c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_off.as<u32>(),
+                      c->cons_cnt.as<u32>(), c->ginfo.as<uint4>());
+    C2A_LAUNCH(k_init_frontier, G, kThreads, s, n, (const uint4*)c->ginfo.as<uint4>(), c->order.as<u32>(),
+               c->frec.as<uint4>(), c->posof.as<u32>(), c->fcount.as<u32>());
     return C2A_OK;
 }
 
@@ -194,8 +197,8 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
     const u32 n = c->n;
     hipStream_t s = c->stream;
     PeelArgs A;
-    A.n = n; A.dep0 = c->dep0.as<u32>(); A.dep1 = c->dep1.as<u32>(); A.cons_off = c->cons_off.as<u32>();
-    A.cons_cnt = c->cons_cnt.as<u32>(); A.cand = c->cand.as<u32>(); A.fill = c->fill.as<u32>();
+    A.n = n; A.ginfo = c->ginfo.as<uint4>(); A.frec = c->frec.as<uint4>();
+    A.cand = c->cand.as<u32>(); A.fill = c->fill.as<u32>();
     A.order = c->order.as<u32>(); A.posof = c->posof.as<u32>(); A.meta = c->meta.as<uint4>(); A.anc = c->anc.as<u32>();
     A.fbase = c->fbase.as<u32>(); A.fcount = c->fcount.as<u32>();
     A.levels = c->scalars.as<u32>() + SC_LEVELS;
@@ -219,7 +222,8 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
         // narrow frontier -> one wave per gate (latency ~ one path comparison per level);
         // wide frontier   -> one lane per gate (throughput)
         const bool wave_mode = est <= c->peel_wave_max;
-        const u32 want = wave_mode ? (u32)(((u64)est * 2 + kWavesPerBlock - 1) / kWavesPerBlock)
+        const u32 wpb = c->peel_wpb;
+        const u32 want = wave_mode ? (u32)(((u64)est * 5 / 4 + wpb - 1) / wpb) + 4
                                    : (u32)(((u64)est * 2 + kThreads - 1) / kThreads);
         const u32 blocks = std::max<u32>(8u, std::min<u32>(max_blocks, want));
         for (u32 i = 0; i < batch; ++i) {
@@ -227,7 +231,9 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
                 // the very first launch sees the (possibly huge) level-0 frontier: sinks have no consumers
                 C2A_LAUNCH_NOSYNC(k_peel_level, grid_for(f0, max_blocks), kThreads, s, A, level);
             } else if (wave_mode) {
-                C2A_LAUNCH(k_peel_level_wave, blocks, kPeelWaveThreads, s, A, level);
+                if (wpb == 16) C2A_LAUNCH((k_peel_level_wave<16>), blocks, 1024, s, A, level);
+                else if (wpb == 8) C2A_LAUNCH((k_peel_level_wave<8>), blocks, 512, s, A, level);
+                else C2A_LAUNCH((k_peel_level_wave<4>), blocks, 256, s, A, level);
             } else {
                 C2A_LAUNCH_NOSYNC(k_peel_level, blocks, kThreads, s, A, level);
             }
@@ -478,6 +484,7 @@ int c2a_create(int device_id, c2a_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
         c->n_cu = prop.multiProcessorCount;
+    if (const char* e = std::getenv("C2A_PEEL_WPB")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 4 || v == 8 || v == 16) c->peel_wpb = v; }
     if (const char* e = std::getenv("C2A_PEEL_WAVE_MAX")) c->peel_wave_max = (u32)std::strtoul(e, nullptr, 10);   // tuning / test knob
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return C2A_ERR_HIP; }
     for (int i = 0; i < EV_COUNT; ++i)
@@ -527,6 +534,7 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     ENSURE(c->prod1, nn4); ENSURE(c->dep0, n4); ENSURE(c->dep1, n4); ENSURE(c->cons_cnt, n4);
     ENSURE(c->cons_off, n4 + 4); ENSURE(c->fill, n4); ENSURE(c->cand, 2 * n4);
     ENSURE(c->order, n4); ENSURE(c->posof, n4); ENSURE(c->meta, (size_t)n * 16);
+    ENSURE(c->ginfo, (size_t)n * 16); ENSURE(c->frec, (size_t)n * 16);
     ENSURE(c->anc, (size_t)c->planes * n * 64);
     ENSURE(c->fbase, n4 + 8); ENSURE(c->fcount, n4 + 8);
     ENSURE(c->rflag, n4); ENSURE(c->ridx, n4 + 4); ENSURE(c->rlist, n4);

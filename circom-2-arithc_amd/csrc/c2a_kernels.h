@@ -118,14 +118,23 @@ __device__ __forceinline__ u32 block_append_slot(bool want, u32* counter) {
     return slot;
 }
 
+// per-gate static record {dep0, dep1, cons_off, cons_cnt}: one 16-byte load instead of four
+__global__ void k_ginfo(u32 n, const u32* __restrict__ dep0, const u32* __restrict__ dep1,
+                        const u32* __restrict__ cons_off, const u32* __restrict__ cons_cnt, uint4* ginfo) {
+    for (u64 g = gtid(); g < n; g += gstride()) ginfo[g] = make_uint4(dep0[g], dep1[g], cons_off[g], cons_cnt[g]);
+}
+
 // level 0 of the reverse Kahn peel: gates nobody consumes.  fcount[0] must be zero.
-__global__ void __launch_bounds__(kThreads) k_init_frontier(u32 n, const u32* __restrict__ cons_cnt, u32* order,
-                                                            u32* posof, u32* fcount) {
+// frec[p] carries the gate's static record next to order[p], so a level starts with ONE contiguous read.
+__global__ void __launch_bounds__(kThreads) k_init_frontier(u32 n, const uint4* __restrict__ ginfo, u32* order,
+                                                            uint4* frec, u32* posof, u32* fcount) {
     for (u64 base = (u64)blockIdx.x * kThreads; base < n; base += (u64)gridDim.x * kThreads) {
         const u64 g = base + threadIdx.x;
-        const bool sink = g < n && cons_cnt[g] == 0;
+        uint4 gi = make_uint4(0, 0, 0, 1);
+        if (g < n) gi = ginfo[g];
+        const bool sink = g < n && gi.w == 0;
         const u32 p = block_append_slot(sink, &fcount[0]);
-        if (sink) { order[p] = (u32)g; posof[g] = p; }
+        if (sink) { order[p] = (u32)g; frec[p] = gi; posof[g] = p; }
     }
 }
 
@@ -139,10 +148,8 @@ __global__ void __launch_bounds__(kThreads) k_init_frontier(u32 n, const u32* __
 // the gate whose push completes d's list (k + 1 == cons_cnt[d]) appends d to the next frontier.
 struct PeelArgs {
     u32 n;
-    const u32* dep0;
-    const u32* dep1;
-    const u32* cons_off;
-    const u32* cons_cnt;
+    const uint4* ginfo;   // [n] {dep0, dep1, cons_off, cons_cnt}
+    uint4* frec;          // [n] ginfo of order[p]
     u32* cand;
     u32* fill;       // pushes so far per gate (zeroed)
     u32* order;      // peel order (frontier lists back to back)
@@ -222,11 +229,11 @@ __device__ __forceinline__ bool path_less(const u32* anc, u64 plane, const uint4
     return meta[a].w < meta[b].w;
 }
 
-// gate at position p pushes itself into producer d's candidate list; returns true when that completes it
-__device__ __forceinline__ bool push_cand(const PeelArgs& A, u32 d, u32 p, u32 label) {
+// gate at position p pushes itself into producer d's candidate list (gd = ginfo[d]); true when that completes it
+__device__ __forceinline__ bool push_cand(const PeelArgs& A, u32 d, const uint4& gd, u32 p, u32 label) {
     const u32 k = atomicAdd(&A.fill[d], 1u);
-    A.cand[A.cons_off[d] + k] = (p << 1) | label;
-    return k + 1 == A.cons_cnt[d];
+    A.cand[gd.z + k] = (p << 1) | label;
+    return k + 1 == gd.w;
 }
 
 // Variant 1: one lane per frontier gate, candidates compared one after the other.  Used while the frontier
@@ -243,9 +250,10 @@ __global__ void __launch_bounds__(kThreads) k_peel_level(PeelArgs A, u32 level) 
     for (u64 i = gtid(); i < cnt; i += gstride()) {
         const u32 pos = lo + (u32)i;
         const u32 g = A.order[pos];
+        const uint4 gi = A.frec[pos];
         // ---- tournament over the candidate paths: [g] (child of the virtual root) and P(c).l per consumer
         u32 best = C2A_NONE, best_label = 0, best_root = g, best_depth = 0;
-        const u32 e0 = A.cons_off[g], e1 = e0 + A.cons_cnt[g];
+        const u32 e0 = gi.z, e1 = e0 + gi.w;
         for (u32 e = e0; e < e1; ++e) {
             const u32 ce = A.cand[e];
             const u32 pc = ce >> 1, l = ce & 1u;
@@ -277,14 +285,20 @@ __global__ void __launch_bounds__(kThreads) k_peel_level(PeelArgs A, u32 level) 
             }
         }
         // ---- tell the producers; a producer joins the next frontier when its last consumer has been peeled
-        const u32 d0 = A.dep0[g], d1 = A.dep1[g];
-        if (d0 != C2A_NONE && push_cand(A, d0, pos, 0)) {
-            const u32 p = next_base + atomicAdd(&A.fcount[level + 1], 1u);
-            A.order[p] = d0; A.posof[d0] = p;
+        const u32 d0 = gi.x, d1 = gi.y;
+        if (d0 != C2A_NONE) {
+            const uint4 gd = A.ginfo[d0];
+            if (push_cand(A, d0, gd, pos, 0)) {
+                const u32 p = next_base + atomicAdd(&A.fcount[level + 1], 1u);
+                A.order[p] = d0; A.frec[p] = gd; A.posof[d0] = p;
+            }
         }
-        if (d1 != C2A_NONE && push_cand(A, d1, pos, 1)) {
-            const u32 p = next_base + atomicAdd(&A.fcount[level + 1], 1u);
-            A.order[p] = d1; A.posof[d1] = p;
+        if (d1 != C2A_NONE) {
+            const uint4 gd = A.ginfo[d1];
+            if (push_cand(A, d1, gd, pos, 1)) {
+                const u32 p = next_base + atomicAdd(&A.fcount[level + 1], 1u);
+                A.order[p] = d1; A.frec[p] = gd; A.posof[d1] = p;
+            }
         }
     }
 }
@@ -293,8 +307,6 @@ __global__ void __launch_bounds__(kThreads) k_peel_level(PeelArgs A, u32 level) 
 // DFS root are dropped by a wave-wide min, and the survivors play a one-round all-pairs tournament (one path
 // comparison per lane, <= 11 candidates = 55 pairs per round) — so the latency per level is about ONE path
 // comparison whatever the fan-out.  Ancestor rows are written 16 lanes wide (one 64-byte line per plane).
-constexpr int kPeelWaveThreads = 1024;
-constexpr int kWavesPerBlock = kPeelWaveThreads / 64;     // 16 gates per workgroup pass
 constexpr int kGroup = 11;                                // 11*10/2 = 55 pairs <= 64 lanes
 
 __device__ __forceinline__ u32 wave_min_u32(u32 v) {
@@ -330,15 +342,19 @@ constexpr u32 kProfLevel0 = 256, kProfLevels = 32, kProfWaves = 32768;
 #define C2A_PROF(slot)                                                                                          \
     do {                                                                                                        \
         if (A.prof && lane == 0 && level >= kProfLevel0 && level < kProfLevel0 + kProfLevels) {                 \
-            const u32 wg_ = blockIdx.x * kWavesPerBlock + wv;                                                   \
+            const u32 wg_ = blockIdx.x * WPB + wv;                                                              \
             if (wg_ < kProfWaves) A.prof[((u64)(level - kProfLevel0) * kProfWaves + wg_) * 8 + (slot)] = c2a_now() - t_begin; \
         }                                                                                                       \
     } while (0)
 
-__global__ void __launch_bounds__(kPeelWaveThreads) k_peel_level_wave(PeelArgs A, u32 level) {
+// WPB = waves (= gates per pass) per workgroup: 16 -> fewest appends on the frontier counter, 4/8 -> shorter
+// wait for the slowest wave of the group
+template <int WPB>
+__global__ void __launch_bounds__(WPB * 64) k_peel_level_wave(PeelArgs A, u32 level) {
     const ull t_begin = A.prof ? c2a_now() : 0;
-    __shared__ u32 s_c[kWavesPerBlock][72], s_l[kWavesPerBlock][72], s_d[kWavesPerBlock][72];
-    __shared__ u32 s_ready[2 * kWavesPerBlock];
+    __shared__ u32 s_c[WPB][72], s_l[WPB][72], s_d[WPB][72];
+    __shared__ u32 s_ready[2 * WPB];
+    __shared__ uint4 s_rec[2 * WPB];
     __shared__ u32 s_base;
     const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const u32 lo = A.fbase[level];
@@ -350,23 +366,27 @@ __global__ void __launch_bounds__(kPeelWaveThreads) k_peel_level_wave(PeelArgs A
     }
     const u64 plane = (u64)A.n * 16;
     const u64 lt_mask = (1ull << lane) - 1ull;
-    for (u32 chunk = blockIdx.x; (u64)chunk * kWavesPerBlock < cnt; chunk += gridDim.x) {
-        const u32 i = chunk * kWavesPerBlock + wv;
-        u32 r0 = C2A_NONE, r1 = C2A_NONE;               // producers released by this wave's gate (lane 0 / lane 1)
+    for (u32 chunk = blockIdx.x; (u64)chunk * WPB < cnt; chunk += gridDim.x) {
+        const u32 i = chunk * WPB + wv;
+        u32 rdy = C2A_NONE;                              // producer completed by this wave's gate (lanes 0 / 1)
+        uint4 rdy_rec = make_uint4(0, 0, 0, 0);
         if (i < cnt) {
             const u32 pos = lo + i;
             const u32 g = A.order[pos];
-            const u32 d0 = A.dep0[g], d1 = A.dep1[g];
-            const u32 e0 = A.cons_off[g], e1 = e0 + A.cons_cnt[g];
+            const uint4 gi = A.frec[pos];
+            const u32 e0 = gi.z, e1 = e0 + gi.w;
+            // lanes 0/1 own the two producers: fetch their records and bump their fill counters now — the
+            // round trips hide under the tournament; the results are only needed at the end
+            const u32 dl = lane == 0 ? gi.x : (lane == 1 ? gi.y : C2A_NONE);
+            uint4 gd = make_uint4(0, 0, 0, 0);
+            u32 kfill = 0;
+            if (dl != C2A_NONE) { gd = A.ginfo[dl]; kfill = atomicAdd(&A.fill[dl], 1u); }
             C2A_PROF(0);
-            if (A.prof && lane == 0 && level >= kProfLevel0 && level < kProfLevel0 + kProfLevels && blockIdx.x * kWavesPerBlock + wv < kProfWaves)
+            if (A.prof && lane == 0 && level >= kProfLevel0 && level < kProfLevel0 + kProfLevels && blockIdx.x * WPB + wv < kProfWaves)
             {
-                A.prof[((u64)(level - kProfLevel0) * kProfWaves + blockIdx.x * kWavesPerBlock + wv) * 8 + 7] = e1 - e0 + 1000;
-                A.prof[((u64)(level - kProfLevel0) * kProfWaves + blockIdx.x * kWavesPerBlock + wv) * 8 + 6] = t_begin;
+                A.prof[((u64)(level - kProfLevel0) * kProfWaves + blockIdx.x * WPB + wv) * 8 + 7] = e1 - e0 + 1000;
+                A.prof[((u64)(level - kProfLevel0) * kProfWaves + blockIdx.x * WPB + wv) * 8 + 6] = t_begin;
             }
-            // the pushes only need `pos`: issue them first so their round trips hide under the tournament
-            if (lane == 0 && d0 != C2A_NONE && push_cand(A, d0, pos, 0)) r0 = d0;
-            if (lane == 1 && d1 != C2A_NONE && push_cand(A, d1, pos, 1)) r1 = d1;
             // champion so far (wave-uniform); NONE = the virtual-root candidate [g]
             u32 ch = C2A_NONE, ch_label = 0, ch_root = g, ch_depth = 0;
             for (u32 eb = e0; eb < e1; eb += 64) {
@@ -442,23 +462,26 @@ __global__ void __launch_bounds__(kPeelWaveThreads) k_peel_level_wave(PeelArgs A
                     need <<= 4;
                 }
             }
+            if (dl != C2A_NONE) {
+                A.cand[gd.z + kfill] = (pos << 1) | lane;             // lane == label
+                if (kfill + 1 == gd.w) { rdy = dl; rdy_rec = gd; }
+            }
             C2A_PROF(3);
         }
         // ---- one append per workgroup: a single counter takes ~12 ns per atomic, so per-gate appends would
         // cost more than the whole level (MI355X_MICROARCH.md price list, row "fanin")
-        if (lane == 0) s_ready[2 * wv] = r0;
-        if (lane == 1) s_ready[2 * wv + 1] = r1;
+        if (lane < 2) { s_ready[2 * wv + lane] = rdy; s_rec[2 * wv + lane] = rdy_rec; }
         __syncthreads();
         C2A_PROF(4);
         if (wv == 0) {
-            const u32 d = lane < 2 * kWavesPerBlock ? s_ready[lane] : C2A_NONE;
+            const u32 d = lane < 2 * WPB ? s_ready[lane] : C2A_NONE;
             const u64 mask = __ballot(d != C2A_NONE);
             if (mask) {
                 if (lane == 0) s_base = atomicAdd(&A.fcount[level + 1], (u32)__popcll(mask));
                 wave_lds_sync();
                 if (d != C2A_NONE) {
                     const u32 p = next_base + s_base + (u32)__popcll(mask & lt_mask);
-                    A.order[p] = d; A.posof[d] = p;
+                    A.order[p] = d; A.frec[p] = s_rec[lane]; A.posof[d] = p;
                 }
             }
         }

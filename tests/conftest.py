@@ -57,13 +57,52 @@ def emul_lib():
 BACKENDS = [pytest.param("emul", id="emul"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
 
 
+class _Env:
+    """Temporarily set the library's tuning knobs (read once in c2a_create)."""
+
+    def __init__(self, **kv):
+        self.kv = {k: str(v) for k, v in kv.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 @pytest.fixture(params=BACKENDS)
 def backend(request, c2a):
+    """Emulated build: the per-level kernel is forced to its one-lane-per-gate variant (the wave-per-gate
+    variant costs ~1000 fibers per workgroup under emulation; it has its own tests through `backend_wave`).
+    Real GPU: library defaults (wave-per-gate on narrow frontiers)."""
     if request.param == "emul":
-        be = c2a.Backend(0, lib_path=request.getfixturevalue("emul_lib"))
+        with _Env(C2A_PEEL_WAVE_MAX=0):
+            be = c2a.Backend(0, lib_path=request.getfixturevalue("emul_lib"))
     else:
         be = c2a.Backend(0)
         assert "hip" in be.version
+    yield be
+    be.close()
+
+
+WAVE_BACKENDS = [pytest.param(("emul", 4), id="emul-wpb4")] + [
+    pytest.param(("hip", w), id=f"hip-wpb{w}", marks=pytest.mark.gpu) for w in (4, 8, 16)] + [
+    pytest.param(("hip", 0), id="hip-lane-per-gate", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(params=WAVE_BACKENDS)
+def backend_wave(request, c2a):
+    """Every level (however wide) through the wave-per-gate kernel, at each workgroup shape; plus, on the GPU,
+    every level through the lane-per-gate kernel."""
+    kind, wpb = request.param
+    env = _Env(C2A_PEEL_WAVE_MAX=0) if wpb == 0 else _Env(C2A_PEEL_WAVE_MAX=1 << 30, C2A_PEEL_WPB=wpb)
+    with env:
+        be = c2a.Backend(0, lib_path=request.getfixturevalue("emul_lib")) if kind == "emul" else c2a.Backend(0)
     yield be
     be.close()
 

@@ -139,3 +139,41 @@ def test_deep_chain_exercises_upper_ancestor_planes(backend, orc):
              input_nodes=np.array([1, 2], np.uint32), output_nodes=np.array([10 + depth - 1], np.uint32))
     assert _compare(backend, orc, p, check_serial=False) == "ok"
     assert backend.stats()["max_depth"] >= 4096
+
+
+def test_wave_per_gate_kernel_small_graphs(backend_wave, orc):
+    """k_peel_level_wave (all-pairs tournament, workgroup-aggregated appends) on adversarial small graphs."""
+    rng = np.random.default_rng(4242)
+    seen = {"ok": 0, "cyclic": 0, "inconsistent": 0, "cyclic-and-inconsistent": 0}
+    for trial in range(40):
+        n = int(rng.integers(1, 48))
+        p = random_gate_graph(rng, n, p_dup_out=0.1 if trial % 3 == 0 else 0.0, p_same=0.15,
+                              p_cycle=0.08 if trial % 4 == 0 else 0.0)
+        seen[_compare(backend_wave, orc, p, check_serial=False)] += 1
+    assert seen["ok"] >= 8, seen
+
+
+def test_wave_per_gate_kernel_high_fanout(backend_wave, orc):
+    """One producer read by 150 consumers spread over several DFS roots: chunks of 64 candidates, groups of 11,
+    champion carried across chunks."""
+    rng = np.random.default_rng(77)
+    n_cons = 150
+    chain = 40
+    n = 1 + n_cons + chain
+    perm = rng.permutation(n)
+    lh = np.empty(n, np.uint32); rh = np.empty(n, np.uint32); out = np.empty(n, np.uint32)
+    hub = perm[0]
+    lh[hub], rh[hub], out[hub] = 1, 2, 10                        # the hub gate: node 10
+    for k in range(n_cons):                                       # consumers of the hub, some via lh some via rh
+        g = perm[1 + k]
+        other = 10 + 1 + int(rng.integers(0, k)) if k and rng.random() < 0.7 else 1
+        lh[g], rh[g] = (10, other) if rng.random() < 0.5 else (other, 10)
+        out[g] = 11 + k
+    for k in range(chain):                                        # a chain on top so consumers sit at many depths
+        g = perm[1 + n_cons + k]
+        lh[g] = 11 + int(rng.integers(0, n_cons)) if k == 0 else 11 + n_cons + k - 1
+        rh[g] = 11 + int(rng.integers(0, n_cons))
+        out[g] = 11 + n_cons + k
+    p = dict(lh=lh, rh=rh, out=out, op=rng.integers(0, 20, n).astype(np.uint8), n_nodes=11 + n + 2,
+             input_nodes=np.array([1, 2], np.uint32), output_nodes=np.array([11 + n_cons + chain - 1], np.uint32))
+    assert _compare(backend_wave, orc, p, check_serial=False) == "ok"
