@@ -40,7 +40,7 @@ struct c2a_ctx {
     Stage stage = ST_EMPTY;
     int n_cu = 256;
     u32 peel_wave_max = 8192;      // frontier size up to which a level gets one wave per gate
-    u32 peel_wpb = 16;             // gates (waves) per workgroup in wave mode: 4, 8 or 16
+    u32 peel_wpb = 8;              // gates (waves) per workgroup in wave mode: 4, 8 or 16 (8 measured best)
 
     // problem
     u32 n = 0, n_nodes = 0, n_in = 0, n_out = 0;
