@@ -753,6 +753,26 @@ __device__ __forceinline__ u32 bool_wire(u32 W, u32 bit, u32 width, u32 M, u64 o
     return W < M ? W * width + bit : (u32)(out_base + (u64)(W - M) * width + bit);
 }
 
+__device__ __forceinline__ void bool_gate(const BoolArgs& A, const u64* s_aoff, const u32* s_in0, const u32* s_in1,
+                                          const u32* s_out, const u32* s_top, u32 idx, u32 k, u32& o0, u32& o1, u32& o2,
+                                          u32& oop) {
+    const uint4 e = A.tmpl[s_top[idx] + k];
+    const u32 refs[3] = {e.x, e.y, e.z};
+    u32 w3[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const u32 kind = refs[r] >> 30, id = refs[r] & 0x3FFFFFFFu;
+        u32 v;
+        if (kind == 3) v = (u32)(A.aux_base + s_aoff[idx] + id);
+        else v = bool_wire(kind == 0 ? s_in0[idx] : (kind == 1 ? s_in1[idx] : s_out[idx]), id, A.width, A.M, A.out_base);
+        w3[r] = v;
+    }
+    o0 = w3[0]; o1 = w3[1]; o2 = w3[2]; oop = e.w;
+}
+
+// One workgroup per kBoolChunk arithmetic gates.  Every lane produces FOUR consecutive boolean gates and stores
+// them as one 16-byte vector per SoA stream (4-byte-per-lane stores are issue-bound on gfx950, not
+// bandwidth-bound); the <= 3 unaligned gates at each end of the workgroup's range go out as scalars.
 __global__ void __launch_bounds__(kThreads) k_boolify(BoolArgs A, const BoolTables* __restrict__ T) {
     __shared__ u64 s_goff[kBoolChunk + 1];
     __shared__ u64 s_aoff[kBoolChunk];
@@ -769,29 +789,45 @@ __global__ void __launch_bounds__(kThreads) k_boolify(BoolArgs A, const BoolTabl
     }
     __syncthreads();
     const u64 q0 = s_goff[0], q1 = s_goff[cnt];
-    for (u64 q = q0 + threadIdx.x; q < q1; q += blockDim.x) {
-        // largest i with s_goff[i] <= q
-        u32 lo = 0, hi = cnt;
+    u64 a0 = (q0 + 3) & ~3ull;
+    if (a0 > q1) a0 = q1;
+    u64 a1 = q1 & ~3ull;
+    if (a1 < a0) a1 = a0;
+    // ---- aligned body: groups of 4
+    for (u64 q = a0 + 4ull * threadIdx.x; q < a1; q += 4ull * blockDim.x) {
+        u32 lo = 0, hi = cnt;                        // largest i with s_goff[i] <= q
         while (hi - lo > 1) {
             const u32 mid = (lo + hi) >> 1;
             if (s_goff[mid] <= q) lo = mid; else hi = mid;
         }
-        const u32 k = (u32)(q - s_goff[lo]);
-        const uint4 e = A.tmpl[s_top[lo] + k];
-        const u32 refs[3] = {e.x, e.y, e.z};
-        u32 w3[3];
+        u32 v0[4], v1[4], v2[4], vop = 0;
+        u32 idx = lo;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const u32 kind = refs[r] >> 30, idx = refs[r] & 0x3FFFFFFFu;
-            u32 v;
-            if (kind == 3) v = (u32)(A.aux_base + s_aoff[lo] + idx);
-            else v = bool_wire(kind == 0 ? s_in0[lo] : (kind == 1 ? s_in1[lo] : s_out[lo]), idx, A.width, A.M, A.out_base);
-            w3[r] = v;
+        for (int j = 0; j < 4; ++j) {
+            while (q + j >= s_goff[idx + 1]) ++idx;
+            u32 oop;
+            bool_gate(A, s_aoff, s_in0, s_in1, s_out, s_top, idx, (u32)(q + j - s_goff[idx]), v0[j], v1[j], v2[j], oop);
+            vop |= (oop & 0xFFu) << (8 * j);
         }
-        A.b_in0[q] = w3[0];
-        A.b_in1[q] = w3[1];
-        A.b_out[q] = w3[2];
-        A.b_op[q] = (u8)e.w;
+        *reinterpret_cast<uint4*>(A.b_in0 + q) = make_uint4(v0[0], v0[1], v0[2], v0[3]);
+        *reinterpret_cast<uint4*>(A.b_in1 + q) = make_uint4(v1[0], v1[1], v1[2], v1[3]);
+        *reinterpret_cast<uint4*>(A.b_out + q) = make_uint4(v2[0], v2[1], v2[2], v2[3]);
+        *reinterpret_cast<u32*>(A.b_op + q) = vop;
+    }
+    // ---- unaligned head [q0,a0) and tail [a1,q1): at most 3 + 3 gates
+    {
+        const u32 nh = (u32)(a0 - q0), nt = (u32)(q1 - a1);
+        if (threadIdx.x < nh + nt) {
+            const u64 q = threadIdx.x < nh ? q0 + threadIdx.x : a1 + (threadIdx.x - nh);
+            u32 lo = 0, hi = cnt;
+            while (hi - lo > 1) {
+                const u32 mid = (lo + hi) >> 1;
+                if (s_goff[mid] <= q) lo = mid; else hi = mid;
+            }
+            u32 o0, o1, o2, oop;
+            bool_gate(A, s_aoff, s_in0, s_in1, s_out, s_top, lo, (u32)(q - s_goff[lo]), o0, o1, o2, oop);
+            A.b_in0[q] = o0; A.b_in1[q] = o1; A.b_out[q] = o2; A.b_op[q] = (u8)oop;
+        }
     }
 }
 
