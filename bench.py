@@ -33,6 +33,36 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
+def timed_region(warm_step, step, steps, warmup, dist=None, torch=None, device=None):
+    """W untimed warm-up steps, then EXACTLY `steps` timed steps bracketed by barrier + device sync on both sides;
+    returns the MAX over ranks of the elapsed seconds.  (Every c2a call ends with a hipStreamSynchronize, so the
+    host clock brackets device work.)  dist/torch are None for a single process."""
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+            if device == "cuda":
+                torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        warm_step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device or "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def whole_job_rate(world, units_per_rank, steps, elapsed_max):
+    """value = units processed by ALL ranks / max-over-ranks time (weak scaling: one graph per rank)."""
+    return world * units_per_rank * steps / elapsed_max
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,27 +107,16 @@ def main():
         be.build_circuit()
         return be.boolify(args.width)
 
-    def sync_all():
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    t_start = time.perf_counter()
     stage_acc = {}
-    info = None
-    for _ in range(args.steps):
-        info = step()
+    last = {}
+
+    def timed_step():
+        last["info"] = step()
         for k, v in be.timings().items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
-    sync_all()
-    elapsed = time.perf_counter() - t_start
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    elapsed = timed_region(step, timed_step, args.steps, args.warmup, dist, torch, "cuda" if dist is not None else None)
+    info = last.get("info")
 
     if rank != 0:
         if dist is not None:
@@ -109,7 +128,7 @@ def main():
     steps = max(1, args.steps)
     stages = {k: v / steps for k, v in stage_acc.items()}
     ms_per_step = elapsed * 1e3 / steps
-    value = world * n * steps / elapsed
+    value = whole_job_rate(world, n, steps, elapsed)
     algo_bytes = 13.0 * n + 13.0 * info.n_gates                  # per k_boolify launch
     bool_ms = stages.get("bool_map", 0.0)
     achieved = algo_bytes / (bool_ms * 1e-3) / 1e9 if bool_ms > 0 else 0.0
@@ -137,11 +156,16 @@ def main():
                          f"structure-faithful build_circuit (hash maps, per-visit Vec) {t1 - t0:.2f}s + bit-blast of {ng} "
                          f"boolean gates {t2 - t1:.2f}s; flat-array build_circuit variant {tf1 - tf0:.2f}s",
                "host_cores_available": os.cpu_count()}
-        if args.check:
-            exp = orc.build_circuit(fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes, mode=1)
-            backend_mod = importlib.import_module("circom-2-arithc_amd.backend")
-            assert be.checksum("sorted") == backend_mod.checksum_host(exp.sorted), "sorted mismatch vs oracle"
-            assert be.checksum("out") == backend_mod.checksum_host(exp.out), "wire numbering mismatch vs oracle"
+
+    checked = None
+    if args.check:
+        # full-size parity of the build_circuit outputs against the oracle, by position-salted checksums
+        from oracle import oracle as orc
+        backend_mod = importlib.import_module("circom-2-arithc_amd.backend")
+        exp = orc.build_circuit(fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes, mode=1)
+        for name, arr in (("sorted", exp.sorted), ("in0", exp.in0), ("in1", exp.in1), ("out", exp.out), ("op", exp.op)):
+            assert be.checksum(name) == backend_mod.checksum_host(arr), f"{name} differs from the oracle"
+        checked = "sorted/in0/in1/out/op checksums == oracle at full size"
 
     line = {
         "metric": "gates/sec (topo-sort + boolify), 10M-gate DAG",
@@ -161,6 +185,7 @@ def main():
         "whole_job_algorithmic_GBps": (30.0 * n + algo_bytes) / (ms_per_step * 1e-3) / 1e9,
         "setup_s": {"generate": gen_s, "h2d_and_alloc": h2d_s},
         "stats": stats,
+        "checked": checked,
     }
     print(json.dumps(line))
     if dist is not None:

@@ -576,30 +576,39 @@ int orc_template_size(int op, uint32_t w, uint64_t* n_gates, uint64_t* n_aux) {
  *     W >= M : M*w + aux_total + (W-M)*w + b            (outputs last)
  *   aux wires of the gate at sorted position p: M*w + auxoff[p] + k
  */
-int orc_boolify(const orc_circuit* c, uint32_t w, orc_bool** result) {
+/* gates of the arithmetic gates at sorted positions [first, first+count) only, with the GLOBAL wire/aux
+ * numbering of the whole circuit (for slice-wise parity checks at sizes where the full boolean circuit would
+ * not fit in host memory).  *gate_first = global index of the first boolean gate of the slice. */
+int orc_boolify_range(const orc_circuit* c, uint32_t w, uint64_t first, uint64_t count, orc_bool** result,
+                      uint64_t* gate_first) {
     *result = NULL;
-    if (w == 0 || w > 64) return ORC_ARG;
+    if (w == 0 || w > 64 || first > c->n || count > c->n - first) return ORC_ARG;
     uint64_t tg[A_NUM_OPS], ta[A_NUM_OPS];
     for (int op = 0; op < A_NUM_OPS; ++op) { int rc = orc_template_size(op, w, &tg[op], &ta[op]); if (rc) return rc; }
-    uint64_t G = 0, AUX = 0;
-    for (uint64_t p = 0; p < c->n; ++p) { G += tg[c->op[p]]; AUX += ta[c->op[p]]; }
+    uint64_t G = 0, AUX = 0, g_first = 0, a_first = 0, g_slice = 0;
+    for (uint64_t p = 0; p < c->n; ++p) {
+        if (p == first) { g_first = G; a_first = AUX; }
+        if (p >= first && p < first + count) g_slice += tg[c->op[p]];
+        G += tg[c->op[p]]; AUX += ta[c->op[p]];
+    }
+    if (first == c->n) { g_first = G; a_first = AUX; }
     uint64_t M = (uint64_t)c->wire_count - c->n_out;
     uint64_t total_wires = (uint64_t)c->wire_count * w + AUX;
     if (total_wires >= 0xFFFFFFFFull) return ORC_OVERFLOW;
     orc_bool* b = (orc_bool*)calloc(1, sizeof(orc_bool));
     if (!b) return ORC_NOMEM;
-    uint64_t ga = G ? G : 1;
+    uint64_t ga = g_slice ? g_slice : 1;
     b->in0 = (uint32_t*)malloc(ga * 4); b->in1 = (uint32_t*)malloc(ga * 4); b->out = (uint32_t*)malloc(ga * 4);
     b->op = (uint8_t*)malloc(ga);
     uint32_t m = w + 2;
     uint32_t* buf = (uint32_t*)malloc((size_t)m * 4 * 10);
     if (!b->in0 || !b->in1 || !b->out || !b->op || !buf) { free(buf); orc_free_bool(b); return ORC_NOMEM; }
-    b->n_gates = G; b->wire_count = total_wires; b->width = w; b->n_in = c->n_in; b->n_out = c->n_out;
+    b->n_gates = g_slice; b->wire_count = total_wires; b->width = w; b->n_in = c->n_in; b->n_out = c->n_out;
     uint32_t *A = buf, *B = buf + m, *O = buf + 2 * m;
     emitter e = {b->in0, b->in1, b->out, b->op, 0, M * w, 0, 0};
     uint64_t out_base = M * w + AUX;
-    uint64_t auxoff = 0;
-    for (uint64_t p = 0; p < c->n; ++p) {
+    uint64_t auxoff = a_first;
+    for (uint64_t p = first; p < first + count; ++p) {
         uint32_t wa = c->in0[p], wb = c->in1[p], wo = c->out[p];
         for (uint32_t i = 0; i < w; ++i) {
             A[i] = (uint32_t)(wa < M ? (uint64_t)wa * w + i : out_base + ((uint64_t)wa - M) * w + i);
@@ -611,9 +620,14 @@ int orc_boolify(const orc_circuit* c, uint32_t w, orc_bool** result) {
         auxoff += ta[c->op[p]];
     }
     free(buf);
-    if (e.overflow || e.k != G) { orc_free_bool(b); return ORC_OVERFLOW; }
+    if (e.overflow || e.k != g_slice) { orc_free_bool(b); return ORC_OVERFLOW; }
     *result = b;
+    if (gate_first) *gate_first = g_first;
     return ORC_OK;
+}
+
+int orc_boolify(const orc_circuit* c, uint32_t w, orc_bool** result) {
+    return orc_boolify_range(c, w, 0, c->n, result, NULL);
 }
 
 /* boolean wire of (arithmetic wire W, bit b) under the layout above */

@@ -350,6 +350,9 @@ def lib():
         L.orc_boolify.restype = ctypes.c_int
         L.orc_boolify.argtypes = [ctypes.POINTER(_OrcCircuit), ctypes.c_uint32,
                                   ctypes.POINTER(ctypes.POINTER(_OrcBool))]
+        L.orc_boolify_range.restype = ctypes.c_int
+        L.orc_boolify_range.argtypes = [ctypes.POINTER(_OrcCircuit), ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64,
+                                        ctypes.POINTER(ctypes.POINTER(_OrcBool)), u64p]
         L.orc_free_bool.argtypes = [ctypes.POINTER(_OrcBool)]
         L.orc_free_bool.restype = None
         L.orc_template_size.restype = ctypes.c_int
@@ -476,6 +479,41 @@ def boolify_handle(handle, width: int, copy: bool = True):
         lib().orc_free_bool(res)
         return bc
     return bc, res
+
+
+def _as_handle(circ: ArithCircuit):
+    c = _OrcCircuit()
+    keep = [_c(circ.sorted, np.uint32), _c(circ.in0, np.uint32), _c(circ.in1, np.uint32), _c(circ.out, np.uint32),
+            _c(circ.op, np.uint8), _c(circ.node_wire, np.uint32)]
+    c.n = len(keep[1])
+    c.n_nodes = len(keep[5])
+    c.n_in, c.n_out, c.wire_count = circ.n_in, circ.n_out, circ.wire_count
+    c.sorted, c.in0, c.in1, c.out = (_p(keep[0], ctypes.c_uint32), _p(keep[1], ctypes.c_uint32),
+                                     _p(keep[2], ctypes.c_uint32), _p(keep[3], ctypes.c_uint32))
+    c.op, c.node_wire = _p(keep[4], ctypes.c_uint8), _p(keep[5], ctypes.c_uint32)
+    return c, keep
+
+
+def boolify_range(circ: ArithCircuit, width: int, first: int, count: int):
+    """Boolean gates of the arithmetic gates at sorted positions [first, first+count) with the global numbering;
+    returns (BoolCircuit slice, global index of its first boolean gate)."""
+    c, keep = _as_handle(circ)
+    res = ctypes.POINTER(_OrcBool)()
+    g0 = ctypes.c_uint64(0)
+    rc = lib().orc_boolify_range(ctypes.pointer(c), width, first, count, ctypes.byref(res), ctypes.byref(g0))
+    if rc:
+        raise RuntimeError(f"oracle error {rc}")
+    b = res.contents
+    g = int(b.n_gates)
+
+    def arr(ptr, dt):
+        return np.ctypeslib.as_array(ptr, shape=(g,)).astype(dt, copy=True) if g else np.empty(0, dtype=dt)
+
+    bc = BoolCircuit(in0=arr(b.in0, np.uint32), in1=arr(b.in1, np.uint32), out=arr(b.out, np.uint32),
+                     op=arr(b.op, np.uint8), wire_count=int(b.wire_count), width=width, n_in=int(b.n_in),
+                     n_out=int(b.n_out))
+    lib().orc_free_bool(res)
+    return bc, g0.value
 
 
 def boolify(circ: ArithCircuit, width: int) -> BoolCircuit:
