@@ -133,6 +133,16 @@ def main():
     bool_ms = stages.get("bool_map", 0.0)
     achieved = algo_bytes / (bool_ms * 1e-3) / 1e9 if bool_ms > 0 else 0.0
     stats = be.stats()
+    # HBM bytes of the dominant kernel from the PMC passes committed under profiles/ (bench.py cannot run
+    # rocprofv3 on itself): only quoted when the workload is the one those passes measured
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_bytes.json")) as f:
+            pmc = json.load(f)
+        if pmc["workload"] == {"n_gates": n, "width": args.width}:
+            traffic = pmc["kernels"]["c2a::k_boolify"]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
 
     cpu = None
     if args.cpu_sample_layers > 0:
@@ -178,7 +188,8 @@ def main():
                    "levels": stats["levels"], "dfs_tree_depth": stats["max_depth"],
                    "parallelism": "1 graph per GPU (replicated pipeline, no collective)" if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "kernel": "k_boolify", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": "profiles/r01_pmc_hbm_bytes.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None,
                      "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": bool_ms},
         "cpu_baseline": cpu,
         "stages_ms": stages,
