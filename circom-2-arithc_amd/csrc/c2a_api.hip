@@ -53,7 +53,7 @@ struct c2a_ctx {
 
     // device buffers
     DevBuf lh, rh, out, op, in_nodes, out_nodes;
-    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, fill, cand, order, posof, meta, anc, fbase, fcount, ginfo, frec;
+    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, fill, cand, meta, anc, fcount, fbase, order, posof, ginfo, slots0, slots1;
     DevBuf rflag, ridx, rlist, next, owner, local, slist, snext, ssum, jnxt, jval, sorted;
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op;
     DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof;
@@ -62,7 +62,7 @@ struct c2a_ctx {
 
     c2a_ctx() {
         all = {&lh, &rh, &out, &op, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &fill, &cand,
-               &order, &posof, &ginfo, &frec, &meta, &anc, &fbase, &fcount, &rflag, &ridx, &rlist, &next,
+               &ginfo, &slots0, &slots1, &meta, &anc, &fcount, &fbase, &order, &posof, &rflag, &ridx, &rlist, &next,
                &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
                &node_wire, &e_in0, &e_in1, &e_out, &e_op, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &tsz, &asz, &goff,
                &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op};
@@ -72,7 +72,7 @@ struct c2a_ctx {
 namespace {
 
 // scalars block layout (u32 words unless noted)
-enum Scalar { SC_MAXDEPTH = 0, SC_SCOUNT = 1, SC_ERR = 2, SC_NMID = 3, SC_NROOTS = 4, SC_LEVELS = 5, SC_DFS = 8 /*3 words*/,
+enum Scalar { SC_MAXDEPTH = 0, SC_SCOUNT = 1, SC_ERR = 2, SC_NMID = 3, SC_NROOTS = 4, SC_LEVELS = 5, SC_PEELED = 6 /*2 words*/, SC_DFS = 8 /*3 words*/,
               SC_TOTAL64 = 16 /* u64 slots from here: 16..31 */, SC_WORDS = 64 };
 
 int fail(c2a_ctx* c, int code, const std::string& msg) {
@@ -186,8 +186,8 @@ int do_prep(c2a_ctx* c) {
     if (r) return r;
     C2A_LAUNCH_NOSYNC(k_ginfo, G, kThreads, s, n, c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_off.as<u32>(),
                       c->cons_cnt.as<u32>(), c->ginfo.as<uint4>());
-    C2A_LAUNCH(k_init_frontier, G, kThreads, s, n, (const uint4*)c->ginfo.as<uint4>(), c->order.as<u32>(),
-               c->frec.as<uint4>(), c->posof.as<u32>(), c->fcount.as<u32>());
+    C2A_LAUNCH(k_init_frontier, G, kThreads, s, n, (const uint4*)c->ginfo.as<uint4>(), c->slots0.as<FrontierSlot>(),
+               c->fcount.as<u32>());
     return C2A_OK;
 }
 
@@ -197,17 +197,18 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
     const u32 n = c->n;
     hipStream_t s = c->stream;
     PeelArgs A;
-    A.n = n; A.ginfo = c->ginfo.as<uint4>(); A.frec = c->frec.as<uint4>();
-    A.cand = c->cand.as<u32>(); A.fill = c->fill.as<u32>();
-    A.order = c->order.as<u32>(); A.posof = c->posof.as<u32>(); A.meta = c->meta.as<uint4>(); A.anc = c->anc.as<u32>();
-    A.fbase = c->fbase.as<u32>(); A.fcount = c->fcount.as<u32>();
-    A.levels = c->scalars.as<u32>() + SC_LEVELS;
-    A.prof = nullptr;
+    A.n = n; A.ginfo = c->ginfo.as<uint4>();
+    A.slots[0] = c->slots0.as<FrontierSlot>(); A.slots[1] = c->slots1.as<FrontierSlot>();
+    A.cand = c->cand.as<uint4>(); A.fill = c->fill.as<u32>();
+    A.meta = c->meta.as<uint4>(); A.anc = c->anc.as<u32>(); A.fcount = c->fcount.as<u32>(); A.fbase = c->fbase.as<u32>();
+    A.order = c->order.as<u32>(); A.posof = c->posof.as<u32>();
+    A.prof = nullptr; A.prof_level0 = 256;
     const bool profiling = std::getenv("C2A_PEEL_PROFILE") != nullptr;
     if (profiling) {
         ENSURE(c->peel_prof, (size_t)kProfLevels * kProfWaves * 8 * sizeof(ull));
         HIP_TRY(hipMemsetAsync(c->peel_prof.p, 0, (size_t)kProfLevels * kProfWaves * 8 * sizeof(ull), s));
         A.prof = c->peel_prof.as<ull>();
+        A.prof_level0 = (u32)std::strtoul(std::getenv("C2A_PEEL_PROFILE"), nullptr, 10);
     }
 
     u32 level = 0, launches = 0;
@@ -244,16 +245,22 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
         u32 tail[9] = {0};
         const u32 look = std::min<u32>(8u, level);
         HIP_TRY(hipMemcpyAsync(tail, c->fcount.as<u32>() + (level - look), (look + 1) * 4, hipMemcpyDeviceToHost, s));
-        u32 base_next = 0;
-        HIP_TRY(hipMemcpyAsync(&base_next, c->fbase.as<u32>() + level, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         const u32 next_cnt = tail[look];
-        peeled = base_next + next_cnt;
         if (next_cnt == 0 || level > n) break;
         u32 mx = next_cnt;
         for (u32 k = 0; k <= look; ++k) mx = std::max(mx, tail[k]);
         est = mx;
         batch = std::min<u32>(batch * 2, 512u);
+    }
+    {
+        u32* tot = c->scalars.as<u32>() + SC_PEELED;
+        C2A_LAUNCH(k_peel_totals, 1, kThreads, s, (const u32*)c->fcount.as<u32>(), level + 1, tot);
+        u32 t2[2] = {0, 0};
+        int r = read_scalars(c, t2, SC_PEELED, 2);
+        if (r) return r;
+        peeled = t2[0];
+        c->stats.levels = t2[1];
     }
     c->stats.level_launches = launches;
     if (profiling) {   // diagnostics: mean over levels of the slowest wave's phase timestamps (ns since kernel entry)
@@ -275,7 +282,7 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
             if (!act) continue;
             const ull* r = &hp[((size_t)L * kProfWaves + slow) * 8];
             std::fprintf(stderr, "[c2a peel profile] level %u: %u gate-waves (last wave id with a record %u); mean ns loaded=%.0f cand=%.0f tourn=%.0f rows=%.0f sync=%.0f end=%.0f | "
-                         "max end=%llu start-skew=%llu first-start->last-finish=%llu | slowest wave %u: %llu %llu %llu %llu %llu %llu cands=%llu\n", L + kProfLevel0, act, last_active,
+                         "max end=%llu start-skew=%llu first-start->last-finish=%llu | slowest wave %u: %llu %llu %llu %llu %llu %llu cands=%llu\n", L + A.prof_level0, act, last_active,
                          mean[0] / act, mean[1] / act, mean[2] / act, mean[3] / act, mean[4] / act, mean[5] / act, (unsigned long long)mx[5], (unsigned long long)(tmax - tmin) * 10, (unsigned long long)(fin - tmin) * 10, slow,
                          (unsigned long long)r[0] * 10, (unsigned long long)r[1] * 10, (unsigned long long)r[2] * 10, (unsigned long long)r[3] * 10,
                          (unsigned long long)r[4] * 10, (unsigned long long)r[5] * 10, (unsigned long long)(r[7] - 1000));
@@ -300,7 +307,7 @@ int do_order(c2a_ctx* c) {
     HIP_TRY(hipStreamSynchronize(s));
     c->stats.n_roots = n_roots;
     C2A_LAUNCH_NOSYNC(k_euler_next, G, kThreads, s, n, c->meta.as<uint4>(), c->order.as<u32>(), c->posof.as<u32>(),
-                      c->dep0.as<u32>(), c->dep1.as<u32>(), c->ridx.as<u32>(), c->rlist.as<u32>(), n_roots,
+                      (const uint4*)c->ginfo.as<uint4>(), c->ridx.as<u32>(), c->rlist.as<u32>(), n_roots,
                       c->next.as<u32>());
     const u32 m = 2 * n;
     u32* scount = c->scalars.as<u32>() + SC_SCOUNT;
@@ -364,12 +371,10 @@ int do_topo_sort(c2a_ctx* c, u64* cycle_at) {
     if (r) return r;
     rec(c, EV_PEEL1);
     {
-        u32 edges = 0, lv = 0;
+        u32 edges = 0;
         HIP_TRY(hipMemcpyAsync(&edges, c->cons_off.as<u32>() + n, 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(&lv, c->scalars.as<u32>() + SC_LEVELS, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->stats.n_edges = edges;
-        c->stats.levels = lv;
     }
     if (peeled != n) {
         // leftover gates sit on or above a dependency cycle: replay the reference's DFS for its message
@@ -532,11 +537,12 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     ENSURE(c->lh, n4); ENSURE(c->rh, n4); ENSURE(c->out, n4); ENSURE(c->op, n);
     ENSURE(c->in_nodes, (size_t)n_in * 4); ENSURE(c->out_nodes, (size_t)n_out * 4);
     ENSURE(c->prod1, nn4); ENSURE(c->dep0, n4); ENSURE(c->dep1, n4); ENSURE(c->cons_cnt, n4);
-    ENSURE(c->cons_off, n4 + 4); ENSURE(c->fill, n4); ENSURE(c->cand, 2 * n4);
-    ENSURE(c->order, n4); ENSURE(c->posof, n4); ENSURE(c->meta, (size_t)n * 16);
-    ENSURE(c->ginfo, (size_t)n * 16); ENSURE(c->frec, (size_t)n * 16);
+    ENSURE(c->cons_off, n4 + 4); ENSURE(c->fill, n4); ENSURE(c->cand, (size_t)n * 2 * 16);
+    ENSURE(c->meta, (size_t)n * 16); ENSURE(c->ginfo, (size_t)n * 16);
+    ENSURE(c->slots0, ((size_t)n + 1) * sizeof(FrontierSlot)); ENSURE(c->slots1, ((size_t)n + 1) * sizeof(FrontierSlot));
+
     ENSURE(c->anc, (size_t)c->planes * n * 64);
-    ENSURE(c->fbase, n4 + 8); ENSURE(c->fcount, n4 + 8);
+    ENSURE(c->fcount, n4 + 8); ENSURE(c->fbase, n4 + 8); ENSURE(c->order, n4); ENSURE(c->posof, n4);
     ENSURE(c->rflag, n4); ENSURE(c->ridx, n4 + 4); ENSURE(c->rlist, n4);
     ENSURE(c->next, 2 * n4); ENSURE(c->owner, 2 * n4); ENSURE(c->local, 2 * n4); ENSURE(c->slist, 2 * n4);
     ENSURE(c->snext, 2 * n4); ENSURE(c->ssum, 2 * n4); ENSURE(c->jnxt, 2 * n4); ENSURE(c->jval, 2 * n4);

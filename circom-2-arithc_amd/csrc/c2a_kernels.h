@@ -124,57 +124,71 @@ __global__ void k_ginfo(u32 n, const u32* __restrict__ dep0, const u32* __restri
     for (u64 g = gtid(); g < n; g += gstride()) ginfo[g] = make_uint4(dep0[g], dep1[g], cons_off[g], cons_cnt[g]);
 }
 
+// Frontier slot: 32 bytes {gate, dep0, dep1, cons_off} {cons_cnt, -, -, -}.  Two slot arrays alternate by level
+// parity and slot i of level L is at a fixed address, so a level's first hop (the slot) does not wait for the
+// frontier size: fcount[L] is loaded alongside it.
+struct FrontierSlot { uint4 a, b; };
+
 // level 0 of the reverse Kahn peel: gates nobody consumes.  fcount[0] must be zero.
-// frec[p] carries the gate's static record next to order[p], so a level starts with ONE contiguous read.
-__global__ void __launch_bounds__(kThreads) k_init_frontier(u32 n, const uint4* __restrict__ ginfo, u32* order,
-                                                            uint4* frec, u32* posof, u32* fcount) {
+__global__ void __launch_bounds__(kThreads) k_init_frontier(u32 n, const uint4* __restrict__ ginfo, FrontierSlot* slots,
+                                                            u32* fcount) {
     for (u64 base = (u64)blockIdx.x * kThreads; base < n; base += (u64)gridDim.x * kThreads) {
         const u64 g = base + threadIdx.x;
         uint4 gi = make_uint4(0, 0, 0, 1);
         if (g < n) gi = ginfo[g];
         const bool sink = g < n && gi.w == 0;
         const u32 p = block_append_slot(sink, &fcount[0]);
-        if (sink) { order[p] = (u32)g; frec[p] = gi; posof[g] = p; }
+        if (sink) { slots[p].a = make_uint4((u32)g, gi.x, gi.y, gi.z); slots[p].b = make_uint4(gi.w, 0, 0, 0); }
     }
+}
+
+// totals after the peel: {gates peeled, non-empty levels}
+__global__ void k_peel_totals(const u32* __restrict__ fcount, u32 n_levels, u32* out2) {
+    __shared__ u32 s_sum[kThreads], s_lv[kThreads];
+    u32 sum = 0, lv = 0;
+    for (u32 i = threadIdx.x; i < n_levels; i += kThreads) { const u32 c = fcount[i]; sum += c; lv += c ? 1u : 0u; }
+    s_sum[threadIdx.x] = sum; s_lv[threadIdx.x] = lv;
+    __syncthreads();
+    for (u32 off = kThreads / 2; off; off >>= 1) {
+        if (threadIdx.x < off) { s_sum[threadIdx.x] += s_sum[threadIdx.x + off]; s_lv[threadIdx.x] += s_lv[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out2[0] = s_sum[0]; out2[1] = s_lv[0]; }
 }
 
 // ------------------------------------------------------------------------------------------------
 // peel one level + pick DFS-tree parents
 // ------------------------------------------------------------------------------------------------
-// tree node == peel position (index into order[]): nodes of recent levels are contiguous, so the hops of a
-// path comparison that stay near the frontier stay in cache.  meta[pos] = {parent pos | NONE, depth, root
-// gate id, label}.  anc plane j, row pos: 16 ancestors at distances (d+1)*16^j, valid while <= depth.
-// Candidate lists are filled as consumers are peeled: cand[cons_off[d] + k] = (consumer pos << 1) | label;
-// the gate whose push completes d's list (k + 1 == cons_cnt[d]) appends d to the next frontier.
+// Tree node == peel position (fbase[level] + slot index): nodes of recent levels are contiguous, which keeps
+// the short hops of a path comparison inside a few MB (at 10 M gates the tables span GBs and a scattered hop
+// costs ~2x a local one).  meta[pos] = {parent pos | NONE, depth, root gate id, label of the edge parent->node}.
+// anc plane j, row pos: 16 entries = ancestor at distance (d+1)*16^j, valid while <= depth, each entry
+// carrying that ancestor's own edge label in bit 31 (so a path comparison never has to fetch meta[]).
+// Candidate lists are filled as consumers are peeled, AFTER their tournament, with everything a comparison
+// starts from: cand[cons_off[d] + k] = {consumer | edge label << 31, consumer depth, consumer root, consumer's
+// own edge label}; the push that completes d's list (k + 1 == cons_cnt[d]) writes d's frontier slot.
+// Dependent memory hops on a level's critical path: slot -> candidate records -> <= 3 (lift) + <= 3 (diverge)
+// ancestor rows -> max(<= 3 row copies, fill atomic + slot atomic).
+constexpr u32 kIdMask = 0x7FFFFFFFu;
+
 struct PeelArgs {
     u32 n;
-    const uint4* ginfo;   // [n] {dep0, dep1, cons_off, cons_cnt}
-    uint4* frec;          // [n] ginfo of order[p]
-    u32* cand;
-    u32* fill;       // pushes so far per gate (zeroed)
-    u32* order;      // peel order (frontier lists back to back)
-    u32* posof;      // gate -> peel position
-    uint4* meta;
-    u32* anc;        // [planes][n][16]
-    u32* fbase;      // [levels+2]
-    u32* fcount;     // [levels+2]
-    u32* levels;     // number of non-empty levels (stat)
-    ull* prof;       // optional [levels][64 sampled waves][8] phase timestamps (diagnostics; nullptr normally)
+    const uint4* ginfo;        // [n] {dep0, dep1, cons_off, cons_cnt}
+    FrontierSlot* slots[2];    // by level parity
+    uint4* cand;               // [edges]
+    u32* fill;                 // pushes so far per gate (zeroed)
+    uint4* meta;               // [n] by position
+    u32* anc;                  // [planes][n][16] by position
+    u32* order;                // position -> gate
+    u32* posof;                // gate -> position
+    u32* fbase;                // [levels+2] first position of each level
+    u32* fcount;               // [levels+2] frontier sizes (slot allocation + host monitoring)
+    ull* prof;                 // optional phase timestamps (diagnostics; nullptr normally)
+    u32 prof_level0;           // first level recorded
 };
 
 __device__ __forceinline__ u32 anc_entry(const u32* anc, u64 plane, int j, u32 x, u32 d) {
     return anc[(u64)j * plane + (u64)x * 16 + d];
-}
-
-__device__ __forceinline__ u32 level_anc(const u32* anc, u64 plane, u32 x, u32 dist) {
-    int j = 0;
-    while (dist) {
-        const u32 d = dist & 15u;
-        if (d) x = anc_entry(anc, plane, j, x, d - 1);
-        dist >>= 4;
-        ++j;
-    }
-    return x;
 }
 
 __device__ __forceinline__ void load_row(const u32* anc, u64 plane, int j, u32 x, u32 (&r)[16]) {
@@ -186,9 +200,27 @@ __device__ __forceinline__ void load_row(const u32* anc, u64 plane, int j, u32 x
     }
 }
 
-// a != b at equal depth D >= 1 under one root: walk both up to the children of their lowest common
-// ancestor (one 64-byte row per node per base-16 digit).
-__device__ __forceinline__ void diverge(const u32* anc, u64 plane, u32& a, u32& b, u32 D) {
+// Two lifts of the same node in one pass (their loads are independent and overlap): xe = ancestor at `dist`,
+// ye = ancestor at `dist - 1`, both as labelled entries.  dist >= 1; `self` = the node's own labelled entry.
+__device__ __forceinline__ void lift2(const u32* anc, u64 plane, u32 self, u32 dist, u32& xe, u32& ye) {
+    u32 x = self, y = self;
+    u32 dx = dist, dy = dist - 1;
+    int j = 0;
+    while (dx | dy) {
+        const u32 ex = dx & 15u, ey = dy & 15u;
+        u32 nx = x, ny = y;
+        if (ex) nx = anc_entry(anc, plane, j, x & kIdMask, ex - 1);
+        if (ey) ny = anc_entry(anc, plane, j, y & kIdMask, ey - 1);
+        x = nx; y = ny;
+        dx >>= 4; dy >>= 4;
+        ++j;
+    }
+    xe = x; ye = y;
+}
+
+// ae != be (ids) at equal depth D >= 1 under one root: walk both up to the children of their lowest common
+// ancestor, one 64-byte row per node per base-16 digit; entries keep their label bits.
+__device__ __forceinline__ void diverge(const u32* anc, u64 plane, u32& ae, u32& be, u32 D) {
     if (D == 0) return;
     int j = (31 - __clz(D)) >> 2;
     for (; j >= 0; --j) {
@@ -196,84 +228,78 @@ __device__ __forceinline__ void diverge(const u32* anc, u64 plane, u32& a, u32& 
         if (m == 0) continue;
         if (m > 16) m = 16;
         u32 ra[16], rb[16];
-        load_row(anc, plane, j, a, ra);
-        load_row(anc, plane, j, b, rb);
-        u32 pa = a, pb = b, pd = 0;
+        load_row(anc, plane, j, ae & kIdMask, ra);
+        load_row(anc, plane, j, be & kIdMask, rb);
+        u32 pa = ae, pb = be, pd = 0;
 #pragma unroll
         for (u32 d = 0; d < 16; ++d) {
-            if (d < m && ra[d] != rb[d]) { pa = ra[d]; pb = rb[d]; pd = d + 1; }
+            if (d < m && ((ra[d] ^ rb[d]) & kIdMask)) { pa = ra[d]; pb = rb[d]; pd = d + 1; }
         }
-        a = pa; b = pb;
+        ae = pa; be = pb;
         D -= pd << (4 * j);
     }
 }
 
-// is P(a).la < P(b).lb ?  a != b, same root; da/db = depths.
-__device__ __forceinline__ bool path_less(const u32* anc, u64 plane, const uint4* meta, u32 a, u32 la, u32 da, u32 b,
-                                          u32 lb, u32 db) {
+// A candidate = "the path to consumer c, then edge `el`".  ce = c | own edge label of c << 31.
+// is P(a).ela < P(b).elb ?  ids differ, same root.
+__device__ __forceinline__ bool path_less(const u32* anc, u64 plane, u32 ae, u32 ela, u32 da, u32 be, u32 elb, u32 db) {
     if (da > db) {
-        const u32 a1 = level_anc(anc, plane, a, da - db - 1);
-        const uint4 m1 = meta[a1];
-        if (m1.x == b) return m1.w < lb;   // b is an ancestor of a
-        a = m1.x;
-        diverge(anc, plane, a, b, db);
+        u32 up, below;
+        lift2(anc, plane, ae, da - db, up, below);
+        if (((up ^ be) & kIdMask) == 0) return (below >> 31) < elb;      // b is an ancestor of a
+        ae = up;
+        diverge(anc, plane, ae, be, db);
     } else if (db > da) {
-        const u32 b1 = level_anc(anc, plane, b, db - da - 1);
-        const uint4 m1 = meta[b1];
-        if (m1.x == a) return la < m1.w;   // a is an ancestor of b
-        b = m1.x;
-        diverge(anc, plane, a, b, da);
+        u32 up, below;
+        lift2(anc, plane, be, db - da, up, below);
+        if (((up ^ ae) & kIdMask) == 0) return ela < (below >> 31);      // a is an ancestor of b
+        be = up;
+        diverge(anc, plane, ae, be, da);
     } else {
-        diverge(anc, plane, a, b, da);
+        diverge(anc, plane, ae, be, da);
     }
-    return meta[a].w < meta[b].w;
-}
-
-// gate at position p pushes itself into producer d's candidate list (gd = ginfo[d]); true when that completes it
-__device__ __forceinline__ bool push_cand(const PeelArgs& A, u32 d, const uint4& gd, u32 p, u32 label) {
-    const u32 k = atomicAdd(&A.fill[d], 1u);
-    A.cand[gd.z + k] = (p << 1) | label;
-    return k + 1 == gd.w;
+    return (ae >> 31) < (be >> 31);
 }
 
 // Variant 1: one lane per frontier gate, candidates compared one after the other.  Used while the frontier
 // is wide (the first levels); its latency per level is (largest fan-out) x (one path comparison).
 __global__ void __launch_bounds__(kThreads) k_peel_level(PeelArgs A, u32 level) {
-    const u32 lo = A.fbase[level];
-    const u32 cnt = A.fcount[level];
-    const u32 next_base = lo + cnt;
-    if (gtid() == 0) {
-        A.fbase[level + 1] = next_base;
-        if (cnt) atomicMax(A.levels, level + 1);
-    }
+    FrontierSlot* cur = A.slots[level & 1u];
+    FrontierSlot* nxt = A.slots[(level + 1) & 1u];
     const u64 plane = (u64)A.n * 16;
-    for (u64 i = gtid(); i < cnt; i += gstride()) {
+    const u32 n_front = A.fcount[level];
+    const u32 lo = A.fbase[level];
+    if (gtid() == 0) A.fbase[level + 1] = lo + n_front;
+    for (u64 i = gtid(); i < n_front; i += gstride()) {
+        const uint4 sa = cur[i].a;
+        const u32 cnt = cur[i].b.x;
+        const u32 g = sa.x;
         const u32 pos = lo + (u32)i;
-        const u32 g = A.order[pos];
-        const uint4 gi = A.frec[pos];
         // ---- tournament over the candidate paths: [g] (child of the virtual root) and P(c).l per consumer
-        u32 best = C2A_NONE, best_label = 0, best_root = g, best_depth = 0;
-        const u32 e0 = gi.z, e1 = e0 + gi.w;
+        u32 best = C2A_NONE, best_el = 0, best_root = g, best_depth = 0;     // best = labelled entry of the consumer
+        const u32 e0 = sa.w, e1 = e0 + cnt;
         for (u32 e = e0; e < e1; ++e) {
-            const u32 ce = A.cand[e];
-            const u32 pc = ce >> 1, l = ce & 1u;
-            const uint4 mc = A.meta[pc];
+            const uint4 cr = A.cand[e];
+            const u32 ce = (cr.x & kIdMask) | (cr.w << 31), el = cr.x >> 31;
             bool take;
-            if (best == C2A_NONE) take = mc.z < g;
-            else if (mc.z != best_root) take = mc.z < best_root;
-            else if (pc == best) take = l < best_label;
-            else take = path_less(A.anc, plane, A.meta, pc, l, mc.y, best, best_label, best_depth);
-            if (take) { best = pc; best_label = l; best_root = mc.z; best_depth = mc.y; }
+            if (best == C2A_NONE) take = cr.z < g;
+            else if (cr.z != best_root) take = cr.z < best_root;
+            else if (((ce ^ best) & kIdMask) == 0) take = el < best_el;
+            else take = path_less(A.anc, plane, ce, el, cr.y, best, best_el, best_depth);
+            if (take) { best = ce; best_el = el; best_root = cr.z; best_depth = cr.y; }
         }
         const u32 depth = best == C2A_NONE ? 0u : best_depth + 1;
-        A.meta[pos] = make_uint4(best, depth, best_root, best == C2A_NONE ? 0u : best_label);
+        const u32 my_label = best == C2A_NONE ? 0u : best_el;
+        A.meta[pos] = make_uint4(best == C2A_NONE ? C2A_NONE : (best & kIdMask), depth, best_root, my_label);
+        A.order[pos] = g;
+        A.posof[g] = pos;
         // ---- ancestor rows: row j = [q_j, row_j(q_j)[0..14]], q_0 = parent, q_{j+1} = my ancestor at 16^(j+1)
         if (depth) {
-            u32 q = best;
-            u32 need = 1;   // 16^j
+            u32 q = best;                                   // labelled entry
+            u32 need = 1;                                   // 16^j
             for (int j = 0; need <= depth; ++j) {
                 u32 r[16];
-                load_row(A.anc, plane, j, q, r);
+                load_row(A.anc, plane, j, q & kIdMask, r);
                 uint4* dst = reinterpret_cast<uint4*>(A.anc + (u64)j * plane + (u64)pos * 16);
                 dst[0] = make_uint4(q, r[0], r[1], r[2]);
                 dst[1] = make_uint4(r[3], r[4], r[5], r[6]);
@@ -285,28 +311,28 @@ __global__ void __launch_bounds__(kThreads) k_peel_level(PeelArgs A, u32 level) 
             }
         }
         // ---- tell the producers; a producer joins the next frontier when its last consumer has been peeled
-        const u32 d0 = gi.x, d1 = gi.y;
-        if (d0 != C2A_NONE) {
-            const uint4 gd = A.ginfo[d0];
-            if (push_cand(A, d0, gd, pos, 0)) {
-                const u32 p = next_base + atomicAdd(&A.fcount[level + 1], 1u);
-                A.order[p] = d0; A.frec[p] = gd; A.posof[d0] = p;
-            }
-        }
-        if (d1 != C2A_NONE) {
-            const uint4 gd = A.ginfo[d1];
-            if (push_cand(A, d1, gd, pos, 1)) {
-                const u32 p = next_base + atomicAdd(&A.fcount[level + 1], 1u);
-                A.order[p] = d1; A.frec[p] = gd; A.posof[d1] = p;
+        const u32 deps[2] = {sa.y, sa.z};
+#pragma unroll
+        for (u32 l = 0; l < 2; ++l) {
+            const u32 d = deps[l];
+            if (d == C2A_NONE) continue;
+            const uint4 gd = A.ginfo[d];
+            const u32 k = atomicAdd(&A.fill[d], 1u);
+            A.cand[gd.z + k] = make_uint4(pos | (l << 31), depth, best_root, my_label);
+            if (k + 1 == gd.w) {
+                const u32 p = atomicAdd(&A.fcount[level + 1], 1u);
+                nxt[p].b = make_uint4(gd.w, 0, 0, 0);
+                nxt[p].a = make_uint4(d, gd.x, gd.y, gd.z);
             }
         }
     }
 }
 
-// Variant 2: one WAVE per frontier gate.  Lanes load the consumers in parallel, candidates with a larger
-// DFS root are dropped by a wave-wide min, and the survivors play a one-round all-pairs tournament (one path
-// comparison per lane, <= 11 candidates = 55 pairs per round) — so the latency per level is about ONE path
-// comparison whatever the fan-out.  Ancestor rows are written 16 lanes wide (one 64-byte line per plane).
+// Variant 2: one WAVE per frontier gate.  Lanes load the candidate records in parallel, candidates with a
+// larger DFS root are dropped by a wave-wide min, and the survivors play a one-round all-pairs tournament (one
+// path comparison per lane, <= 11 candidates = 55 pairs per round) — so the latency per level is about ONE path
+// comparison whatever the fan-out.  Ancestor rows are copied 16 lanes wide (one 64-byte line per plane) while
+// the producers' fill atomics and the workgroup's single frontier append are in flight.
 constexpr int kGroup = 11;                                // 11*10/2 = 55 pairs <= 64 lanes
 
 __device__ __forceinline__ u32 wave_min_u32(u32 v) {
@@ -337,13 +363,13 @@ __device__ __forceinline__ ull c2a_now() {
     return wall_clock64();      // constant 100 MHz
 #endif
 }
-// diagnostics: every wave of levels [256, 288) stores its phase timestamps (slot 7 = candidates of its gate)
-constexpr u32 kProfLevel0 = 256, kProfLevels = 32, kProfWaves = 32768;
-#define C2A_PROF(slot)                                                                                          \
+// diagnostics: every wave of levels [256, 288) stores its phase timestamps (slot 6 = start, 7 = candidates)
+constexpr u32 kProfLevels = 32, kProfWaves = 32768;
+#define C2A_PROF(slot, value)                                                                                   \
     do {                                                                                                        \
-        if (A.prof && lane == 0 && level >= kProfLevel0 && level < kProfLevel0 + kProfLevels) {                 \
+        if (A.prof && lane == 0 && level >= A.prof_level0 && level < A.prof_level0 + kProfLevels) {             \
             const u32 wg_ = blockIdx.x * WPB + wv;                                                              \
-            if (wg_ < kProfWaves) A.prof[((u64)(level - kProfLevel0) * kProfWaves + wg_) * 8 + (slot)] = c2a_now() - t_begin; \
+            if (wg_ < kProfWaves) A.prof[((u64)(level - A.prof_level0) * kProfWaves + wg_) * 8 + (slot)] = (value); \
         }                                                                                                       \
     } while (0)
 
@@ -357,50 +383,50 @@ __global__ void __launch_bounds__(WPB * 64) k_peel_level_wave(PeelArgs A, u32 le
     __shared__ uint4 s_rec[2 * WPB];
     __shared__ u32 s_base;
     const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const u32 lo = A.fbase[level];
-    const u32 cnt = A.fcount[level];
-    const u32 next_base = lo + cnt;
-    if (gtid() == 0) {
-        A.fbase[level + 1] = next_base;
-        if (cnt) atomicMax(A.levels, level + 1);
-    }
+    FrontierSlot* cur = A.slots[level & 1u];
+    FrontierSlot* nxt = A.slots[(level + 1) & 1u];
     const u64 plane = (u64)A.n * 16;
     const u64 lt_mask = (1ull << lane) - 1ull;
-    for (u32 chunk = blockIdx.x; (u64)chunk * WPB < cnt; chunk += gridDim.x) {
-        const u32 i = chunk * WPB + wv;
+    // slot i sits at a fixed address: issue its load before the frontier size is known
+    uint4 sa0 = make_uint4(0, 0, 0, 0);
+    u32 cnt0 = 0;
+    {
+        const u64 i0 = (u64)blockIdx.x * WPB + wv;
+        if (i0 < A.n) { sa0 = cur[i0].a; cnt0 = cur[i0].b.x; }
+    }
+    const u32 n_front = A.fcount[level];
+    const u32 lo = A.fbase[level];                       // only needed after the tournament
+    if (gtid() == 0) A.fbase[level + 1] = lo + n_front;
+    for (u32 chunk = blockIdx.x; (u64)chunk * WPB < n_front; chunk += gridDim.x) {
+        const u64 i = (u64)chunk * WPB + wv;
         u32 rdy = C2A_NONE;                              // producer completed by this wave's gate (lanes 0 / 1)
         uint4 rdy_rec = make_uint4(0, 0, 0, 0);
-        if (i < cnt) {
-            const u32 pos = lo + i;
-            const u32 g = A.order[pos];
-            const uint4 gi = A.frec[pos];
-            const u32 e0 = gi.z, e1 = e0 + gi.w;
-            // lanes 0/1 own the two producers: fetch their records and bump their fill counters now — the
-            // round trips hide under the tournament; the results are only needed at the end
-            const u32 dl = lane == 0 ? gi.x : (lane == 1 ? gi.y : C2A_NONE);
+        uint4 sa = sa0;
+        u32 cnt = cnt0;
+        if (chunk != blockIdx.x && i < n_front) { sa = cur[i].a; cnt = cur[i].b.x; }
+        if (i < n_front) {
+            const u32 g = sa.x;
+            const u32 e0 = sa.w, e1 = e0 + cnt;
+            // lanes 0/1 own the two producers: fetch their records now, off the critical path
+            const u32 dl = lane == 0 ? sa.y : (lane == 1 ? sa.z : C2A_NONE);
             uint4 gd = make_uint4(0, 0, 0, 0);
-            u32 kfill = 0;
-            if (dl != C2A_NONE) { gd = A.ginfo[dl]; kfill = atomicAdd(&A.fill[dl], 1u); }
-            C2A_PROF(0);
-            if (A.prof && lane == 0 && level >= kProfLevel0 && level < kProfLevel0 + kProfLevels && blockIdx.x * WPB + wv < kProfWaves)
-            {
-                A.prof[((u64)(level - kProfLevel0) * kProfWaves + blockIdx.x * WPB + wv) * 8 + 7] = e1 - e0 + 1000;
-                A.prof[((u64)(level - kProfLevel0) * kProfWaves + blockIdx.x * WPB + wv) * 8 + 6] = t_begin;
-            }
-            // champion so far (wave-uniform); NONE = the virtual-root candidate [g]
-            u32 ch = C2A_NONE, ch_label = 0, ch_root = g, ch_depth = 0;
+            if (dl != C2A_NONE) gd = A.ginfo[dl];
+            C2A_PROF(0, c2a_now() - t_begin);
+            C2A_PROF(6, t_begin);
+            C2A_PROF(7, (ull)cnt + 1000);
+            // champion so far (wave-uniform): labelled consumer entry; NONE = the virtual-root candidate [g]
+            u32 ch = C2A_NONE, ch_el = 0, ch_root = g, ch_depth = 0;
             for (u32 eb = e0; eb < e1; eb += 64) {
                 const u32 e = eb + lane;
                 const bool valid = e < e1;
                 u32 c = 0, l = 0, cdepth = 0, croot = 0xFFFFFFFFu;
                 if (valid) {
-                    const u32 ce = A.cand[e];
-                    c = ce >> 1; l = ce & 1u;
-                    const uint4 mc = A.meta[c];
-                    cdepth = mc.y; croot = mc.z;
+                    const uint4 cr = A.cand[e];
+                    c = (cr.x & kIdMask) | (cr.w << 31); l = cr.x >> 31;
+                    cdepth = cr.y; croot = cr.z;
                 }
                 const u32 rmin = wave_min_u32(croot);
-                C2A_PROF(1);
+                C2A_PROF(1, c2a_now() - t_begin);
                 if (rmin > ch_root) continue;                       // the whole chunk starts from a later DFS root
                 const bool keep_ch = (ch != C2A_NONE) && (ch_root == rmin);
                 const bool surv = valid && croot == rmin;
@@ -410,7 +436,7 @@ __global__ void __launch_bounds__(WPB * 64) k_peel_level_wave(PeelArgs A, u32 le
                     const u32 k = (u32)__popcll(smask & lt_mask);
                     s_c[wv][k] = c; s_l[wv][k] = l; s_d[wv][k] = cdepth;
                 }
-                if (keep_ch && lane == 0) { s_c[wv][m] = ch; s_l[wv][m] = ch_label; s_d[wv][m] = ch_depth; }
+                if (keep_ch && lane == 0) { s_c[wv][m] = ch; s_l[wv][m] = ch_el; s_d[wv][m] = ch_depth; }
                 m += keep_ch ? 1u : 0u;
                 wave_lds_sync();
                 // all-pairs rounds over groups of <= kGroup candidates: [winner so far] + next candidates
@@ -432,8 +458,8 @@ __global__ void __launch_bounds__(WPB * 64) k_peel_level_wave(PeelArgs A, u32 le
                         const u32 ci = s_c[wv][xi], cj = s_c[wv][xj];
                         const u32 li = s_l[wv][xi], lj = s_l[wv][xj];
                         bool less;
-                        if (ci == cj) less = li < lj;
-                        else less = path_less(A.anc, plane, A.meta, ci, li, s_d[wv][xi], cj, lj, s_d[wv][xj]);
+                        if (((ci ^ cj) & kIdMask) == 0) less = li < lj;
+                        else less = path_less(A.anc, plane, ci, li, s_d[wv][xi], cj, lj, s_d[wv][xj]);
                         loser = less ? pj : pi;
                     }
                     u32 w = 0;
@@ -444,18 +470,27 @@ __global__ void __launch_bounds__(WPB * 64) k_peel_level_wave(PeelArgs A, u32 le
                     win = w == 0 ? win : next + w - 1;
                     next += take;
                 }
-                ch = s_c[wv][win]; ch_label = s_l[wv][win]; ch_depth = s_d[wv][win]; ch_root = rmin;
+                ch = s_c[wv][win]; ch_el = s_l[wv][win]; ch_depth = s_d[wv][win]; ch_root = rmin;
                 wave_lds_sync();
             }
-            C2A_PROF(2);
+            C2A_PROF(2, c2a_now() - t_begin);
             const u32 depth = ch == C2A_NONE ? 0u : ch_depth + 1;
-            if (lane == 0) A.meta[pos] = make_uint4(ch, depth, ch_root, ch == C2A_NONE ? 0u : ch_label);
+            const u32 my_label = ch == C2A_NONE ? 0u : ch_el;
+            const u32 pos = lo + (u32)i;
+            if (lane == 0) {
+                A.meta[pos] = make_uint4(ch == C2A_NONE ? C2A_NONE : (ch & kIdMask), depth, ch_root, my_label);
+                A.order[pos] = g;
+                A.posof[g] = pos;
+            }
+            // push myself to the producers (lanes 0/1): the atomic's round trip overlaps the row copies below
+            u32 kfill = 0;
+            if (dl != C2A_NONE) kfill = atomicAdd(&A.fill[dl], 1u);
             if (depth) {
-                u32 q = ch;
+                u32 q = ch;                                 // labelled entry
                 u32 need = 1;
                 for (int j = 0; need <= depth; ++j) {
                     u32 v = q;
-                    if (lane >= 1 && lane < 16) v = anc_entry(A.anc, plane, j, q, lane - 1);
+                    if (lane >= 1 && lane < 16) v = anc_entry(A.anc, plane, j, q & kIdMask, lane - 1);
                     if (lane < 16) A.anc[(u64)j * plane + (u64)pos * 16 + lane] = v;
                     q = __shfl(v, 15, 64);
                     if (need > (0xFFFFFFFFu >> 4)) break;
@@ -463,16 +498,16 @@ __global__ void __launch_bounds__(WPB * 64) k_peel_level_wave(PeelArgs A, u32 le
                 }
             }
             if (dl != C2A_NONE) {
-                A.cand[gd.z + kfill] = (pos << 1) | lane;             // lane == label
+                A.cand[gd.z + kfill] = make_uint4(pos | (lane << 31), depth, ch_root, my_label);   // lane == edge label
                 if (kfill + 1 == gd.w) { rdy = dl; rdy_rec = gd; }
             }
-            C2A_PROF(3);
+            C2A_PROF(3, c2a_now() - t_begin);
         }
         // ---- one append per workgroup: a single counter takes ~12 ns per atomic, so per-gate appends would
         // cost more than the whole level (MI355X_MICROARCH.md price list, row "fanin")
         if (lane < 2) { s_ready[2 * wv + lane] = rdy; s_rec[2 * wv + lane] = rdy_rec; }
         __syncthreads();
-        C2A_PROF(4);
+        C2A_PROF(4, c2a_now() - t_begin);
         if (wv == 0) {
             const u32 d = lane < 2 * WPB ? s_ready[lane] : C2A_NONE;
             const u64 mask = __ballot(d != C2A_NONE);
@@ -480,13 +515,15 @@ __global__ void __launch_bounds__(WPB * 64) k_peel_level_wave(PeelArgs A, u32 le
                 if (lane == 0) s_base = atomicAdd(&A.fcount[level + 1], (u32)__popcll(mask));
                 wave_lds_sync();
                 if (d != C2A_NONE) {
-                    const u32 p = next_base + s_base + (u32)__popcll(mask & lt_mask);
-                    A.order[p] = d; A.frec[p] = s_rec[lane]; A.posof[d] = p;
+                    const u32 p = s_base + (u32)__popcll(mask & lt_mask);
+                    const uint4 gd = s_rec[lane];
+                    nxt[p].b = make_uint4(gd.w, 0, 0, 0);
+                    nxt[p].a = make_uint4(d, gd.x, gd.y, gd.z);
                 }
             }
         }
         __syncthreads();
-        C2A_PROF(5);
+        C2A_PROF(5, c2a_now() - t_begin);
     }
 }
 
@@ -529,12 +566,13 @@ __device__ __forceinline__ u32 tree_child(const uint4* meta, const u32* posof, u
 
 // element 2x = enter(x), 2x+1 = exit(x); the tour visits label-0 child, label-1 child, then exits.
 __global__ void k_euler_next(u32 n, const uint4* __restrict__ meta, const u32* __restrict__ order,
-                             const u32* __restrict__ posof, const u32* __restrict__ dep0, const u32* __restrict__ dep1,
+                             const u32* __restrict__ posof, const uint4* __restrict__ ginfo,
                              const u32* __restrict__ ridx, const u32* __restrict__ rlist, u32 n_roots, u32* next) {
     for (u64 i = gtid(); i < n; i += gstride()) {
         const u32 x = (u32)i;
         const u32 g = order[x];
-        const u32 c0 = tree_child(meta, posof, x, dep0[g], 0), c1 = tree_child(meta, posof, x, dep1[g], 1);
+        const uint4 gi = ginfo[g];
+        const u32 c0 = tree_child(meta, posof, x, gi.x, 0), c1 = tree_child(meta, posof, x, gi.y, 1);
         next[2 * i] = c0 != C2A_NONE ? 2 * c0 : (c1 != C2A_NONE ? 2 * c1 : 2 * x + 1);
         const uint4 m = meta[x];
         u32 nx;
@@ -542,7 +580,7 @@ __global__ void k_euler_next(u32 n, const uint4* __restrict__ meta, const u32* _
             const u32 k = ridx[g];
             nx = k + 1 < n_roots ? 2 * rlist[k + 1] : C2A_NONE;
         } else {
-            const u32 s1 = m.w == 0 ? tree_child(meta, posof, m.x, dep1[order[m.x]], 1) : C2A_NONE;
+            const u32 s1 = m.w == 0 ? tree_child(meta, posof, m.x, ginfo[order[m.x]].y, 1) : C2A_NONE;
             nx = s1 != C2A_NONE ? 2 * s1 : 2 * m.x + 1;
         }
         next[2 * i + 1] = nx;
