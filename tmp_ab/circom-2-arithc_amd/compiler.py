@@ -1,0 +1,227 @@
+"""Host mirror of the reference's `Compiler` (src/compiler.rs:107-115) for the flat-gate-graph path.
+
+Same method names, argument meaning and errors as the reference, so code written against
+`circom_2_arithc::compiler::Compiler` reads the same here:
+
+    add_signal / add_gate / add_connection / add_inputs / add_outputs / get_signals   (src/compiler.rs:130-278)
+    build_circuit() -> BristolCircuit                                                  (src/compiler.rs:321-494)
+    boolify(circuit, width) -> BristolCircuit                                          (src/main.rs:30-32)
+
+What differs is where the work happens.  The gate-graph builder keeps a signal->node index and a
+node-forwarding table instead of the reference's O(nodes)+O(gates) scans per call
+(src/compiler.rs:185-195, :219-226, :260-270); `build_circuit` does the string work on the host
+(src/compiler.rs:323-383) and ships the flat gate SoA through the C ABI (include/c2a.h) where the
+topological sort, wire numbering, gate emission and bit-blast run as HIP kernels on the MI355X.
+There is no CPU implementation of those steps in this package.
+
+Canonical ordering: the reference iterates std HashMaps for the input / output wire order
+(src/compiler.rs:392-395, :446-449) — not deterministic run to run.  Here inputs and outputs are ordered
+by ascending signal id of the named IO signal.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from .backend import (BOOL_OP_NAMES, NO_WIRE, OP, OP_NAMES, Backend, CircuitError, CyclicDependency,  # noqa: F401
+                      Inconsistency)
+from .bristol import BristolCircuit, CircuitInfo, ConstantInfo
+
+
+class CannotMergeOutputNodes(CircuitError):        # compiler.rs:554-555
+    def __init__(self):
+        super().__init__("Cannot merge output nodes")
+
+
+class CannotMergeConstantNodes(CircuitError):      # compiler.rs:552-553
+    def __init__(self):
+        super().__init__("Cannot merge constant nodes")
+
+
+class SignalAlreadyDeclared(CircuitError):         # compiler.rs:564-565
+    def __init__(self):
+        super().__init__("Signal already declared")
+
+
+@dataclass
+class _Node:
+    is_const: bool
+    is_out: bool
+    signals: List[int]
+
+
+class Compiler:
+    def __init__(self, backend: Optional[Backend] = None, device: int = 0):
+        self._backend = backend
+        self._device = device
+        self.node_count = 0
+        self.inputs: Dict[int, str] = {}
+        self.outputs: Dict[int, str] = {}
+        self.signals: Dict[int, Tuple[str, Optional[int]]] = {}
+        self.nodes: Dict[int, _Node] = {}
+        self._sig_node: Dict[int, int] = {}
+        self._fwd: Dict[int, int] = {}              # merged node id -> the node that replaced it
+        self._g_op: List[int] = []
+        self._g_lh: List[int] = []
+        self._g_rh: List[int] = []
+        self._g_out: List[int] = []
+
+    # -- reference API ---------------------------------------------------------------------------
+    def add_inputs(self, inputs: Dict[int, str]) -> None:           # compiler.rs:130-132
+        self.inputs.update(inputs)
+
+    def add_outputs(self, outputs: Dict[int, str]) -> None:         # compiler.rs:134-136
+        self.outputs.update(outputs)
+
+    def _get_node_id(self) -> int:                                  # compiler.rs:497-500
+        self.node_count += 1
+        return self.node_count
+
+    def add_signal(self, id: int, name: str, value: Optional[int] = None) -> None:   # compiler.rs:139-161
+        if id in self.signals:
+            raise SignalAlreadyDeclared()
+        self.signals[id] = (name, value)
+        nid = self._get_node_id()
+        self.nodes[nid] = _Node(value is not None, False, [id])
+        self._sig_node[id] = nid
+
+    def get_signals(self, filter: str) -> Dict[int, str]:           # compiler.rs:163-171
+        return {sid: nm for sid, (nm, _) in self.signals.items() if nm.startswith(filter)}
+
+    def add_gate(self, gate_type, lhs_signal_id: int, rhs_signal_id: int, output_signal_id: int) -> None:
+        """compiler.rs:174-209.  gate_type: AGateType name or discriminant.  An unknown signal maps to node 0
+        like the reference's zero-initialised scan result."""
+        op = OP[gate_type] if isinstance(gate_type, str) else int(gate_type)
+        n0 = self._sig_node.get(lhs_signal_id, 0)
+        n1 = self._sig_node.get(rhs_signal_id, 0)
+        n2 = self._sig_node.get(output_signal_id, 0)
+        self.nodes[n2].is_out = True                                 # KeyError == the reference's unwrap() panic
+        self._g_op.append(op)
+        self._g_lh.append(n0)
+        self._g_rh.append(n1)
+        self._g_out.append(n2)
+
+    def add_connection(self, a: int, b: int) -> None:               # compiler.rs:213-278
+        na, nb = self._sig_node.get(a, 0), self._sig_node.get(b, 0)
+        if na == nb:
+            return
+        node_a, node_b = self.nodes[na], self.nodes[nb]
+        if node_a.is_out and node_b.is_out:
+            raise CannotMergeOutputNodes()
+        if node_a.is_const and node_b.is_const:
+            raise CannotMergeConstantNodes()
+        merged = _Node(node_a.is_const or node_b.is_const, node_a.is_out or node_b.is_out,
+                       node_a.signals + node_b.signals)
+        mid = self._get_node_id()
+        # the reference rewrites every gate here (:260-270); we forward lazily and resolve in _flat()
+        self._fwd[na] = mid
+        self._fwd[nb] = mid
+        del self.nodes[na]
+        del self.nodes[nb]
+        self.nodes[mid] = merged
+        for sid in merged.signals:
+            self._sig_node[sid] = mid
+
+    # -- flat payload ----------------------------------------------------------------------------
+    def _resolve(self, nid: int) -> int:
+        root = nid
+        while root in self._fwd:
+            root = self._fwd[root]
+        while nid in self._fwd:                                      # path compression
+            nxt = self._fwd[nid]
+            self._fwd[nid] = root
+            nid = nxt
+        return root
+
+    @property
+    def gates(self) -> List[Tuple[str, int, int, int]]:
+        """Vec<ArithmeticGate> as (op name, lh_in, rh_in, out) with merges applied (compiler.rs:113)."""
+        return [(OP_NAMES[o], self._resolve(a), self._resolve(b), self._resolve(c))
+                for o, a, b, c in zip(self._g_op, self._g_lh, self._g_rh, self._g_out)]
+
+    def _flat(self):
+        n = len(self._g_op)
+        lh = np.fromiter((self._resolve(x) for x in self._g_lh), dtype=np.uint32, count=n)
+        rh = np.fromiter((self._resolve(x) for x in self._g_rh), dtype=np.uint32, count=n)
+        out = np.fromiter((self._resolve(x) for x in self._g_out), dtype=np.uint32, count=n)
+        op = np.asarray(self._g_op, dtype=np.uint8)
+        return lh, rh, out, op
+
+    def _io_maps(self):
+        """compiler.rs:323-383 in canonical order: ([(input name, node)], [(output name, node)],
+        {constant key: (node, value string)})."""
+        inputs: List[Tuple[str, int]] = []
+        outputs: List[Tuple[str, int]] = []
+        constants: Dict[str, Tuple[int, str]] = {}
+        seen_in, seen_out = set(), set()
+        for sid in sorted(self._sig_node):
+            nid = self._sig_node[sid]
+            if sid in self.inputs:
+                name = self.inputs[sid]
+                if name in seen_in:
+                    raise Inconsistency(f"Duplicate input {name}")              # :335-339
+                seen_in.add(name)
+                inputs.append((name, nid))
+            if sid in self.outputs:
+                name = self.outputs[sid]
+                if name in seen_out:
+                    raise Inconsistency(f"Duplicate output {name}")             # :345-349
+                seen_out.add(name)
+                outputs.append((name, nid))
+            name, value = self.signals[sid]
+            if value is not None:
+                constants[f"{name}_{sid}"] = (nid, str(value))                    # :354-359
+        node_to_input = {nid: name for name, nid in inputs}
+        for name, nid in outputs:                                                 # :363-383
+            if nid in node_to_input:
+                raise Inconsistency(f"Node {nid} used for both input {node_to_input[nid]} and output {name}")
+        return inputs, outputs, constants
+
+    def backend(self) -> Backend:
+        if self._backend is None:
+            self._backend = Backend(self._device)
+        return self._backend
+
+    def build_circuit(self) -> BristolCircuit:
+        """compiler.rs:321-494.  Raises CyclicDependency / Inconsistency like the reference returns them."""
+        inputs, outputs, constants = self._io_maps()
+        lh, rh, out, op = self._flat()
+        be = self.backend()
+        be.load_gates(lh, rh, out, op, self.node_count + 1, [nid for _, nid in inputs], [nid for _, nid in outputs])
+        sorted_ids = be.topo_sort()                                               # :408-421
+        node_wire, wire_count = be.assign_wires()                                 # :388-449
+        in0, in1, o, g_op = be.emit_gates()                                       # :451-464
+        consts: Dict[str, ConstantInfo] = {}
+        for key, (nid, value) in constants.items():                               # :466-476
+            w = int(node_wire[nid])
+            if w == NO_WIRE:
+                raise KeyError(f"constant node {nid} has no wire")                # the reference panics (HashMap index)
+            consts[key] = ConstantInfo(value, w)
+        info = CircuitInfo(
+            input_name_to_wire_index={nm: int(node_wire[nid]) for nm, nid in inputs},
+            constants=consts,
+            output_name_to_wire_index={nm: int(node_wire[nid]) for nm, nid in outputs})
+        self._last = dict(n_in=len(inputs), n_out=len(outputs))
+        return BristolCircuit(wire_count=wire_count, info=info, in0=in0, in1=in1, out=o, op=g_op, op_names=OP_NAMES,
+                              io_widths=None, sorted_gate_ids=sorted_ids)
+
+    def boolify(self, circuit: BristolCircuit, width: int, fetch: bool = True) -> BristolCircuit:
+        """boolify(&circuit, width) (src/main.rs:30-32) of the circuit just built by build_circuit(); frozen
+        bit-blast spec of DESIGN.md §5.  With fetch=False the boolean SoA stays in HBM (arrays are empty)."""
+        be = self.backend()
+        bi = be.boolify(width)
+        if fetch:
+            in0, in1, out, op = be.bool_read()
+        else:
+            in0 = in1 = out = np.empty(0, np.uint32)
+            op = np.empty(0, np.uint8)
+        ci = circuit.info
+        info = CircuitInfo(
+            input_name_to_wire_index={k: int(bi.wire(v)) for k, v in ci.input_name_to_wire_index.items()},
+            constants={k: ConstantInfo(c.value, int(bi.wire(c.wire_index))) for k, c in ci.constants.items()},
+            output_name_to_wire_index={k: int(bi.wire(v)) for k, v in ci.output_name_to_wire_index.items()})
+        return BristolCircuit(wire_count=bi.wire_count, info=info, in0=in0, in1=in1, out=out, op=op,
+                              op_names=BOOL_OP_NAMES, io_widths=([width] * bi.n_in, [width] * bi.n_out),
+                              unary_ops=(2,))

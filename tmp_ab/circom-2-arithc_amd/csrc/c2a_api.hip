@@ -40,7 +40,6 @@ struct c2a_ctx {
     Stage stage = ST_EMPTY;
     int n_cu = 256;
     u32 peel_wave_max = 8192;      // frontier size up to which a level gets one wave per gate
-    u32 bool_chunk = 256;          // arithmetic gates per k_boolify workgroup: 128, 256 (measured best) or 512
     u32 peel_wpb = 8;              // gates (waves) per workgroup in wave mode: 4, 8 or 16 (8 measured best)
 
     // problem
@@ -490,7 +489,6 @@ int c2a_create(int device_id, c2a_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
         c->n_cu = prop.multiProcessorCount;
-    if (const char* e = std::getenv("C2A_BOOL_CHUNK")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 128 || v == 256 || v == 512) c->bool_chunk = v; }
     if (const char* e = std::getenv("C2A_PEEL_WPB")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 4 || v == 8 || v == 16) c->peel_wpb = v; }
     if (const char* e = std::getenv("C2A_PEEL_WAVE_MAX")) c->peel_wave_max = (u32)std::strtoul(e, nullptr, 10);   // tuning / test knob
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return C2A_ERR_HIP; }
@@ -715,12 +713,8 @@ int c2a_boolify(c2a_ctx* c, uint32_t width, c2a_bool_info* info) {
         A.e_in0 = c->e_in0.as<u32>(); A.e_in1 = c->e_in1.as<u32>(); A.e_out = c->e_out.as<u32>(); A.e_op = c->e_op.as<u8>();
         A.goff = c->goff.as<u64>(); A.aoff = c->aoff.as<u64>(); A.tmpl = c->tmpl.as<uint4>();
         A.b_in0 = c->b_in0.as<u32>(); A.b_in1 = c->b_in1.as<u32>(); A.b_out = c->b_out.as<u32>(); A.b_op = c->b_op.as<u8>();
-        const BoolTables* Tb = c->tables.as<BoolTables>();
-        const u32 ch = c->bool_chunk;
-        const u32 blocks = (n + ch - 1) / ch;
-        if (ch == 128) C2A_LAUNCH((k_boolify<128>), blocks, kThreads, s, A, Tb);
-        else if (ch == 512) C2A_LAUNCH((k_boolify<512>), blocks, kThreads, s, A, Tb);
-        else C2A_LAUNCH((k_boolify<256>), blocks, kThreads, s, A, Tb);
+        const u32 blocks = (n + kBoolChunk - 1) / kBoolChunk;
+        C2A_LAUNCH(k_boolify, blocks, kThreads, s, A, (const BoolTables*)c->tables.as<BoolTables>());
     }
     rec(c, EV_BMAP1);
     HIP_TRY(hipStreamSynchronize(s));

@@ -785,85 +785,86 @@ struct BoolArgs {
     u32* b_in0; u32* b_in1; u32* b_out; u8* b_op;
 };
 
+constexpr int kBoolChunk = 128;   // arithmetic gates per workgroup
 
 __device__ __forceinline__ u32 bool_wire(u32 W, u32 bit, u32 width, u32 M, u64 out_base) {
     return W < M ? W * width + bit : (u32)(out_base + (u64)(W - M) * width + bit);
 }
 
-// largest i with s_goff[i] <= r
-__device__ __forceinline__ u32 bool_owner(u32 r, const u32* s_goff, u32 cnt) {
-    u32 lo = 0, hi = cnt;
-    while (hi - lo > 1) {
-        const u32 mid = (lo + hi) >> 1;
-        if (s_goff[mid] <= r) lo = mid; else hi = mid;
+__device__ __forceinline__ void bool_gate(const BoolArgs& A, const u64* s_aoff, const u32* s_in0, const u32* s_in1,
+                                          const u32* s_out, const u32* s_top, u32 idx, u32 k, u32& o0, u32& o1, u32& o2,
+                                          u32& oop) {
+    const uint4 e = A.tmpl[s_top[idx] + k];
+    const u32 refs[3] = {e.x, e.y, e.z};
+    u32 w3[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const u32 kind = refs[r] >> 30, id = refs[r] & 0x3FFFFFFFu;
+        u32 v;
+        if (kind == 3) v = (u32)(A.aux_base + s_aoff[idx] + id);
+        else v = bool_wire(kind == 0 ? s_in0[idx] : (kind == 1 ? s_in1[idx] : s_out[idx]), id, A.width, A.M, A.out_base);
+        w3[r] = v;
     }
-    return lo;
+    o0 = w3[0]; o1 = w3[1]; o2 = w3[2]; oop = e.w;
 }
 
-// One workgroup per CHUNK arithmetic gates.  The prologue turns each of them into four wire bases
-// {A bits, B bits, O bits, aux} (so a symbolic ref resolves as base[kind] + index: one LDS read and one add),
-// its template offset and the block-relative index of its first boolean gate.  Every lane then produces FOUR
-// consecutive boolean gates per iteration — owner by binary search over the block's <= CHUNK offsets in LDS —
-// and stores them as one 16-byte vector per SoA stream (4-byte-per-lane stores are issue-bound on gfx950, not
+// One workgroup per kBoolChunk arithmetic gates.  Every lane produces FOUR consecutive boolean gates and stores
+// them as one 16-byte vector per SoA stream (4-byte-per-lane stores are issue-bound on gfx950, not
 // bandwidth-bound); the <= 3 unaligned gates at each end of the workgroup's range go out as scalars.
-// Measured alternatives that LOST in interleaved same-session A/B runs (kept out of the tree): a start-bit map
-// + popcount instead of the search, a "four gates, one owner" fast path, software-pipelined template loads,
-// persistent workgroups with LDS-staged packed templates, non-temporal stores (profiles/r01_boolify_ab.txt).
-template <int CHUNK>
 __global__ void __launch_bounds__(kThreads) k_boolify(BoolArgs A, const BoolTables* __restrict__ T) {
-    __shared__ u32 s_goff[CHUNK + 1];       // first boolean gate of each arithmetic gate, relative to the block's first
-    __shared__ uint4 s_base[CHUNK];         // wire bases per ref kind
-    __shared__ u32 s_top[CHUNK];            // template offset
-    const u32 tid = threadIdx.x;
-    const u64 p0 = (u64)blockIdx.x * CHUNK;
-    const u32 cnt = (u32)((A.n - p0) < (u64)CHUNK ? (A.n - p0) : (u64)CHUNK);
-    const u64 q0 = A.goff[p0];
-    for (u32 i = tid; i <= cnt; i += kThreads) s_goff[i] = (u32)(A.goff[p0 + i] - q0);
-    for (u32 i = tid; i < cnt; i += kThreads) {
-        const u32 wa = A.e_in0[p0 + i], wb = A.e_in1[p0 + i], wo = A.e_out[p0 + i];
-        s_base[i] = make_uint4(bool_wire(wa, 0, A.width, A.M, A.out_base), bool_wire(wb, 0, A.width, A.M, A.out_base),
-                               bool_wire(wo, 0, A.width, A.M, A.out_base), (u32)(A.aux_base + A.aoff[p0 + i]));
+    __shared__ u64 s_goff[kBoolChunk + 1];
+    __shared__ u64 s_aoff[kBoolChunk];
+    __shared__ u32 s_in0[kBoolChunk], s_in1[kBoolChunk], s_out[kBoolChunk], s_top[kBoolChunk];
+    const u64 p0 = (u64)blockIdx.x * kBoolChunk;
+    const u32 cnt = (u32)((A.n - p0) < (u64)kBoolChunk ? (A.n - p0) : (u64)kBoolChunk);
+    for (u32 i = threadIdx.x; i <= cnt; i += blockDim.x) s_goff[i] = A.goff[p0 + i];
+    for (u32 i = threadIdx.x; i < cnt; i += blockDim.x) {
+        s_aoff[i] = A.aoff[p0 + i];
+        s_in0[i] = A.e_in0[p0 + i];
+        s_in1[i] = A.e_in1[p0 + i];
+        s_out[i] = A.e_out[p0 + i];
         s_top[i] = T->toff[A.e_op[p0 + i]];
     }
     __syncthreads();
-    const u32 total = s_goff[cnt];                       // boolean gates of this block (< 2^32 by construction)
-    const u32 head = (u32)((4 - (q0 & 3)) & 3);          // unaligned gates before the first 16-byte boundary
-    const u32 r0 = head < total ? head : total;
-    const u32 r1 = r0 + ((total - r0) & ~3u);
-    const u32* base_words = reinterpret_cast<const u32*>(s_base);
-    typedef u32 u32x4 __attribute__((vector_size(16)));
-    // ---- aligned body: groups of 4 (r = block-relative index)
-    for (u32 r = r0 + 4u * tid; r < r1; r += 4u * kThreads) {
-        u32 idx = bool_owner(r, s_goff, cnt);
-        u32 start = s_goff[idx], bound = s_goff[idx + 1], top = s_top[idx];
+    const u64 q0 = s_goff[0], q1 = s_goff[cnt];
+    u64 a0 = (q0 + 3) & ~3ull;
+    if (a0 > q1) a0 = q1;
+    u64 a1 = q1 & ~3ull;
+    if (a1 < a0) a1 = a0;
+    // ---- aligned body: groups of 4
+    for (u64 q = a0 + 4ull * threadIdx.x; q < a1; q += 4ull * blockDim.x) {
+        u32 lo = 0, hi = cnt;                        // largest i with s_goff[i] <= q
+        while (hi - lo > 1) {
+            const u32 mid = (lo + hi) >> 1;
+            if (s_goff[mid] <= q) lo = mid; else hi = mid;
+        }
         u32 v0[4], v1[4], v2[4], vop = 0;
+        u32 idx = lo;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            while (r + j >= bound) { ++idx; start = bound; bound = s_goff[idx + 1]; top = s_top[idx]; }
-            const uint4 e = A.tmpl[top + (r + j - start)];
-            v0[j] = base_words[idx * 4 + (e.x >> 30)] + (e.x & 0x3FFFFFFFu);
-            v1[j] = base_words[idx * 4 + (e.y >> 30)] + (e.y & 0x3FFFFFFFu);
-            v2[j] = base_words[idx * 4 + (e.z >> 30)] + (e.z & 0x3FFFFFFFu);
-            vop |= (e.w & 0xFFu) << (8 * j);
+            while (q + j >= s_goff[idx + 1]) ++idx;
+            u32 oop;
+            bool_gate(A, s_aoff, s_in0, s_in1, s_out, s_top, idx, (u32)(q + j - s_goff[idx]), v0[j], v1[j], v2[j], oop);
+            vop |= (oop & 0xFFu) << (8 * j);
         }
-        const u64 q = q0 + r;
-        *reinterpret_cast<u32x4*>(A.b_in0 + q) = u32x4{v0[0], v0[1], v0[2], v0[3]};
-        *reinterpret_cast<u32x4*>(A.b_in1 + q) = u32x4{v1[0], v1[1], v1[2], v1[3]};
-        *reinterpret_cast<u32x4*>(A.b_out + q) = u32x4{v2[0], v2[1], v2[2], v2[3]};
+        *reinterpret_cast<uint4*>(A.b_in0 + q) = make_uint4(v0[0], v0[1], v0[2], v0[3]);
+        *reinterpret_cast<uint4*>(A.b_in1 + q) = make_uint4(v1[0], v1[1], v1[2], v1[3]);
+        *reinterpret_cast<uint4*>(A.b_out + q) = make_uint4(v2[0], v2[1], v2[2], v2[3]);
         *reinterpret_cast<u32*>(A.b_op + q) = vop;
     }
-    // ---- unaligned head [0,r0) and tail [r1,total): at most 3 + 3 gates
+    // ---- unaligned head [q0,a0) and tail [a1,q1): at most 3 + 3 gates
     {
-        const u32 nh = r0, nt = total - r1;
-        if (tid < nh + nt) {
-            const u32 r = tid < nh ? tid : r1 + (tid - nh);
-            const u32 lo = bool_owner(r, s_goff, cnt);
-            const uint4 e = A.tmpl[s_top[lo] + (r - s_goff[lo])];
-            const u64 q = q0 + r;
-            A.b_in0[q] = base_words[lo * 4 + (e.x >> 30)] + (e.x & 0x3FFFFFFFu);
-            A.b_in1[q] = base_words[lo * 4 + (e.y >> 30)] + (e.y & 0x3FFFFFFFu);
-            A.b_out[q] = base_words[lo * 4 + (e.z >> 30)] + (e.z & 0x3FFFFFFFu);
-            A.b_op[q] = (u8)e.w;
+        const u32 nh = (u32)(a0 - q0), nt = (u32)(q1 - a1);
+        if (threadIdx.x < nh + nt) {
+            const u64 q = threadIdx.x < nh ? q0 + threadIdx.x : a1 + (threadIdx.x - nh);
+            u32 lo = 0, hi = cnt;
+            while (hi - lo > 1) {
+                const u32 mid = (lo + hi) >> 1;
+                if (s_goff[mid] <= q) lo = mid; else hi = mid;
+            }
+            u32 o0, o1, o2, oop;
+            bool_gate(A, s_aoff, s_in0, s_in1, s_out, s_top, lo, (u32)(q - s_goff[lo]), o0, o1, o2, oop);
+            A.b_in0[q] = o0; A.b_in1[q] = o1; A.b_out[q] = o2; A.b_op[q] = (u8)oop;
         }
     }
 }

@@ -1,0 +1,146 @@
+/*
+ * c2a.h — C ABI of the MI355X-native back end for the flat-gate-graph stage of circom-2-arithc.
+ *
+ * The reference (Rust, /root/reference) has no FFI seam; this header IS the seam a maintainer binds
+ * (INTEGRATION.md shows the Rust `extern "C"` block).  Every entry point names the reference code it
+ * replaces.  Conventions:
+ *   - plain pointers and sizes only; strings never cross the ABI (the host keeps the name tables of
+ *     src/compiler.rs:323-361 and rebuilds CircuitInfo from node_to_wire);
+ *   - caller-owned inputs are copied during c2a_load_gates and may be freed afterwards;
+ *     library-owned device results live until the next c2a_load_gates / c2a_destroy;
+ *   - every call returns an int status: 0 = OK, >0 = a reference-level error (CircuitError),
+ *     <0 = argument / state / HIP failure; c2a_last_error() gives a message; no exceptions, no aborts;
+ *   - one context per host thread; contexts are independent (one HIP stream each).
+ *   - node ids are the reference's raw u32 node ids (sparse, src/compiler.rs:497-500); n_nodes is
+ *     max node id + 1 (the library direct-addresses them: no remap needed).
+ */
+#ifndef C2A_H
+#define C2A_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct c2a_ctx c2a_ctx;
+
+enum c2a_status {
+    C2A_OK = 0,
+    C2A_ERR_CYCLIC = 1,          /* CircuitError::CyclicDependency (src/compiler.rs:570-571); *cycle_at = i of "detected at i={}" (src/topological_sort.rs:34-38) */
+    C2A_ERR_INCONSISTENCY = 2,   /* CircuitError::Inconsistency: a node is both input and output (src/compiler.rs:363-383) */
+    C2A_ERR_OVERFLOW = 3,        /* boolean wire ids would not fit u32 */
+    C2A_ERR_ARG = -1,
+    C2A_ERR_STATE = -2,          /* call order violated (load -> topo_sort -> assign_wires -> emit -> boolify) */
+    C2A_ERR_HIP = -3,
+    C2A_ERR_NOMEM = -4
+};
+
+/* AGateType discriminants == declaration order of src/a_gate_type.rs:8-27 */
+enum c2a_gate_type {
+    C2A_AAdd = 0, C2A_ADiv, C2A_AEq, C2A_AGEq, C2A_AGt, C2A_ALEq, C2A_ALt, C2A_AMul, C2A_ANeq, C2A_ASub,
+    C2A_AXor, C2A_APow, C2A_AIntDiv, C2A_AMod, C2A_AShiftL, C2A_AShiftR, C2A_ABoolOr, C2A_ABoolAnd,
+    C2A_ABitOr, C2A_ABitAnd, C2A_NUM_GATE_TYPES
+};
+
+/* boolean ops of the frozen bit-blast spec: Bristol-fashion XOR / AND / INV */
+enum c2a_bool_op { C2A_XOR = 0, C2A_AND = 1, C2A_INV = 2 };
+
+#define C2A_NO_WIRE 0xFFFFFFFFu
+
+typedef struct c2a_bool_info {
+    uint64_t n_gates;        /* boolean gates */
+    uint64_t wire_count;     /* boolean wires = arithmetic wire_count*width + aux_total */
+    uint64_t aux_total;      /* template-internal wires */
+    uint32_t width;
+    uint32_t n_in, n_out;    /* arithmetic IO counts; io_widths = ([width; n_in], [width; n_out]) */
+    uint32_t m_wires;        /* M = arithmetic wire_count - n_out; bit b of wire W is W*width+b for W<M,
+                                else M*width + aux_total + (W-M)*width + b */
+} c2a_bool_info;
+
+typedef struct c2a_timings {     /* milliseconds, HIP events on the context's stream, last run */
+    float prep;                  /* producer map, deps, consumer CSR, level-0 frontier */
+    float peel;                  /* reverse Kahn peel + DFS-tree parent selection (all levels) */
+    float order;                 /* Euler tour + list ranking -> sorted_gate_ids */
+    float wires;                 /* first-seen wire numbering */
+    float emit;                  /* gate emission */
+    float bool_prep;             /* template sizes + offset scans */
+    float bool_map;              /* the boolify map kernel alone (dominant kernel; roofline) */
+    float build_total;           /* c2a_build_circuit wall (events) */
+    float boolify_total;         /* c2a_boolify wall (events) */
+} c2a_timings;
+
+typedef struct c2a_stats {
+    uint64_t n_gates;
+    uint64_t n_edges;            /* dependency edges after dedupe */
+    uint32_t levels;             /* reverse Kahn levels */
+    uint32_t max_depth;          /* depth of the DFS tree */
+    uint32_t n_roots;            /* DFS roots (children of the virtual root) */
+    uint32_t n_splitters;        /* list-ranking sublists */
+    uint32_t level_launches;     /* k_peel_level launches incl. empty tail launches */
+    uint32_t anc_planes;
+} c2a_stats;
+
+/* Create a context on HIP device `device_id` (>= 0).  Fails with C2A_ERR_HIP when no device / runtime. */
+int c2a_create(int device_id, c2a_ctx** ctx);
+void c2a_destroy(c2a_ctx* ctx);
+const char* c2a_last_error(const c2a_ctx* ctx);
+const char* c2a_version(void);
+
+/*
+ * Marshal `Compiler.gates` (src/compiler.rs:113, :85-90) as SoA plus the IO node lists that
+ * build_circuit derives at src/compiler.rs:323-361 (in the canonical order of DESIGN.md §3; the
+ * reference iterates a std HashMap there).  Host pointers; copied to HBM.  Also sizes all workspace.
+ */
+int c2a_load_gates(c2a_ctx* ctx, uint64_t n, const uint32_t* lh, const uint32_t* rh, const uint32_t* out,
+                   const uint8_t* op, uint32_t n_nodes, uint32_t n_in, const uint32_t* input_nodes, uint32_t n_out,
+                   const uint32_t* output_nodes);
+
+/*
+ * == topological_sort(len, get_deps) (src/topological_sort.rs:3-21) with the deps closure of
+ * src/compiler.rs:408-421.  sorted_gate_ids (host, n entries) may be NULL (result stays in HBM).
+ * On C2A_ERR_CYCLIC *cycle_at is the gate index of the reference's message.
+ */
+int c2a_topo_sort(c2a_ctx* ctx, uint32_t* sorted_gate_ids, uint64_t* cycle_at);
+
+/* Same contract, executed as the literal DFS on one GPU lane (diagnostics / cross-check; slow). */
+int c2a_topo_sort_serial(c2a_ctx* ctx, uint32_t* sorted_gate_ids, uint64_t* cycle_at);
+
+/*
+ * == wire numbering of src/compiler.rs:388-449: inputs first (list order), then first-seen along the
+ * sorted gates, outputs last (list order).  node_to_wire (host, n_nodes entries, C2A_NO_WIRE = none)
+ * may be NULL.  *wire_count == BristolCircuit.wire_count (src/compiler.rs:479).
+ */
+int c2a_assign_wires(c2a_ctx* ctx, uint32_t* node_to_wire, uint32_t* wire_count);
+
+/* == gate emission of src/compiler.rs:451-464 in sorted order; any host pointer may be NULL. */
+int c2a_emit_gates(c2a_ctx* ctx, uint32_t* in0, uint32_t* in1, uint32_t* out, uint8_t* op);
+
+/* == Compiler::build_circuit numeric core (src/compiler.rs:385-464): the three calls above back to
+ * back with everything left resident in HBM (this is the timed unit of bench.py). */
+int c2a_build_circuit(c2a_ctx* ctx, uint64_t* cycle_at, uint32_t* wire_count);
+
+/*
+ * == boolify(&circuit, width) (src/main.rs:30-32), under the frozen bit-blast spec of DESIGN.md §5
+ * (the crate's source is absent: parity with it is unpinned).  Result stays in HBM as SoA
+ * in0[]/in1[]/out[]/op[]; read ranges back with c2a_bool_read.  1 <= width <= 64.
+ */
+int c2a_boolify(c2a_ctx* ctx, uint32_t width, c2a_bool_info* info);
+int c2a_bool_read(c2a_ctx* ctx, uint64_t first, uint64_t count, uint32_t* in0, uint32_t* in1, uint32_t* out,
+                  uint8_t* op);
+
+/* T(op,width) and AUX(op,width) of the frozen spec (host-side query; no GPU work). */
+int c2a_template_size(uint32_t op, uint32_t width, uint64_t* n_gates, uint64_t* n_aux);
+
+/* Position-salted 64-bit checksums computed on the GPU over resident results (full-size parity):
+ * which: 0 sorted_gate_ids, 1 arith in0, 2 arith in1, 3 arith out, 4 arith op,
+ *        5 bool in0, 6 bool in1, 7 bool out, 8 bool op, 9 node_to_wire */
+int c2a_checksum(c2a_ctx* ctx, int which, uint64_t* value);
+
+int c2a_get_timings(c2a_ctx* ctx, c2a_timings* t);
+int c2a_get_stats(c2a_ctx* ctx, c2a_stats* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* C2A_H */

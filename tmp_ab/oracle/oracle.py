@@ -1,0 +1,572 @@
+"""CPU oracle for the flat-gate-graph stage of circom-2-arithc — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product path (circom-2-arithc_amd/) never does.
+
+Two layers:
+
+* pure-Python *literal* restatements (recursion kept, dicts kept) of
+    - src/topological_sort.rs:3-50            -> topological_sort_literal
+    - src/compiler.rs:139-278 (gate-graph builder) -> CompilerModel.add_signal/add_gate/add_connection
+    - src/compiler.rs:321-494 (build_circuit) -> CompilerModel.build_circuit
+  used on small cases to pin the C restatement and to replay the reference's integration fixtures;
+* ctypes bindings to oracle/c2a_oracle.c (same algorithms, explicit stack, fast) used for the
+  seeded random parity tests and as bench.py's cpu_baseline.
+
+Parity status: the reference cannot be built here (Rust, un-vendored git deps) — pinned against
+tests/integration.rs expectations + SURVEY.md Appendix A hand traces (tests/golden/).
+boolify / write_bristol sources are absent (third-party crates) => PARITY UNPINNED for those; the
+bit-blast follows the frozen spec of DESIGN.md §5.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import sys
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libc2a_oracle.so")
+
+NONE = 0xFFFFFFFF
+
+# src/a_gate_type.rs:8-27, declaration order == discriminant
+OP_NAMES = [
+    "AAdd", "ADiv", "AEq", "AGEq", "AGt", "ALEq", "ALt", "AMul", "ANeq", "ASub", "AXor", "APow",
+    "AIntDiv", "AMod", "AShiftL", "AShiftR", "ABoolOr", "ABoolAnd", "ABitOr", "ABitAnd",
+]
+OP = {name: i for i, name in enumerate(OP_NAMES)}
+BOOL_OP_NAMES = ["XOR", "AND", "INV"]
+
+ORC_OK, ORC_CYCLIC, ORC_INCONSISTENCY, ORC_OVERFLOW, ORC_ARG, ORC_NOMEM = range(6)
+
+
+class CircuitError(Exception):
+    """Mirror of CircuitError (src/compiler.rs:550-575); str() matches the thiserror Display."""
+
+
+class CyclicDependency(CircuitError):
+    def __init__(self, message: str):
+        self.message = message
+        super().__init__(f"Cyclic dependency: {message}")
+
+
+class Inconsistency(CircuitError):
+    def __init__(self, message: str):
+        self.message = message
+        super().__init__(f"Inconsistency: {message}")
+
+
+# ---------------------------------------------------------------------------------------------
+# literal restatement of src/topological_sort.rs
+# ---------------------------------------------------------------------------------------------
+def topological_sort_literal(length: int, get_deps: Callable[[int], List[int]]) -> List[int]:
+    """src/topological_sort.rs:3-21 (recursive, like the reference)."""
+    sorted_: List[int] = []
+    visiting = [False] * length
+    visited = [False] * length
+    old = sys.getrecursionlimit()
+    sys.setrecursionlimit(max(old, length * 2 + 1000))
+    try:
+        for i in range(length):
+            _topological_sort_visit(i, visiting, visited, get_deps, sorted_)
+    finally:
+        sys.setrecursionlimit(old)
+    assert len(sorted_) == length, "Topological sort did not return all elements"
+    return sorted_
+
+
+def _topological_sort_visit(i, visiting, visited, get_deps, sorted_):
+    """src/topological_sort.rs:23-50."""
+    if visited[i]:
+        return
+    if visiting[i]:
+        raise CyclicDependency(f"detected at i={i}")
+    visiting[i] = True
+    for j in get_deps(i):
+        _topological_sort_visit(j, visiting, visited, get_deps, sorted_)
+    sorted_.append(i)
+    visited[i] = True
+
+
+# ---------------------------------------------------------------------------------------------
+# literal restatement of the gate-graph builder + build_circuit (src/compiler.rs)
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class Signal:          # compiler.rs:16-20
+    name: str
+    value: Optional[int]
+
+
+@dataclass
+class Node:            # compiler.rs:32-36
+    is_const: bool = False
+    is_out: bool = False
+    signals: List[int] = field(default_factory=list)
+
+
+@dataclass
+class ArithmeticGate:  # compiler.rs:85-90
+    op: int
+    lh_in: int
+    rh_in: int
+    out: int
+
+
+@dataclass
+class ConstantInfo:    # bristol-circuit ConstantInfo as used at compiler.rs:471-474
+    value: str
+    wire_index: int
+
+
+@dataclass
+class BristolCircuit:  # bristol-circuit types as used at compiler.rs:478-493
+    wire_count: int
+    input_name_to_wire_index: Dict[str, int]
+    constants: Dict[str, ConstantInfo]
+    output_name_to_wire_index: Dict[str, int]
+    gates: List[Tuple[int, int, int, str]]          # (in0, in1, out, op name)
+    sorted_gate_ids: List[int]
+    node_id_to_wire_id: Dict[int, int]
+    io_widths: Optional[Tuple[List[int], List[int]]] = None
+
+
+class CompilerModel:
+    """Python mirror of `Compiler` (src/compiler.rs:107-115) with the mutators the unroller calls."""
+
+    def __init__(self):
+        self.node_count = 0
+        self.inputs: Dict[int, str] = {}
+        self.outputs: Dict[int, str] = {}
+        self.signals: Dict[int, Signal] = {}
+        self.nodes: Dict[int, Node] = {}
+        self.gates: List[ArithmeticGate] = []
+
+    def _get_node_id(self) -> int:                      # compiler.rs:497-500
+        self.node_count += 1
+        return self.node_count
+
+    def add_inputs(self, inputs: Dict[int, str]):       # compiler.rs:130-132
+        self.inputs.update(inputs)
+
+    def add_outputs(self, outputs: Dict[int, str]):     # compiler.rs:134-136
+        self.outputs.update(outputs)
+
+    def add_signal(self, sid: int, name: str, value: Optional[int] = None):   # compiler.rs:139-161
+        if sid in self.signals:
+            raise CircuitError("Signal already declared")
+        self.signals[sid] = Signal(name, value)
+        node = Node(is_const=value is not None, is_out=False, signals=[sid])
+        self.nodes[self._get_node_id()] = node
+
+    def get_signals(self, flt: str) -> Dict[int, str]:  # compiler.rs:163-171
+        return {sid: s.name for sid, s in self.signals.items() if s.name.startswith(flt)}
+
+    def _node_of(self, sid: int) -> int:
+        found = 0
+        for nid, node in self.nodes.items():
+            if sid in node.signals:
+                found = nid
+        return found
+
+    def add_gate(self, op: int, lhs: int, rhs: int, out: int):                 # compiler.rs:174-209
+        ids = [self._node_of(lhs), self._node_of(rhs), self._node_of(out)]
+        self.nodes[ids[2]].is_out = True
+        self.gates.append(ArithmeticGate(op, ids[0], ids[1], ids[2]))
+
+    def add_connection(self, a: int, b: int):                                  # compiler.rs:213-278
+        na, nb = self._node_of(a), self._node_of(b)
+        if na == nb:
+            return
+        node_a, node_b = self.nodes[na], self.nodes[nb]
+        if node_a.is_out and node_b.is_out:
+            raise CircuitError("Cannot merge output nodes")
+        if node_a.is_const and node_b.is_const:
+            raise CircuitError("Cannot merge constant nodes")
+        merged = Node(is_const=node_a.is_const or node_b.is_const, is_out=node_a.is_out or node_b.is_out,
+                      signals=list(node_a.signals) + list(node_b.signals))
+        mid = self._get_node_id()
+        for g in self.gates:
+            if g.lh_in in (na, nb):
+                g.lh_in = mid
+            if g.rh_in in (na, nb):
+                g.rh_in = mid
+            if g.out in (na, nb):
+                g.out = mid
+        del self.nodes[na]
+        del self.nodes[nb]
+        self.nodes[mid] = merged
+
+    # -- name maps (compiler.rs:323-383), canonical order of DESIGN.md §3 -------------------------
+    def io_maps(self):
+        """Returns (inputs [(name,node)], outputs [(name,node)], constants {key:(node,value)}).
+
+        The reference fills std HashMaps and later iterates them (order undefined);
+        the canonical order is ascending signal id of the named IO signal.
+        """
+        sig_node = {sid: nid for nid, node in self.nodes.items() for sid in node.signals}
+        inputs: List[Tuple[str, int]] = []
+        outputs: List[Tuple[str, int]] = []
+        constants: Dict[str, Tuple[int, str]] = {}
+        seen_in, seen_out = set(), set()
+        for sid in sorted(sig_node):
+            nid = sig_node[sid]
+            if sid in self.inputs:
+                name = self.inputs[sid]
+                if name in seen_in:
+                    raise Inconsistency(f"Duplicate input {name}")         # compiler.rs:335-339
+                seen_in.add(name)
+                inputs.append((name, nid))
+            if sid in self.outputs:
+                name = self.outputs[sid]
+                if name in seen_out:
+                    raise Inconsistency(f"Duplicate output {name}")        # compiler.rs:345-349
+                seen_out.add(name)
+                outputs.append((name, nid))
+            sig = self.signals[sid]
+            if sig.value is not None:
+                constants[f"{sig.name}_{sid}"] = (nid, str(sig.value))       # compiler.rs:354-359
+        node_to_input = {nid: name for name, nid in inputs}
+        for name, nid in outputs:                                            # compiler.rs:363-383
+            if nid in node_to_input:
+                raise Inconsistency(
+                    f"Node {nid} used for both input {node_to_input[nid]} and output {name}")
+        return inputs, outputs, constants
+
+    def build_circuit(self) -> BristolCircuit:
+        """Literal restatement of src/compiler.rs:321-494 (dicts for HashMaps, recursive DFS)."""
+        inputs, outputs, constants = self.io_maps()
+        node_id_to_wire_id: Dict[int, int] = {}
+        next_wire_id = 0
+        for _, nid in inputs:                                                # :392-395
+            node_id_to_wire_id[nid] = next_wire_id
+            next_wire_id += 1
+        node_id_to_required_gate: Dict[int, int] = {}
+        for gid, gate in enumerate(self.gates):                              # :403-406
+            node_id_to_required_gate[gate.out] = gid
+
+        def get_deps(gid: int) -> List[int]:                                 # :408-421
+            gate = self.gates[gid]
+            deps = []
+            if gate.lh_in in node_id_to_required_gate:
+                deps.append(node_id_to_required_gate[gate.lh_in])
+            if gate.rh_in in node_id_to_required_gate:
+                deps.append(node_id_to_required_gate[gate.rh_in])
+            return deps
+
+        sorted_gate_ids = topological_sort_literal(len(self.gates), get_deps)
+        output_node_ids = {nid for _, nid in outputs}                        # :423
+        for gid in sorted_gate_ids:                                          # :427-443
+            gate = self.gates[gid]
+            for nid in (gate.lh_in, gate.rh_in, gate.out):
+                if nid in output_node_ids:
+                    continue
+                if nid in node_id_to_wire_id:
+                    continue
+                node_id_to_wire_id[nid] = next_wire_id
+                next_wire_id += 1
+        for _, nid in outputs:                                               # :446-449
+            node_id_to_wire_id[nid] = next_wire_id
+            next_wire_id += 1
+        new_gates = []
+        for gid in sorted_gate_ids:                                          # :453-464
+            gate = self.gates[gid]
+            new_gates.append((node_id_to_wire_id[gate.lh_in], node_id_to_wire_id[gate.rh_in],
+                              node_id_to_wire_id[gate.out], OP_NAMES[gate.op]))
+        consts = {name: ConstantInfo(value, node_id_to_wire_id[nid])         # :466-476 (KeyError == Rust panic)
+                  for name, (nid, value) in constants.items()}
+        return BristolCircuit(
+            wire_count=next_wire_id,
+            input_name_to_wire_index={n: node_id_to_wire_id[nid] for n, nid in inputs},
+            constants=consts,
+            output_name_to_wire_index={n: node_id_to_wire_id[nid] for n, nid in outputs},
+            gates=new_gates, sorted_gate_ids=sorted_gate_ids, node_id_to_wire_id=node_id_to_wire_id)
+
+    # -- boundary payload ----------------------------------------------------------------------
+    def flat_payload(self):
+        """The flat SoA payload that crosses the C-ABI: raw node ids, canonical IO."""
+        inputs, outputs, constants = self.io_maps()
+        n = len(self.gates)
+        lh = np.fromiter((g.lh_in for g in self.gates), dtype=np.uint32, count=n)
+        rh = np.fromiter((g.rh_in for g in self.gates), dtype=np.uint32, count=n)
+        out = np.fromiter((g.out for g in self.gates), dtype=np.uint32, count=n)
+        op = np.fromiter((g.op for g in self.gates), dtype=np.uint8, count=n)
+        return dict(lh=lh, rh=rh, out=out, op=op, n_nodes=self.node_count + 1,
+                    input_nodes=np.array([nid for _, nid in inputs], dtype=np.uint32),
+                    output_nodes=np.array([nid for _, nid in outputs], dtype=np.uint32),
+                    input_names=[nm for nm, _ in inputs], output_names=[nm for nm, _ in outputs],
+                    constants=constants)
+
+
+# ---------------------------------------------------------------------------------------------
+# ctypes bindings to c2a_oracle.c
+# ---------------------------------------------------------------------------------------------
+class _OrcCircuit(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_uint64), ("n_nodes", ctypes.c_uint32), ("n_in", ctypes.c_uint32),
+                ("n_out", ctypes.c_uint32), ("wire_count", ctypes.c_uint32),
+                ("sorted", ctypes.POINTER(ctypes.c_uint32)), ("in0", ctypes.POINTER(ctypes.c_uint32)),
+                ("in1", ctypes.POINTER(ctypes.c_uint32)), ("out", ctypes.POINTER(ctypes.c_uint32)),
+                ("op", ctypes.POINTER(ctypes.c_uint8)), ("node_wire", ctypes.POINTER(ctypes.c_uint32))]
+
+
+class _OrcBool(ctypes.Structure):
+    _fields_ = [("n_gates", ctypes.c_uint64), ("wire_count", ctypes.c_uint64), ("width", ctypes.c_uint32),
+                ("n_in", ctypes.c_uint32), ("n_out", ctypes.c_uint32),
+                ("in0", ctypes.POINTER(ctypes.c_uint32)), ("in1", ctypes.POINTER(ctypes.c_uint32)),
+                ("out", ctypes.POINTER(ctypes.c_uint32)), ("op", ctypes.POINTER(ctypes.c_uint8))]
+
+
+_lib = None
+
+
+def build_lib(force: bool = False) -> str:
+    src = os.path.join(_HERE, "c2a_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or (
+            os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_LIB_PATH)):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libc2a_oracle.so"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build_lib()
+        L = ctypes.CDLL(_LIB_PATH)
+        u32p, u8p, u64p = (ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint8),
+                           ctypes.POINTER(ctypes.c_uint64))
+        L.orc_build_circuit.restype = ctypes.c_int
+        L.orc_build_circuit.argtypes = [ctypes.c_uint64, u32p, u32p, u32p, u8p, ctypes.c_uint32, ctypes.c_uint32,
+                                        u32p, ctypes.c_uint32, u32p, ctypes.c_int,
+                                        ctypes.POINTER(ctypes.POINTER(_OrcCircuit)), u64p]
+        L.orc_free_circuit.argtypes = [ctypes.POINTER(_OrcCircuit)]
+        L.orc_free_circuit.restype = None
+        L.orc_topo_sort_deps.restype = ctypes.c_int
+        L.orc_topo_sort_deps.argtypes = [ctypes.c_uint64, ctypes.POINTER(ctypes.c_int64),
+                                         ctypes.POINTER(ctypes.c_int64), u32p, u64p]
+        L.orc_boolify.restype = ctypes.c_int
+        L.orc_boolify.argtypes = [ctypes.POINTER(_OrcCircuit), ctypes.c_uint32,
+                                  ctypes.POINTER(ctypes.POINTER(_OrcBool))]
+        L.orc_boolify_range.restype = ctypes.c_int
+        L.orc_boolify_range.argtypes = [ctypes.POINTER(_OrcCircuit), ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64,
+                                        ctypes.POINTER(ctypes.POINTER(_OrcBool)), u64p]
+        L.orc_free_bool.argtypes = [ctypes.POINTER(_OrcBool)]
+        L.orc_free_bool.restype = None
+        L.orc_template_size.restype = ctypes.c_int
+        L.orc_template_size.argtypes = [ctypes.c_int, ctypes.c_uint32, u64p, u64p]
+        L.orc_eval_op.restype = ctypes.c_uint64
+        L.orc_eval_op.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32]
+        L.orc_eval_arith.restype = ctypes.c_int
+        L.orc_eval_arith.argtypes = [ctypes.c_uint64, u32p, u32p, u32p, u8p, ctypes.c_uint32, ctypes.c_uint64, u64p]
+        L.orc_eval_bool.restype = ctypes.c_int
+        L.orc_eval_bool.argtypes = [ctypes.c_uint64, u32p, u32p, u32p, u8p, u64p]
+        L.orc_fnv1a.restype = ctypes.c_uint64
+        L.orc_fnv1a.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
+        _lib = L
+    return _lib
+
+
+def _p(a: np.ndarray, ct):
+    return a.ctypes.data_as(ctypes.POINTER(ct))
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+@dataclass
+class ArithCircuit:
+    """Numeric result of build_circuit (sorted order, dense wire ids)."""
+    sorted: np.ndarray
+    in0: np.ndarray
+    in1: np.ndarray
+    out: np.ndarray
+    op: np.ndarray
+    node_wire: np.ndarray
+    wire_count: int
+    n_in: int
+    n_out: int
+
+
+@dataclass
+class BoolCircuit:
+    in0: np.ndarray
+    in1: np.ndarray
+    out: np.ndarray
+    op: np.ndarray
+    wire_count: int
+    width: int
+    n_in: int
+    n_out: int
+
+
+def topo_sort_deps(dep0, dep1) -> np.ndarray:
+    """DFS post-order for explicit deps (-1 = none) — C restatement of topological_sort.rs."""
+    d0, d1 = _c(dep0, np.int64), _c(dep1, np.int64)
+    n = len(d0)
+    out = np.empty(max(n, 1), dtype=np.uint32)
+    cyc = ctypes.c_uint64(0)
+    rc = lib().orc_topo_sort_deps(n, _p(d0, ctypes.c_int64), _p(d1, ctypes.c_int64), _p(out, ctypes.c_uint32),
+                                  ctypes.byref(cyc))
+    if rc == ORC_CYCLIC:
+        raise CyclicDependency(f"detected at i={cyc.value}")
+    if rc:
+        raise RuntimeError(f"oracle error {rc}")
+    return out[:n]
+
+
+def build_circuit(lh, rh, out, op, n_nodes, input_nodes, output_nodes, mode: int = 1,
+                  keep_handle: bool = False):
+    """C restatement of compiler.rs:385-493 on the flat payload. mode 0 = faithful (hash maps), 1 = flat."""
+    lh, rh, out, op = _c(lh, np.uint32), _c(rh, np.uint32), _c(out, np.uint32), _c(op, np.uint8)
+    inn, outn = _c(input_nodes, np.uint32), _c(output_nodes, np.uint32)
+    n = len(lh)
+    res = ctypes.POINTER(_OrcCircuit)()
+    cyc = ctypes.c_uint64(0)
+    rc = lib().orc_build_circuit(n, _p(lh, ctypes.c_uint32), _p(rh, ctypes.c_uint32), _p(out, ctypes.c_uint32),
+                                 _p(op, ctypes.c_uint8), int(n_nodes), len(inn), _p(inn, ctypes.c_uint32),
+                                 len(outn), _p(outn, ctypes.c_uint32), mode, ctypes.byref(res), ctypes.byref(cyc))
+    if rc == ORC_CYCLIC:
+        raise CyclicDependency(f"detected at i={cyc.value}")
+    if rc == ORC_INCONSISTENCY:
+        raise Inconsistency("node used for both input and output")
+    if rc:
+        raise RuntimeError(f"oracle error {rc}")
+    c = res.contents
+
+    def arr(ptr, count, dt):
+        if count == 0:
+            return np.empty(0, dtype=dt)
+        return np.ctypeslib.as_array(ptr, shape=(count,)).astype(dt, copy=True)
+
+    circ = ArithCircuit(sorted=arr(c.sorted, n, np.uint32), in0=arr(c.in0, n, np.uint32),
+                        in1=arr(c.in1, n, np.uint32), out=arr(c.out, n, np.uint32), op=arr(c.op, n, np.uint8),
+                        node_wire=arr(c.node_wire, int(n_nodes), np.uint32), wire_count=int(c.wire_count),
+                        n_in=len(inn), n_out=len(outn))
+    if keep_handle:
+        return circ, res
+    lib().orc_free_circuit(res)
+    return circ
+
+
+def free_circuit(handle):
+    lib().orc_free_circuit(handle)
+
+
+def boolify_handle(handle, width: int, copy: bool = True):
+    res = ctypes.POINTER(_OrcBool)()
+    rc = lib().orc_boolify(handle, width, ctypes.byref(res))
+    if rc == ORC_OVERFLOW:
+        raise OverflowError("boolean wire ids exceed u32")
+    if rc:
+        raise RuntimeError(f"oracle error {rc}")
+    b = res.contents
+    g = int(b.n_gates)
+
+    def arr(ptr, dt):
+        if g == 0:
+            return np.empty(0, dtype=dt)
+        a = np.ctypeslib.as_array(ptr, shape=(g,))
+        return a.astype(dt, copy=True) if copy else a
+
+    bc = BoolCircuit(in0=arr(b.in0, np.uint32), in1=arr(b.in1, np.uint32), out=arr(b.out, np.uint32),
+                     op=arr(b.op, np.uint8), wire_count=int(b.wire_count), width=width, n_in=int(b.n_in),
+                     n_out=int(b.n_out))
+    if copy:
+        lib().orc_free_bool(res)
+        return bc
+    return bc, res
+
+
+def _as_handle(circ: ArithCircuit):
+    c = _OrcCircuit()
+    keep = [_c(circ.sorted, np.uint32), _c(circ.in0, np.uint32), _c(circ.in1, np.uint32), _c(circ.out, np.uint32),
+            _c(circ.op, np.uint8), _c(circ.node_wire, np.uint32)]
+    c.n = len(keep[1])
+    c.n_nodes = len(keep[5])
+    c.n_in, c.n_out, c.wire_count = circ.n_in, circ.n_out, circ.wire_count
+    c.sorted, c.in0, c.in1, c.out = (_p(keep[0], ctypes.c_uint32), _p(keep[1], ctypes.c_uint32),
+                                     _p(keep[2], ctypes.c_uint32), _p(keep[3], ctypes.c_uint32))
+    c.op, c.node_wire = _p(keep[4], ctypes.c_uint8), _p(keep[5], ctypes.c_uint32)
+    return c, keep
+
+
+def boolify_range(circ: ArithCircuit, width: int, first: int, count: int):
+    """Boolean gates of the arithmetic gates at sorted positions [first, first+count) with the global numbering;
+    returns (BoolCircuit slice, global index of its first boolean gate)."""
+    c, keep = _as_handle(circ)
+    res = ctypes.POINTER(_OrcBool)()
+    g0 = ctypes.c_uint64(0)
+    rc = lib().orc_boolify_range(ctypes.pointer(c), width, first, count, ctypes.byref(res), ctypes.byref(g0))
+    if rc:
+        raise RuntimeError(f"oracle error {rc}")
+    b = res.contents
+    g = int(b.n_gates)
+
+    def arr(ptr, dt):
+        return np.ctypeslib.as_array(ptr, shape=(g,)).astype(dt, copy=True) if g else np.empty(0, dtype=dt)
+
+    bc = BoolCircuit(in0=arr(b.in0, np.uint32), in1=arr(b.in1, np.uint32), out=arr(b.out, np.uint32),
+                     op=arr(b.op, np.uint8), wire_count=int(b.wire_count), width=width, n_in=int(b.n_in),
+                     n_out=int(b.n_out))
+    lib().orc_free_bool(res)
+    return bc, g0.value
+
+
+def boolify(circ: ArithCircuit, width: int) -> BoolCircuit:
+    """Frozen bit-blast spec applied to an arithmetic circuit in sorted order."""
+    c = _OrcCircuit()
+    keep = [_c(circ.sorted, np.uint32), _c(circ.in0, np.uint32), _c(circ.in1, np.uint32), _c(circ.out, np.uint32),
+            _c(circ.op, np.uint8), _c(circ.node_wire, np.uint32)]
+    c.n = len(keep[1])
+    c.n_nodes = len(keep[5])
+    c.n_in, c.n_out, c.wire_count = circ.n_in, circ.n_out, circ.wire_count
+    c.sorted, c.in0, c.in1, c.out = (_p(keep[0], ctypes.c_uint32), _p(keep[1], ctypes.c_uint32),
+                                     _p(keep[2], ctypes.c_uint32), _p(keep[3], ctypes.c_uint32))
+    c.op, c.node_wire = _p(keep[4], ctypes.c_uint8), _p(keep[5], ctypes.c_uint32)
+    return boolify_handle(ctypes.pointer(c), width)
+
+
+def template_size(op: int, width: int) -> Tuple[int, int]:
+    g, a = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    rc = lib().orc_template_size(op, width, ctypes.byref(g), ctypes.byref(a))
+    if rc:
+        raise RuntimeError(f"oracle error {rc}")
+    return g.value, a.value
+
+
+def bool_wire(circ: ArithCircuit, aux_total: int, width: int, W, bit=0):
+    """Boolean wire id of (arithmetic wire W, bit) — layout of DESIGN.md §5.1."""
+    W = np.asarray(W, dtype=np.int64)
+    M = circ.wire_count - circ.n_out
+    return np.where(W < M, W * width + bit, M * width + aux_total + (W - M) * width + bit)
+
+
+def eval_op(op: int, a: int, b: int, width: int) -> int:
+    return int(lib().orc_eval_op(op, a, b, width))
+
+
+def eval_arith(circ: ArithCircuit, width: int, wires: np.ndarray) -> np.ndarray:
+    """wires: uint64 [wire_count, T] with inputs/constants filled; evaluated in place and returned."""
+    assert wires.dtype == np.uint64 and wires.flags.c_contiguous and wires.shape[0] == circ.wire_count
+    in0, in1, out, op = _c(circ.in0, np.uint32), _c(circ.in1, np.uint32), _c(circ.out, np.uint32), _c(circ.op, np.uint8)
+    lib().orc_eval_arith(len(in0), _p(in0, ctypes.c_uint32), _p(in1, ctypes.c_uint32), _p(out, ctypes.c_uint32),
+                         _p(op, ctypes.c_uint8), width, wires.shape[1], _p(wires, ctypes.c_uint64))
+    return wires
+
+
+def eval_bool(bc: BoolCircuit, wires: np.ndarray) -> np.ndarray:
+    """wires: uint64 [bool wire_count], 64 test vectors per word, inputs/constants filled."""
+    assert wires.dtype == np.uint64 and wires.shape[0] == bc.wire_count
+    in0, in1, out, op = _c(bc.in0, np.uint32), _c(bc.in1, np.uint32), _c(bc.out, np.uint32), _c(bc.op, np.uint8)
+    lib().orc_eval_bool(len(in0), _p(in0, ctypes.c_uint32), _p(in1, ctypes.c_uint32), _p(out, ctypes.c_uint32),
+                        _p(op, ctypes.c_uint8), _p(wires, ctypes.c_uint64))
+    return wires
+
+
+def fnv1a(a: np.ndarray, seed: int = 0) -> int:
+    a = np.ascontiguousarray(a)
+    return int(lib().orc_fnv1a(a.ctypes.data, a.nbytes, seed))

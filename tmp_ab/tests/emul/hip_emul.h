@@ -1,0 +1,268 @@
+// hip_emul.h — host emulation of the small HIP subset used by circom-2-arithc_amd/csrc.
+//
+// TEST INFRASTRUCTURE ONLY.  There is no GPU in the build container, so the kernel sources are also
+// compiled with g++ against this header (-DC2A_EMULATE) into tests/emul/libc2a_emul.so and driven
+// through the same C ABI by the `-m "not gpu"` tests.  The product library (libc2a_hip.so) never
+// includes this file and the Python host layer never loads the emulated library.
+//
+// Model: one OS thread; a launch runs blocks sequentially; the threads of a block are ucontext fibers
+// that run round-robin between __syncthreads() calls.  Atomics are plain read-modify-writes.
+// Wave-level intrinsics (__ballot, __shfl*, __any, __all) rendezvous the 64 fibers of a wave.
+#pragma once
+#include <ucontext.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint4 { unsigned x, y, z, w; };
+struct uint2 { unsigned x, y; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+
+namespace hipemu {
+struct Fiber {
+    ucontext_t ctx;
+    char* stack = nullptr;
+    dim3 tid;
+    bool done = false;
+    int wait_kind = 0;  // 0 none, 1 block barrier, 2 wave rendezvous
+};
+struct State {
+    dim3 tid, bid, bdim, gdim;
+    Fiber* cur = nullptr;
+    ucontext_t sched;
+    std::function<void()> body;
+    // wave rendezvous scratch
+    unsigned long long wave_vals[64];
+    unsigned wave_arrived = 0;
+    unsigned wave_epoch = 0;
+};
+inline State& st() { static State s; return s; }
+inline void trampoline() {
+    State& s = st();
+    s.body();
+    s.cur->done = true;
+    swapcontext(&s.cur->ctx, &s.sched);
+}
+inline void yield(int kind) {
+    State& s = st();
+    if (!s.cur) { std::fprintf(stderr, "hip_emul: sync primitive used in a NOSYNC launch\n"); std::abort(); }
+    s.cur->wait_kind = kind;
+    swapcontext(&s.cur->ctx, &s.sched);
+}
+constexpr size_t kStack = 256 * 1024;
+
+template <class F>
+void run_block_fibers(unsigned nthreads, dim3 bdim, F&& per_thread) {
+    State& s = st();
+    std::vector<Fiber> fibers(nthreads);
+    for (unsigned t = 0; t < nthreads; ++t) {
+        Fiber& f = fibers[t];
+        f.stack = (char*)std::malloc(kStack);
+        f.tid = dim3(t % bdim.x, (t / bdim.x) % bdim.y, t / (bdim.x * bdim.y));
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = kStack;
+        f.ctx.uc_link = &s.sched;
+        makecontext(&f.ctx, (void (*)())trampoline, 0);
+    }
+    s.body = per_thread;
+    // Waves are scheduled as units so that wave rendezvous complete: run each wave's fibers round-robin
+    // until every fiber of the wave is done or parked at a block barrier; then next wave; repeat.
+    unsigned nwaves = (nthreads + 63) / 64;
+    for (;;) {
+        bool any_alive = false;
+        for (unsigned wv = 0; wv < nwaves; ++wv) {
+            unsigned lo = wv * 64, hi = std::min(nthreads, lo + 64);
+            for (;;) {
+                bool progressed = false;
+                for (unsigned t = lo; t < hi; ++t) {
+                    Fiber& f = fibers[t];
+                    if (f.done || f.wait_kind == 1) continue;
+                    f.wait_kind = 0;
+                    s.cur = &f; s.tid = f.tid;
+                    swapcontext(&s.sched, &f.ctx);
+                    progressed = true;
+                }
+                bool all_parked = true;
+                for (unsigned t = lo; t < hi; ++t) if (!fibers[t].done && fibers[t].wait_kind != 1) all_parked = false;
+                if (all_parked) break;
+                if (!progressed) { std::fprintf(stderr, "hip_emul: wave deadlock\n"); std::abort(); }
+            }
+        }
+        for (unsigned t = 0; t < nthreads; ++t) if (!fibers[t].done) { any_alive = true; fibers[t].wait_kind = 0; }
+        if (!any_alive) break;
+    }
+    s.cur = nullptr;
+    for (auto& f : fibers) std::free(f.stack);
+}
+}  // namespace hipemu
+
+#define threadIdx (hipemu::st().tid)
+#define blockIdx (hipemu::st().bid)
+#define blockDim (hipemu::st().bdim)
+#define gridDim (hipemu::st().gdim)
+#define warpSize 64
+
+inline void __syncthreads() { hipemu::yield(1); }
+inline void __threadfence() {}
+inline void __threadfence_block() {}
+
+// ---- wave intrinsics (all 64 lanes of the wave must call them convergently) ----
+namespace hipemu {
+inline unsigned lane_id() { State& s = st(); return (s.tid.x + s.tid.y * s.bdim.x + s.tid.z * s.bdim.x * s.bdim.y) & 63; }
+inline unsigned wave_width() {
+    State& s = st();
+    unsigned nt = s.bdim.x * s.bdim.y * s.bdim.z;
+    unsigned flat = s.tid.x + s.tid.y * s.bdim.x + s.tid.z * s.bdim.x * s.bdim.y;
+    unsigned lo = flat & ~63u;
+    return std::min(64u, nt - lo);
+}
+// deposit v, wait for the whole wave, return pointer to the 64 values (valid until next rendezvous)
+inline const unsigned long long* rendezvous(unsigned long long v) {
+    State& s = st();
+    static unsigned long long snapshot[64];
+    unsigned width = wave_width();
+    unsigned my_epoch = s.wave_epoch;
+    s.wave_vals[lane_id()] = v;
+    s.wave_arrived++;
+    if (s.wave_arrived == width) {
+        for (unsigned i = 0; i < 64; ++i) snapshot[i] = i < width ? s.wave_vals[i] : 0;
+        s.wave_arrived = 0;
+        s.wave_epoch++;
+    } else {
+        while (s.wave_epoch == my_epoch) yield(2);
+    }
+    return snapshot;
+}
+}  // namespace hipemu
+inline unsigned long long __ballot(int pred) {
+    const unsigned long long* v = hipemu::rendezvous(pred ? 1 : 0);
+    unsigned long long m = 0;
+    for (unsigned i = 0; i < 64; ++i) if (v[i]) m |= 1ull << i;
+    // second rendezvous so nobody overwrites the snapshot before all lanes have read it
+    unsigned long long r = m; hipemu::rendezvous(0);
+    return r;
+}
+inline int __any(int pred) { return __ballot(pred) != 0; }
+inline int __all(int pred) { unsigned w = hipemu::wave_width(); unsigned long long full = w == 64 ? ~0ull : ((1ull << w) - 1); return (__ballot(pred) & full) == full; }
+template <class T> inline T __shfl(T val, int src, int width = 64) {
+    static_assert(sizeof(T) <= 8, "shfl");
+    unsigned long long bits = 0; std::memcpy(&bits, &val, sizeof(T));
+    const unsigned long long* v = hipemu::rendezvous(bits);
+    unsigned lane = hipemu::lane_id();
+    unsigned base = lane & ~(unsigned)(width - 1);
+    unsigned long long got = v[base + ((unsigned)src & (unsigned)(width - 1))];
+    hipemu::rendezvous(0);
+    T out; std::memcpy(&out, &got, sizeof(T)); return out;
+}
+template <class T> inline T __shfl_up(T val, unsigned delta, int width = 64) {
+    unsigned lane = hipemu::lane_id(); unsigned in = lane & (unsigned)(width - 1);
+    T o = __shfl(val, in >= delta ? (int)(in - delta) : (int)in, width);
+    return in >= delta ? o : val;
+}
+template <class T> inline T __shfl_down(T val, unsigned delta, int width = 64) {
+    unsigned lane = hipemu::lane_id(); unsigned in = lane & (unsigned)(width - 1);
+    T o = __shfl(val, in + delta < (unsigned)width ? (int)(in + delta) : (int)in, width);
+    return in + delta < (unsigned)width ? o : val;
+}
+template <class T> inline T __shfl_xor(T val, int mask, int width = 64) {
+    unsigned lane = hipemu::lane_id(); unsigned in = lane & (unsigned)(width - 1);
+    return __shfl(val, (int)(in ^ (unsigned)mask), width);
+}
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+inline int __popc(unsigned x) { return __builtin_popcount(x); }
+inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+inline int __ffs(unsigned x) { return __builtin_ffs((int)x); }
+inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
+inline int __clzll(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
+inline unsigned __lane_id() { return hipemu::lane_id(); }
+
+// ---- atomics ----
+template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> inline T atomicSub(T* p, T v) { T o = *p; *p = o - v; return o; }
+template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <class T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <class T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <class T> inline T atomicAnd(T* p, T v) { T o = *p; *p = o & v; return o; }
+template <class T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
+template <class T> inline T atomicCAS(T* p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
+
+// ---- runtime ----
+typedef int hipError_t;
+typedef int hipStream_t;
+struct hipEventImpl { std::chrono::steady_clock::time_point t; };
+typedef hipEventImpl* hipEvent_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+struct hipDeviceProp_t { int multiProcessorCount; char name[64]; char gcnArchName[64]; size_t totalGlobalMem; };
+
+inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hip_emul error"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+    p->multiProcessorCount = 4; std::strcpy(p->name, "hip_emul"); std::strcpy(p->gcnArchName, "emul"); p->totalGlobalMem = 1ull << 34; return hipSuccess;
+}
+inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); if (*p) std::memset(*p, 0xA5, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { if (n) std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) std::memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { if (n) std::memset(d, v, n); return hipSuccess; }
+inline hipError_t hipStreamCreate(hipStream_t* s) { *s = 0; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipEventImpl(); return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess;
+}
+inline hipError_t hipMemGetInfo(size_t* f, size_t* t) { *f = 1ull << 33; *t = 1ull << 34; return hipSuccess; }
+
+// ---- launches ----
+// kernels that use __syncthreads / wave intrinsics: fibers
+template <class K, class... A>
+inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, A... args) {
+    hipemu::State& s = hipemu::st();
+    s.gdim = grid; s.bdim = block;
+    unsigned nthreads = block.x * block.y * block.z;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                s.bid = dim3(bx, by, bz);
+                hipemu::run_block_fibers(nthreads, block, [&]() { kernel(args...); });
+            }
+}
+// kernels with no intra-block synchronisation: plain loops (fast path)
+template <class K, class... A>
+inline void hipemuLaunchNoSync(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, A... args) {
+    hipemu::State& s = hipemu::st();
+    s.gdim = grid; s.bdim = block; s.cur = nullptr;
+    for (unsigned bx = 0; bx < grid.x; ++bx) {
+        s.bid = dim3(bx, 0, 0);
+        for (unsigned tx = 0; tx < block.x; ++tx) { s.tid = dim3(tx, 0, 0); kernel(args...); }
+    }
+}

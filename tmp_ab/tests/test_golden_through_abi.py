@@ -1,0 +1,111 @@
+"""The reference's integration tests (tests/integration.rs:279-441), replayed through the product's host
+mirror of `Compiler` and the C ABI (HIP kernels; or the emulated build on a CPU-only box).
+Reads like the reference's tests: build the Compiler state, build_circuit(), check maps / simulate."""
+import importlib
+
+import numpy as np
+import pytest
+
+from helpers import load_fixtures, simulate_arith, simulate_bool
+
+FX = load_fixtures()
+SCRIPTED = [n for n in FX if FX[n]["script"] is not None]
+
+
+def _compiler(fx, backend):
+    comp_mod = importlib.import_module("circom-2-arithc_amd.compiler")
+    c = comp_mod.Compiler(backend=backend)
+    for step in fx["script"]:
+        if step[0] == "signal":
+            c.add_signal(step[1], step[2], step[3])
+        elif step[0] == "gate":
+            c.add_gate(step[1], step[2], step[3], step[4])
+        else:
+            c.add_connection(step[1], step[2])
+    for p in fx["input_prefixes"]:
+        c.add_inputs(c.get_signals(f"0.{p}"))
+    for p in fx["output_prefixes"]:
+        c.add_outputs(c.get_signals(f"0.{p}"))
+    return c
+
+
+@pytest.mark.parametrize("name", SCRIPTED)
+def test_integration_fixture(name, backend, orc):
+    fx = FX[name]
+    comp = _compiler(fx, backend)
+    assert [list(g) for g in comp.gates] == fx["gates"]
+    circuit = comp.build_circuit()
+    exp = fx["expect"]
+    consts = {k: {"value": c.value, "wire_index": c.wire_index} for k, c in circuit.info.constants.items()}
+    if "hand" in exp:
+        assert circuit.wire_count == exp["hand"]["wire_count"]
+        for k, v in exp["hand"].get("constants", {}).items():
+            assert consts[k] == v
+    if "constants_exact" in exp:                                          # test_constant_sum
+        assert consts == exp["constants_exact"]
+    if "outputs_exact" in exp:                                            # test_direct_output
+        assert circuit.info.output_name_to_wire_index == exp["outputs_exact"]
+        assert len(consts) == exp["constants_len"]
+        (k, v), = exp["constant_exact"].items()
+        assert consts[k] == v
+    if "io" in exp:                                                       # simulation_test
+        ins = {circuit.info.input_name_to_wire_index[k]: v for k, v in exp["io"]["inputs"].items()}
+        cst = {c.wire_index: int(c.value) for c in circuit.info.constants.values()}
+        vals = simulate_arith(orc, circuit.in0, circuit.in1, circuit.out, circuit.op, circuit.wire_count,
+                              len(ins), len(exp["io"]["outputs"]), ins, cst)
+        for k, v in exp["io"]["outputs"].items():
+            assert int(vals[circuit.info.output_name_to_wire_index[k]]) == v, k
+        # --boolify-width 32 (src/main.rs:30-32): same answers from the boolean circuit
+        bi_circ = comp.boolify(circuit, 32)
+        bi = comp.backend().bool_info
+        val = simulate_bool(orc, bi_circ.in0, bi_circ.in1, bi_circ.out, bi_circ.op, bi_circ.wire_count, 32,
+                            lambda W, b: bi.wire(W, b), ins, cst)
+        for k, v in exp["io"]["outputs"].items():
+            assert val(circuit.info.output_name_to_wire_index[k]) == v, k
+        assert bi_circ.io_widths == ([32] * len(ins), [32] * len(exp["io"]["outputs"]))
+        for k, w in circuit.info.input_name_to_wire_index.items():
+            assert bi_circ.info.input_name_to_wire_index[k] == w * 32
+
+
+def test_argmax2_shipped_input(backend, orc):
+    """BASELINE config C1: input/circuit.circom = ArgMax(2), flat list of SURVEY A.5."""
+    fx = FX["argmax2"]
+    g = fx["gates"]
+    backend.load_gates([x[1] for x in g], [x[2] for x in g], [x[3] for x in g], [orc.OP[x[0]] for x in g],
+                       fx["n_nodes"], fx["input_nodes"], fx["output_nodes"])
+    np.testing.assert_array_equal(backend.topo_sort(), np.arange(len(g)))
+    nw, wc = backend.assign_wires()
+    h = fx["expect"]["hand"]
+    assert wc == h["wire_count"]
+    for node, w in h["node_wire"].items():
+        assert int(nw[int(node)]) == w
+    in0, in1, out, op = backend.emit_gates()
+    cst = {int(nw[v[0]]): int(v[1]) for v in fx["constants"].values()}
+    for case in fx["expect"]["io_cases"]:
+        ins = {int(nw[n]): case["inputs"][nm] for nm, n in zip(fx["input_names"], fx["input_nodes"])}
+        vals = simulate_arith(orc, in0, in1, out, op, wc, 2, 1, ins, cst)
+        assert int(vals[int(nw[fx["output_nodes"][0]])]) == case["outputs"]["0.out"]
+
+
+def test_bristol_text_and_info_json_round_trip(backend, orc, tmp_path):
+    """Artefacts of src/main.rs:34-47: circuit.txt + circuit_info.json."""
+    bristol = importlib.import_module("circom-2-arithc_amd.bristol")
+    comp = _compiler(FX["addZero"], backend)
+    circuit = comp.build_circuit()
+    p = tmp_path / "circuit.txt"
+    with open(p, "w") as f:
+        circuit.write_bristol(f)
+    ng, nw, iw, ow, gates = bristol.read_bristol(p.read_text())
+    assert (ng, nw, iw, ow) == (1, 3, [1], [1])
+    assert gates == [([0, 1], [2], "AAdd")]
+    import json
+    info = json.loads(circuit.info_json())
+    assert info == {"input_name_to_wire_index": {"0.in": 0},
+                    "constants": {"0.const_signal_0_2": {"value": "0", "wire_index": 1}},
+                    "output_name_to_wire_index": {"0.out": 2}}
+    b = comp.boolify(circuit, 4)
+    with open(p, "w") as f:
+        b.write_bristol(f)
+    ng, nw, iw, ow, gates = bristol.read_bristol(p.read_text())
+    assert ng == b.n_gates and nw == b.wire_count and iw == [4] and ow == [4]
+    assert all(len(g[0]) == (1 if g[2] == "INV" else 2) for g in gates)

@@ -1,0 +1,106 @@
+"""Parity of the HIP boolify map (c2a_boolify, replacing boolify(&circuit, w) of src/main.rs:30-32) with the
+oracle's procedural restatement of the frozen bit-blast spec — bit-exact SoA — plus functional
+equivalence with the arithmetic circuit under the semantics of tests/integration.rs:94-115 (mod 2^w).
+(The boolify crate itself is absent: gate-level parity with it is unpinned.)"""
+import numpy as np
+import pytest
+
+
+def _load(be, fg):
+    be.load_gates(fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes)
+    be.build_circuit()
+
+
+def _oracle(orc, fg):
+    return orc.build_circuit(fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes, mode=1)
+
+
+def test_template_sizes_match_spec(backend, orc):
+    for w in (1, 2, 3, 8, 31, 32, 64):
+        for op in range(20):
+            if op == orc.OP["APow"] and w > 32:
+                continue
+            assert backend.template_size(op, w) == orc.template_size(op, w), (orc.OP_NAMES[op], w)
+
+
+@pytest.mark.parametrize("width", [1, 2, 7, 8, 32, 64])
+def test_boolify_bit_exact(backend, orc, c2a, width):
+    mix = c2a.synth.MIX_ALL if width <= 8 else tuple(m for m in c2a.synth.MIX_ALL if m[0] != "APow")
+    fg = c2a.synth.layered_dag(12, 24, n_in=16, n_const=4, window=4, mix=mix, seed=100 + width)
+    _load(backend, fg)
+    info = backend.boolify(width)
+    exp_c = _oracle(orc, fg)
+    exp = orc.boolify(exp_c, width)
+    assert info.n_gates == len(exp.in0)
+    assert info.wire_count == exp.wire_count
+    assert (info.n_in, info.n_out, info.m_wires) == (exp_c.n_in, exp_c.n_out, exp_c.wire_count - exp_c.n_out)
+    in0, in1, out, op = backend.bool_read()
+    np.testing.assert_array_equal(op, exp.op)
+    np.testing.assert_array_equal(in0, exp.in0)
+    np.testing.assert_array_equal(in1, exp.in1)
+    np.testing.assert_array_equal(out, exp.out)
+    # ranged read-back
+    a = backend.bool_read(5, 11)
+    np.testing.assert_array_equal(a[2], exp.out[5:16])
+
+
+@pytest.mark.parametrize("width", [8, 32])
+def test_boolean_circuit_computes_the_arithmetic_circuit(backend, orc, c2a, width):
+    """64 random input vectors: every arithmetic wire's value == its w boolean wires."""
+    mix = tuple(m for m in c2a.synth.MIX_ALL if m[0] != "APow") if width > 8 else c2a.synth.MIX_ALL
+    fg = c2a.synth.layered_dag(10, 16, n_in=8, n_const=3, window=3, mix=mix, seed=width)
+    _load(backend, fg)
+    nw, wc = backend.assign_wires()
+    in0, in1, out, op = backend.emit_gates()
+    info = backend.boolify(width)
+    b = backend.bool_read()
+    rng = np.random.default_rng(width)
+    T = 64
+    mask = (1 << width) - 1
+    free = [int(nw[n]) for n in list(fg.input_nodes) + list(fg.const_nodes) if nw[n] != 0xFFFFFFFF]
+    circ = orc.ArithCircuit(sorted=np.empty(0, np.uint32), in0=in0, in1=in1, out=out, op=op,
+                            node_wire=np.empty(0, np.uint32), wire_count=wc, n_in=len(fg.input_nodes),
+                            n_out=len(fg.output_nodes))
+    vals = np.zeros((wc, T), np.uint64)
+    for W in free:
+        vals[W] = rng.integers(0, 2 ** 63, T, dtype=np.uint64) & np.uint64(mask)
+        vals[W, :4] = [0, mask, 1, mask >> 1]
+    orc.eval_arith(circ, width, vals)
+    bw = np.zeros(info.wire_count, np.uint64)
+    for W in free:
+        for bit in range(width):
+            word = 0
+            for t in range(T):
+                word |= ((int(vals[W, t]) >> bit) & 1) << t
+            bw[int(info.wire(W, bit))] = word
+    bc = orc.BoolCircuit(in0=b[0], in1=b[1], out=b[2], op=b[3], wire_count=info.wire_count, width=width, n_in=0, n_out=0)
+    orc.eval_bool(bc, bw)
+    produced = np.unique(out)
+    for W in produced.tolist():
+        for t in (0, 1, 2, 3, 17, 63):
+            got = 0
+            for bit in range(width):
+                got |= ((int(bw[int(info.wire(W, bit))]) >> t) & 1) << bit
+            assert got == int(vals[W, t]), (W, t)
+
+
+def test_boolify_empty_circuit(backend):
+    e = np.empty(0, np.uint32)
+    backend.load_gates(e, e, e, np.empty(0, np.uint8), 4, [1], [2])
+    assert backend.build_circuit() == 2
+    info = backend.boolify(16)
+    assert (info.n_gates, info.wire_count, info.aux_total) == (0, 32, 0)
+
+
+def test_call_order_is_enforced(backend, c2a):
+    e = np.empty(0, np.uint32)
+    backend.load_gates(e, e, e, np.empty(0, np.uint8), 2, [], [])
+    with pytest.raises(c2a.BackendError):
+        backend.boolify(8)
+    with pytest.raises(c2a.BackendError):
+        backend.emit_gates()
+    backend.build_circuit()
+    with pytest.raises(c2a.BackendError):
+        backend.boolify(0)
+    with pytest.raises(c2a.BackendError):
+        backend.boolify(65)

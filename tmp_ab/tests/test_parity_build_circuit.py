@@ -1,0 +1,179 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle for the build_circuit numeric core:
+sorted_gate_ids (src/topological_sort.rs:3-50), node->wire numbering (src/compiler.rs:388-449), emitted
+gates (src/compiler.rs:451-464), and the cycle diagnostic.  Bit-exact: integer/index work."""
+import numpy as np
+import pytest
+
+from conftest import random_gate_graph
+
+
+def _compare(be, orc, p, check_serial=True):
+    args = (p["lh"], p["rh"], p["out"], p["op"], p["n_nodes"], p["input_nodes"], p["output_nodes"])
+    try:
+        exp = orc.build_circuit(*args, mode=1)
+        exp_err = None
+    except (orc.CyclicDependency, orc.Inconsistency) as e:
+        exp, exp_err = None, e
+    be.load_gates(*args)
+    if isinstance(exp_err, orc.Inconsistency):
+        # the in/out clash is checked before the sort in the reference (compiler.rs:363-383); the ABI reports
+        # it from c2a_assign_wires — the host mirror (compiler.py) checks names first, like the reference.
+        try:
+            be.topo_sort()
+        except Exception:
+            return "cyclic-and-inconsistent"
+        with pytest.raises(Exception) as ei:
+            be.assign_wires()
+        assert "Inconsistency" in str(ei.value)
+        return "inconsistent"
+    if exp_err is not None:
+        with pytest.raises(Exception) as ei:
+            be.topo_sort()
+        assert str(ei.value) == str(exp_err), (str(ei.value), str(exp_err))
+        if check_serial:
+            with pytest.raises(Exception) as ei2:
+                be.topo_sort(serial=True)
+            assert str(ei2.value) == str(exp_err)
+        return "cyclic"
+    got_sorted = be.topo_sort()
+    np.testing.assert_array_equal(got_sorted, exp.sorted)
+    if check_serial:
+        np.testing.assert_array_equal(be.topo_sort(serial=True), exp.sorted)
+        be.topo_sort()
+    nw, wc = be.assign_wires()
+    assert wc == exp.wire_count
+    np.testing.assert_array_equal(nw, exp.node_wire)
+    in0, in1, out, op = be.emit_gates()
+    np.testing.assert_array_equal(in0, exp.in0)
+    np.testing.assert_array_equal(in1, exp.in1)
+    np.testing.assert_array_equal(out, exp.out)
+    np.testing.assert_array_equal(op, exp.op)
+    return "ok"
+
+
+def test_random_small_graphs(backend, orc):
+    rng = np.random.default_rng(20241008)
+    seen = {"ok": 0, "cyclic": 0, "inconsistent": 0, "cyclic-and-inconsistent": 0}
+    for trial in range(250):
+        n = int(rng.integers(1, 60))
+        p = random_gate_graph(rng, n, p_dup_out=0.1 if trial % 3 == 0 else 0.0, p_same=0.15,
+                              p_cycle=0.08 if trial % 4 == 0 else 0.0)
+        seen[_compare(backend, orc, p)] += 1
+    assert seen["ok"] > 60 and seen["cyclic"] > 5, seen
+
+
+def test_empty_and_single(backend, orc):
+    e = np.empty(0, np.uint32)
+    p = dict(lh=e, rh=e, out=e, op=np.empty(0, np.uint8), n_nodes=5, input_nodes=np.array([1, 2], np.uint32),
+             output_nodes=np.array([4], np.uint32))
+    assert _compare(backend, orc, p) == "ok"
+    # zero gates, zero IO
+    p = dict(lh=e, rh=e, out=e, op=np.empty(0, np.uint8), n_nodes=1, input_nodes=e, output_nodes=e)
+    assert _compare(backend, orc, p) == "ok"
+    # one gate reading one node twice (xEqX shape)
+    p = dict(lh=np.array([1], np.uint32), rh=np.array([1], np.uint32), out=np.array([4], np.uint32),
+             op=np.array([2], np.uint8), n_nodes=5, input_nodes=np.array([1], np.uint32),
+             output_nodes=np.array([4], np.uint32))
+    assert _compare(backend, orc, p) == "ok"
+
+
+def test_self_loop_and_two_cycle(backend, orc):
+    # gate 0 reads its own output
+    p = dict(lh=np.array([3], np.uint32), rh=np.array([1], np.uint32), out=np.array([3], np.uint32),
+             op=np.array([0], np.uint8), n_nodes=4, input_nodes=np.array([1], np.uint32),
+             output_nodes=np.empty(0, np.uint32))
+    assert _compare(backend, orc, p) == "cyclic"
+    # a sink consumes a 2-cycle: the DFS enters the cycle through the peeled gate
+    p = dict(lh=np.array([5, 6, 7], np.uint32), rh=np.array([1, 1, 5], np.uint32), out=np.array([6, 5, 8], np.uint32),
+             op=np.zeros(3, np.uint8), n_nodes=9, input_nodes=np.array([1], np.uint32),
+             output_nodes=np.array([8], np.uint32))
+    assert _compare(backend, orc, p) == "cyclic"
+
+
+def test_input_is_output_inconsistency(backend, orc):
+    p = dict(lh=np.array([1], np.uint32), rh=np.array([2], np.uint32), out=np.array([3], np.uint32),
+             op=np.array([0], np.uint8), n_nodes=4, input_nodes=np.array([1, 2], np.uint32),
+             output_nodes=np.array([2], np.uint32))
+    assert _compare(backend, orc, p) == "inconsistent"
+
+
+def test_duplicate_io_nodes_last_wins(backend, orc):
+    # two input names on one node / two output names on one node: later insert overwrites (compiler.rs:392-395,446-449)
+    p = dict(lh=np.array([1, 3], np.uint32), rh=np.array([2, 1], np.uint32), out=np.array([3, 4], np.uint32),
+             op=np.array([0, 7], np.uint8), n_nodes=5, input_nodes=np.array([1, 2, 1], np.uint32),
+             output_nodes=np.array([4, 4], np.uint32))
+    assert _compare(backend, orc, p) == "ok"
+
+
+@pytest.mark.parametrize("layers,width,window", [(40, 25, 4), (300, 12, 64), (700, 3, 2)])
+def test_layered_dags(backend, orc, c2a, layers, width, window):
+    fg = c2a.synth.layered_dag(layers, width, n_in=32, n_const=4, window=window, mix=c2a.synth.MIX_ALL, seed=7 + layers)
+    p = dict(lh=fg.lh, rh=fg.rh, out=fg.out, op=fg.op, n_nodes=fg.n_nodes, input_nodes=fg.input_nodes,
+             output_nodes=fg.output_nodes)
+    assert _compare(backend, orc, p, check_serial=(layers <= 300)) == "ok"
+    st = backend.stats()
+    assert st["levels"] >= layers
+
+
+def test_deep_chain_exercises_upper_ancestor_planes(backend, orc):
+    """A 9000-deep dependency chain with side branches: tree depth > 16^3, so all four base-16 digit planes
+    of the ancestor table and the long level-ancestor jumps are used."""
+    rng = np.random.default_rng(5)
+    depth = 9000
+    # chain gate k (ids permuted) : out = node 10+k, lh = node 10+k-1 ; side gates hang off random chain nodes
+    n_side = 1500
+    n = depth + n_side
+    perm = rng.permutation(n)
+    lh = np.empty(n, np.uint32); rh = np.empty(n, np.uint32); out = np.empty(n, np.uint32)
+    for k in range(depth):
+        g = perm[k]
+        out[g] = 10 + k
+        lh[g] = 10 + k - 1 if k else 1
+        rh[g] = 2 if rng.random() < 0.9 else (10 + int(rng.integers(0, k)) if k else 2)
+    for s in range(n_side):
+        g = perm[depth + s]
+        out[g] = 10 + depth + s
+        a = 10 + int(rng.integers(0, depth)); b = 10 + int(rng.integers(0, depth + s))
+        lh[g], rh[g] = (a, b) if rng.random() < 0.5 else (b, a)
+    p = dict(lh=lh, rh=rh, out=out, op=rng.integers(0, 20, n).astype(np.uint8), n_nodes=10 + n + 1,
+             input_nodes=np.array([1, 2], np.uint32), output_nodes=np.array([10 + depth - 1], np.uint32))
+    assert _compare(backend, orc, p, check_serial=False) == "ok"
+    assert backend.stats()["max_depth"] >= 4096
+
+
+def test_wave_per_gate_kernel_small_graphs(backend_wave, orc):
+    """k_peel_level_wave (all-pairs tournament, workgroup-aggregated appends) on adversarial small graphs."""
+    rng = np.random.default_rng(4242)
+    seen = {"ok": 0, "cyclic": 0, "inconsistent": 0, "cyclic-and-inconsistent": 0}
+    for trial in range(40):
+        n = int(rng.integers(1, 48))
+        p = random_gate_graph(rng, n, p_dup_out=0.1 if trial % 3 == 0 else 0.0, p_same=0.15,
+                              p_cycle=0.08 if trial % 4 == 0 else 0.0)
+        seen[_compare(backend_wave, orc, p, check_serial=False)] += 1
+    assert seen["ok"] >= 8, seen
+
+
+def test_wave_per_gate_kernel_high_fanout(backend_wave, orc):
+    """One producer read by 150 consumers spread over several DFS roots: chunks of 64 candidates, groups of 11,
+    champion carried across chunks."""
+    rng = np.random.default_rng(77)
+    n_cons = 150
+    chain = 40
+    n = 1 + n_cons + chain
+    perm = rng.permutation(n)
+    lh = np.empty(n, np.uint32); rh = np.empty(n, np.uint32); out = np.empty(n, np.uint32)
+    hub = perm[0]
+    lh[hub], rh[hub], out[hub] = 1, 2, 10                        # the hub gate: node 10
+    for k in range(n_cons):                                       # consumers of the hub, some via lh some via rh
+        g = perm[1 + k]
+        other = 10 + 1 + int(rng.integers(0, k)) if k and rng.random() < 0.7 else 1
+        lh[g], rh[g] = (10, other) if rng.random() < 0.5 else (other, 10)
+        out[g] = 11 + k
+    for k in range(chain):                                        # a chain on top so consumers sit at many depths
+        g = perm[1 + n_cons + k]
+        lh[g] = 11 + int(rng.integers(0, n_cons)) if k == 0 else 11 + n_cons + k - 1
+        rh[g] = 11 + int(rng.integers(0, n_cons))
+        out[g] = 11 + n_cons + k
+    p = dict(lh=lh, rh=rh, out=out, op=rng.integers(0, 20, n).astype(np.uint8), n_nodes=11 + n + 2,
+             input_nodes=np.array([1, 2], np.uint32), output_nodes=np.array([11 + n_cons + chain - 1], np.uint32))
+    assert _compare(backend_wave, orc, p, check_serial=False) == "ok"
