@@ -41,6 +41,9 @@ struct c2a_ctx {
     int n_cu = 256;
     u32 peel_wave_max = 8192;      // frontier size up to which a level gets one wave per gate
     u32 bool_chunk = 256;          // arithmetic gates per k_boolify workgroup: 128, 256 (measured best) or 512
+    bool peel_persist_sc1 = true;  // persistent peel: bulk data by sc1 accesses (true) or plain accesses + fences (false)
+    u32 peel_persist_max = 0;      // frontier size below which the rest of the peel runs as ONE persistent single-XCD launch;
+                                   // 0 = never (default: measured 1.8x SLOWER than a launch per level)
     u32 peel_wpb = 8;              // gates (waves) per workgroup in wave mode: 4, 8 or 16 (8 measured best)
 
     // problem
@@ -57,7 +60,7 @@ struct c2a_ctx {
     DevBuf prod1, dep0, dep1, cons_cnt, cons_off, fill, cand, meta, anc, fcount, fbase, order, posof, ginfo, slots0, slots1;
     DevBuf rflag, ridx, rlist, next, owner, local, slist, snext, ssum, jnxt, jval, sorted;
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op;
-    DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof;
+    DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof, peel_ctl;
     DevBuf tsz, asz, goff, aoff, tmpl, tables, b_in0, b_in1, b_out, b_op;
     std::vector<DevBuf*> all;
 
@@ -65,7 +68,7 @@ struct c2a_ctx {
         all = {&lh, &rh, &out, &op, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &fill, &cand,
                &ginfo, &slots0, &slots1, &meta, &anc, &fcount, &fbase, &order, &posof, &rflag, &ridx, &rlist, &next,
                &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
-               &node_wire, &e_in0, &e_in1, &e_out, &e_op, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &tsz, &asz, &goff,
+               &node_wire, &e_in0, &e_in1, &e_out, &e_op, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &peel_ctl, &tsz, &asz, &goff,
                &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op};
     }
 };
@@ -220,6 +223,7 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
     u32 batch = 8;
     const u32 max_blocks = (u32)c->n_cu * 8;
     u32 peeled = 0;
+    bool profiling_done = false;
     while (true) {
         // narrow frontier -> one wave per gate (latency ~ one path comparison per level);
         // wide frontier   -> one lane per gate (throughput)
@@ -253,6 +257,46 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
         for (u32 k = 0; k <= look; ++k) mx = std::max(mx, tail[k]);
         est = mx;
         batch = std::min<u32>(batch * 2, 512u);
+        if (c->peel_persist_max && est <= c->peel_persist_max) {
+            // the frontier has narrowed: finish every remaining level inside one persistent launch
+            ENSURE(c->peel_ctl, sizeof(PeelCtl));
+            PeelCtl init;
+            std::memset(&init, 0, sizeof(init));
+            init.chosen_xcd = 0xFFFFFFFFu;
+            HIP_TRY(hipMemcpyAsync(c->peel_ctl.p, &init, sizeof(init), hipMemcpyHostToDevice, s));
+#ifdef C2A_EMULATE
+            const u32 wgs = 1;                       // the emulation runs workgroups one after the other
+#else
+            const u32 wgs = (u32)c->n_cu;            // one per CU: all resident, one XCD's worth takes part
+#endif
+            if (c->peel_persist_sc1) C2A_LAUNCH((k_peel_persistent<true>), wgs, kPGroupsPerWg * 16, s, A, level, c->peel_ctl.as<PeelCtl>());
+            else C2A_LAUNCH((k_peel_persistent<false>), wgs, kPGroupsPerWg * 16, s, A, level, c->peel_ctl.as<PeelCtl>());
+            ++launches;
+            PeelCtl fin;
+            HIP_TRY(hipMemcpyAsync(&fin, c->peel_ctl.p, sizeof(fin), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (profiling) {
+                std::vector<ull> hp(64 * 64 * 8);
+                HIP_TRY(hipMemcpy(hp.data(), c->peel_prof.p, hp.size() * sizeof(ull), hipMemcpyDeviceToHost));
+                double acc[6] = {0}; u32 used = 0; double fr = 0;
+                for (u32 L = 8; L < 64; ++L) {
+                    fr += (double)hp[((size_t)L * 64 + 63) * 8 + 7];
+                    // per level: slowest workgroup's deltas since that level's earliest start
+                    ull t0 = ~0ull; ull mx[6] = {0};
+                    for (u32 r = 0; r < fin.joined && r < 64; ++r) { const ull* q = &hp[((size_t)L * 64 + r) * 8]; if (q[0]) t0 = std::min(t0, q[0]); }
+                    if (t0 == ~0ull) continue;
+                    for (u32 r = 0; r < fin.joined && r < 64; ++r) { const ull* q = &hp[((size_t)L * 64 + r) * 8]; for (int k = 0; k < 6; ++k) if (q[k]) mx[k] = std::max(mx[k], q[k] - t0); }
+                    ++used;
+                    for (int k = 0; k < 6; ++k) acc[k] += (double)mx[k] * 10.0;
+                }
+                if (used) std::fprintf(stderr, "[c2a persistent profile] %u levels (mean frontier %.0f), ns since the level's first workgroup started (max over %u workgroups): start-skew=%.0f groups-done=%.0f sync1=%.0f appended=%.0f drained=%.0f barrier-done=%.0f\n",
+                                       used, fr / 56.0, fin.joined, acc[0] / used, acc[1] / used, acc[2] / used, acc[3] / used, acc[4] / used, acc[5] / used);
+            }
+            level = fin.last_level;
+            c->stats.persistent_wgs = fin.joined;
+            profiling_done = true;
+            break;
+        }
     }
     {
         u32* tot = c->scalars.as<u32>() + SC_PEELED;
@@ -264,7 +308,7 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
         c->stats.levels = t2[1];
     }
     c->stats.level_launches = launches;
-    if (profiling) {   // diagnostics: mean over levels of the slowest wave's phase timestamps (ns since kernel entry)
+    if (profiling && !profiling_done) {   // diagnostics: mean over levels of the slowest wave's phase timestamps (ns since kernel entry)
         std::vector<ull> hp((size_t)kProfLevels * kProfWaves * 8);
         HIP_TRY(hipMemcpy(hp.data(), c->peel_prof.p, hp.size() * sizeof(ull), hipMemcpyDeviceToHost));
         for (u32 L = 0; L < kProfLevels; L += 8) {
@@ -491,6 +535,8 @@ int c2a_create(int device_id, c2a_ctx** out) {
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
         c->n_cu = prop.multiProcessorCount;
     if (const char* e = std::getenv("C2A_BOOL_CHUNK")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 128 || v == 256 || v == 512) c->bool_chunk = v; }
+    if (const char* e = std::getenv("C2A_PEEL_PERSIST_SC1")) c->peel_persist_sc1 = std::strtoul(e, nullptr, 10) != 0;
+    if (const char* e = std::getenv("C2A_PEEL_PERSIST_MAX")) c->peel_persist_max = (u32)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("C2A_PEEL_WPB")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 4 || v == 8 || v == 16) c->peel_wpb = v; }
     if (const char* e = std::getenv("C2A_PEEL_WAVE_MAX")) c->peel_wave_max = (u32)std::strtoul(e, nullptr, 10);   // tuning / test knob
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return C2A_ERR_HIP; }

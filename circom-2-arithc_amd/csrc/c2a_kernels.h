@@ -187,21 +187,55 @@ struct PeelArgs {
     u32 prof_level0;           // first level recorded
 };
 
-__device__ __forceinline__ u32 anc_entry(const u32* anc, u64 plane, int j, u32 x, u32 d) {
-    return anc[(u64)j * plane + (u64)x * 16 + d];
+// Two access flavours.  SC1 = false: plain loads/stores — data produced by EARLIER launches (the kernel
+// boundary publishes it).  SC1 = true: relaxed agent-scope atomics (global_load/store ... sc1: write-through
+// stores, L1-bypassing loads) — data exchanged between workgroups INSIDE one persistent launch; the only form
+// that handed off without stale reads in tools/ubench/xcd.hip (plain stores + nt or sc1 loads did not).
+template <bool SC1> __device__ __forceinline__ u32 ld_u32(const u32* p) {
+    if (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool SC1> __device__ __forceinline__ void st_u32(u32* p, u32 v) {
+    if (SC1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool SC1> __device__ __forceinline__ uint4 ld_u128(const uint4* p) {
+    if (SC1) {
+        const u64* q = reinterpret_cast<const u64*>(p);
+        const u64 a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_uint4((u32)a, (u32)(a >> 32), (u32)b, (u32)(b >> 32));
+    }
+    return *p;
+}
+template <bool SC1> __device__ __forceinline__ void st_u128(uint4* p, const uint4& v) {
+    if (SC1) {
+        u64* q = reinterpret_cast<u64*>(p);
+        __hip_atomic_store(q, (u64)v.x | ((u64)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 1, (u64)v.z | ((u64)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *p = v;
+    }
 }
 
+template <bool SC1>
+__device__ __forceinline__ u32 anc_entry(const u32* anc, u64 plane, int j, u32 x, u32 d) {
+    return ld_u32<SC1>(anc + (u64)j * plane + (u64)x * 16 + d);
+}
+
+template <bool SC1>
 __device__ __forceinline__ void load_row(const u32* anc, u64 plane, int j, u32 x, u32 (&r)[16]) {
     const uint4* p = reinterpret_cast<const uint4*>(anc + (u64)j * plane + (u64)x * 16);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const uint4 v = p[q];
+        const uint4 v = ld_u128<SC1>(p + q);
         r[4 * q + 0] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
     }
 }
 
 // Two lifts of the same node in one pass (their loads are independent and overlap): xe = ancestor at `dist`,
 // ye = ancestor at `dist - 1`, both as labelled entries.  dist >= 1; `self` = the node's own labelled entry.
+template <bool SC1>
 __device__ __forceinline__ void lift2(const u32* anc, u64 plane, u32 self, u32 dist, u32& xe, u32& ye) {
     u32 x = self, y = self;
     u32 dx = dist, dy = dist - 1;
@@ -209,8 +243,8 @@ __device__ __forceinline__ void lift2(const u32* anc, u64 plane, u32 self, u32 d
     while (dx | dy) {
         const u32 ex = dx & 15u, ey = dy & 15u;
         u32 nx = x, ny = y;
-        if (ex) nx = anc_entry(anc, plane, j, x & kIdMask, ex - 1);
-        if (ey) ny = anc_entry(anc, plane, j, y & kIdMask, ey - 1);
+        if (ex) nx = anc_entry<SC1>(anc, plane, j, x & kIdMask, ex - 1);
+        if (ey) ny = anc_entry<SC1>(anc, plane, j, y & kIdMask, ey - 1);
         x = nx; y = ny;
         dx >>= 4; dy >>= 4;
         ++j;
@@ -220,6 +254,7 @@ __device__ __forceinline__ void lift2(const u32* anc, u64 plane, u32 self, u32 d
 
 // ae != be (ids) at equal depth D >= 1 under one root: walk both up to the children of their lowest common
 // ancestor, one 64-byte row per node per base-16 digit; entries keep their label bits.
+template <bool SC1>
 __device__ __forceinline__ void diverge(const u32* anc, u64 plane, u32& ae, u32& be, u32 D) {
     if (D == 0) return;
     int j = (31 - __clz(D)) >> 2;
@@ -228,8 +263,8 @@ __device__ __forceinline__ void diverge(const u32* anc, u64 plane, u32& ae, u32&
         if (m == 0) continue;
         if (m > 16) m = 16;
         u32 ra[16], rb[16];
-        load_row(anc, plane, j, ae & kIdMask, ra);
-        load_row(anc, plane, j, be & kIdMask, rb);
+        load_row<SC1>(anc, plane, j, ae & kIdMask, ra);
+        load_row<SC1>(anc, plane, j, be & kIdMask, rb);
         u32 pa = ae, pb = be, pd = 0;
 #pragma unroll
         for (u32 d = 0; d < 16; ++d) {
@@ -242,21 +277,22 @@ __device__ __forceinline__ void diverge(const u32* anc, u64 plane, u32& ae, u32&
 
 // A candidate = "the path to consumer c, then edge `el`".  ce = c | own edge label of c << 31.
 // is P(a).ela < P(b).elb ?  ids differ, same root.
+template <bool SC1>
 __device__ __forceinline__ bool path_less(const u32* anc, u64 plane, u32 ae, u32 ela, u32 da, u32 be, u32 elb, u32 db) {
     if (da > db) {
         u32 up, below;
-        lift2(anc, plane, ae, da - db, up, below);
+        lift2<SC1>(anc, plane, ae, da - db, up, below);
         if (((up ^ be) & kIdMask) == 0) return (below >> 31) < elb;      // b is an ancestor of a
         ae = up;
-        diverge(anc, plane, ae, be, db);
+        diverge<SC1>(anc, plane, ae, be, db);
     } else if (db > da) {
         u32 up, below;
-        lift2(anc, plane, be, db - da, up, below);
+        lift2<SC1>(anc, plane, be, db - da, up, below);
         if (((up ^ ae) & kIdMask) == 0) return ela < (below >> 31);      // a is an ancestor of b
         be = up;
-        diverge(anc, plane, ae, be, da);
+        diverge<SC1>(anc, plane, ae, be, da);
     } else {
-        diverge(anc, plane, ae, be, da);
+        diverge<SC1>(anc, plane, ae, be, da);
     }
     return (ae >> 31) < (be >> 31);
 }
@@ -285,7 +321,7 @@ __global__ void __launch_bounds__(kThreads) k_peel_level(PeelArgs A, u32 level) 
             if (best == C2A_NONE) take = cr.z < g;
             else if (cr.z != best_root) take = cr.z < best_root;
             else if (((ce ^ best) & kIdMask) == 0) take = el < best_el;
-            else take = path_less(A.anc, plane, ce, el, cr.y, best, best_el, best_depth);
+            else take = path_less<false>(A.anc, plane, ce, el, cr.y, best, best_el, best_depth);
             if (take) { best = ce; best_el = el; best_root = cr.z; best_depth = cr.y; }
         }
         const u32 depth = best == C2A_NONE ? 0u : best_depth + 1;
@@ -299,7 +335,7 @@ __global__ void __launch_bounds__(kThreads) k_peel_level(PeelArgs A, u32 level) 
             u32 need = 1;                                   // 16^j
             for (int j = 0; need <= depth; ++j) {
                 u32 r[16];
-                load_row(A.anc, plane, j, q & kIdMask, r);
+                load_row<false>(A.anc, plane, j, q & kIdMask, r);
                 uint4* dst = reinterpret_cast<uint4*>(A.anc + (u64)j * plane + (u64)pos * 16);
                 dst[0] = make_uint4(q, r[0], r[1], r[2]);
                 dst[1] = make_uint4(r[3], r[4], r[5], r[6]);
@@ -459,7 +495,7 @@ __global__ void __launch_bounds__(WPB * 64) k_peel_level_wave(PeelArgs A, u32 le
                         const u32 li = s_l[wv][xi], lj = s_l[wv][xj];
                         bool less;
                         if (((ci ^ cj) & kIdMask) == 0) less = li < lj;
-                        else less = path_less(A.anc, plane, ci, li, s_d[wv][xi], cj, lj, s_d[wv][xj]);
+                        else less = path_less<false>(A.anc, plane, ci, li, s_d[wv][xi], cj, lj, s_d[wv][xj]);
                         loser = less ? pj : pi;
                     }
                     u32 w = 0;
@@ -490,7 +526,7 @@ __global__ void __launch_bounds__(WPB * 64) k_peel_level_wave(PeelArgs A, u32 le
                 u32 need = 1;
                 for (int j = 0; need <= depth; ++j) {
                     u32 v = q;
-                    if (lane >= 1 && lane < 16) v = anc_entry(A.anc, plane, j, q & kIdMask, lane - 1);
+                    if (lane >= 1 && lane < 16) v = anc_entry<false>(A.anc, plane, j, q & kIdMask, lane - 1);
                     if (lane < 16) A.anc[(u64)j * plane + (u64)pos * 16 + lane] = v;
                     q = __shfl(v, 15, 64);
                     if (need > (0xFFFFFFFFu >> 4)) break;
@@ -524,6 +560,245 @@ __global__ void __launch_bounds__(WPB * 64) k_peel_level_wave(PeelArgs A, u32 le
         }
         __syncthreads();
         C2A_PROF(5, c2a_now() - t_begin);
+    }
+}
+
+// Variant 3: ONE persistent launch for all remaining (narrow) levels, confined to one XCD.
+// A kernel boundary per level costs ~13 us here (cold caches after every boundary: ~0.6 us per dependent hop,
+// plus launch/teardown).  Inside one launch the level step is a workgroup-aggregated append + a counter barrier:
+// measured 1.7 us per produce/barrier/consume iteration for the 32 workgroups of one XCD (tools/ubench/xcd.hip).
+// Rules (cdna_hip_programming.md §6 G16): every word exchanged between workgroups in the launch is accessed with
+// agent-scope relaxed atomics (sc1), every storing wave drains vmcnt before the barrier, correctness never
+// depends on placement — the XCD filter only decides WHO works (HW_REG_XCC_ID is ground truth, the first
+// workgroup to arrive picks the XCD), the census tells the participants how many they are, and they are all
+// resident by then (they have all reported).  One 16-lane group per gate, four gates per wave:
+// candidates in chunks of 16, all-pairs rounds of <= 6 candidates (15 pairs), all cross-lane traffic by
+// width-16 shuffles (group-uniform control flow).
+struct PeelCtl {
+    u32 chosen_xcd;     // 0xFFFFFFFF until the first workgroup arrives
+    u32 joined, bystanders;
+    u32 arrive, gen;    // barrier
+    u32 last_level;     // first empty level (out)
+    u32 pad[10];
+};
+
+constexpr int kPGroupsPerWg = 64;           // 1024 threads
+constexpr int kPGroup = 6;                  // 6*5/2 = 15 pairs <= 16 lanes
+
+__device__ __forceinline__ u32 xcc_id() {
+#ifdef C2A_EMULATE
+    return 0;
+#else
+    return __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 0xFu;      // HW_REG_XCC_ID[3:0]
+#endif
+}
+
+// LDS hand-off between the lanes of one 16-lane group (group-uniform control flow): DS ops of a wave execute in
+// order, so only the compiler has to be stopped; the emulation needs a real rendezvous of the group's fibers
+__device__ __forceinline__ void group_lds_sync() {
+#ifdef C2A_EMULATE
+    (void)__shfl(0u, 0, 16);
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
+__device__ __forceinline__ u32 group_or16(u32 v) {
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) v |= __shfl_xor(v, off, 16);
+    return v;
+}
+__device__ __forceinline__ u32 group_min16(u32 v) {
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) { const u32 o = __shfl_xor(v, off, 16); v = o < v ? o : v; }
+    return v;
+}
+
+// DS = true: bulk data (slots, candidate records, meta, ancestor rows) by sc1 accesses, no fences.
+// DS = false: bulk data by plain accesses + one agent-scope release and acquire per workgroup per level (G16 recipe).
+template <bool DS>
+__global__ void __launch_bounds__(kPGroupsPerWg * 16) k_peel_persistent(PeelArgs A, u32 level0, PeelCtl* ctl) {
+    __shared__ u32 s_c[kPGroupsPerWg][20], s_l[kPGroupsPerWg][20], s_d[kPGroupsPerWg][20];
+    __shared__ u32 s_ready[2 * kPGroupsPerWg];
+    __shared__ uint4 s_rec[2 * kPGroupsPerWg];
+    __shared__ u32 s_cnt[2];
+    __shared__ u32 s_base, s_P, s_rank, s_go;
+    const u32 tid = threadIdx.x, lane = tid & 63u, l16 = tid & 15u, gq = tid >> 4;
+    // ---- who works: the XCD of the first workgroup to arrive
+    if (tid == 0) {
+        const u32 x = xcc_id();
+        const u32 prev = atomicCAS(&ctl->chosen_xcd, 0xFFFFFFFFu, x);
+        const bool mine = prev == 0xFFFFFFFFu || prev == x;
+        s_go = mine ? 1u : 0u;
+        if (mine) s_rank = atomicAdd(&ctl->joined, 1u); else atomicAdd(&ctl->bystanders, 1u);
+    }
+    __syncthreads();
+    if (!s_go) return;
+    if (tid == 0) {
+        while (ld_u32<true>(&ctl->joined) + ld_u32<true>(&ctl->bystanders) < gridDim.x) __builtin_amdgcn_s_sleep(2);
+        s_P = ld_u32<true>(&ctl->joined);
+    }
+    __syncthreads();
+    const u32 P = s_P, rank = s_rank;
+    const u32 total_groups = P * kPGroupsPerWg;
+    const u64 plane = (u64)A.n * 16;
+    u32 epoch = 0;
+    // diagnostics: per workgroup, per level (first 64 levels of the launch), wall-clock ticks (10 ns) at the phase ends
+#define C2A_PPROF(slot)                                                                                        \
+    do {                                                                                                       \
+        if (A.prof && tid == 0 && level >= A.prof_level0 && level - A.prof_level0 < 64) A.prof[(((u64)(level - A.prof_level0)) * 64 + rank) * 8 + (slot)] = c2a_now(); \
+    } while (0)
+    for (u32 level = level0;; ++level) {
+        C2A_PPROF(0);
+        const u32 n_front = ld_u32<true>(&A.fcount[level]);
+        if (A.prof && tid == 0 && rank == 0 && level >= A.prof_level0 && level - A.prof_level0 < 64) A.prof[(((u64)(level - A.prof_level0)) * 64 + 63) * 8 + 7] = n_front;
+        if (n_front == 0) {                               // every participant reads the same value: uniform exit
+            if (rank == 0 && tid == 0) st_u32<true>(&ctl->last_level, level);
+            break;
+        }
+        const u32 lo = ld_u32<true>(&A.fbase[level]);
+        if (rank == 0 && tid == 0) st_u32<true>(&A.fbase[level + 1], lo + n_front);
+        FrontierSlot* cur = A.slots[level & 1u];
+        FrontierSlot* nxt = A.slots[(level + 1) & 1u];
+        for (u32 base = 0; base < n_front; base += total_groups) {
+            const u32 i = base + rank * kPGroupsPerWg + gq;
+            u32 rdy = C2A_NONE;
+            uint4 rdy_rec = make_uint4(0, 0, 0, 0);
+            if (i < n_front) {
+                const uint4 sa = ld_u128<DS>(&cur[i].a);
+                const u32 cnt = ld_u32<DS>(&cur[i].b.x);
+                const u32 g = sa.x;
+                const u32 e0 = sa.w, e1 = e0 + cnt;
+                const u32 dl = l16 == 0 ? sa.y : (l16 == 1 ? sa.z : C2A_NONE);
+                uint4 gd = make_uint4(0, 0, 0, 0);
+                if (dl != C2A_NONE) gd = A.ginfo[dl];                 // static (written before this launch)
+                u32 ch = C2A_NONE, ch_el = 0, ch_root = g, ch_depth = 0;
+                for (u32 eb = e0; eb < e1; eb += 16) {
+                    const u32 e = eb + l16;
+                    const bool valid = e < e1;
+                    u32 c = 0, l = 0, cdepth = 0, croot = 0xFFFFFFFFu;
+                    if (valid) {
+                        const uint4 cr = ld_u128<DS>(&A.cand[e]);
+                        c = (cr.x & kIdMask) | (cr.w << 31); l = cr.x >> 31;
+                        cdepth = cr.y; croot = cr.z;
+                    }
+                    const u32 rmin = group_min16(croot);
+                    if (rmin > ch_root) continue;
+                    const bool keep_ch = (ch != C2A_NONE) && (ch_root == rmin);
+                    const bool surv = valid && croot == rmin;
+                    const u32 smask = group_or16(surv ? (1u << l16) : 0u);
+                    u32 m = (u32)__popc(smask);
+                    if (surv) {
+                        const u32 k = (u32)__popc(smask & ((1u << l16) - 1u));
+                        s_c[gq][k] = c; s_l[gq][k] = l; s_d[gq][k] = cdepth;
+                    }
+                    if (keep_ch && l16 == 0) { s_c[gq][m] = ch; s_l[gq][m] = ch_el; s_d[gq][m] = ch_depth; }
+                    m += keep_ch ? 1u : 0u;
+                    group_lds_sync();
+                    u32 win = 0, next = 1;
+                    while (next < m) {
+                        const u32 take = (m - next) < (u32)(kPGroup - 1) ? (m - next) : (u32)(kPGroup - 1);
+                        const u32 q = take + 1;
+                        const u32 NP = q * (q - 1) / 2;
+                        u32 pi = 0, pj = 1;
+                        {
+                            u32 rem = l16, row = 0, len = q - 1;
+                            while (len && rem >= len) { rem -= len; ++row; --len; }
+                            pi = row; pj = row + 1 + rem;
+                        }
+                        u32 lost_bit = 0;
+                        if (l16 < NP) {
+                            const u32 xi = pi == 0 ? win : next + pi - 1, xj = next + pj - 1;
+                            const u32 ci = s_c[gq][xi], cj = s_c[gq][xj];
+                            const u32 li = s_l[gq][xi], lj = s_l[gq][xj];
+                            bool less;
+                            if (((ci ^ cj) & kIdMask) == 0) less = li < lj;
+                            else less = path_less<DS>(A.anc, plane, ci, li, s_d[gq][xi], cj, lj, s_d[gq][xj]);
+                            lost_bit = 1u << (less ? pj : pi);
+                        }
+                        const u32 lost = group_or16(lost_bit);
+                        const u32 w = (u32)__ffs((int)(~lost & ((1u << q) - 1u))) - 1u;    // the one member that never lost
+                        win = w == 0 ? win : next + w - 1;
+                        next += take;
+                    }
+                    ch = s_c[gq][win]; ch_el = s_l[gq][win]; ch_depth = s_d[gq][win]; ch_root = rmin;
+                    group_lds_sync();
+                }
+                const u32 depth = ch == C2A_NONE ? 0u : ch_depth + 1;
+                const u32 my_label = ch == C2A_NONE ? 0u : ch_el;
+                const u32 pos = lo + i;
+                if (l16 == 0) {
+                    st_u128<DS>(&A.meta[pos], make_uint4(ch == C2A_NONE ? C2A_NONE : (ch & kIdMask), depth, ch_root, my_label));
+                    st_u32<DS>(&A.order[pos], g);
+                    st_u32<DS>(&A.posof[g], pos);
+                }
+                u32 kfill = 0;
+                if (dl != C2A_NONE) kfill = atomicAdd(&A.fill[dl], 1u);
+                if (depth) {
+                    u32 q = ch, need = 1;
+                    for (int j = 0; need <= depth; ++j) {
+                        u32 v = q;
+                        if (l16 >= 1) v = anc_entry<DS>(A.anc, plane, j, q & kIdMask, l16 - 1);
+                        st_u32<DS>(&A.anc[(u64)j * plane + (u64)pos * 16 + l16], v);
+                        q = __shfl(v, 15, 16);
+                        if (need > (0xFFFFFFFFu >> 4)) break;
+                        need <<= 4;
+                    }
+                }
+                if (dl != C2A_NONE) {
+                    st_u128<DS>(&A.cand[gd.z + kfill], make_uint4(pos | (l16 << 31), depth, ch_root, my_label));   // l16 == edge label
+                    if (kfill + 1 == gd.w) { rdy = dl; rdy_rec = gd; }
+                }
+            }
+            C2A_PPROF(1);
+            // ---- one append per workgroup
+            if (l16 < 2) { s_ready[2 * gq + l16] = rdy; s_rec[2 * gq + l16] = rdy_rec; }
+            __syncthreads();
+            C2A_PPROF(2);
+            u32 d = C2A_NONE;
+            u64 mask = 0;
+            if (tid < 2 * kPGroupsPerWg) {                           // waves 0 and 1, whole waves
+                d = s_ready[tid];
+                mask = __ballot(d != C2A_NONE);
+                if (lane == 0) s_cnt[tid >> 6] = (u32)__popcll(mask);
+            }
+            __syncthreads();
+            if (tid == 0) { const u32 tot = s_cnt[0] + s_cnt[1]; s_base = tot ? atomicAdd(&A.fcount[level + 1], tot) : 0u; }
+            __syncthreads();
+            if (d != C2A_NONE) {
+                const u32 p = s_base + (tid >= 64 ? s_cnt[0] : 0u) + (u32)__popcll(mask & ((1ull << lane) - 1ull));
+                const uint4 gd = s_rec[tid];
+                st_u32<DS>(&nxt[p].b.x, gd.w);
+                st_u128<DS>(&nxt[p].a, make_uint4(d, gd.x, gd.y, gd.z));
+            }
+            __syncthreads();
+            C2A_PPROF(3);
+        }
+        // ---- level barrier: drain every wave's write-through stores, then arrive / wait
+#ifndef C2A_EMULATE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        __syncthreads();
+        C2A_PPROF(4);
+        ++epoch;
+        if (tid == 0) {
+#ifndef C2A_EMULATE
+            if (!DS) {      // publish this workgroup's plain stores (the asm wait restates the post-wbl2 wait: G16 pitfall 12)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+#endif
+            const u32 a = atomicAdd(&ctl->arrive, 1u);
+            if (a == P * epoch - 1) st_u32<true>(&ctl->gen, epoch);
+            while (ld_u32<true>(&ctl->gen) < epoch) __builtin_amdgcn_s_sleep(1);
+#ifndef C2A_EMULATE
+            if (!DS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // one lane's acquire + the barrier below covers the workgroup
+#endif
+        }
+        __syncthreads();
+        C2A_PPROF(5);
     }
 }
 

@@ -77,8 +77,10 @@ typedef struct c2a_stats {
     uint32_t max_depth;          /* depth of the DFS tree */
     uint32_t n_roots;            /* DFS roots (children of the virtual root) */
     uint32_t n_splitters;        /* list-ranking sublists */
-    uint32_t level_launches;     /* k_peel_level launches incl. empty tail launches */
+    uint32_t level_launches;     /* peel kernel launches (incl. empty tail launches and the persistent one) */
     uint32_t anc_planes;
+    uint32_t persistent_wgs;     /* workgroups that took part in the persistent peel launch (0 = not used) */
+    uint32_t reserved;
 } c2a_stats;
 
 /* Create a context on HIP device `device_id` (>= 0).  Fails with C2A_ERR_HIP when no device / runtime. */

@@ -90,17 +90,24 @@ def backend(request, c2a):
     be.close()
 
 
-WAVE_BACKENDS = [pytest.param(("emul", 4), id="emul-wpb4")] + [
+WAVE_BACKENDS = [pytest.param(("emul", 4), id="emul-wpb4"), pytest.param(("emul", "persist-sc1"), id="emul-persistent")] + [
     pytest.param(("hip", w), id=f"hip-wpb{w}", marks=pytest.mark.gpu) for w in (4, 8, 16)] + [
-    pytest.param(("hip", 0), id="hip-lane-per-gate", marks=pytest.mark.gpu)]
+    pytest.param(("hip", 0), id="hip-lane-per-gate", marks=pytest.mark.gpu),
+    pytest.param(("hip", "persist-sc1"), id="hip-persistent-sc1", marks=pytest.mark.gpu),
+    pytest.param(("hip", "persist-fence"), id="hip-persistent-fence", marks=pytest.mark.gpu)]
 
 
 @pytest.fixture(params=WAVE_BACKENDS)
 def backend_wave(request, c2a):
-    """Every level (however wide) through the wave-per-gate kernel, at each workgroup shape; plus, on the GPU,
-    every level through the lane-per-gate kernel."""
+    """Every level (however wide) through the wave-per-gate kernel, at each workgroup shape; every level through the
+    lane-per-gate kernel; and everything after the first batch through the persistent single-XCD kernel."""
     kind, wpb = request.param
-    env = _Env(C2A_PEEL_WAVE_MAX=0) if wpb == 0 else _Env(C2A_PEEL_WAVE_MAX=1 << 30, C2A_PEEL_WPB=wpb)
+    if wpb == 0:
+        env = _Env(C2A_PEEL_WAVE_MAX=0)
+    elif isinstance(wpb, str):     # the optional single-XCD persistent launch (off by default), both hand-off flavours
+        env = _Env(C2A_PEEL_PERSIST_MAX=1 << 30, C2A_PEEL_PERSIST_SC1=1 if wpb == "persist-sc1" else 0)
+    else:
+        env = _Env(C2A_PEEL_WAVE_MAX=1 << 30, C2A_PEEL_WPB=wpb)
     with env:
         be = c2a.Backend(0, lib_path=request.getfixturevalue("emul_lib")) if kind == "emul" else c2a.Backend(0)
     yield be

@@ -135,20 +135,27 @@ inline unsigned wave_width() {
     unsigned lo = flat & ~63u;
     return std::min(64u, nt - lo);
 }
-// deposit v, wait for the whole wave, return pointer to the 64 values (valid until next rendezvous)
-inline const unsigned long long* rendezvous(unsigned long long v) {
+// deposit v, wait for the lanes of the `width`-aligned subgroup (whole wave for width 64), return a pointer to the
+// wave's 64 value slots (only the caller's subgroup slots are meaningful; valid until that subgroup's next rendezvous)
+struct SubSync { unsigned arrived = 0; unsigned epoch = 0; };
+inline const unsigned long long* rendezvous(unsigned long long v, unsigned width = 64) {
     State& s = st();
     static unsigned long long snapshot[64];
-    unsigned width = wave_width();
-    unsigned my_epoch = s.wave_epoch;
-    s.wave_vals[lane_id()] = v;
-    s.wave_arrived++;
-    if (s.wave_arrived == width) {
-        for (unsigned i = 0; i < 64; ++i) snapshot[i] = i < width ? s.wave_vals[i] : 0;
-        s.wave_arrived = 0;
-        s.wave_epoch++;
+    static SubSync sync[7][64];                     // [log2 width][subgroup]
+    unsigned lg = 0; while ((1u << lg) < width) ++lg;
+    const unsigned lane = lane_id();
+    const unsigned sub = lane / width, base = sub * width;
+    unsigned members = std::min(wave_width() > base ? wave_width() - base : 0u, width);
+    SubSync& y = sync[lg][sub];
+    const unsigned my_epoch = y.epoch;
+    s.wave_vals[lane] = v;
+    y.arrived++;
+    if (y.arrived == members) {
+        for (unsigned i = base; i < base + width; ++i) snapshot[i] = i < base + members ? s.wave_vals[i] : 0;
+        y.arrived = 0;
+        y.epoch++;
     } else {
-        while (s.wave_epoch == my_epoch) yield(2);
+        while (y.epoch == my_epoch) yield(2);
     }
     return snapshot;
 }
@@ -166,11 +173,11 @@ inline int __all(int pred) { unsigned w = hipemu::wave_width(); unsigned long lo
 template <class T> inline T __shfl(T val, int src, int width = 64) {
     static_assert(sizeof(T) <= 8, "shfl");
     unsigned long long bits = 0; std::memcpy(&bits, &val, sizeof(T));
-    const unsigned long long* v = hipemu::rendezvous(bits);
+    const unsigned long long* v = hipemu::rendezvous(bits, (unsigned)width);
     unsigned lane = hipemu::lane_id();
     unsigned base = lane & ~(unsigned)(width - 1);
     unsigned long long got = v[base + ((unsigned)src & (unsigned)(width - 1))];
-    hipemu::rendezvous(0);
+    hipemu::rendezvous(0, (unsigned)width);
     T out; std::memcpy(&out, &got, sizeof(T)); return out;
 }
 template <class T> inline T __shfl_up(T val, unsigned delta, int width = 64) {
@@ -204,6 +211,15 @@ template <class T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o
 template <class T> inline T atomicAnd(T* p, T v) { T o = *p; *p = o & v; return o; }
 template <class T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 template <class T> inline T atomicCAS(T* p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
+
+// ---- scoped atomic load/store builtins (sc1 accesses on the GPU; plain here) + misc ----
+#ifndef __HIP_MEMORY_SCOPE_AGENT
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#endif
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) ((void)(*(p) = (v)))
+inline void __builtin_amdgcn_s_sleep(int) {}
+inline unsigned long long wall_clock64() { return 0; }
 
 // ---- runtime ----
 typedef int hipError_t;
