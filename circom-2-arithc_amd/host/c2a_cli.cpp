@@ -1,0 +1,86 @@
+// c2a_cli.cpp — command-line driver mirroring src/main.rs:15-50 for the flat-gate-graph stage.
+//
+//   circom-2-arithc-amd -i <calls.txt> -o <output dir> [--boolify-width W] [--device D]
+//
+// The reference's front-end (iden3 Circom parser + template unroller, src/process.rs) is out of scope and not
+// available here, so the input is what that front-end PRODUCES: the sequence of calls it makes on `Compiler`
+// (src/process.rs:75-101, :466-475, :235-269; src/program.rs:57-66), one per line:
+//     signal <signal id> <name> [<constant value>]      ac.add_signal(id, name, value)
+//     gate <AGateType> <lhs id> <rhs id> <out id>        ac.add_gate(type, lhs, rhs, out)
+//     connect <a id> <b id>                              ac.add_connection(a, b)
+//     inputs <prefix>      / outputs <prefix>            compiler.add_inputs/outputs(compiler.get_signals("0.<prefix>"))
+// Outputs, as in the reference (src/main.rs:34-44): <out>/circuit.txt and <out>/circuit_info.json.
+// (report.json, src/main.rs:46-47, belongs to the out-of-scope front-end report.)
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "c2a_host.hpp"
+
+using namespace c2a::host;
+
+int main(int argc, char** argv) {
+    std::string input = "./input/calls.txt", output = "./output/";        // cli.rs:23-33 defaults (input kind differs)
+    std::optional<uint32_t> boolify_width;
+    int device = 0;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto need = [&](const char* what) -> std::string {
+            if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", what); std::exit(2); }
+            return argv[++i];
+        };
+        if (a == "-i" || a == "--input") input = need("--input");
+        else if (a == "-o" || a == "--output") output = need("--output");
+        else if (a == "--boolify-width") boolify_width = (uint32_t)std::stoul(need("--boolify-width"));
+        else if (a == "--device") device = std::stoi(need("--device"));
+        else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+    }
+    try {
+        Backend backend(device);
+        Compiler compiler(backend);
+        std::ifstream in(input);
+        if (!in) { std::fprintf(stderr, "cannot open %s\n", input.c_str()); return 1; }
+        std::string line;
+        while (std::getline(in, line)) {
+            std::istringstream ls(line);
+            std::string kind;
+            if (!(ls >> kind) || kind[0] == '#') continue;
+            if (kind == "signal") {
+                uint32_t id; std::string name; uint32_t v;
+                ls >> id >> name;
+                if (ls >> v) compiler.add_signal(id, name, v); else compiler.add_signal(id, name, std::nullopt);
+            } else if (kind == "gate") {
+                std::string op; uint32_t a, b, o;
+                ls >> op >> a >> b >> o;
+                auto t = parse_gate_type(op);
+                if (!t) { std::fprintf(stderr, "unsupported gate type: %s\n", op.c_str()); return 1; }    // compiler.rs:566-567
+                compiler.add_gate(*t, a, b, o);
+            } else if (kind == "connect") {
+                uint32_t a, b; ls >> a >> b;
+                compiler.add_connection(a, b);
+            } else if (kind == "inputs" || kind == "outputs") {
+                std::string prefix; ls >> prefix;
+                auto sigs = compiler.get_signals("0." + prefix);                                              // program.rs:57-66
+                if (kind == "inputs") compiler.add_inputs(sigs); else compiler.add_outputs(sigs);
+            } else { std::fprintf(stderr, "unknown line kind: %s\n", kind.c_str()); return 1; }
+        }
+        BristolCircuit circuit = compiler.build_circuit();                                                    // main.rs:28
+        if (boolify_width) circuit = boolify(compiler, circuit, *boolify_width);                              // main.rs:30-32
+        if (!output.empty() && output.back() != '/') output += '/';
+        std::system(("mkdir -p '" + output + "'").c_str());                                                   // main.rs:25-26
+        {
+            std::ofstream f(output + "circuit.txt");                                                          // main.rs:34-35
+            circuit.write_bristol(f);
+        }
+        {
+            std::ofstream f(output + "circuit_info.json");                                                    // main.rs:43-44
+            f << circuit.info_json();
+        }
+        return 0;
+    } catch (const CircuitError& e) {
+        std::fprintf(stderr, "Error: %s\n", e.what());
+        return 1;
+    }
+}
