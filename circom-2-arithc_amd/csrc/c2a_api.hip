@@ -44,6 +44,8 @@ struct c2a_ctx {
     bool peel_persist_sc1 = true;  // persistent peel: bulk data by sc1 accesses (true) or plain accesses + fences (false)
     u32 peel_persist_max = 0;      // frontier size below which the rest of the peel runs as ONE persistent single-XCD launch;
                                    // 0 = never (default: measured 1.8x SLOWER than a launch per level)
+    u32 anc_bits = 4;              // log2(entries per ancestor row): 4 (64-B rows, default) or 6 (256-B rows: one hop fewer per
+                                   // lift/diverge/copy at depth < 4096 but measured 1.45x slower: 182 VGPRs, 32 loads per hop)
     u32 peel_wpb = 8;              // gates (waves) per workgroup in wave mode: 4, 8 or 16 (8 measured best)
 
     // problem
@@ -165,11 +167,11 @@ int read_scalars(c2a_ctx* c, u32* host, int first, int count) {
     return C2A_OK;
 }
 
-u32 planes_for(u64 n) {
-    // tree depth < n, so 16^planes > n-1 is always enough
+u32 planes_for(u64 n, u32 bits) {
+    // tree depth < n, so (2^bits)^planes > n-1 is always enough
     u32 p = 1;
-    u64 reach = 16;
-    while (reach < n) { reach <<= 4; ++p; }
+    u64 reach = 1ull << bits;
+    while (reach < n) { reach <<= bits; ++p; }
     return p;
 }
 
@@ -235,13 +237,21 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
         for (u32 i = 0; i < batch; ++i) {
             if (level == 0) {
                 // the very first launch sees the (possibly huge) level-0 frontier: sinks have no consumers
-                C2A_LAUNCH_NOSYNC(k_peel_level, grid_for(f0, max_blocks), kThreads, s, A, level);
+                if (c->anc_bits == 6) C2A_LAUNCH_NOSYNC((k_peel_level<6>), grid_for(f0, max_blocks), kThreads, s, A, level);
+                else C2A_LAUNCH_NOSYNC((k_peel_level<4>), grid_for(f0, max_blocks), kThreads, s, A, level);
             } else if (wave_mode) {
-                if (wpb == 16) C2A_LAUNCH((k_peel_level_wave<16>), blocks, 1024, s, A, level);
-                else if (wpb == 8) C2A_LAUNCH((k_peel_level_wave<8>), blocks, 512, s, A, level);
-                else C2A_LAUNCH((k_peel_level_wave<4>), blocks, 256, s, A, level);
+                if (c->anc_bits == 6) {
+                    if (wpb == 16) C2A_LAUNCH((k_peel_level_wave<16, 6>), blocks, 1024, s, A, level);
+                    else if (wpb == 8) C2A_LAUNCH((k_peel_level_wave<8, 6>), blocks, 512, s, A, level);
+                    else C2A_LAUNCH((k_peel_level_wave<4, 6>), blocks, 256, s, A, level);
+                } else {
+                    if (wpb == 16) C2A_LAUNCH((k_peel_level_wave<16, 4>), blocks, 1024, s, A, level);
+                    else if (wpb == 8) C2A_LAUNCH((k_peel_level_wave<8, 4>), blocks, 512, s, A, level);
+                    else C2A_LAUNCH((k_peel_level_wave<4, 4>), blocks, 256, s, A, level);
+                }
             } else {
-                C2A_LAUNCH_NOSYNC(k_peel_level, blocks, kThreads, s, A, level);
+                if (c->anc_bits == 6) C2A_LAUNCH_NOSYNC((k_peel_level<6>), blocks, kThreads, s, A, level);
+                else C2A_LAUNCH_NOSYNC((k_peel_level<4>), blocks, kThreads, s, A, level);
             }
             ++level; ++launches;
             if (level > n) break;
@@ -257,7 +267,7 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
         for (u32 k = 0; k <= look; ++k) mx = std::max(mx, tail[k]);
         est = mx;
         batch = std::min<u32>(batch * 2, 512u);
-        if (c->peel_persist_max && est <= c->peel_persist_max) {
+        if (c->peel_persist_max && c->anc_bits == 4 && est <= c->peel_persist_max) {      // the persistent kernel is base-16 only
             // the frontier has narrowed: finish every remaining level inside one persistent launch
             ENSURE(c->peel_ctl, sizeof(PeelCtl));
             PeelCtl init;
@@ -537,6 +547,7 @@ int c2a_create(int device_id, c2a_ctx** out) {
     if (const char* e = std::getenv("C2A_BOOL_CHUNK")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 128 || v == 256 || v == 512) c->bool_chunk = v; }
     if (const char* e = std::getenv("C2A_PEEL_PERSIST_SC1")) c->peel_persist_sc1 = std::strtoul(e, nullptr, 10) != 0;
     if (const char* e = std::getenv("C2A_PEEL_PERSIST_MAX")) c->peel_persist_max = (u32)std::strtoul(e, nullptr, 10);
+    if (const char* e = std::getenv("C2A_ANC_BITS")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 4 || v == 6) c->anc_bits = v; }
     if (const char* e = std::getenv("C2A_PEEL_WPB")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 4 || v == 8 || v == 16) c->peel_wpb = v; }
     if (const char* e = std::getenv("C2A_PEEL_WAVE_MAX")) c->peel_wave_max = (u32)std::strtoul(e, nullptr, 10);   // tuning / test knob
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return C2A_ERR_HIP; }
@@ -580,7 +591,7 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
         if (output_nodes[i] >= n_nodes) return fail(c, C2A_ERR_ARG, "c2a_load_gates: output node id >= n_nodes");
     HIP_TRY(hipSetDevice(c->device));
     c->n = n; c->n_nodes = n_nodes; c->n_in = n_in; c->n_out = n_out;
-    c->planes = planes_for(n);
+    c->planes = planes_for(n, c->anc_bits);
     const size_t n4 = (size_t)n * 4, nn4 = (size_t)n_nodes * 4;
     ENSURE(c->lh, n4); ENSURE(c->rh, n4); ENSURE(c->out, n4); ENSURE(c->op, n);
     ENSURE(c->in_nodes, (size_t)n_in * 4); ENSURE(c->out_nodes, (size_t)n_out * 4);
@@ -589,7 +600,7 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     ENSURE(c->meta, (size_t)n * 16); ENSURE(c->ginfo, (size_t)n * 16);
     ENSURE(c->slots0, ((size_t)n + 1) * sizeof(FrontierSlot)); ENSURE(c->slots1, ((size_t)n + 1) * sizeof(FrontierSlot));
 
-    ENSURE(c->anc, (size_t)c->planes * n * 64);
+    ENSURE(c->anc, ((size_t)c->planes * n * 4) << c->anc_bits);
     ENSURE(c->fcount, n4 + 8); ENSURE(c->fbase, n4 + 8); ENSURE(c->order, n4); ENSURE(c->posof, n4);
     ENSURE(c->rflag, n4); ENSURE(c->ridx, n4 + 4); ENSURE(c->rlist, n4);
     ENSURE(c->next, 2 * n4); ENSURE(c->owner, 2 * n4); ENSURE(c->local, 2 * n4); ENSURE(c->slist, 2 * n4);

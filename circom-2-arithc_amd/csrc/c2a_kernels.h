@@ -218,16 +218,19 @@ template <bool SC1> __device__ __forceinline__ void st_u128(uint4* p, const uint
     }
 }
 
-template <bool SC1>
+// B = log2(entries per ancestor row): 4 -> base-16 rows of 64 B, 6 -> base-64 rows of 256 B.  A wider row costs
+// bytes (not the budget here) and removes dependent hops (the budget): at depth < 4096 a lift, a divergence search
+// and a row copy take <= 2 hops each with B = 6 instead of <= 3 with B = 4.
+template <bool SC1, int B>
 __device__ __forceinline__ u32 anc_entry(const u32* anc, u64 plane, int j, u32 x, u32 d) {
-    return ld_u32<SC1>(anc + (u64)j * plane + (u64)x * 16 + d);
+    return ld_u32<SC1>(anc + (u64)j * plane + ((u64)x << B) + d);
 }
 
-template <bool SC1>
-__device__ __forceinline__ void load_row(const u32* anc, u64 plane, int j, u32 x, u32 (&r)[16]) {
-    const uint4* p = reinterpret_cast<const uint4*>(anc + (u64)j * plane + (u64)x * 16);
+template <bool SC1, int B>
+__device__ __forceinline__ void load_row(const u32* anc, u64 plane, int j, u32 x, u32 (&r)[1 << B]) {
+    const uint4* p = reinterpret_cast<const uint4*>(anc + (u64)j * plane + ((u64)x << B));
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < (1 << B) / 4; ++q) {
         const uint4 v = ld_u128<SC1>(p + q);
         r[4 * q + 0] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
     }
@@ -235,18 +238,18 @@ __device__ __forceinline__ void load_row(const u32* anc, u64 plane, int j, u32 x
 
 // Two lifts of the same node in one pass (their loads are independent and overlap): xe = ancestor at `dist`,
 // ye = ancestor at `dist - 1`, both as labelled entries.  dist >= 1; `self` = the node's own labelled entry.
-template <bool SC1>
+template <bool SC1, int B>
 __device__ __forceinline__ void lift2(const u32* anc, u64 plane, u32 self, u32 dist, u32& xe, u32& ye) {
     u32 x = self, y = self;
     u32 dx = dist, dy = dist - 1;
     int j = 0;
     while (dx | dy) {
-        const u32 ex = dx & 15u, ey = dy & 15u;
+        const u32 ex = dx & ((1u << B) - 1u), ey = dy & ((1u << B) - 1u);
         u32 nx = x, ny = y;
-        if (ex) nx = anc_entry<SC1>(anc, plane, j, x & kIdMask, ex - 1);
-        if (ey) ny = anc_entry<SC1>(anc, plane, j, y & kIdMask, ey - 1);
+        if (ex) nx = anc_entry<SC1, B>(anc, plane, j, x & kIdMask, ex - 1);
+        if (ey) ny = anc_entry<SC1, B>(anc, plane, j, y & kIdMask, ey - 1);
         x = nx; y = ny;
-        dx >>= 4; dy >>= 4;
+        dx >>= B; dy >>= B;
         ++j;
     }
     xe = x; ye = y;
@@ -254,55 +257,58 @@ __device__ __forceinline__ void lift2(const u32* anc, u64 plane, u32 self, u32 d
 
 // ae != be (ids) at equal depth D >= 1 under one root: walk both up to the children of their lowest common
 // ancestor, one 64-byte row per node per base-16 digit; entries keep their label bits.
-template <bool SC1>
+template <bool SC1, int B>
 __device__ __forceinline__ void diverge(const u32* anc, u64 plane, u32& ae, u32& be, u32 D) {
     if (D == 0) return;
-    int j = (31 - __clz(D)) >> 2;
+    constexpr u32 R = 1u << B;
+    int j = (31 - __clz(D)) / B;
     for (; j >= 0; --j) {
-        u32 m = D >> (4 * j);
+        u32 m = D >> (B * j);
         if (m == 0) continue;
-        if (m > 16) m = 16;
-        u32 ra[16], rb[16];
-        load_row<SC1>(anc, plane, j, ae & kIdMask, ra);
-        load_row<SC1>(anc, plane, j, be & kIdMask, rb);
+        if (m > R) m = R;
+        u32 ra[R], rb[R];
+        load_row<SC1, B>(anc, plane, j, ae & kIdMask, ra);
+        load_row<SC1, B>(anc, plane, j, be & kIdMask, rb);
         u32 pa = ae, pb = be, pd = 0;
 #pragma unroll
-        for (u32 d = 0; d < 16; ++d) {
+        for (u32 d = 0; d < R; ++d) {
             if (d < m && ((ra[d] ^ rb[d]) & kIdMask)) { pa = ra[d]; pb = rb[d]; pd = d + 1; }
         }
         ae = pa; be = pb;
-        D -= pd << (4 * j);
+        D -= pd << (B * j);
     }
 }
 
 // A candidate = "the path to consumer c, then edge `el`".  ce = c | own edge label of c << 31.
 // is P(a).ela < P(b).elb ?  ids differ, same root.
-template <bool SC1>
+template <bool SC1, int B>
 __device__ __forceinline__ bool path_less(const u32* anc, u64 plane, u32 ae, u32 ela, u32 da, u32 be, u32 elb, u32 db) {
     if (da > db) {
         u32 up, below;
-        lift2<SC1>(anc, plane, ae, da - db, up, below);
+        lift2<SC1, B>(anc, plane, ae, da - db, up, below);
         if (((up ^ be) & kIdMask) == 0) return (below >> 31) < elb;      // b is an ancestor of a
         ae = up;
-        diverge<SC1>(anc, plane, ae, be, db);
+        diverge<SC1, B>(anc, plane, ae, be, db);
     } else if (db > da) {
         u32 up, below;
-        lift2<SC1>(anc, plane, be, db - da, up, below);
+        lift2<SC1, B>(anc, plane, be, db - da, up, below);
         if (((up ^ ae) & kIdMask) == 0) return ela < (below >> 31);      // a is an ancestor of b
         be = up;
-        diverge<SC1>(anc, plane, ae, be, da);
+        diverge<SC1, B>(anc, plane, ae, be, da);
     } else {
-        diverge<SC1>(anc, plane, ae, be, da);
+        diverge<SC1, B>(anc, plane, ae, be, da);
     }
     return (ae >> 31) < (be >> 31);
 }
 
 // Variant 1: one lane per frontier gate, candidates compared one after the other.  Used while the frontier
 // is wide (the first levels); its latency per level is (largest fan-out) x (one path comparison).
+template <int B>
 __global__ void __launch_bounds__(kThreads) k_peel_level(PeelArgs A, u32 level) {
     FrontierSlot* cur = A.slots[level & 1u];
     FrontierSlot* nxt = A.slots[(level + 1) & 1u];
-    const u64 plane = (u64)A.n * 16;
+    constexpr u32 R = 1u << B;
+    const u64 plane = (u64)A.n << B;
     const u32 n_front = A.fcount[level];
     const u32 lo = A.fbase[level];
     if (gtid() == 0) A.fbase[level + 1] = lo + n_front;
@@ -321,7 +327,7 @@ __global__ void __launch_bounds__(kThreads) k_peel_level(PeelArgs A, u32 level) 
             if (best == C2A_NONE) take = cr.z < g;
             else if (cr.z != best_root) take = cr.z < best_root;
             else if (((ce ^ best) & kIdMask) == 0) take = el < best_el;
-            else take = path_less<false>(A.anc, plane, ce, el, cr.y, best, best_el, best_depth);
+            else take = path_less<false, B>(A.anc, plane, ce, el, cr.y, best, best_el, best_depth);
             if (take) { best = ce; best_el = el; best_root = cr.z; best_depth = cr.y; }
         }
         const u32 depth = best == C2A_NONE ? 0u : best_depth + 1;
@@ -329,21 +335,20 @@ __global__ void __launch_bounds__(kThreads) k_peel_level(PeelArgs A, u32 level) 
         A.meta[pos] = make_uint4(best == C2A_NONE ? C2A_NONE : (best & kIdMask), depth, best_root, my_label);
         A.order[pos] = g;
         A.posof[g] = pos;
-        // ---- ancestor rows: row j = [q_j, row_j(q_j)[0..14]], q_0 = parent, q_{j+1} = my ancestor at 16^(j+1)
+        // ---- ancestor rows: row j = [q_j, row_j(q_j)[0..R-2]], q_0 = parent, q_{j+1} = my ancestor at R^(j+1)
         if (depth) {
             u32 q = best;                                   // labelled entry
-            u32 need = 1;                                   // 16^j
+            u32 need = 1;                                   // R^j
             for (int j = 0; need <= depth; ++j) {
-                u32 r[16];
-                load_row<false>(A.anc, plane, j, q & kIdMask, r);
-                uint4* dst = reinterpret_cast<uint4*>(A.anc + (u64)j * plane + (u64)pos * 16);
+                u32 r[R];
+                load_row<false, B>(A.anc, plane, j, q & kIdMask, r);
+                uint4* dst = reinterpret_cast<uint4*>(A.anc + (u64)j * plane + ((u64)pos << B));
                 dst[0] = make_uint4(q, r[0], r[1], r[2]);
-                dst[1] = make_uint4(r[3], r[4], r[5], r[6]);
-                dst[2] = make_uint4(r[7], r[8], r[9], r[10]);
-                dst[3] = make_uint4(r[11], r[12], r[13], r[14]);
-                q = r[14];
-                if (need > (0xFFFFFFFFu >> 4)) break;
-                need <<= 4;
+#pragma unroll
+                for (u32 t = 1; t < R / 4; ++t) dst[t] = make_uint4(r[4 * t - 1], r[4 * t], r[4 * t + 1], r[4 * t + 2]);
+                q = r[R - 2];
+                if (need > (0xFFFFFFFFu >> B)) break;
+                need <<= B;
             }
         }
         // ---- tell the producers; a producer joins the next frontier when its last consumer has been peeled
@@ -411,7 +416,7 @@ constexpr u32 kProfLevels = 32, kProfWaves = 32768;
 
 // WPB = waves (= gates per pass) per workgroup: 16 -> fewest appends on the frontier counter, 4/8 -> shorter
 // wait for the slowest wave of the group
-template <int WPB>
+template <int WPB, int B>
 __global__ void __launch_bounds__(WPB * 64) k_peel_level_wave(PeelArgs A, u32 level) {
     const ull t_begin = A.prof ? c2a_now() : 0;
     __shared__ u32 s_c[WPB][72], s_l[WPB][72], s_d[WPB][72];
@@ -421,7 +426,8 @@ __global__ void __launch_bounds__(WPB * 64) k_peel_level_wave(PeelArgs A, u32 le
     const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     FrontierSlot* cur = A.slots[level & 1u];
     FrontierSlot* nxt = A.slots[(level + 1) & 1u];
-    const u64 plane = (u64)A.n * 16;
+    constexpr u32 R = 1u << B;
+    const u64 plane = (u64)A.n << B;
     const u64 lt_mask = (1ull << lane) - 1ull;
     // slot i sits at a fixed address: issue its load before the frontier size is known
     uint4 sa0 = make_uint4(0, 0, 0, 0);
@@ -495,7 +501,7 @@ __global__ void __launch_bounds__(WPB * 64) k_peel_level_wave(PeelArgs A, u32 le
                         const u32 li = s_l[wv][xi], lj = s_l[wv][xj];
                         bool less;
                         if (((ci ^ cj) & kIdMask) == 0) less = li < lj;
-                        else less = path_less<false>(A.anc, plane, ci, li, s_d[wv][xi], cj, lj, s_d[wv][xj]);
+                        else less = path_less<false, B>(A.anc, plane, ci, li, s_d[wv][xi], cj, lj, s_d[wv][xj]);
                         loser = less ? pj : pi;
                     }
                     u32 w = 0;
@@ -526,11 +532,11 @@ __global__ void __launch_bounds__(WPB * 64) k_peel_level_wave(PeelArgs A, u32 le
                 u32 need = 1;
                 for (int j = 0; need <= depth; ++j) {
                     u32 v = q;
-                    if (lane >= 1 && lane < 16) v = anc_entry<false>(A.anc, plane, j, q & kIdMask, lane - 1);
-                    if (lane < 16) A.anc[(u64)j * plane + (u64)pos * 16 + lane] = v;
-                    q = __shfl(v, 15, 64);
-                    if (need > (0xFFFFFFFFu >> 4)) break;
-                    need <<= 4;
+                    if (lane >= 1 && lane < R) v = anc_entry<false, B>(A.anc, plane, j, q & kIdMask, lane - 1);
+                    if (lane < R) A.anc[(u64)j * plane + ((u64)pos << B) + lane] = v;
+                    q = __shfl(v, (int)R - 1, 64);
+                    if (need > (0xFFFFFFFFu >> B)) break;
+                    need <<= B;
                 }
             }
             if (dl != C2A_NONE) {
@@ -715,7 +721,7 @@ __global__ void __launch_bounds__(kPGroupsPerWg * 16) k_peel_persistent(PeelArgs
                             const u32 li = s_l[gq][xi], lj = s_l[gq][xj];
                             bool less;
                             if (((ci ^ cj) & kIdMask) == 0) less = li < lj;
-                            else less = path_less<DS>(A.anc, plane, ci, li, s_d[gq][xi], cj, lj, s_d[gq][xj]);
+                            else less = path_less<DS, 4>(A.anc, plane, ci, li, s_d[gq][xi], cj, lj, s_d[gq][xj]);
                             lost_bit = 1u << (less ? pj : pi);
                         }
                         const u32 lost = group_or16(lost_bit);
@@ -740,7 +746,7 @@ __global__ void __launch_bounds__(kPGroupsPerWg * 16) k_peel_persistent(PeelArgs
                     u32 q = ch, need = 1;
                     for (int j = 0; need <= depth; ++j) {
                         u32 v = q;
-                        if (l16 >= 1) v = anc_entry<DS>(A.anc, plane, j, q & kIdMask, l16 - 1);
+                        if (l16 >= 1) v = anc_entry<DS, 4>(A.anc, plane, j, q & kIdMask, l16 - 1);
                         st_u32<DS>(&A.anc[(u64)j * plane + (u64)pos * 16 + l16], v);
                         q = __shfl(v, 15, 16);
                         if (need > (0xFFFFFFFFu >> 4)) break;

@@ -94,7 +94,9 @@ WAVE_BACKENDS = [pytest.param(("emul", 4), id="emul-wpb4"), pytest.param(("emul"
     pytest.param(("hip", w), id=f"hip-wpb{w}", marks=pytest.mark.gpu) for w in (4, 8, 16)] + [
     pytest.param(("hip", 0), id="hip-lane-per-gate", marks=pytest.mark.gpu),
     pytest.param(("hip", "persist-sc1"), id="hip-persistent-sc1", marks=pytest.mark.gpu),
-    pytest.param(("hip", "persist-fence"), id="hip-persistent-fence", marks=pytest.mark.gpu)]
+    pytest.param(("hip", "persist-fence"), id="hip-persistent-fence", marks=pytest.mark.gpu),
+    pytest.param(("hip", "base64"), id="hip-base64-rows", marks=pytest.mark.gpu),
+    pytest.param(("emul", "base64"), id="emul-base64-rows")]
 
 
 @pytest.fixture(params=WAVE_BACKENDS)
@@ -104,8 +106,10 @@ def backend_wave(request, c2a):
     kind, wpb = request.param
     if wpb == 0:
         env = _Env(C2A_PEEL_WAVE_MAX=0)
+    elif wpb == "base64":          # 256-byte ancestor rows (default is base 16)
+        env = _Env(C2A_ANC_BITS=6)
     elif isinstance(wpb, str):     # the optional single-XCD persistent launch (off by default), both hand-off flavours
-        env = _Env(C2A_PEEL_PERSIST_MAX=1 << 30, C2A_PEEL_PERSIST_SC1=1 if wpb == "persist-sc1" else 0)
+        env = _Env(C2A_PEEL_PERSIST_MAX=1 << 30, C2A_ANC_BITS=4, C2A_PEEL_PERSIST_SC1=1 if wpb == "persist-sc1" else 0)
     else:
         env = _Env(C2A_PEEL_WAVE_MAX=1 << 30, C2A_PEEL_WPB=wpb)
     with env:
