@@ -85,7 +85,8 @@ def main():
 
     dist = None
     torch = None
-    if world > 1:
+    # one rank per GPU under torch.distributed.run; a 1-rank launch takes the same path (RANK is set by the launcher)
+    if world > 1 or ("RANK" in os.environ and os.environ.get("C2A_BENCH_PLAIN") is None and "TORCHELASTIC_RUN_ID" in os.environ):
         import torch
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
