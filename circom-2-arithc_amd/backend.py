@@ -87,7 +87,8 @@ class BoolInfo:
 
 _EXPORTS = ["c2a_create", "c2a_destroy", "c2a_last_error", "c2a_version", "c2a_load_gates", "c2a_topo_sort",
             "c2a_topo_sort_serial", "c2a_assign_wires", "c2a_emit_gates", "c2a_build_circuit", "c2a_boolify",
-            "c2a_bool_read", "c2a_template_size", "c2a_checksum", "c2a_get_timings", "c2a_get_stats"]
+            "c2a_bool_read", "c2a_template_size", "c2a_checksum", "c2a_get_timings", "c2a_get_stats", "c2a_verify_boolify",
+            "c2a_debug_patch_bool_op"]
 
 
 def library_path() -> str:
@@ -136,6 +137,10 @@ def load_library(lib_path: Optional[str] = None):
     L.c2a_template_size.argtypes = [ctypes.c_uint32, ctypes.c_uint32, u64p, u64p]
     L.c2a_checksum.restype = ctypes.c_int
     L.c2a_checksum.argtypes = [vp, ctypes.c_int, u64p]
+    L.c2a_verify_boolify.restype = ctypes.c_int
+    L.c2a_verify_boolify.argtypes = [vp, ctypes.c_uint64, u64p, u64p]
+    L.c2a_debug_patch_bool_op.restype = ctypes.c_int
+    L.c2a_debug_patch_bool_op.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint8]
     L.c2a_get_timings.restype = ctypes.c_int
     L.c2a_get_timings.argtypes = [vp, ctypes.POINTER(_Timings)]
     L.c2a_get_stats.restype = ctypes.c_int
@@ -285,6 +290,17 @@ class Backend:
         v = ctypes.c_uint64(0)
         self._check(self._lib.c2a_checksum(self._ctx, CHECKSUM_STREAMS[stream], ctypes.byref(v)))
         return v.value
+
+    def verify_boolify(self, seed: int = 1) -> Tuple[int, int]:
+        """GPU simulation of the arithmetic circuit and its boolean image on 64 seeded vectors; returns
+        (number of (wire, vector) pairs compared, number that differ)."""
+        chk, bad = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._check(self._lib.c2a_verify_boolify(self._ctx, int(seed), ctypes.byref(chk), ctypes.byref(bad)))
+        return chk.value, bad.value
+
+    def debug_patch_bool_op(self, index: int, new_op: int):
+        """Fault injection for the verifier's tests."""
+        self._check(self._lib.c2a_debug_patch_bool_op(self._ctx, int(index), int(new_op)))
 
     def timings(self) -> dict:
         t = _Timings()

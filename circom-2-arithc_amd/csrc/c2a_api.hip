@@ -64,6 +64,9 @@ struct c2a_ctx {
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op;
     DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof, peel_ctl;
     DevBuf tsz, asz, goff, aoff, tmpl, tables, b_in0, b_in1, b_out, b_op;
+    DevBuf ev_produced, ev_spos, ev_aval, ev_bval;
+    std::vector<u32> h_fbase;      // level boundaries of the last peel (host copy)
+    u32 n_levels_run = 0;
     std::vector<DevBuf*> all;
 
     c2a_ctx() {
@@ -71,7 +74,7 @@ struct c2a_ctx {
                &ginfo, &slots0, &slots1, &meta, &anc, &fcount, &fbase, &order, &posof, &rflag, &ridx, &rlist, &next,
                &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
                &node_wire, &e_in0, &e_in1, &e_out, &e_op, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &peel_ctl, &tsz, &asz, &goff,
-               &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op};
+               &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &ev_produced, &ev_spos, &ev_aval, &ev_bval};
     }
 };
 
@@ -316,6 +319,7 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
         if (r) return r;
         peeled = t2[0];
         c->stats.levels = t2[1];
+        c->n_levels_run = level;
     }
     c->stats.level_launches = launches;
     if (profiling && !profiling_done) {   // diagnostics: mean over levels of the slowest wave's phase timestamps (ns since kernel entry)
@@ -832,6 +836,64 @@ int c2a_checksum(c2a_ctx* c, int which, uint64_t* value) {
     HIP_TRY(hipMemcpyAsync(&v, acc, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     *value = v;
+    return C2A_OK;
+}
+
+int c2a_verify_boolify(c2a_ctx* c, uint64_t seed, uint64_t* n_checked, uint64_t* n_mismatch) {
+    if (!c) return C2A_ERR_ARG;
+    if (c->stage < ST_BOOLIFIED) return fail(c, C2A_ERR_STATE, "c2a_verify_boolify: call c2a_boolify first");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const u32 n = c->n, wc = c->wire_count, width = c->binfo.width, M = c->binfo.m_wires;
+    const u64 out_base = (u64)M * width + c->binfo.aux_total;
+    ENSURE(c->ev_produced, wc);
+    ENSURE(c->ev_spos, (size_t)n * 4);
+    ENSURE(c->ev_aval, (size_t)wc * 64 * 8);
+    ENSURE(c->ev_bval, (size_t)c->binfo.wire_count * 8);
+    HIP_TRY(hipMemsetAsync(c->ev_produced.p, 0, wc, s));
+    ull* acc = reinterpret_cast<ull*>(c->scalars.as<u32>() + SC_TOTAL64);
+    HIP_TRY(hipMemsetAsync(acc, 0, 8, s));
+    if (n) {
+        C2A_LAUNCH_NOSYNC(k_eval_mark_produced, grid_for(n, 4096), kThreads, s, n, c->e_out.as<u32>(), c->ev_produced.as<u8>());
+        C2A_LAUNCH_NOSYNC(k_eval_inverse, grid_for(n, 4096), kThreads, s, n, c->sorted.as<u32>(), c->ev_spos.as<u32>());
+    }
+    if (wc)
+        C2A_LAUNCH_NOSYNC(k_eval_init, grid_for((u64)wc * 64, 8192), kThreads, s, wc, width, M, out_base, (u64)seed,
+                          (const u8*)c->ev_produced.as<u8>(), c->ev_aval.as<u64>(), c->ev_bval.as<u64>());
+    // the peel's level lists, last level first: producers before consumers, gates of one level independent
+    const u32 L = c->n_levels_run;
+    std::vector<u32> fb((size_t)L + 1, 0);               // fbase[k+1] is written by the launch of level k: valid up to index L
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(fb.data(), c->fbase.p, ((size_t)L + 1) * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    for (u32 lv = L; n && lv-- > 0;) {
+        const u32 lo = fb[lv], hi = fb[lv + 1];
+        if (hi <= lo || hi > n) continue;
+        const u32 cnt = hi - lo;
+        C2A_LAUNCH_NOSYNC(k_eval_level_arith, grid_for((u64)cnt * 64, 4096), kThreads, s, lo, cnt, width, c->order.as<u32>(),
+                          c->ev_spos.as<u32>(), c->e_in0.as<u32>(), c->e_in1.as<u32>(), c->e_out.as<u32>(), c->e_op.as<u8>(),
+                          c->ev_aval.as<u64>());
+        C2A_LAUNCH_NOSYNC(k_eval_level_bool, grid_for(cnt, 4096), kThreads, s, lo, cnt, c->order.as<u32>(), c->ev_spos.as<u32>(),
+                          (const u64*)c->goff.as<u64>(), c->b_in0.as<u32>(), c->b_in1.as<u32>(), c->b_out.as<u32>(),
+                          c->b_op.as<u8>(), c->ev_bval.as<u64>());
+    }
+    if (wc)
+        C2A_LAUNCH_NOSYNC(k_eval_compare, grid_for((u64)wc * 64, 8192), kThreads, s, wc, width, M, out_base,
+                          (const u64*)c->ev_aval.as<u64>(), (const u64*)c->ev_bval.as<u64>(), acc);
+    u64 bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, acc, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (n_checked) *n_checked = (u64)wc * 64;
+    if (n_mismatch) *n_mismatch = bad;
+    return C2A_OK;
+}
+
+int c2a_debug_patch_bool_op(c2a_ctx* c, uint64_t index, uint8_t new_op) {
+    if (!c) return C2A_ERR_ARG;
+    if (c->stage < ST_BOOLIFIED || index >= c->binfo.n_gates || new_op > C2A_INV) return fail(c, C2A_ERR_ARG, "c2a_debug_patch_bool_op: bad index / op");
+    HIP_TRY(hipMemcpyAsync(c->b_op.as<u8>() + index, &new_op, 1, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return C2A_OK;
 }
 

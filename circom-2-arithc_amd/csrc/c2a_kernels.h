@@ -1155,6 +1155,111 @@ __device__ __forceinline__ u64 mix64(u64 x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
     return x;
 }
+// ------------------------------------------------------------------------------------------------
+// Functional check at scale — the reference's simulation harness (tests/integration.rs:191-237: run the Bristol
+// circuit on inputs, compare outputs) as HIP kernels, for circuits far too large for a CPU simulator: the
+// arithmetic circuit and its boolean image are both evaluated on 64 pseudo-random input vectors and EVERY
+// arithmetic wire is compared with its w boolean wires.  Gates of one reverse-Kahn level are independent and
+// producers always sit in a higher level than their consumers, so the peel's level lists, walked from the last
+// level down to level 0, are a ready-made parallel schedule.
+// Semantics: tests/integration.rs:94-115 taken mod 2^w; where the reference would panic the value is defined by
+// DESIGN.md §5.2 (wrap-around, x/0 = 2^w-1, x%0 = x, shifts by >= w give 0).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 eval_arith_op(u32 op, u64 a, u64 b, u32 w, u64 mk) {
+    u64 r = 0;
+    switch (op) {
+    case 0: r = a + b; break;                       // AAdd
+    case 1: case 12: r = b ? a / b : mk; break;     // ADiv, AIntDiv
+    case 2: r = a == b; break;                      // AEq
+    case 3: r = a >= b; break;                      // AGEq
+    case 4: r = a > b; break;                       // AGt
+    case 5: r = a <= b; break;                      // ALEq
+    case 6: r = a < b; break;                       // ALt
+    case 7: r = a * b; break;                       // AMul
+    case 8: r = a != b; break;                      // ANeq
+    case 9: r = a - b; break;                       // ASub
+    case 10: r = a ^ b; break;                      // AXor
+    case 11: { u64 base = a, acc = 1, ex = b; while (ex) { if (ex & 1) acc *= base; base *= base; ex >>= 1; } r = acc; } break;   // APow
+    case 13: r = b ? a % b : a; break;              // AMod
+    case 14: r = b >= w ? 0 : a << b; break;        // AShiftL
+    case 15: r = b >= w ? 0 : a >> b; break;        // AShiftR
+    case 16: r = (a != 0) || (b != 0); break;       // ABoolOr
+    case 17: r = (a != 0) && (b != 0); break;       // ABoolAnd
+    case 18: r = a | b; break;                      // ABitOr
+    case 19: r = a & b; break;                      // ABitAnd
+    default: r = 0;
+    }
+    return r & mk;
+}
+
+__global__ void k_eval_mark_produced(u32 n, const u32* __restrict__ e_out, u8* produced) {
+    for (u64 p = gtid(); p < n; p += gstride()) produced[e_out[p]] = 1;
+}
+__global__ void k_eval_inverse(u32 n, const u32* __restrict__ sorted, u32* spos) {
+    for (u64 p = gtid(); p < n; p += gstride()) spos[sorted[p]] = (u32)p;
+}
+
+// free wires (inputs, constants: not produced by any gate) get pseudo-random w-bit values, 64 vectors per wire
+// (vectors 0..3 are the corner values 0, 2^w-1, 1, 2^(w-1)); boolean image = the transposed bits
+__global__ void k_eval_init(u32 wire_count, u32 width, u32 M, u64 out_base, u64 seed, const u8* __restrict__ produced,
+                            u64* aval, u64* bval) {
+    const u64 mk = width >= 64 ? ~0ull : ((1ull << width) - 1ull);
+    for (u64 i = gtid(); i < (u64)wire_count * 64; i += gstride()) {
+        const u32 W = (u32)(i >> 6), t = (u32)(i & 63);
+        if (produced[W]) continue;
+        u64 v = mix64(seed ^ ((u64)W << 8) ^ t) & mk;
+        if (t == 0) v = 0; else if (t == 1) v = mk; else if (t == 2) v = 1 & mk; else if (t == 3) v = (1ull << (width - 1)) & mk;
+        aval[i] = v;
+    }
+    for (u64 i = gtid(); i < (u64)wire_count * width; i += gstride()) {
+        const u32 W = (u32)(i / width), bit = (u32)(i - (u64)W * width);
+        if (produced[W]) continue;
+        const u64 mk2 = mk;
+        u64 word = 0;
+        for (u32 t = 0; t < 64; ++t) {
+            u64 v = mix64(seed ^ ((u64)W << 8) ^ t) & mk2;
+            if (t == 0) v = 0; else if (t == 1) v = mk2; else if (t == 2) v = 1 & mk2; else if (t == 3) v = (1ull << (width - 1)) & mk2;
+            word |= ((v >> bit) & 1ull) << t;
+        }
+        bval[bool_wire(W, bit, width, M, out_base)] = word;
+    }
+}
+
+// one level: lane per (gate, vector) for the arithmetic side, lane per gate for its boolean template
+__global__ void k_eval_level_arith(u32 lo, u32 cnt, u32 width, const u32* __restrict__ order, const u32* __restrict__ spos,
+                                   const u32* __restrict__ e_in0, const u32* __restrict__ e_in1, const u32* __restrict__ e_out,
+                                   const u8* __restrict__ e_op, u64* aval) {
+    const u64 mk = width >= 64 ? ~0ull : ((1ull << width) - 1ull);
+    for (u64 i = gtid(); i < (u64)cnt * 64; i += gstride()) {
+        const u32 p = spos[order[lo + (u32)(i >> 6)]], t = (u32)(i & 63);
+        aval[(u64)e_out[p] * 64 + t] = eval_arith_op(e_op[p], aval[(u64)e_in0[p] * 64 + t], aval[(u64)e_in1[p] * 64 + t], width, mk);
+    }
+}
+__global__ void k_eval_level_bool(u32 lo, u32 cnt, const u32* __restrict__ order, const u32* __restrict__ spos,
+                                  const u64* __restrict__ goff, const u32* __restrict__ b_in0, const u32* __restrict__ b_in1,
+                                  const u32* __restrict__ b_out, const u8* __restrict__ b_op, u64* bval) {
+    for (u64 i = gtid(); i < cnt; i += gstride()) {
+        const u32 p = spos[order[lo + (u32)i]];
+        for (u64 k = goff[p]; k < goff[p + 1]; ++k) {
+            const u64 a = bval[b_in0[k]], b = bval[b_in1[k]];
+            const u32 o = b_op[k];
+            bval[b_out[k]] = o == 0 ? (a ^ b) : (o == 1 ? (a & b) : ~a);
+        }
+    }
+}
+// every (arithmetic wire, vector): value == the w boolean wires read back
+__global__ void k_eval_compare(u32 wire_count, u32 width, u32 M, u64 out_base, const u64* __restrict__ aval,
+                               const u64* __restrict__ bval, ull* mismatches) {
+    u64 bad = 0;
+    for (u64 i = gtid(); i < (u64)wire_count * 64; i += gstride()) {
+        const u32 W = (u32)(i >> 6), t = (u32)(i & 63);
+        u64 v = 0;
+        for (u32 bit = 0; bit < width; ++bit) v |= ((bval[bool_wire(W, bit, width, M, out_base)] >> t) & 1ull) << bit;
+        bad += v != aval[i];
+    }
+    if (bad) atomicAdd(mismatches, (ull)bad);
+}
+
 __global__ void k_checksum_u32(u64 n, const u32* __restrict__ v, ull* acc) {
     u64 local = 0;
     for (u64 i = gtid(); i < n; i += gstride()) local += mix64((i << 32) ^ (i >> 32) ^ ((u64)v[i] * 0x9E3779B97F4A7C15ULL));

@@ -139,6 +139,17 @@ int c2a_template_size(uint32_t op, uint32_t width, uint64_t* n_gates, uint64_t* 
  *        5 bool in0, 6 bool in1, 7 bool out, 8 bool op, 9 node_to_wire */
 int c2a_checksum(c2a_ctx* ctx, int which, uint64_t* value);
 
+/*
+ * Functional check at scale — the reference's simulation harness (tests/integration.rs:191-237) as HIP kernels:
+ * evaluates the arithmetic circuit of c2a_build_circuit and the boolean circuit of c2a_boolify on 64 seeded
+ * pseudo-random input vectors and compares EVERY arithmetic wire with its `width` boolean wires.
+ * *n_checked = wire_count * 64 (wire, vector) pairs, *n_mismatch = how many differ (0 when the bit-blast is right).
+ * Needs ~8 B per (arithmetic wire x 64) + 8 B per boolean wire of scratch HBM; requires c2a_boolify.
+ */
+int c2a_verify_boolify(c2a_ctx* ctx, uint64_t seed, uint64_t* n_checked, uint64_t* n_mismatch);
+/* Fault injection for the tests of the verifier: overwrite the op of one boolean gate in HBM. */
+int c2a_debug_patch_bool_op(c2a_ctx* ctx, uint64_t index, uint8_t new_op);
+
 int c2a_get_timings(c2a_ctx* ctx, c2a_timings* t);
 int c2a_get_stats(c2a_ctx* ctx, c2a_stats* s);
 
