@@ -73,6 +73,9 @@ def main():
     ap.add_argument("--layer-width", type=int, default=2000)
     ap.add_argument("--cpu-sample-layers", type=int, default=1000, help="layers of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--check", action="store_true", help="verify the GPU result against the oracle (sample-sized run)")
+    ap.add_argument("--mode", choices=["replicas", "shard"], default="replicas",
+                    help="N>1: 'replicas' = one independent graph per rank (weak scaling, default); 'shard' = ONE graph, "
+                         "sort replicated on every rank, boolify sharded by sorted-position range (strong scaling, DESIGN.md §7)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -97,15 +100,23 @@ def main():
     synth = c2a.synth
 
     t0 = time.time()
-    fg = synth.layered_dag(args.layers, args.layer_width, seed=synth.SEED + rank)
+    shard = args.mode == "shard" and world > 1
+    fg = synth.layered_dag(args.layers, args.layer_width, seed=synth.SEED + (0 if shard else rank))
     gen_s = time.time() - t0
     be = c2a.Backend(local_rank)
     t0 = time.time()
     be.load_gates(fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes)
     h2d_s = time.time() - t0
 
+    n_all = fg.n
+    my_lo, my_hi = (rank * n_all) // world, ((rank + 1) * n_all) // world
+
     def step():
         be.build_circuit()
+        if shard:      # every rank holds the whole sorted circuit, so it can place its own range without any exchange
+            info = be.boolify_plan(args.width)
+            be.boolify_chunk(my_lo, my_hi - my_lo, fetch=False)
+            return info
         return be.boolify(args.width)
 
     stage_acc = {}
@@ -129,7 +140,7 @@ def main():
     steps = max(1, args.steps)
     stages = {k: v / steps for k, v in stage_acc.items()}
     ms_per_step = elapsed * 1e3 / steps
-    value = whole_job_rate(world, n, steps, elapsed)
+    value = whole_job_rate(1 if shard else world, n, steps, elapsed)
     algo_bytes = 13.0 * n + 13.0 * info.n_gates                  # per k_boolify launch
     bool_ms = stages.get("bool_map", 0.0)
     achieved = algo_bytes / (bool_ms * 1e-3) / 1e9 if bool_ms > 0 else 0.0
@@ -181,13 +192,14 @@ def main():
     line = {
         "metric": "gates/sec (topo-sort + boolify), 10M-gate DAG",
         "value": value, "unit": "gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": f"synthetic layered DAG, {args.layers} layers x {args.layer_width} = {n} gates/GPU, fan-in 2, "
                                f"gate ids permuted, sparse node ids, seed {synth.SEED}(+rank), --boolify-width {args.width}",
                    "n_gates_per_gpu": n, "boolean_gates_per_gpu": info.n_gates, "boolify_width": args.width,
                    "levels": stats["levels"], "dfs_tree_depth": stats["max_depth"],
-                   "parallelism": "1 graph per GPU (replicated pipeline, no collective)" if world > 1 else "single GPU"},
+                   "parallelism": ("1 graph, sort replicated, boolify sharded by sorted-position range" if shard else
+                                   "1 graph per GPU (replicated pipeline, no collective)") if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "kernel": "k_boolify", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": "profiles/r01_pmc_hbm_bytes.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None,

@@ -88,7 +88,7 @@ class BoolInfo:
 _EXPORTS = ["c2a_create", "c2a_destroy", "c2a_last_error", "c2a_version", "c2a_load_gates", "c2a_topo_sort",
             "c2a_topo_sort_serial", "c2a_assign_wires", "c2a_emit_gates", "c2a_build_circuit", "c2a_boolify",
             "c2a_bool_read", "c2a_template_size", "c2a_checksum", "c2a_get_timings", "c2a_get_stats", "c2a_verify_boolify",
-            "c2a_debug_patch_bool_op"]
+            "c2a_debug_patch_bool_op", "c2a_boolify_plan", "c2a_boolify_chunk"]
 
 
 def library_path() -> str:
@@ -131,6 +131,10 @@ def load_library(lib_path: Optional[str] = None):
     L.c2a_build_circuit.argtypes = [vp, u64p, u32p]
     L.c2a_boolify.restype = ctypes.c_int
     L.c2a_boolify.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(_BoolInfo)]
+    L.c2a_boolify_plan.restype = ctypes.c_int
+    L.c2a_boolify_plan.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(_BoolInfo)]
+    L.c2a_boolify_chunk.restype = ctypes.c_int
+    L.c2a_boolify_chunk.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64, u32p, u32p, u32p, u8p, u64p, u64p]
     L.c2a_bool_read.restype = ctypes.c_int
     L.c2a_bool_read.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64, u32p, u32p, u32p, u8p]
     L.c2a_template_size.restype = ctypes.c_int
@@ -268,6 +272,32 @@ class Backend:
         self.bool_info = BoolInfo(int(info.n_gates), int(info.wire_count), int(info.aux_total), int(info.width),
                                   int(info.n_in), int(info.n_out), int(info.m_wires))
         return self.bool_info
+
+    def boolify_plan(self, width: int) -> BoolInfo:
+        """Sizes / offsets / wire layout only (no boolean gates are produced)."""
+        info = _BoolInfo()
+        self._check(self._lib.c2a_boolify_plan(self._ctx, int(width), ctypes.byref(info)))
+        self.bool_info = BoolInfo(int(info.n_gates), int(info.wire_count), int(info.aux_total), int(info.width),
+                                  int(info.n_in), int(info.n_out), int(info.m_wires))
+        return self.bool_info
+
+    def boolify_chunk(self, first_gate: int, n_gates: int, fetch: bool = True):
+        """Boolean gates of the arithmetic gates at sorted positions [first_gate, first_gate + n_gates).
+        Returns (first boolean gate index, (in0, in1, out, op))."""
+        q0, cnt = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        if not fetch:
+            self._check(self._lib.c2a_boolify_chunk(self._ctx, int(first_gate), int(n_gates), None, None, None, None,
+                                                    ctypes.byref(q0), ctypes.byref(cnt)))
+            return q0.value, cnt.value
+        # size the host arrays from the plan: run once without copies to learn the count
+        self._check(self._lib.c2a_boolify_chunk(self._ctx, int(first_gate), int(n_gates), None, None, None, None,
+                                                ctypes.byref(q0), ctypes.byref(cnt)))
+        in0, in1, out = (np.empty(cnt.value, dtype=np.uint32) for _ in range(3))
+        op = np.empty(cnt.value, dtype=np.uint8)
+        self._check(self._lib.c2a_boolify_chunk(self._ctx, int(first_gate), int(n_gates), _p(in0, ctypes.c_uint32),
+                                                _p(in1, ctypes.c_uint32), _p(out, ctypes.c_uint32), _p(op, ctypes.c_uint8),
+                                                ctypes.byref(q0), ctypes.byref(cnt)))
+        return q0.value, (in0, in1, out, op)
 
     def bool_read(self, first: int = 0, count: Optional[int] = None):
         if count is None:

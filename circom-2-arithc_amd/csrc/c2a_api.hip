@@ -64,7 +64,8 @@ struct c2a_ctx {
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op;
     DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof, peel_ctl;
     DevBuf tsz, asz, goff, aoff, tmpl, tables, b_in0, b_in1, b_out, b_op;
-    DevBuf ev_produced, ev_spos, ev_aval, ev_bval;
+    DevBuf ev_produced, ev_spos, ev_aval, ev_bval, cb_in0, cb_in1, cb_out, cb_op;
+    bool bool_planned = false;
     std::vector<u32> h_fbase;      // level boundaries of the last peel (host copy)
     u32 n_levels_run = 0;
     std::vector<DevBuf*> all;
@@ -74,7 +75,7 @@ struct c2a_ctx {
                &ginfo, &slots0, &slots1, &meta, &anc, &fcount, &fbase, &order, &posof, &rflag, &ridx, &rlist, &next,
                &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
                &node_wire, &e_in0, &e_in1, &e_out, &e_op, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &peel_ctl, &tsz, &asz, &goff,
-               &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &ev_produced, &ev_spos, &ev_aval, &ev_bval};
+               &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &cb_in0, &cb_in1, &cb_out, &cb_op};
     }
 };
 
@@ -414,6 +415,7 @@ int run_serial_dfs(c2a_ctx* c, u32* status, u64* cycle_at) {
 int do_topo_sort(c2a_ctx* c, u64* cycle_at) {
     if (c->stage < ST_LOADED) return fail(c, C2A_ERR_STATE, "c2a_topo_sort: no gates loaded");
     c->stage = ST_LOADED;
+    c->bool_planned = false;
     const u32 n = c->n;
     std::memset(c->ev_valid, 0, sizeof(c->ev_valid));
     c->stats = c2a_stats{};
@@ -724,11 +726,14 @@ int c2a_template_size(uint32_t op, uint32_t width, uint64_t* n_gates, uint64_t* 
     return C2A_OK;
 }
 
-int c2a_boolify(c2a_ctx* c, uint32_t width, c2a_bool_info* info) {
-    if (!c) return C2A_ERR_ARG;
+}  // extern "C"
+
+namespace {
+
+// templates, per-gate sizes and the two offset scans; fills c->binfo (no output buffers)
+int bool_plan(c2a_ctx* c, uint32_t width) {
     if (c->stage < ST_EMITTED) return fail(c, C2A_ERR_STATE, "c2a_boolify: call c2a_emit_gates / c2a_build_circuit first");
     if (width == 0 || width > 64) return fail(c, C2A_ERR_ARG, "c2a_boolify: width must be in 1..64");
-    HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const u32 n = c->n;
     // templates for this width (host-generated once per width, cached in HBM)
@@ -767,28 +772,84 @@ int c2a_boolify(c2a_ctx* c, uint32_t width, c2a_bool_info* info) {
     const u64 G = totals[0], AUX = totals[1];
     const u64 wires = (u64)c->wire_count * width + AUX;
     if (wires >= 0xFFFFFFFFull) return fail(c, C2A_ERR_OVERFLOW, "c2a_boolify: boolean wire ids exceed u32");
+    c->binfo.n_gates = G; c->binfo.wire_count = wires; c->binfo.aux_total = AUX; c->binfo.width = width;
+    c->binfo.n_in = c->n_in; c->binfo.n_out = c->n_out; c->binfo.m_wires = c->wire_count - c->n_out;
+    c->bool_planned = true;
+    return C2A_OK;
+}
+
+// the map kernel over sorted positions [p_first, p_end) into buffers where boolean gate q sits at q - q_bias
+int bool_map(c2a_ctx* c, u32 p_first, u32 p_end, u64 q_bias, u32* o_in0, u32* o_in1, u32* o_out, u8* o_op) {
+    if (p_end <= p_first) return C2A_OK;
+    const u32 width = c->binfo.width, M = c->binfo.m_wires;
+    BoolArgs A;
+    A.n = c->n; A.width = width; A.M = M; A.aux_base = (u64)M * width; A.out_base = (u64)M * width + c->binfo.aux_total;
+    A.e_in0 = c->e_in0.as<u32>(); A.e_in1 = c->e_in1.as<u32>(); A.e_out = c->e_out.as<u32>(); A.e_op = c->e_op.as<u8>();
+    A.goff = c->goff.as<u64>(); A.aoff = c->aoff.as<u64>(); A.tmpl = c->tmpl.as<uint4>();
+    A.b_in0 = o_in0; A.b_in1 = o_in1; A.b_out = o_out; A.b_op = o_op;
+    A.p_first = p_first; A.p_end = p_end; A.q_bias = q_bias;
+    const BoolTables* Tb = c->tables.as<BoolTables>();
+    const u32 ch = c->bool_chunk;
+    const u32 blocks = (p_end - p_first + ch - 1) / ch;
+    if (ch == 128) C2A_LAUNCH((k_boolify<128>), blocks, kThreads, c->stream, A, Tb);
+    else if (ch == 512) C2A_LAUNCH((k_boolify<512>), blocks, kThreads, c->stream, A, Tb);
+    else C2A_LAUNCH((k_boolify<256>), blocks, kThreads, c->stream, A, Tb);
+    return C2A_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int c2a_boolify(c2a_ctx* c, uint32_t width, c2a_bool_info* info) {
+    if (!c) return C2A_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    int r = bool_plan(c, width);
+    if (r) return r;
+    const u64 G = c->binfo.n_gates;
     ENSURE(c->b_in0, G * 4); ENSURE(c->b_in1, G * 4); ENSURE(c->b_out, G * 4); ENSURE(c->b_op, G);
     rec(c, EV_BPREP1);
-    const u32 M = c->wire_count - c->n_out;
-    if (n) {
-        BoolArgs A;
-        A.n = n; A.width = width; A.M = M; A.aux_base = (u64)M * width; A.out_base = (u64)M * width + AUX;
-        A.e_in0 = c->e_in0.as<u32>(); A.e_in1 = c->e_in1.as<u32>(); A.e_out = c->e_out.as<u32>(); A.e_op = c->e_op.as<u8>();
-        A.goff = c->goff.as<u64>(); A.aoff = c->aoff.as<u64>(); A.tmpl = c->tmpl.as<uint4>();
-        A.b_in0 = c->b_in0.as<u32>(); A.b_in1 = c->b_in1.as<u32>(); A.b_out = c->b_out.as<u32>(); A.b_op = c->b_op.as<u8>();
-        const BoolTables* Tb = c->tables.as<BoolTables>();
-        const u32 ch = c->bool_chunk;
-        const u32 blocks = (n + ch - 1) / ch;
-        if (ch == 128) C2A_LAUNCH((k_boolify<128>), blocks, kThreads, s, A, Tb);
-        else if (ch == 512) C2A_LAUNCH((k_boolify<512>), blocks, kThreads, s, A, Tb);
-        else C2A_LAUNCH((k_boolify<256>), blocks, kThreads, s, A, Tb);
-    }
+    r = bool_map(c, 0, c->n, 0, c->b_in0.as<u32>(), c->b_in1.as<u32>(), c->b_out.as<u32>(), c->b_op.as<u8>());
+    if (r) return r;
     rec(c, EV_BMAP1);
-    HIP_TRY(hipStreamSynchronize(s));
-    c->binfo.n_gates = G; c->binfo.wire_count = wires; c->binfo.aux_total = AUX; c->binfo.width = width;
-    c->binfo.n_in = c->n_in; c->binfo.n_out = c->n_out; c->binfo.m_wires = M;
+    HIP_TRY(hipStreamSynchronize(c->stream));
     if (info) *info = c->binfo;
     c->stage = ST_BOOLIFIED;
+    return C2A_OK;
+}
+
+int c2a_boolify_plan(c2a_ctx* c, uint32_t width, c2a_bool_info* info) {
+    if (!c) return C2A_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    int r = bool_plan(c, width);
+    if (r) return r;
+    if (c->stage > ST_EMITTED) c->stage = ST_EMITTED;        // a full boolean circuit of another width is no longer valid
+    if (info) *info = c->binfo;
+    return C2A_OK;
+}
+
+int c2a_boolify_chunk(c2a_ctx* c, uint64_t first_gate, uint64_t n_gates, uint32_t* in0, uint32_t* in1, uint32_t* out,
+                      uint8_t* op, uint64_t* first_bool_gate, uint64_t* n_bool_gates) {
+    if (!c) return C2A_ERR_ARG;
+    if (!c->bool_planned || c->stage < ST_EMITTED) return fail(c, C2A_ERR_STATE, "c2a_boolify_chunk: call c2a_boolify_plan first");
+    if (first_gate > c->n || n_gates > c->n - first_gate) return fail(c, C2A_ERR_ARG, "c2a_boolify_chunk: range out of bounds");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    u64 q[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(&q[0], c->goff.as<u64>() + first_gate, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&q[1], c->goff.as<u64>() + first_gate + n_gates, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const u64 cntq = q[1] - q[0], bias = q[0] & ~3ull, lead = q[0] - bias;
+    ENSURE(c->cb_in0, (cntq + 8) * 4); ENSURE(c->cb_in1, (cntq + 8) * 4); ENSURE(c->cb_out, (cntq + 8) * 4); ENSURE(c->cb_op, cntq + 8);
+    int r = bool_map(c, (u32)first_gate, (u32)(first_gate + n_gates), bias, c->cb_in0.as<u32>(), c->cb_in1.as<u32>(),
+                     c->cb_out.as<u32>(), c->cb_op.as<u8>());
+    if (r) return r;
+    if ((r = copy_out(c, in0, c->cb_in0.as<u32>() + lead, cntq * 4)) || (r = copy_out(c, in1, c->cb_in1.as<u32>() + lead, cntq * 4)) ||
+        (r = copy_out(c, out, c->cb_out.as<u32>() + lead, cntq * 4)) || (r = copy_out(c, op, c->cb_op.as<u8>() + lead, cntq)))
+        return r;
+    HIP_TRY(hipStreamSynchronize(s));
+    if (first_bool_gate) *first_bool_gate = q[0];
+    if (n_bool_gates) *n_bool_gates = cntq;
     return C2A_OK;
 }
 

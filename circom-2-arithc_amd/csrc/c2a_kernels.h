@@ -1064,6 +1064,9 @@ struct BoolArgs {
     const u64* aoff;  // [n+1] first aux wire (relative) of each arithmetic gate
     const uint4* tmpl;
     u32* b_in0; u32* b_in1; u32* b_out; u8* b_op;
+    u32 p_first;      // first arithmetic gate (sorted position) of this launch
+    u32 p_end;        // one past the last
+    u64 q_bias;       // boolean gate q is stored at index q - q_bias (multiple of 4: keeps the 16-byte alignment)
 };
 
 
@@ -1096,8 +1099,8 @@ __global__ void __launch_bounds__(kThreads) k_boolify(BoolArgs A, const BoolTabl
     __shared__ uint4 s_base[CHUNK];         // wire bases per ref kind
     __shared__ u32 s_top[CHUNK];            // template offset
     const u32 tid = threadIdx.x;
-    const u64 p0 = (u64)blockIdx.x * CHUNK;
-    const u32 cnt = (u32)((A.n - p0) < (u64)CHUNK ? (A.n - p0) : (u64)CHUNK);
+    const u64 p0 = (u64)A.p_first + (u64)blockIdx.x * CHUNK;
+    const u32 cnt = (u32)((A.p_end - p0) < (u64)CHUNK ? (A.p_end - p0) : (u64)CHUNK);
     const u64 q0 = A.goff[p0];
     for (u32 i = tid; i <= cnt; i += kThreads) s_goff[i] = (u32)(A.goff[p0 + i] - q0);
     for (u32 i = tid; i < cnt; i += kThreads) {
@@ -1127,7 +1130,7 @@ __global__ void __launch_bounds__(kThreads) k_boolify(BoolArgs A, const BoolTabl
             v2[j] = base_words[idx * 4 + (e.z >> 30)] + (e.z & 0x3FFFFFFFu);
             vop |= (e.w & 0xFFu) << (8 * j);
         }
-        const u64 q = q0 + r;
+        const u64 q = q0 + r - A.q_bias;
         *reinterpret_cast<u32x4*>(A.b_in0 + q) = u32x4{v0[0], v0[1], v0[2], v0[3]};
         *reinterpret_cast<u32x4*>(A.b_in1 + q) = u32x4{v1[0], v1[1], v1[2], v1[3]};
         *reinterpret_cast<u32x4*>(A.b_out + q) = u32x4{v2[0], v2[1], v2[2], v2[3]};
@@ -1140,7 +1143,7 @@ __global__ void __launch_bounds__(kThreads) k_boolify(BoolArgs A, const BoolTabl
             const u32 r = tid < nh ? tid : r1 + (tid - nh);
             const u32 lo = bool_owner(r, s_goff, cnt);
             const uint4 e = A.tmpl[s_top[lo] + (r - s_goff[lo])];
-            const u64 q = q0 + r;
+            const u64 q = q0 + r - A.q_bias;
             A.b_in0[q] = base_words[lo * 4 + (e.x >> 30)] + (e.x & 0x3FFFFFFFu);
             A.b_in1[q] = base_words[lo * 4 + (e.y >> 30)] + (e.y & 0x3FFFFFFFu);
             A.b_out[q] = base_words[lo * 4 + (e.z >> 30)] + (e.z & 0x3FFFFFFFu);

@@ -131,6 +131,17 @@ int c2a_boolify(c2a_ctx* ctx, uint32_t width, c2a_bool_info* info);
 int c2a_bool_read(c2a_ctx* ctx, uint64_t first, uint64_t count, uint32_t* in0, uint32_t* in1, uint32_t* out,
                   uint8_t* op);
 
+/*
+ * Chunked emission, for boolean circuits larger than the HBM left over (or to stream them to disk / to shard them
+ * over GPUs by sorted-position range): c2a_boolify_plan computes sizes, offsets and the wire layout only;
+ * c2a_boolify_chunk then bit-blasts the arithmetic gates at sorted positions [first_gate, first_gate + n_gates) into a
+ * chunk-sized buffer and copies them to the host arrays (any may be NULL).  The gates are identical to the
+ * corresponding range [*first_bool_gate, +*n_bool_gates) of the full c2a_boolify result.
+ */
+int c2a_boolify_plan(c2a_ctx* ctx, uint32_t width, c2a_bool_info* info);
+int c2a_boolify_chunk(c2a_ctx* ctx, uint64_t first_gate, uint64_t n_gates, uint32_t* in0, uint32_t* in1, uint32_t* out,
+                      uint8_t* op, uint64_t* first_bool_gate, uint64_t* n_bool_gates);
+
 /* T(op,width) and AUX(op,width) of the frozen spec (host-side query; no GPU work). */
 int c2a_template_size(uint32_t op, uint32_t width, uint64_t* n_gates, uint64_t* n_aux);
 

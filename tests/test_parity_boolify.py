@@ -135,3 +135,34 @@ def test_gpu_verifier_agrees_and_detects_faults(backend, c2a, width):
         backend.debug_patch_bool_op(k, int(op[k]))
     assert caught >= (len(picks) + 1) // 2, (caught, len(picks))
     assert backend.verify_boolify(seed=42)[1] == 0
+
+
+@pytest.mark.parametrize("width", [3, 32])
+def test_chunked_boolify_equals_the_full_result(backend, orc, c2a, width):
+    """c2a_boolify_plan + c2a_boolify_chunk (streaming emission / sharding by sorted-position range): every chunk is
+    bit-identical to the matching slice of the full circuit, whatever the chunk boundaries."""
+    mix = tuple(m for m in c2a.synth.MIX_ALL if m[0] != "APow")
+    fg = c2a.synth.layered_dag(11, 23, n_in=8, n_const=3, window=3, mix=mix, seed=77 + width)
+    _load(backend, fg)
+    exp = orc.boolify(_oracle(orc, fg), width)
+    info = backend.boolify_plan(width)
+    assert info.n_gates == len(exp.in0) and info.wire_count == exp.wire_count
+    n = fg.n
+    cuts = [0, 1, 2, 7, n // 3, n // 3 + 1, n - 5, n]
+    total = 0
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        q0, got = backend.boolify_chunk(a, b - a)
+        assert q0 == total
+        for x, y in zip(got, (exp.in0, exp.in1, exp.out, exp.op)):
+            np.testing.assert_array_equal(x, y[q0:q0 + len(x)])
+        total += len(got[0])
+    assert total == info.n_gates
+    q0, got = backend.boolify_chunk(5, 0)                  # empty chunk
+    assert len(got[0]) == 0
+    with pytest.raises(c2a.BackendError):
+        backend.boolify_chunk(n - 1, 2)
+    # the full map still works after chunking, and chunking needs a plan
+    assert backend.boolify(width).n_gates == info.n_gates
+    backend.build_circuit()
+    with pytest.raises(c2a.BackendError):
+        backend.boolify_chunk(0, 1)
