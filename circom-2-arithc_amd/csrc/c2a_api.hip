@@ -58,8 +58,8 @@ struct c2a_ctx {
     u32 bool_width = 0;
 
     // device buffers
-    DevBuf lh, rh, out, op, in_nodes, out_nodes;
-    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, fill, cand, meta, anc, fcount, fbase, order, posof, ginfo, slots0, slots1;
+    DevBuf lh, rh, out, op, gate4, in_nodes, out_nodes;
+    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, fill, cand, meta, anc, fcount, fbase, order, posof, child, ginfo, slots0, slots1;
     DevBuf rflag, ridx, rlist, next, owner, local, slist, snext, ssum, jnxt, jval, sorted;
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op;
     DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof, peel_ctl;
@@ -71,8 +71,8 @@ struct c2a_ctx {
     std::vector<DevBuf*> all;
 
     c2a_ctx() {
-        all = {&lh, &rh, &out, &op, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &fill, &cand,
-               &ginfo, &slots0, &slots1, &meta, &anc, &fcount, &fbase, &order, &posof, &rflag, &ridx, &rlist, &next,
+        all = {&lh, &rh, &out, &op, &gate4, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &fill, &cand,
+               &ginfo, &slots0, &slots1, &meta, &anc, &fcount, &fbase, &order, &posof, &child, &rflag, &ridx, &rlist, &next,
                &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
                &node_wire, &e_in0, &e_in1, &e_out, &e_op, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &peel_ctl, &tsz, &asz, &goff,
                &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &cb_in0, &cb_in1, &cb_out, &cb_op};
@@ -188,6 +188,7 @@ int do_prep(c2a_ctx* c) {
     HIP_TRY(hipMemsetAsync(c->fill.p, 0, (size_t)n * 4, s));
     HIP_TRY(hipMemsetAsync(c->fcount.p, 0, ((size_t)n + 2) * 4, s));
     HIP_TRY(hipMemsetAsync(c->fbase.p, 0, 8, s));
+    HIP_TRY(hipMemsetAsync(c->child.p, 0xFF, (size_t)n * 8, s));
     HIP_TRY(hipMemsetAsync(c->scalars.p, 0, SC_WORDS * 4, s));
     C2A_LAUNCH_NOSYNC(k_producer, G, kThreads, s, n, c->out.as<u32>(), c->prod1.as<u32>());
     C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->prod1.as<u32>(), c->dep0.as<u32>(),
@@ -211,7 +212,7 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
     A.slots[0] = c->slots0.as<FrontierSlot>(); A.slots[1] = c->slots1.as<FrontierSlot>();
     A.cand = c->cand.as<uint4>(); A.fill = c->fill.as<u32>();
     A.meta = c->meta.as<uint4>(); A.anc = c->anc.as<u32>(); A.fcount = c->fcount.as<u32>(); A.fbase = c->fbase.as<u32>();
-    A.order = c->order.as<u32>(); A.posof = c->posof.as<u32>();
+    A.order = c->order.as<u32>(); A.posof = c->posof.as<u32>(); A.child = c->child.as<u32>();
     A.prof = nullptr; A.prof_level0 = 256;
     const bool profiling = std::getenv("C2A_PEEL_PROFILE") != nullptr;
     if (profiling) {
@@ -366,12 +367,11 @@ int do_order(c2a_ctx* c) {
     HIP_TRY(hipMemcpyAsync(&n_roots, c->ridx.as<u32>() + n, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     c->stats.n_roots = n_roots;
-    C2A_LAUNCH_NOSYNC(k_euler_next, G, kThreads, s, n, c->meta.as<uint4>(), c->order.as<u32>(), c->posof.as<u32>(),
-                      (const uint4*)c->ginfo.as<uint4>(), c->ridx.as<u32>(), c->rlist.as<u32>(), n_roots,
-                      c->next.as<u32>());
+    C2A_LAUNCH_NOSYNC(k_euler_next, G, kThreads, s, n, c->meta.as<uint4>(), c->order.as<u32>(), c->child.as<u32>(),
+                      c->ridx.as<u32>(), c->rlist.as<u32>(), n_roots, c->next.as<u32>());
     const u32 m = 2 * n;
     u32* scount = c->scalars.as<u32>() + SC_SCOUNT;
-    C2A_LAUNCH(k_rank_mark, grid_for(m, 2048), kThreads, s, m, c->rlist.as<u32>(), scount, c->slist.as<u32>(),
+    C2A_LAUNCH(k_rank_mark, std::max<u32>(1u, std::min<u32>(2048u, (m + kThreads * 8 - 1) / (kThreads * 8))), kThreads, s, m, c->rlist.as<u32>(), scount, c->slist.as<u32>(),
                       c->owner.as<u32>());
     u32 sc[2] = {0, 0};                       // SC_MAXDEPTH, SC_SCOUNT are adjacent
     r = read_scalars(c, sc, SC_MAXDEPTH, 2);
@@ -471,17 +471,17 @@ int do_assign_wires(c2a_ctx* c) {
         C2A_LAUNCH_NOSYNC(k_mark_outputs, grid_for(c->n_out, 1024), kThreads, s, c->n_out, c->out_nodes.as<u32>(),
                           c->nflag.as<u8>(), c->scalars.as<u32>() + SC_ERR);
     if (n) {
-        const u32 G = grid_for(m, 4096);
-        C2A_LAUNCH_NOSYNC(k_first_seen, G, kThreads, s, m, c->sorted.as<u32>(), c->lh.as<u32>(), c->rh.as<u32>(),
-                          c->out.as<u32>(), c->first.as<u32>());
-        C2A_LAUNCH_NOSYNC(k_new_wire_flags, G, kThreads, s, m, c->sorted.as<u32>(), c->lh.as<u32>(), c->rh.as<u32>(),
-                          c->out.as<u32>(), c->first.as<u32>(), c->nflag.as<u8>(), c->wflag.as<u32>());
+        const u32 G = grid_for(n, 4096);
+        C2A_LAUNCH_NOSYNC(k_first_seen, G, kThreads, s, n, c->sorted.as<u32>(), (const uint4*)c->gate4.as<uint4>(),
+                          c->first.as<u32>());
+        C2A_LAUNCH_NOSYNC(k_new_wire_flags, G, kThreads, s, n, c->sorted.as<u32>(), (const uint4*)c->gate4.as<uint4>(),
+                          c->first.as<u32>(), c->nflag.as<u8>(), c->wflag.as<u32>());
     }
     int r = scan_exclusive<u32>(c, c->wflag.as<u32>(), c->widx.as<u32>(), m);
     if (r) return r;
     if (n) {
-        C2A_LAUNCH_NOSYNC(k_assign_wires, grid_for(m, 4096), kThreads, s, m, c->sorted.as<u32>(), c->lh.as<u32>(),
-                          c->rh.as<u32>(), c->out.as<u32>(), c->wflag.as<u32>(), c->widx.as<u32>(), c->n_in,
+        C2A_LAUNCH_NOSYNC(k_assign_wires, grid_for(n, 4096), kThreads, s, n, c->sorted.as<u32>(),
+                          (const uint4*)c->gate4.as<uint4>(), c->wflag.as<u32>(), c->widx.as<u32>(), c->n_in,
                           c->node_wire1.as<u32>());
     }
     if (c->n_out)
@@ -503,9 +503,9 @@ int do_emit(c2a_ctx* c) {
     if (c->stage < ST_WIRED) return fail(c, C2A_ERR_STATE, "c2a_emit_gates: call c2a_assign_wires first");
     rec(c, EV_EMIT0);
     if (c->n)
-        C2A_LAUNCH_NOSYNC(k_emit, grid_for(c->n, 4096), kThreads, c->stream, c->n, c->sorted.as<u32>(), c->lh.as<u32>(),
-                          c->rh.as<u32>(), c->out.as<u32>(), c->op.as<u8>(), c->node_wire1.as<u32>(), c->e_in0.as<u32>(),
-                          c->e_in1.as<u32>(), c->e_out.as<u32>(), c->e_op.as<u8>());
+        C2A_LAUNCH_NOSYNC(k_emit, grid_for(c->n, 4096), kThreads, c->stream, c->n, c->sorted.as<u32>(),
+                          (const uint4*)c->gate4.as<uint4>(), c->node_wire1.as<u32>(), c->e_in0.as<u32>(), c->e_in1.as<u32>(),
+                          c->e_out.as<u32>(), c->e_op.as<u8>());
     rec(c, EV_EMIT1);
     c->stage = ST_EMITTED;
     return C2A_OK;
@@ -599,7 +599,7 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     c->n = n; c->n_nodes = n_nodes; c->n_in = n_in; c->n_out = n_out;
     c->planes = planes_for(n, c->anc_bits);
     const size_t n4 = (size_t)n * 4, nn4 = (size_t)n_nodes * 4;
-    ENSURE(c->lh, n4); ENSURE(c->rh, n4); ENSURE(c->out, n4); ENSURE(c->op, n);
+    ENSURE(c->lh, n4); ENSURE(c->rh, n4); ENSURE(c->out, n4); ENSURE(c->op, n); ENSURE(c->gate4, (size_t)n * 16);
     ENSURE(c->in_nodes, (size_t)n_in * 4); ENSURE(c->out_nodes, (size_t)n_out * 4);
     ENSURE(c->prod1, nn4); ENSURE(c->dep0, n4); ENSURE(c->dep1, n4); ENSURE(c->cons_cnt, n4);
     ENSURE(c->cons_off, n4 + 4); ENSURE(c->fill, n4); ENSURE(c->cand, (size_t)n * 2 * 16);
@@ -607,7 +607,7 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     ENSURE(c->slots0, ((size_t)n + 1) * sizeof(FrontierSlot)); ENSURE(c->slots1, ((size_t)n + 1) * sizeof(FrontierSlot));
 
     ENSURE(c->anc, ((size_t)c->planes * n * 4) << c->anc_bits);
-    ENSURE(c->fcount, n4 + 8); ENSURE(c->fbase, n4 + 8); ENSURE(c->order, n4); ENSURE(c->posof, n4);
+    ENSURE(c->fcount, n4 + 8); ENSURE(c->fbase, n4 + 8); ENSURE(c->order, n4); ENSURE(c->posof, n4); ENSURE(c->child, 2 * n4);
     ENSURE(c->rflag, n4); ENSURE(c->ridx, n4 + 4); ENSURE(c->rlist, n4);
     ENSURE(c->next, 2 * n4); ENSURE(c->owner, 2 * n4); ENSURE(c->local, 2 * n4); ENSURE(c->slist, 2 * n4);
     ENSURE(c->snext, 2 * n4); ENSURE(c->ssum, 2 * n4); ENSURE(c->jnxt, 2 * n4); ENSURE(c->jval, 2 * n4);
@@ -623,6 +623,8 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
         HIP_TRY(hipMemcpyAsync(c->out.p, out, n4, hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(c->op.p, op, n, hipMemcpyHostToDevice, s));
     }
+    if (n) C2A_LAUNCH_NOSYNC(k_pack_gates, grid_for(n, 4096), kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->out.as<u32>(),
+                             c->op.as<u8>(), c->gate4.as<uint4>());
     if (n_in) HIP_TRY(hipMemcpyAsync(c->in_nodes.p, input_nodes, (size_t)n_in * 4, hipMemcpyHostToDevice, s));
     if (n_out) HIP_TRY(hipMemcpyAsync(c->out_nodes.p, output_nodes, (size_t)n_out * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));

@@ -180,6 +180,7 @@ struct PeelArgs {
     uint4* meta;               // [n] by position
     u32* anc;                  // [planes][n][16] by position
     u32* order;                // position -> gate
+    u32* child;                // [2n] tree children by label: child[2*p + l] (written as each gate picks its parent)
     u32* posof;                // gate -> position
     u32* fbase;                // [levels+2] first position of each level
     u32* fcount;               // [levels+2] frontier sizes (slot allocation + host monitoring)
@@ -335,6 +336,7 @@ __global__ void __launch_bounds__(kThreads) k_peel_level(PeelArgs A, u32 level) 
         A.meta[pos] = make_uint4(best == C2A_NONE ? C2A_NONE : (best & kIdMask), depth, best_root, my_label);
         A.order[pos] = g;
         A.posof[g] = pos;
+        if (best != C2A_NONE) A.child[2 * (u64)(best & kIdMask) + my_label] = pos;
         // ---- ancestor rows: row j = [q_j, row_j(q_j)[0..R-2]], q_0 = parent, q_{j+1} = my ancestor at R^(j+1)
         if (depth) {
             u32 q = best;                                   // labelled entry
@@ -523,6 +525,7 @@ __global__ void __launch_bounds__(WPB * 64) k_peel_level_wave(PeelArgs A, u32 le
                 A.meta[pos] = make_uint4(ch == C2A_NONE ? C2A_NONE : (ch & kIdMask), depth, ch_root, my_label);
                 A.order[pos] = g;
                 A.posof[g] = pos;
+                if (ch != C2A_NONE) A.child[2 * (u64)(ch & kIdMask) + my_label] = pos;
             }
             // push myself to the producers (lanes 0/1): the atomic's round trip overlaps the row copies below
             u32 kfill = 0;
@@ -739,6 +742,7 @@ __global__ void __launch_bounds__(kPGroupsPerWg * 16) k_peel_persistent(PeelArgs
                     st_u128<DS>(&A.meta[pos], make_uint4(ch == C2A_NONE ? C2A_NONE : (ch & kIdMask), depth, ch_root, my_label));
                     st_u32<DS>(&A.order[pos], g);
                     st_u32<DS>(&A.posof[g], pos);
+                    if (ch != C2A_NONE) st_u32<DS>(&A.child[2 * (u64)(ch & kIdMask) + my_label], pos);
                 }
                 u32 kfill = 0;
                 if (dl != C2A_NONE) kfill = atomicAdd(&A.fill[dl], 1u);
@@ -837,31 +841,22 @@ __global__ void k_rootlist(u32 n, const u32* __restrict__ rflag, const u32* __re
         if (rflag[g]) rlist[ridx[g]] = posof[g];
 }
 
-// tree child of the node at position p along label l: p's dep_l, when that gate chose (p,l) as its parent
-__device__ __forceinline__ u32 tree_child(const uint4* meta, const u32* posof, u32 p, u32 dep, u32 label) {
-    if (dep == C2A_NONE) return C2A_NONE;
-    const u32 pd = posof[dep];
-    const uint4 m = meta[pd];
-    return (m.x == p && m.w == label) ? pd : C2A_NONE;
-}
-
 // element 2x = enter(x), 2x+1 = exit(x); the tour visits label-0 child, label-1 child, then exits.
+// child[2p + l] was written by the peel when the child picked (p, l) as its parent (NONE otherwise).
 __global__ void k_euler_next(u32 n, const uint4* __restrict__ meta, const u32* __restrict__ order,
-                             const u32* __restrict__ posof, const uint4* __restrict__ ginfo,
-                             const u32* __restrict__ ridx, const u32* __restrict__ rlist, u32 n_roots, u32* next) {
+                             const u32* __restrict__ child, const u32* __restrict__ ridx, const u32* __restrict__ rlist,
+                             u32 n_roots, u32* next) {
     for (u64 i = gtid(); i < n; i += gstride()) {
         const u32 x = (u32)i;
-        const u32 g = order[x];
-        const uint4 gi = ginfo[g];
-        const u32 c0 = tree_child(meta, posof, x, gi.x, 0), c1 = tree_child(meta, posof, x, gi.y, 1);
+        const u32 c0 = child[2 * i], c1 = child[2 * i + 1];
         next[2 * i] = c0 != C2A_NONE ? 2 * c0 : (c1 != C2A_NONE ? 2 * c1 : 2 * x + 1);
         const uint4 m = meta[x];
         u32 nx;
         if (m.x == C2A_NONE) {
-            const u32 k = ridx[g];
+            const u32 k = ridx[order[x]];
             nx = k + 1 < n_roots ? 2 * rlist[k + 1] : C2A_NONE;
         } else {
-            const u32 s1 = m.w == 0 ? tree_child(meta, posof, m.x, ginfo[order[m.x]].y, 1) : C2A_NONE;
+            const u32 s1 = m.w == 0 ? child[2 * (u64)m.x + 1] : C2A_NONE;
             nx = s1 != C2A_NONE ? 2 * s1 : 2 * m.x + 1;
         }
         next[2 * i + 1] = nx;
@@ -870,14 +865,42 @@ __global__ void k_euler_next(u32 n, const uint4* __restrict__ meta, const u32* _
 
 __device__ __forceinline__ bool is_splitter(u32 e, u32 head) { return e == head || ((e * 0x9E3779B1u) >> 26) == 0u; }
 
+// splitter compaction, 8 elements per lane: one atomic and three barriers per 2048 elements
 __global__ void __launch_bounds__(kThreads) k_rank_mark(u32 m, const u32* __restrict__ rlist, u32* scount, u32* slist,
                                                         u32* owner) {
+    __shared__ u32 s_w[kThreads / 64];
+    __shared__ u32 s_base;
     const u32 head = 2 * rlist[0];
-    for (u64 base = (u64)blockIdx.x * kThreads; base < m; base += (u64)gridDim.x * kThreads) {
-        const u64 e = base + threadIdx.x;
-        const bool sp = e < m && is_splitter((u32)e, head);
-        const u32 k = block_append_slot(sp, scount);
-        if (sp) { slist[k] = (u32)e; owner[e] = k; }
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    for (u64 base = (u64)blockIdx.x * (kThreads * 8); base < m; base += (u64)gridDim.x * (kThreads * 8)) {
+        const u64 e0 = base + (u64)tid * 8;
+        u32 bits = 0, cnt = 0;
+#pragma unroll
+        for (u32 k = 0; k < 8; ++k) {
+            const u64 e = e0 + k;
+            const u32 sp = (e < m && is_splitter((u32)e, head)) ? 1u : 0u;
+            bits |= sp << k;
+            cnt += sp;
+        }
+        u32 inc = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 o = __shfl_up(inc, off, 64);
+            if (lane >= (u32)off) inc += o;
+        }
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        if (tid == 0) {
+            u32 run = 0;
+            for (int w = 0; w < kThreads / 64; ++w) { const u32 t = s_w[w]; s_w[w] = run; run += t; }
+            s_base = run ? atomicAdd(scount, run) : 0u;
+        }
+        __syncthreads();
+        u32 pos = s_base + s_w[wv] + inc - cnt;
+#pragma unroll
+        for (u32 k = 0; k < 8; ++k)
+            if (bits & (1u << k)) { slist[pos] = (u32)(e0 + k); owner[e0 + k] = pos; ++pos; }
+        __syncthreads();
     }
 }
 
@@ -984,33 +1007,47 @@ __global__ void k_mark_outputs(u32 n_out, const u32* __restrict__ out_nodes, u8*
     }
 }
 
-__device__ __forceinline__ u32 seq_node(u64 i, const u32* sorted, const u32* lh, const u32* rh, const u32* out) {
-    const u64 pos = i / 3;
-    const u32 k = (u32)(i - pos * 3);
-    const u32 g = sorted[pos];
-    return k == 0 ? lh[g] : (k == 1 ? rh[g] : out[g]);
+// the payload as 16-byte records {lh, rh, out, op}: the kernels below visit gates in SORTED order, i.e. at random
+// gate ids — one line per gate instead of four (built once per c2a_load_gates, outside any timed region)
+__global__ void k_pack_gates(u32 n, const u32* __restrict__ lh, const u32* __restrict__ rh, const u32* __restrict__ out,
+                             const u8* __restrict__ op, uint4* gate4) {
+    for (u64 g = gtid(); g < n; g += gstride()) gate4[g] = make_uint4(lh[g], rh[g], out[g], op[g]);
 }
 
-// first[node] = first index in the walk "for gate in sorted: [lh, rh, out]" (compiler.rs:427-430)
-__global__ void k_first_seen(u64 m, const u32* __restrict__ sorted, const u32* __restrict__ lh,
-                             const u32* __restrict__ rh, const u32* __restrict__ out, u32* first) {
-    for (u64 i = gtid(); i < m; i += gstride()) atomicMin(&first[seq_node(i, sorted, lh, rh, out)], (u32)i);
-}
-
-__global__ void k_new_wire_flags(u64 m, const u32* __restrict__ sorted, const u32* __restrict__ lh,
-                                 const u32* __restrict__ rh, const u32* __restrict__ out, const u32* __restrict__ first,
-                                 const u8* __restrict__ nflag, u32* flag) {
-    for (u64 i = gtid(); i < m; i += gstride()) {
-        const u32 node = seq_node(i, sorted, lh, rh, out);
-        flag[i] = (first[node] == (u32)i && nflag[node] == 0) ? 1u : 0u;   // :431-438
+// One lane per sorted position handles its three walk entries [lh, rh, out] (compiler.rs:427-430): walk index 3*pos+k.
+// first[node] = first index in the walk
+__global__ void k_first_seen(u32 n, const u32* __restrict__ sorted, const uint4* __restrict__ gate4, u32* first) {
+    for (u64 pos = gtid(); pos < n; pos += gstride()) {
+        const uint4 g = gate4[sorted[pos]];
+        const u32 i = 3u * (u32)pos;
+        atomicMin(&first[g.x], i);
+        atomicMin(&first[g.y], i + 1);
+        atomicMin(&first[g.z], i + 2);
     }
 }
 
-__global__ void k_assign_wires(u64 m, const u32* __restrict__ sorted, const u32* __restrict__ lh,
-                               const u32* __restrict__ rh, const u32* __restrict__ out, const u32* __restrict__ flag,
-                               const u32* __restrict__ idx, u32 n_in, u32* node_wire1) {
-    for (u64 i = gtid(); i < m; i += gstride())
-        if (flag[i]) node_wire1[seq_node(i, sorted, lh, rh, out)] = n_in + idx[i] + 1;   // :440-441
+__global__ void k_new_wire_flags(u32 n, const u32* __restrict__ sorted, const uint4* __restrict__ gate4,
+                                 const u32* __restrict__ first, const u8* __restrict__ nflag, u32* flag) {
+    for (u64 pos = gtid(); pos < n; pos += gstride()) {
+        const uint4 g = gate4[sorted[pos]];
+        const u32 i = 3u * (u32)pos;
+        flag[i] = (first[g.x] == i && nflag[g.x] == 0) ? 1u : 0u;                 // :431-438
+        flag[i + 1] = (first[g.y] == i + 1 && nflag[g.y] == 0) ? 1u : 0u;
+        flag[i + 2] = (first[g.z] == i + 2 && nflag[g.z] == 0) ? 1u : 0u;
+    }
+}
+
+__global__ void k_assign_wires(u32 n, const u32* __restrict__ sorted, const uint4* __restrict__ gate4,
+                               const u32* __restrict__ flag, const u32* __restrict__ idx, u32 n_in, u32* node_wire1) {
+    for (u64 pos = gtid(); pos < n; pos += gstride()) {
+        const u32 i = 3u * (u32)pos;
+        const u32 f0 = flag[i], f1 = flag[i + 1], f2 = flag[i + 2];
+        if (!(f0 | f1 | f2)) continue;
+        const uint4 g = gate4[sorted[pos]];
+        if (f0) node_wire1[g.x] = n_in + idx[i] + 1;                               // :440-441
+        if (f1) node_wire1[g.y] = n_in + idx[i + 1] + 1;
+        if (f2) node_wire1[g.z] = n_in + idx[i + 2] + 1;
+    }
 }
 
 __global__ void k_assign_outputs(u32 n_out, const u32* __restrict__ out_nodes, u32 n_in, const u32* __restrict__ n_mid,
@@ -1019,15 +1056,14 @@ __global__ void k_assign_outputs(u32 n_out, const u32* __restrict__ out_nodes, u
     for (u64 j = gtid(); j < n_out; j += gstride()) atomicMax(&node_wire1[out_nodes[j]], base + (u32)j + 1);   // :446-449
 }
 
-__global__ void k_emit(u32 n, const u32* __restrict__ sorted, const u32* __restrict__ lh, const u32* __restrict__ rh,
-                       const u32* __restrict__ out, const u8* __restrict__ op, const u32* __restrict__ node_wire1,
-                       u32* e_in0, u32* e_in1, u32* e_out, u8* e_op) {
+__global__ void k_emit(u32 n, const u32* __restrict__ sorted, const uint4* __restrict__ gate4,
+                       const u32* __restrict__ node_wire1, u32* e_in0, u32* e_in1, u32* e_out, u8* e_op) {
     for (u64 pos = gtid(); pos < n; pos += gstride()) {
-        const u32 g = sorted[pos];
-        e_in0[pos] = node_wire1[lh[g]] - 1;
-        e_in1[pos] = node_wire1[rh[g]] - 1;
-        e_out[pos] = node_wire1[out[g]] - 1;
-        e_op[pos] = op[g];
+        const uint4 g = gate4[sorted[pos]];
+        e_in0[pos] = node_wire1[g.x] - 1;
+        e_in1[pos] = node_wire1[g.y] - 1;
+        e_out[pos] = node_wire1[g.z] - 1;
+        e_op[pos] = (u8)g.w;
     }
 }
 
