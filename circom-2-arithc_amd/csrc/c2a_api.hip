@@ -47,6 +47,8 @@ struct c2a_ctx {
     u32 anc_bits = 4;              // log2(entries per ancestor row): 4 (64-B rows, default) or 6 (256-B rows: one hop fewer per
                                    // lift/diverge/copy at depth < 4096 but measured 1.45x slower: 182 VGPRs, 32 loads per hop)
     u32 peel_wpb = 8;              // gates (waves) per workgroup in wave mode: 4, 8 or 16 (8 measured best)
+    u32 peel_strings = 1;          // path representation: 1 = path bit-strings (512 B per node, one hop per comparison),
+                                   // 0 = base-16 ancestor rows (64 B per node and plane, <= 6 hops per comparison)
 
     // problem
     u32 n = 0, n_nodes = 0, n_in = 0, n_out = 0;
@@ -59,7 +61,7 @@ struct c2a_ctx {
 
     // device buffers
     DevBuf lh, rh, out, op, gate4, in_nodes, out_nodes;
-    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, fill, cand, meta, anc, fcount, fbase, order, posof, child, ginfo, slots0, slots1;
+    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, fill, cand, meta, anc, pstr, cprev, fcount, fbase, order, posof, child, ginfo, slots0, slots1;
     DevBuf rflag, ridx, rlist, next, owner, local, slist, snext, ssum, jnxt, jval, sorted;
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op;
     DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof, peel_ctl;
@@ -72,7 +74,7 @@ struct c2a_ctx {
 
     c2a_ctx() {
         all = {&lh, &rh, &out, &op, &gate4, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &fill, &cand,
-               &ginfo, &slots0, &slots1, &meta, &anc, &fcount, &fbase, &order, &posof, &child, &rflag, &ridx, &rlist, &next,
+               &ginfo, &slots0, &slots1, &meta, &anc, &pstr, &cprev, &fcount, &fbase, &order, &posof, &child, &rflag, &ridx, &rlist, &next,
                &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
                &node_wire, &e_in0, &e_in1, &e_out, &e_op, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &peel_ctl, &tsz, &asz, &goff,
                &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &cb_in0, &cb_in1, &cb_out, &cb_op};
@@ -211,7 +213,7 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
     A.n = n; A.ginfo = c->ginfo.as<uint4>();
     A.slots[0] = c->slots0.as<FrontierSlot>(); A.slots[1] = c->slots1.as<FrontierSlot>();
     A.cand = c->cand.as<uint4>(); A.fill = c->fill.as<u32>();
-    A.meta = c->meta.as<uint4>(); A.anc = c->anc.as<u32>(); A.fcount = c->fcount.as<u32>(); A.fbase = c->fbase.as<u32>();
+    A.meta = c->meta.as<uint4>(); A.anc = c->anc.as<u32>(); A.pstr = c->pstr.as<u64>(); A.cprev = c->cprev.as<u32>(); A.fcount = c->fcount.as<u32>(); A.fbase = c->fbase.as<u32>();
     A.order = c->order.as<u32>(); A.posof = c->posof.as<u32>(); A.child = c->child.as<u32>();
     A.prof = nullptr; A.prof_level0 = 256;
     const bool profiling = std::getenv("C2A_PEEL_PROFILE") != nullptr;
@@ -240,7 +242,13 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
                                    : (u32)(((u64)est * 2 + kThreads - 1) / kThreads);
         const u32 blocks = std::max<u32>(8u, std::min<u32>(max_blocks, want));
         for (u32 i = 0; i < batch; ++i) {
-            if (level == 0) {
+            if (c->peel_strings) {
+                if (level == 0) C2A_LAUNCH_NOSYNC(k_peel_level_str, grid_for(f0, max_blocks), kThreads, s, A, level);
+                else if (!wave_mode) C2A_LAUNCH_NOSYNC(k_peel_level_str, blocks, kThreads, s, A, level);
+                else if (wpb == 16) C2A_LAUNCH((k_peel_level_wave_str<16>), blocks, 1024, s, A, level);
+                else if (wpb == 8) C2A_LAUNCH((k_peel_level_wave_str<8>), blocks, 512, s, A, level);
+                else C2A_LAUNCH((k_peel_level_wave_str<4>), blocks, 256, s, A, level);
+            } else if (level == 0) {
                 // the very first launch sees the (possibly huge) level-0 frontier: sinks have no consumers
                 if (c->anc_bits == 6) C2A_LAUNCH_NOSYNC((k_peel_level<6>), grid_for(f0, max_blocks), kThreads, s, A, level);
                 else C2A_LAUNCH_NOSYNC((k_peel_level<4>), grid_for(f0, max_blocks), kThreads, s, A, level);
@@ -272,7 +280,7 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
         for (u32 k = 0; k <= look; ++k) mx = std::max(mx, tail[k]);
         est = mx;
         batch = std::min<u32>(batch * 2, 512u);
-        if (c->peel_persist_max && c->anc_bits == 4 && est <= c->peel_persist_max) {      // the persistent kernel is base-16 only
+        if (c->peel_persist_max && !c->peel_strings && c->anc_bits == 4 && est <= c->peel_persist_max) {      // the persistent kernel is base-16 only
             // the frontier has narrowed: finish every remaining level inside one persistent launch
             ENSURE(c->peel_ctl, sizeof(PeelCtl));
             PeelCtl init;
@@ -554,6 +562,7 @@ int c2a_create(int device_id, c2a_ctx** out) {
     if (const char* e = std::getenv("C2A_PEEL_PERSIST_SC1")) c->peel_persist_sc1 = std::strtoul(e, nullptr, 10) != 0;
     if (const char* e = std::getenv("C2A_PEEL_PERSIST_MAX")) c->peel_persist_max = (u32)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("C2A_ANC_BITS")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 4 || v == 6) c->anc_bits = v; }
+    if (const char* e = std::getenv("C2A_PEEL_STRINGS")) c->peel_strings = std::strtoul(e, nullptr, 10) != 0;
     if (const char* e = std::getenv("C2A_PEEL_WPB")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 4 || v == 8 || v == 16) c->peel_wpb = v; }
     if (const char* e = std::getenv("C2A_PEEL_WAVE_MAX")) c->peel_wave_max = (u32)std::strtoul(e, nullptr, 10);   // tuning / test knob
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return C2A_ERR_HIP; }
@@ -606,7 +615,8 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     ENSURE(c->meta, (size_t)n * 16); ENSURE(c->ginfo, (size_t)n * 16);
     ENSURE(c->slots0, ((size_t)n + 1) * sizeof(FrontierSlot)); ENSURE(c->slots1, ((size_t)n + 1) * sizeof(FrontierSlot));
 
-    ENSURE(c->anc, ((size_t)c->planes * n * 4) << c->anc_bits);
+    if (c->peel_strings) { ENSURE(c->pstr, (size_t)n * kChunkWords * 8); ENSURE(c->cprev, (size_t)n * 4); }
+    else { ENSURE(c->anc, ((size_t)c->planes * n * 4) << c->anc_bits); }
     ENSURE(c->fcount, n4 + 8); ENSURE(c->fbase, n4 + 8); ENSURE(c->order, n4); ENSURE(c->posof, n4); ENSURE(c->child, 2 * n4);
     ENSURE(c->rflag, n4); ENSURE(c->ridx, n4 + 4); ENSURE(c->rlist, n4);
     ENSURE(c->next, 2 * n4); ENSURE(c->owner, 2 * n4); ENSURE(c->local, 2 * n4); ENSURE(c->slist, 2 * n4);

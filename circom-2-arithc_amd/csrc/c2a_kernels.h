@@ -178,7 +178,9 @@ struct PeelArgs {
     uint4* cand;               // [edges]
     u32* fill;                 // pushes so far per gate (zeroed)
     uint4* meta;               // [n] by position
-    u32* anc;                  // [planes][n][16] by position
+    u32* anc;                  // [planes][n][16] by position (ancestor-row representation)
+    u64* pstr;                 // [n][64] path strings by position (path-string representation)
+    u32* cprev;                // [n] ancestor at the start of the node's current chunk (only beyond depth 4096)
     u32* order;                // position -> gate
     u32* child;                // [2n] tree children by label: child[2*p + l] (written as each gate picks its parent)
     u32* posof;                // gate -> position
@@ -569,6 +571,315 @@ __global__ void __launch_bounds__(WPB * 64) k_peel_level_wave(PeelArgs A, u32 le
         }
         __syncthreads();
         C2A_PROF(5, c2a_now() - t_begin);
+    }
+}
+
+// ================================================================================================
+// PATH STRINGS — the second representation of "the path from the DFS root to a tree node", built to cut the
+// dependent memory hops of a path comparison from <= 6 (lift + diverge over ancestor rows) to ONE.
+// Every tree node stores the edge labels of its path as a bit string: bit j = label of the edge entering depth
+// j+1.  A string is held in chunks of kChunkBits = 4096 bits = 512 B = one coalesced 8-byte load per lane of a wave;
+// a node keeps only its CURRENT chunk (bits [ci*K, depth), zero padded) plus cprev = its ancestor at depth ci*K,
+// whose own string is the complete previous chunk — so storage is 512 B per node whatever the depth, and for trees
+// shallower than 4096 (the 10 M-gate headline config: 3 471) comparing two candidates is: load both strings (one
+// round trip, coalesced), XOR, ballot, count trailing zeros.  Deeper trees add one cprev hop per chunk level.
+// A new node's string = parent's string + one bit: ONE hop to build (three for the ancestor rows).
+// ================================================================================================
+constexpr u32 kChunkBits = 4096;
+constexpr u32 kChunkWords = kChunkBits / 64;
+
+__device__ __forceinline__ u32 chunk_of(u32 depth) { return depth ? (depth - 1) / kChunkBits : 0u; }
+__device__ __forceinline__ u32 chunk_len(u32 depth) { return depth - chunk_of(depth) * kChunkBits; }
+__device__ __forceinline__ u32 ctz64(u64 x) { return (u32)__ffsll((long long)x) - 1u; }
+
+// Bring two distinct tree nodes under one root to the first chunk in which their paths can differ.
+// a/b: positions (in/out), lena/lenb: bits of that chunk (out); below_a/below_b: when a (b) had to climb, the
+// node of its chain one chunk below the returned one (its bit 0 is the label right after the returned chunk).
+__device__ __forceinline__ void resolve_chunks(const u32* __restrict__ cprev, u32& a, u32& lena, u32& below_a, u32 da, u32& b,
+                                               u32& lenb, u32& below_b, u32 db) {
+    u32 ia = chunk_of(da), ib = chunk_of(db);
+    lena = chunk_len(da); lenb = chunk_len(db);
+    below_a = C2A_NONE; below_b = C2A_NONE;
+    if ((ia | ib) == 0) return;
+    while (ia > ib) { below_a = a; a = cprev[a]; --ia; lena = kChunkBits; }
+    while (ib > ia) { below_b = b; b = cprev[b]; --ib; lenb = kChunkBits; }
+    while (ia > 0 && a != b) {
+        const u32 pa = cprev[a], pb = cprev[b];
+        if (pa == pb) break;
+        below_a = a; below_b = b;
+        a = pa; b = pb; --ia;
+        lena = lenb = kChunkBits;
+    }
+}
+
+// lane-sequential comparison (one lane owns the whole comparison): is P(a).la < P(b).lb ?
+__device__ __forceinline__ bool str_less_lane(const u64* __restrict__ pstr, const u32* __restrict__ cprev, u32 a, u32 la, u32 da,
+                                              u32 b, u32 lb, u32 db) {
+    u32 lena, lenb, ba, bb;
+    resolve_chunks(cprev, a, lena, ba, da, b, lenb, bb, db);
+    if (a == b) {      // one node is the chunk-boundary ancestor of the other: the other's next label decides
+        if (ba != C2A_NONE) return (pstr[(u64)ba * kChunkWords] & 1ull) < lb;
+        return la < (pstr[(u64)bb * kChunkWords] & 1ull);
+    }
+    const u64* sa = pstr + (u64)a * kChunkWords;
+    const u64* sb = pstr + (u64)b * kChunkWords;
+    const u32 minlen = lena < lenb ? lena : lenb;
+    for (u32 w = 0; w * 64 < minlen; ++w) {
+        const u64 wa = sa[w];
+        u64 x = wa ^ sb[w];
+        const u32 rem = minlen - w * 64;
+        if (rem < 64) x &= (1ull << rem) - 1ull;
+        if (x) return ((wa >> ctz64(x)) & 1ull) == 0;
+    }
+    if (lena == lenb) return la < lb;
+    if (lena < lenb) return la < ((sb[lena >> 6] >> (lena & 63u)) & 1ull);
+    return ((sa[lenb >> 6] >> (lenb & 63u)) & 1ull) < lb;
+}
+
+// wave-cooperative comparison of two strings already in registers (this lane's word of each): wave-uniform result
+__device__ __forceinline__ bool str_less_wave(u64 wa, u32 lena, u32 la, u64 wb, u32 lenb, u32 lb, u32 lane) {
+    const u32 minlen = lena < lenb ? lena : lenb;
+    u64 x = wa ^ wb;
+    const u32 lo = lane * 64;
+    if (lo >= minlen) x = 0;
+    else if (minlen - lo < 64) x &= (1ull << (minlen - lo)) - 1ull;
+    const u64 bal = __ballot(x != 0);
+    if (bal) {
+        const int L = (int)ctz64(bal);
+        const u64 xl = __shfl(x, L, 64);
+        const u64 al = __shfl(wa, L, 64);
+        return ((al >> ctz64(xl)) & 1ull) == 0;
+    }
+    if (lena == lenb) return la < lb;
+    if (lena < lenb) return la < ((__shfl(wb, (int)(lena >> 6), 64) >> (lena & 63u)) & 1ull);
+    return ((__shfl(wa, (int)(lenb >> 6), 64) >> (lenb & 63u)) & 1ull) < lb;
+}
+
+// the new node's string: parent's current chunk + one bit, or a fresh chunk when the parent filled its own
+__device__ __forceinline__ u64 child_word(u64 parent_word, u32 parent_depth, u32 label, u32 word_index, bool& fresh) {
+    const u32 d = parent_depth + 1;
+    fresh = parent_depth == 0 || chunk_of(d) != chunk_of(parent_depth);
+    const u32 bit = (d - 1) - chunk_of(d) * kChunkBits;
+    u64 w = fresh ? 0ull : parent_word;
+    if ((bit >> 6) == word_index) w |= (u64)label << (bit & 63u);
+    return w;
+}
+
+// ---- one lane per gate (wide frontiers)
+__global__ void __launch_bounds__(kThreads) k_peel_level_str(PeelArgs A, u32 level) {
+    FrontierSlot* cur = A.slots[level & 1u];
+    FrontierSlot* nxt = A.slots[(level + 1) & 1u];
+    const u32 n_front = A.fcount[level];
+    const u32 lo = A.fbase[level];
+    if (gtid() == 0) A.fbase[level + 1] = lo + n_front;
+    for (u64 i = gtid(); i < n_front; i += gstride()) {
+        const uint4 sa = cur[i].a;
+        const u32 cnt = cur[i].b.x;
+        const u32 g = sa.x;
+        const u32 pos = lo + (u32)i;
+        u32 best = C2A_NONE, best_el = 0, best_root = g, best_depth = 0;
+        const u32 e0 = sa.w, e1 = e0 + cnt;
+        for (u32 e = e0; e < e1; ++e) {
+            const uint4 cr = A.cand[e];
+            const u32 pc = cr.x & kIdMask, el = cr.x >> 31;
+            bool take;
+            if (best == C2A_NONE) take = cr.z < g;
+            else if (cr.z != best_root) take = cr.z < best_root;
+            else if (pc == best) take = el < best_el;
+            else take = str_less_lane(A.pstr, A.cprev, pc, el, cr.y, best, best_el, best_depth);
+            if (take) { best = pc; best_el = el; best_root = cr.z; best_depth = cr.y; }
+        }
+        const u32 depth = best == C2A_NONE ? 0u : best_depth + 1;
+        const u32 my_label = best == C2A_NONE ? 0u : best_el;
+        A.meta[pos] = make_uint4(best, depth, best_root, my_label);
+        A.order[pos] = g;
+        A.posof[g] = pos;
+        if (best != C2A_NONE) {
+            A.child[2 * (u64)best + my_label] = pos;
+            u64* dst = A.pstr + (u64)pos * kChunkWords;
+            const u64* src = A.pstr + (u64)best * kChunkWords;
+            const u32 bit = (depth - 1) - chunk_of(depth) * kChunkBits;
+            const bool fresh_chunk = best_depth == 0 || chunk_of(depth) != chunk_of(best_depth);
+            const u32 words = (bit >> 6) + 1;                        // words that can be non-zero
+            for (u32 w = 0; w < kChunkWords; ++w) {
+                u64 v = (!fresh_chunk && w < words) ? src[w] : 0ull;
+                if (w == (bit >> 6)) v |= (u64)my_label << (bit & 63u);
+                dst[w] = v;
+            }
+            if (chunk_of(depth)) A.cprev[pos] = fresh_chunk ? best : A.cprev[best];
+        }
+        const u32 deps[2] = {sa.y, sa.z};
+#pragma unroll
+        for (u32 l = 0; l < 2; ++l) {
+            const u32 d = deps[l];
+            if (d == C2A_NONE) continue;
+            const uint4 gd = A.ginfo[d];
+            const u32 k = atomicAdd(&A.fill[d], 1u);
+            A.cand[gd.z + k] = make_uint4(pos | (l << 31), depth, best_root, my_label);
+            if (k + 1 == gd.w) {
+                const u32 p = atomicAdd(&A.fcount[level + 1], 1u);
+                nxt[p].b = make_uint4(gd.w, 0, 0, 0);
+                nxt[p].a = make_uint4(d, gd.x, gd.y, gd.z);
+            }
+        }
+    }
+}
+
+// ---- one wave per gate (narrow frontiers): survivor strings live in registers, the whole tournament costs ONE
+// round trip to memory when every survivor is shallower than a chunk
+constexpr int kStrMax = 12;               // survivor strings held in registers per round
+
+template <int WPB>
+__global__ void __launch_bounds__(WPB * 64) k_peel_level_wave_str(PeelArgs A, u32 level) {
+    __shared__ u32 s_c[WPB][72], s_l[WPB][72], s_d[WPB][72];
+    __shared__ u32 s_ready[2 * WPB];
+    __shared__ uint4 s_rec[2 * WPB];
+    __shared__ u32 s_base;
+    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    FrontierSlot* cur = A.slots[level & 1u];
+    FrontierSlot* nxt = A.slots[(level + 1) & 1u];
+    const u64 lt_mask = (1ull << lane) - 1ull;
+    uint4 sa0 = make_uint4(0, 0, 0, 0);
+    u32 cnt0 = 0;
+    {
+        const u64 i0 = (u64)blockIdx.x * WPB + wv;
+        if (i0 < A.n) { sa0 = cur[i0].a; cnt0 = cur[i0].b.x; }
+    }
+    const u32 n_front = A.fcount[level];
+    const u32 lo = A.fbase[level];
+    if (gtid() == 0) A.fbase[level + 1] = lo + n_front;
+    for (u32 chunk = blockIdx.x; (u64)chunk * WPB < n_front; chunk += gridDim.x) {
+        const u64 i = (u64)chunk * WPB + wv;
+        u32 rdy = C2A_NONE;
+        uint4 rdy_rec = make_uint4(0, 0, 0, 0);
+        uint4 sa = sa0;
+        u32 cnt = cnt0;
+        if (chunk != blockIdx.x && i < n_front) { sa = cur[i].a; cnt = cur[i].b.x; }
+        if (i < n_front) {
+            const u32 g = sa.x;
+            const u32 e0 = sa.w, e1 = e0 + cnt;
+            const u32 dl = lane == 0 ? sa.y : (lane == 1 ? sa.z : C2A_NONE);
+            uint4 gd = make_uint4(0, 0, 0, 0);
+            if (dl != C2A_NONE) gd = A.ginfo[dl];
+            // champion so far (wave-uniform); NONE = the virtual-root candidate [g].  champ_w = this lane's word of
+            // the champion's string when champ_loaded
+            u32 ch = C2A_NONE, ch_el = 0, ch_root = g, ch_depth = 0;
+            u64 champ_w = 0;
+            bool champ_loaded = false;
+            for (u32 eb = e0; eb < e1; eb += 64) {
+                const u32 e = eb + lane;
+                const bool valid = e < e1;
+                u32 c = 0, l = 0, cdepth = 0, croot = 0xFFFFFFFFu;
+                if (valid) {
+                    const uint4 cr = A.cand[e];
+                    c = cr.x & kIdMask; l = cr.x >> 31;
+                    cdepth = cr.y; croot = cr.z;
+                }
+                const u32 rmin = wave_min_u32(croot);
+                if (rmin > ch_root) continue;
+                const bool keep_ch = (ch != C2A_NONE) && (ch_root == rmin);
+                if (!keep_ch) champ_loaded = false;
+                const bool surv = valid && croot == rmin;
+                const u64 smask = __ballot(surv);
+                const u32 m = (u32)__popcll(smask);
+                if (surv) {
+                    const u32 k = (u32)__popcll(smask & lt_mask);
+                    s_c[wv][k] = c; s_l[wv][k] = l; s_d[wv][k] = cdepth;
+                }
+                wave_lds_sync();
+                // sequential tournament, kStrMax survivors per round with their strings in registers
+                u32 next = 0;
+                if (!keep_ch) {      // the first survivor becomes the champion without a comparison
+                    ch = s_c[wv][0]; ch_el = s_l[wv][0]; ch_depth = s_d[wv][0];
+                    next = 1;
+                }
+                ch_root = rmin;
+                while (next < m) {
+                    const u32 take = (m - next) < (u32)kStrMax ? (m - next) : (u32)kStrMax;
+                    // all of this round in chunk 0?  then one coalesced load per string, all issued back to back
+                    bool shallow = ch_depth <= kChunkBits;
+                    for (u32 t = 0; t < take; ++t) shallow = shallow && s_d[wv][next + t] <= kChunkBits;
+                    if (shallow) {
+                        u64 sw[kStrMax];
+#pragma unroll
+                        for (int t = 0; t < kStrMax; ++t)
+                            sw[t] = (u32)t < take ? A.pstr[(u64)s_c[wv][next + t] * kChunkWords + lane] : 0ull;
+                        if (!champ_loaded) { champ_w = ch_depth ? A.pstr[(u64)ch * kChunkWords + lane] : 0ull; champ_loaded = true; }
+#pragma unroll
+                        for (int t = 0; t < kStrMax; ++t) {
+                            if ((u32)t < take) {
+                                const u32 cc = s_c[wv][next + t], cl = s_l[wv][next + t], cd = s_d[wv][next + t];
+                                bool less;
+                                if (cc == ch) less = cl < ch_el;
+                                else less = str_less_wave(sw[t], cd, cl, champ_w, ch_depth, ch_el, lane);
+                                if (less) { ch = cc; ch_el = cl; ch_depth = cd; champ_w = sw[t]; }
+                            }
+                        }
+                    } else {
+                        // deep trees: chunk resolution (cprev hops) per comparison, strings loaded per comparison
+                        for (u32 t = 0; t < take; ++t) {
+                            const u32 cc = s_c[wv][next + t], cl = s_l[wv][next + t], cd = s_d[wv][next + t];
+                            bool less;
+                            if (cc == ch) less = cl < ch_el;
+                            else {
+                                u32 ra = cc, rb = ch, lena, lenb, ba, bb;
+                                resolve_chunks(A.cprev, ra, lena, ba, cd, rb, lenb, bb, ch_depth);
+                                if (ra == rb) {
+                                    if (ba != C2A_NONE) less = (A.pstr[(u64)ba * kChunkWords] & 1ull) < ch_el;
+                                    else less = cl < (A.pstr[(u64)bb * kChunkWords] & 1ull);
+                                } else {
+                                    const u64 wa = lena ? A.pstr[(u64)ra * kChunkWords + lane] : 0ull;
+                                    const u64 wb = lenb ? A.pstr[(u64)rb * kChunkWords + lane] : 0ull;
+                                    less = str_less_wave(wa, lena, cl, wb, lenb, ch_el, lane);
+                                }
+                            }
+                            if (less) { ch = cc; ch_el = cl; ch_depth = cd; champ_loaded = false; }
+                        }
+                    }
+                    next += take;
+                }
+                wave_lds_sync();
+            }
+            const u32 depth = ch == C2A_NONE ? 0u : ch_depth + 1;
+            const u32 my_label = ch == C2A_NONE ? 0u : ch_el;
+            const u32 pos = lo + (u32)i;
+            if (lane == 0) {
+                A.meta[pos] = make_uint4(ch, depth, ch_root, my_label);
+                A.order[pos] = g;
+                A.posof[g] = pos;
+                if (ch != C2A_NONE) A.child[2 * (u64)ch + my_label] = pos;
+            }
+            u32 kfill = 0;
+            if (dl != C2A_NONE) kfill = atomicAdd(&A.fill[dl], 1u);
+            if (ch != C2A_NONE) {
+                const bool need_parent = ch_depth != 0 && chunk_of(depth) == chunk_of(ch_depth);
+                if (need_parent && !champ_loaded) champ_w = A.pstr[(u64)ch * kChunkWords + lane];
+                bool fresh;
+                A.pstr[(u64)pos * kChunkWords + lane] = child_word(need_parent ? champ_w : 0ull, ch_depth, my_label, lane, fresh);
+                if (lane == 0 && chunk_of(depth)) A.cprev[pos] = fresh ? ch : A.cprev[ch];
+            }
+            if (dl != C2A_NONE) {
+                A.cand[gd.z + kfill] = make_uint4(pos | (lane << 31), depth, ch_root, my_label);   // lane == edge label
+                if (kfill + 1 == gd.w) { rdy = dl; rdy_rec = gd; }
+            }
+        }
+        if (lane < 2) { s_ready[2 * wv + lane] = rdy; s_rec[2 * wv + lane] = rdy_rec; }
+        __syncthreads();
+        if (wv == 0) {
+            const u32 d = lane < 2 * WPB ? s_ready[lane] : C2A_NONE;
+            const u64 mask = __ballot(d != C2A_NONE);
+            if (mask) {
+                if (lane == 0) s_base = atomicAdd(&A.fcount[level + 1], (u32)__popcll(mask));
+                wave_lds_sync();
+                if (d != C2A_NONE) {
+                    const u32 p = s_base + (u32)__popcll(mask & lt_mask);
+                    const uint4 gd = s_rec[lane];
+                    nxt[p].b = make_uint4(gd.w, 0, 0, 0);
+                    nxt[p].a = make_uint4(d, gd.x, gd.y, gd.z);
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 

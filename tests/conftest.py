@@ -90,29 +90,37 @@ def backend(request, c2a):
     be.close()
 
 
-WAVE_BACKENDS = [pytest.param(("emul", 4), id="emul-wpb4"), pytest.param(("emul", "persist-sc1"), id="emul-persistent")] + [
-    pytest.param(("hip", w), id=f"hip-wpb{w}", marks=pytest.mark.gpu) for w in (4, 8, 16)] + [
-    pytest.param(("hip", 0), id="hip-lane-per-gate", marks=pytest.mark.gpu),
-    pytest.param(("hip", "persist-sc1"), id="hip-persistent-sc1", marks=pytest.mark.gpu),
-    pytest.param(("hip", "persist-fence"), id="hip-persistent-fence", marks=pytest.mark.gpu),
-    pytest.param(("hip", "base64"), id="hip-base64-rows", marks=pytest.mark.gpu),
-    pytest.param(("emul", "base64"), id="emul-base64-rows")]
+def _variant(kind, mode, rep):
+    marks = [pytest.mark.gpu] if kind == "hip" else []
+    return pytest.param((kind, mode, rep), id=f"{kind}-{rep}-{mode}", marks=marks)
+
+
+# (library build, kernel shape, path representation).  "str" = path bit-strings (library default), "rows" = base-16 /
+# base-64 ancestor rows.  The persistent single-XCD launch and the 256-byte rows exist for the rows representation only.
+WAVE_BACKENDS = [
+    _variant("emul", "wpb4", "str"), _variant("emul", "wpb4", "rows"), _variant("emul", "lane", "rows"),
+    _variant("emul", "persist-sc1", "rows"), _variant("emul", "base64", "rows"),
+    _variant("hip", "wpb4", "str"), _variant("hip", "wpb8", "str"), _variant("hip", "wpb16", "str"), _variant("hip", "lane", "str"),
+    _variant("hip", "wpb4", "rows"), _variant("hip", "wpb8", "rows"), _variant("hip", "wpb16", "rows"), _variant("hip", "lane", "rows"),
+    _variant("hip", "persist-sc1", "rows"), _variant("hip", "persist-fence", "rows"), _variant("hip", "base64", "rows")]
 
 
 @pytest.fixture(params=WAVE_BACKENDS)
 def backend_wave(request, c2a):
     """Every level (however wide) through the wave-per-gate kernel, at each workgroup shape; every level through the
-    lane-per-gate kernel; and everything after the first batch through the persistent single-XCD kernel."""
-    kind, wpb = request.param
-    if wpb == 0:
-        env = _Env(C2A_PEEL_WAVE_MAX=0)
-    elif wpb == "base64":          # 256-byte ancestor rows (default is base 16)
-        env = _Env(C2A_ANC_BITS=6)
-    elif isinstance(wpb, str):     # the optional single-XCD persistent launch (off by default), both hand-off flavours
-        env = _Env(C2A_PEEL_PERSIST_MAX=1 << 30, C2A_ANC_BITS=4, C2A_PEEL_PERSIST_SC1=1 if wpb == "persist-sc1" else 0)
+    lane-per-gate kernel; and everything after the first batch through the persistent single-XCD kernel — for both
+    representations of tree paths."""
+    kind, mode, rep = request.param
+    kv = {"C2A_PEEL_STRINGS": 1 if rep == "str" else 0}
+    if mode == "lane":
+        kv["C2A_PEEL_WAVE_MAX"] = 0
+    elif mode == "base64":         # 256-byte ancestor rows (default is base 16)
+        kv["C2A_ANC_BITS"] = 6
+    elif mode.startswith("persist"):   # the optional single-XCD persistent launch (off by default), both hand-off flavours
+        kv.update(C2A_PEEL_PERSIST_MAX=1 << 30, C2A_ANC_BITS=4, C2A_PEEL_PERSIST_SC1=1 if mode == "persist-sc1" else 0)
     else:
-        env = _Env(C2A_PEEL_WAVE_MAX=1 << 30, C2A_PEEL_WPB=wpb)
-    with env:
+        kv.update(C2A_PEEL_WAVE_MAX=1 << 30, C2A_PEEL_WPB=int(mode[3:]))
+    with _Env(**kv):
         be = c2a.Backend(0, lib_path=request.getfixturevalue("emul_lib")) if kind == "emul" else c2a.Backend(0)
     yield be
     be.close()
