@@ -204,6 +204,32 @@ int do_prep(c2a_ctx* c) {
     return C2A_OK;
 }
 
+int print_persistent_profile(c2a_ctx* c, u32 joined) {
+    std::vector<ull> hp(64 * 64 * 8);
+    HIP_TRY(hipMemcpy(hp.data(), c->peel_prof.p, hp.size() * sizeof(ull), hipMemcpyDeviceToHost));
+    double acc[8] = {0}, mean[8] = {0}; u32 used = 0;
+    for (u32 L = 8; L < 64; ++L) {
+        // per level: slowest workgroup's (and the mean) phase ends since that level's earliest start
+        ull t0 = ~0ull; ull mx[8] = {0}; double sm[8] = {0}; u32 cnt = 0;
+        for (u32 r = 0; r < joined && r < 64; ++r) { const ull* q = &hp[((size_t)L * 64 + r) * 8]; if (q[0]) t0 = std::min(t0, q[0]); }
+        if (t0 == ~0ull) continue;
+        for (u32 r = 0; r < joined && r < 64; ++r) {
+            const ull* q = &hp[((size_t)L * 64 + r) * 8];
+            if (!q[0]) continue;
+            ++cnt;
+            for (int k = 0; k < 8; ++k) if (q[k]) { mx[k] = std::max(mx[k], q[k] - t0); sm[k] += (double)(q[k] - t0); }
+        }
+        ++used;
+        for (int k = 0; k < 8; ++k) { acc[k] += (double)mx[k] * 10.0; mean[k] += sm[k] * 10.0 / cnt; }
+    }
+    if (used) {
+        std::fprintf(stderr, "[c2a persistent profile] %u levels, %u workgroups; phase ends in ns since the level's first workgroup started, max over workgroups (mean):", used, joined);
+        for (int k = 0; k < 8; ++k) std::fprintf(stderr, " p%d=%.0f(%.0f)", k, acc[k] / used, mean[k] / used);
+        std::fprintf(stderr, "\n");
+    }
+    return C2A_OK;
+}
+
 // Reverse Kahn peel: one launch per level, queued in batches; the host only looks at the frontier
 // counters between batches (to stop, and to size the next batch's grid).
 int do_peel(c2a_ctx* c, u32* peeled_out) {
@@ -237,7 +263,8 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
         // narrow frontier -> one wave per gate (latency ~ one path comparison per level);
         // wide frontier   -> one lane per gate (throughput)
         const bool wave_mode = est <= c->peel_wave_max;
-        const u32 wpb = c->peel_wpb;
+        const u32 wpb_sel = c->peel_wpb;
+        const u32 wpb = (c->peel_strings && wpb_sel == 16) ? 15u : wpb_sel;   // string kernel: one more (append) wave per workgroup
         const u32 want = wave_mode ? (u32)(((u64)est * 5 / 4 + wpb - 1) / wpb) + 4
                                    : (u32)(((u64)est * 2 + kThreads - 1) / kThreads);
         const u32 blocks = std::max<u32>(8u, std::min<u32>(max_blocks, want));
@@ -245,21 +272,27 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
             if (c->peel_strings) {
                 if (level == 0) C2A_LAUNCH_NOSYNC(k_peel_level_str, grid_for(f0, max_blocks), kThreads, s, A, level);
                 else if (!wave_mode) C2A_LAUNCH_NOSYNC(k_peel_level_str, blocks, kThreads, s, A, level);
-                else if (wpb == 16) C2A_LAUNCH((k_peel_level_wave_str<16>), blocks, 1024, s, A, level);
-                else if (wpb == 8) C2A_LAUNCH((k_peel_level_wave_str<8>), blocks, 512, s, A, level);
-                else C2A_LAUNCH((k_peel_level_wave_str<4>), blocks, 256, s, A, level);
+                else if (profiling) {
+                    if (wpb_sel == 16) C2A_LAUNCH((k_peel_level_wave_str<15, true>), blocks, 1024, s, A, level);
+                    else if (wpb_sel == 8) C2A_LAUNCH((k_peel_level_wave_str<8, true>), blocks, 576, s, A, level);
+                    else C2A_LAUNCH((k_peel_level_wave_str<4, true>), blocks, 320, s, A, level);
+                } else {
+                    if (wpb_sel == 16) C2A_LAUNCH((k_peel_level_wave_str<15, false>), blocks, 1024, s, A, level);
+                    else if (wpb_sel == 8) C2A_LAUNCH((k_peel_level_wave_str<8, false>), blocks, 576, s, A, level);
+                    else C2A_LAUNCH((k_peel_level_wave_str<4, false>), blocks, 320, s, A, level);
+                }
             } else if (level == 0) {
                 // the very first launch sees the (possibly huge) level-0 frontier: sinks have no consumers
                 if (c->anc_bits == 6) C2A_LAUNCH_NOSYNC((k_peel_level<6>), grid_for(f0, max_blocks), kThreads, s, A, level);
                 else C2A_LAUNCH_NOSYNC((k_peel_level<4>), grid_for(f0, max_blocks), kThreads, s, A, level);
             } else if (wave_mode) {
                 if (c->anc_bits == 6) {
-                    if (wpb == 16) C2A_LAUNCH((k_peel_level_wave<16, 6>), blocks, 1024, s, A, level);
-                    else if (wpb == 8) C2A_LAUNCH((k_peel_level_wave<8, 6>), blocks, 512, s, A, level);
+                    if (wpb_sel == 16) C2A_LAUNCH((k_peel_level_wave<16, 6>), blocks, 1024, s, A, level);
+                    else if (wpb_sel == 8) C2A_LAUNCH((k_peel_level_wave<8, 6>), blocks, 512, s, A, level);
                     else C2A_LAUNCH((k_peel_level_wave<4, 6>), blocks, 256, s, A, level);
                 } else {
-                    if (wpb == 16) C2A_LAUNCH((k_peel_level_wave<16, 4>), blocks, 1024, s, A, level);
-                    else if (wpb == 8) C2A_LAUNCH((k_peel_level_wave<8, 4>), blocks, 512, s, A, level);
+                    if (wpb_sel == 16) C2A_LAUNCH((k_peel_level_wave<16, 4>), blocks, 1024, s, A, level);
+                    else if (wpb_sel == 8) C2A_LAUNCH((k_peel_level_wave<8, 4>), blocks, 512, s, A, level);
                     else C2A_LAUNCH((k_peel_level_wave<4, 4>), blocks, 256, s, A, level);
                 }
             } else {
@@ -280,6 +313,34 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
         for (u32 k = 0; k <= look; ++k) mx = std::max(mx, tail[k]);
         est = mx;
         batch = std::min<u32>(batch * 2, 512u);
+        if (c->peel_persist_max && c->peel_strings && next_cnt <= c->peel_persist_max) {
+            // narrow frontier: all following levels inside ONE launch on ONE XCD, until the frontier is empty or wide again
+            ENSURE(c->peel_ctl, sizeof(PeelCtl));
+            PeelCtl init;
+            std::memset(&init, 0, sizeof(init));
+            init.chosen_xcd = 0xFFFFFFFFu;
+            HIP_TRY(hipMemcpyAsync(c->peel_ctl.p, &init, sizeof(init), hipMemcpyHostToDevice, s));
+#ifdef C2A_EMULATE
+            const u32 wgs = 1;                       // the emulation runs workgroups one after the other
+#else
+            const u32 wgs = (u32)c->n_cu;            // one per CU: an XCD's worth of them takes part
+#endif
+            C2A_LAUNCH(k_peel_persistent_str, wgs, kSGroupsPerWg * 16, s, A, level, c->peel_persist_max, c->peel_ctl.as<PeelCtl>());
+            ++launches;
+            PeelCtl fin;
+            HIP_TRY(hipMemcpyAsync(&fin, c->peel_ctl.p, sizeof(fin), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (profiling) { int pr = print_persistent_profile(c, fin.joined); if (pr) return pr; profiling_done = true; }
+            c->stats.persistent_wgs = fin.joined;
+            level = fin.last_level;
+            u32 cnt_now = 0;
+            HIP_TRY(hipMemcpyAsync(&cnt_now, c->fcount.as<u32>() + level, 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (cnt_now == 0 || level > n) break;
+            est = cnt_now;                           // wide again: a few launches per level, then look again
+            batch = 8;
+            continue;
+        }
         if (c->peel_persist_max && !c->peel_strings && c->anc_bits == 4 && est <= c->peel_persist_max) {      // the persistent kernel is base-16 only
             // the frontier has narrowed: finish every remaining level inside one persistent launch
             ENSURE(c->peel_ctl, sizeof(PeelCtl));
@@ -298,23 +359,7 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
             PeelCtl fin;
             HIP_TRY(hipMemcpyAsync(&fin, c->peel_ctl.p, sizeof(fin), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
-            if (profiling) {
-                std::vector<ull> hp(64 * 64 * 8);
-                HIP_TRY(hipMemcpy(hp.data(), c->peel_prof.p, hp.size() * sizeof(ull), hipMemcpyDeviceToHost));
-                double acc[6] = {0}; u32 used = 0; double fr = 0;
-                for (u32 L = 8; L < 64; ++L) {
-                    fr += (double)hp[((size_t)L * 64 + 63) * 8 + 7];
-                    // per level: slowest workgroup's deltas since that level's earliest start
-                    ull t0 = ~0ull; ull mx[6] = {0};
-                    for (u32 r = 0; r < fin.joined && r < 64; ++r) { const ull* q = &hp[((size_t)L * 64 + r) * 8]; if (q[0]) t0 = std::min(t0, q[0]); }
-                    if (t0 == ~0ull) continue;
-                    for (u32 r = 0; r < fin.joined && r < 64; ++r) { const ull* q = &hp[((size_t)L * 64 + r) * 8]; for (int k = 0; k < 6; ++k) if (q[k]) mx[k] = std::max(mx[k], q[k] - t0); }
-                    ++used;
-                    for (int k = 0; k < 6; ++k) acc[k] += (double)mx[k] * 10.0;
-                }
-                if (used) std::fprintf(stderr, "[c2a persistent profile] %u levels (mean frontier %.0f), ns since the level's first workgroup started (max over %u workgroups): start-skew=%.0f groups-done=%.0f sync1=%.0f appended=%.0f drained=%.0f barrier-done=%.0f\n",
-                                       used, fr / 56.0, fin.joined, acc[0] / used, acc[1] / used, acc[2] / used, acc[3] / used, acc[4] / used, acc[5] / used);
-            }
+            if (profiling) { int pr = print_persistent_profile(c, fin.joined); if (pr) return pr; }
             level = fin.last_level;
             c->stats.persistent_wgs = fin.joined;
             profiling_done = true;
@@ -350,7 +395,7 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
             }
             if (!act) continue;
             const ull* r = &hp[((size_t)L * kProfWaves + slow) * 8];
-            std::fprintf(stderr, "[c2a peel profile] level %u: %u gate-waves (last wave id with a record %u); mean ns loaded=%.0f cand=%.0f tourn=%.0f rows=%.0f sync=%.0f end=%.0f | "
+            std::fprintf(stderr, "[c2a peel profile] level %u: %u gate-waves (last wave id with a record %u); mean ns p0=%.0f p1=%.0f p2=%.0f p3=%.0f p4=%.0f end=%.0f | "
                          "max end=%llu start-skew=%llu first-start->last-finish=%llu | slowest wave %u: %llu %llu %llu %llu %llu %llu cands=%llu\n", L + A.prof_level0, act, last_active,
                          mean[0] / act, mean[1] / act, mean[2] / act, mean[3] / act, mean[4] / act, mean[5] / act, (unsigned long long)mx[5], (unsigned long long)(tmax - tmin) * 10, (unsigned long long)(fin - tmin) * 10, slow,
                          (unsigned long long)r[0] * 10, (unsigned long long)r[1] * 10, (unsigned long long)r[2] * 10, (unsigned long long)r[3] * 10,
@@ -613,7 +658,7 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     ENSURE(c->prod1, nn4); ENSURE(c->dep0, n4); ENSURE(c->dep1, n4); ENSURE(c->cons_cnt, n4);
     ENSURE(c->cons_off, n4 + 4); ENSURE(c->fill, n4); ENSURE(c->cand, (size_t)n * 2 * 16);
     ENSURE(c->meta, (size_t)n * 16); ENSURE(c->ginfo, (size_t)n * 16);
-    ENSURE(c->slots0, ((size_t)n + 1) * sizeof(FrontierSlot)); ENSURE(c->slots1, ((size_t)n + 1) * sizeof(FrontierSlot));
+    ENSURE(c->slots0, ((size_t)n + 1 + kSlotPad) * sizeof(FrontierSlot)); ENSURE(c->slots1, ((size_t)n + 1 + kSlotPad) * sizeof(FrontierSlot));
 
     if (c->peel_strings) { ENSURE(c->pstr, (size_t)n * kChunkWords * 8); ENSURE(c->cprev, (size_t)n * 4); }
     else { ENSURE(c->anc, ((size_t)c->planes * n * 4) << c->anc_bits); }

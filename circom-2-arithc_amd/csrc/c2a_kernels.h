@@ -202,6 +202,10 @@ template <bool SC1> __device__ __forceinline__ void st_u32(u32* p, u32 v) {
     if (SC1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
 }
+template <bool SC1> __device__ __forceinline__ u64 ld_u64(const u64* p) {
+    if (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
 template <bool SC1> __device__ __forceinline__ uint4 ld_u128(const uint4* p) {
     if (SC1) {
         const u64* q = reinterpret_cast<const u64*>(p);
@@ -410,6 +414,7 @@ __device__ __forceinline__ ull c2a_now() {
 }
 // diagnostics: every wave of levels [256, 288) stores its phase timestamps (slot 6 = start, 7 = candidates)
 constexpr u32 kProfLevels = 32, kProfWaves = 32768;
+#define C2A_PROF_IF(on, slot, value) do { if (on) C2A_PROF(slot, value); } while (0)
 #define C2A_PROF(slot, value)                                                                                   \
     do {                                                                                                        \
         if (A.prof && lane == 0 && level >= A.prof_level0 && level < A.prof_level0 + kProfLevels) {             \
@@ -585,6 +590,7 @@ __global__ void __launch_bounds__(WPB * 64) k_peel_level_wave(PeelArgs A, u32 le
 // round trip, coalesced), XOR, ballot, count trailing zeros.  Deeper trees add one cprev hop per chunk level.
 // A new node's string = parent's string + one bit: ONE hop to build (three for the ancestor rows).
 // ================================================================================================
+constexpr u32 kSlotPad = 1u << 16;        // slots past the frontier that a speculative prefetch may touch
 constexpr u32 kChunkBits = 4096;
 constexpr u32 kChunkWords = kChunkBits / 64;
 
@@ -595,16 +601,17 @@ __device__ __forceinline__ u32 ctz64(u64 x) { return (u32)__ffsll((long long)x) 
 // Bring two distinct tree nodes under one root to the first chunk in which their paths can differ.
 // a/b: positions (in/out), lena/lenb: bits of that chunk (out); below_a/below_b: when a (b) had to climb, the
 // node of its chain one chunk below the returned one (its bit 0 is the label right after the returned chunk).
-__device__ __forceinline__ void resolve_chunks(const u32* __restrict__ cprev, u32& a, u32& lena, u32& below_a, u32 da, u32& b,
+template <bool SC1 = false>
+__device__ __forceinline__ void resolve_chunks(const u32* cprev, u32& a, u32& lena, u32& below_a, u32 da, u32& b,
                                                u32& lenb, u32& below_b, u32 db) {
     u32 ia = chunk_of(da), ib = chunk_of(db);
     lena = chunk_len(da); lenb = chunk_len(db);
     below_a = C2A_NONE; below_b = C2A_NONE;
     if ((ia | ib) == 0) return;
-    while (ia > ib) { below_a = a; a = cprev[a]; --ia; lena = kChunkBits; }
-    while (ib > ia) { below_b = b; b = cprev[b]; --ib; lenb = kChunkBits; }
+    while (ia > ib) { below_a = a; a = ld_u32<SC1>(&cprev[a]); --ia; lena = kChunkBits; }
+    while (ib > ia) { below_b = b; b = ld_u32<SC1>(&cprev[b]); --ib; lenb = kChunkBits; }
     while (ia > 0 && a != b) {
-        const u32 pa = cprev[a], pb = cprev[b];
+        const u32 pa = ld_u32<SC1>(&cprev[a]), pb = ld_u32<SC1>(&cprev[b]);
         if (pa == pb) break;
         below_a = a; below_b = b;
         a = pa; b = pb; --ia;
@@ -700,9 +707,9 @@ __global__ void __launch_bounds__(kThreads) k_peel_level_str(PeelArgs A, u32 lev
             const u64* src = A.pstr + (u64)best * kChunkWords;
             const u32 bit = (depth - 1) - chunk_of(depth) * kChunkBits;
             const bool fresh_chunk = best_depth == 0 || chunk_of(depth) != chunk_of(best_depth);
-            const u32 words = (bit >> 6) + 1;                        // words that can be non-zero
-            for (u32 w = 0; w < kChunkWords; ++w) {
-                u64 v = (!fresh_chunk && w < words) ? src[w] : 0ull;
+            // words past a string's end are never written and never read: the parent has `bit` bits, the child bit + 1
+            for (u32 w = 0; w * 64 <= bit; ++w) {
+                u64 v = (!fresh_chunk && w * 64 < bit) ? src[w] : 0ull;
                 if (w == (bit >> 6)) v |= (u64)my_label << (bit & 63u);
                 dst[w] = v;
             }
@@ -729,38 +736,77 @@ __global__ void __launch_bounds__(kThreads) k_peel_level_str(PeelArgs A, u32 lev
 // round trip to memory when every survivor is shallower than a chunk
 constexpr int kStrMax = 12;               // survivor strings held in registers per round
 
-template <int WPB>
-__global__ void __launch_bounds__(WPB * 64) k_peel_level_wave_str(PeelArgs A, u32 level) {
+// Workgroup = WPB gate waves + ONE append wave.  Dependent memory round trips per level:
+//   1. frontier slot (fixed address, prefetched) + this level's count
+//   2. candidate records  ||  ginfo of the two producers  ||  fill[] tickets of the two pushes
+//   3. survivor strings   ||  (append wave) next-level counter ticket -> next-level slots
+//   then only stores (meta, order, child, the new string, the two candidate records).
+// The pushes' tickets need nothing from the tournament, so "am I the last consumer of this producer" — and with it the whole
+// next-level frontier — is known after round trip 2, and the append overlaps the tournament.
+#ifndef C2A_X
+#define C2A_X 0      // timing experiments: 1 = no string loads, 2 = + no candidate loads, 3 = + no tournament/stores (results wrong)
+#endif
+template <int WPB, bool PROF>
+__global__ void __launch_bounds__((WPB + 1) * 64) k_peel_level_wave_str(PeelArgs A, u32 level) {
+    const ull t_begin = PROF ? c2a_now() : 0;
     __shared__ u32 s_c[WPB][72], s_l[WPB][72], s_d[WPB][72];
     __shared__ u32 s_ready[2 * WPB];
     __shared__ uint4 s_rec[2 * WPB];
-    __shared__ u32 s_base;
     const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    FrontierSlot* cur = A.slots[level & 1u];
-    FrontierSlot* nxt = A.slots[(level + 1) & 1u];
+    const bool gate_wave = wv < (u32)WPB;
+    const u32 wvc = gate_wave ? wv : 0u;      // LDS row (the append wave never touches its row)
+    // both pointers come with the one kernarg fetch; indexing the array by level would be a second, dependent scalar load
+    FrontierSlot* cur = (level & 1u) ? A.slots[1] : A.slots[0];
+    FrontierSlot* nxt = (level & 1u) ? A.slots[0] : A.slots[1];
     const u64 lt_mask = (1ull << lane) - 1ull;
     uint4 sa0 = make_uint4(0, 0, 0, 0);
     u32 cnt0 = 0;
-    {
+    if (gate_wave) {
         const u64 i0 = (u64)blockIdx.x * WPB + wv;
-        if (i0 < A.n) { sa0 = cur[i0].a; cnt0 = cur[i0].b.x; }
+        sa0 = cur[i0].a; cnt0 = cur[i0].b.x;      // speculative, before the level's count is known: the slot arrays are padded (kSlotPad)
     }
     const u32 n_front = A.fcount[level];
     const u32 lo = A.fbase[level];
     if (gtid() == 0) A.fbase[level + 1] = lo + n_front;
+    if (gate_wave) { C2A_PROF_IF(PROF, 6, t_begin); C2A_PROF_IF(PROF, 0, c2a_now() - t_begin); }
     for (u32 chunk = blockIdx.x; (u64)chunk * WPB < n_front; chunk += gridDim.x) {
         const u64 i = (u64)chunk * WPB + wv;
-        u32 rdy = C2A_NONE;
-        uint4 rdy_rec = make_uint4(0, 0, 0, 0);
+        const bool active = gate_wave && i < n_front;
         uint4 sa = sa0;
         u32 cnt = cnt0;
-        if (chunk != blockIdx.x && i < n_front) { sa = cur[i].a; cnt = cur[i].b.x; }
-        if (i < n_front) {
-            const u32 g = sa.x;
-            const u32 e0 = sa.w, e1 = e0 + cnt;
-            const u32 dl = lane == 0 ? sa.y : (lane == 1 ? sa.z : C2A_NONE);
-            uint4 gd = make_uint4(0, 0, 0, 0);
-            if (dl != C2A_NONE) gd = A.ginfo[dl];
+        if (chunk != blockIdx.x && active) { sa = cur[i].a; cnt = cur[i].b.x; }
+        // ---- round trip 2: producers' ginfo, fill tickets, first block of candidate records
+        const u32 g = sa.x;
+        const u32 e0 = sa.w, e1 = e0 + cnt;
+        const u32 dl = active ? (lane == 0 ? sa.y : (lane == 1 ? sa.z : C2A_NONE)) : C2A_NONE;
+        uint4 gd = make_uint4(0, 0, 0, 0);
+        u32 kfill = 0;
+        uint4 cr_first = make_uint4(0, 0, 0xFFFFFFFFu, 0);
+#if C2A_X < 2
+        if (active && e0 + lane < e1) cr_first = A.cand[e0 + lane];
+#endif
+        if (dl != C2A_NONE) { gd = A.ginfo[dl]; kfill = atomicAdd(&A.fill[dl], 1u); }
+        const bool last_push = dl != C2A_NONE && kfill + 1 == gd.w;
+        if (gate_wave && lane < 2) { s_ready[2 * wv + lane] = last_push ? dl : C2A_NONE; s_rec[2 * wv + lane] = gd; }
+        if (active) { C2A_PROF_IF(PROF, 7, 1000ull + cnt); C2A_PROF_IF(PROF, 1, c2a_now() - t_begin); }
+        __syncthreads();
+        if (active) C2A_PROF_IF(PROF, 2, c2a_now() - t_begin);
+        if (!gate_wave) {
+            // ---- append wave: one ticket on the next level's counter for the whole workgroup
+            const u32 d = lane < 2 * WPB ? s_ready[lane] : C2A_NONE;
+            const u64 mask = __ballot(d != C2A_NONE);
+            if (mask) {
+                u32 base = 0;
+                if (lane == 0) base = atomicAdd(&A.fcount[level + 1], (u32)__popcll(mask));
+                base = __shfl(base, 0, 64);
+                if (d != C2A_NONE) {
+                    const u32 p = base + (u32)__popcll(mask & lt_mask);
+                    const uint4 r = s_rec[lane];
+                    nxt[p].b = make_uint4(r.w, 0, 0, 0);
+                    nxt[p].a = make_uint4(d, r.x, r.y, r.z);
+                }
+            }
+        } else if (active && C2A_X < 3) {
             // champion so far (wave-uniform); NONE = the virtual-root candidate [g].  champ_w = this lane's word of
             // the champion's string when champ_loaded
             u32 ch = C2A_NONE, ch_el = 0, ch_root = g, ch_depth = 0;
@@ -769,12 +815,10 @@ __global__ void __launch_bounds__(WPB * 64) k_peel_level_wave_str(PeelArgs A, u3
             for (u32 eb = e0; eb < e1; eb += 64) {
                 const u32 e = eb + lane;
                 const bool valid = e < e1;
-                u32 c = 0, l = 0, cdepth = 0, croot = 0xFFFFFFFFu;
-                if (valid) {
-                    const uint4 cr = A.cand[e];
-                    c = cr.x & kIdMask; l = cr.x >> 31;
-                    cdepth = cr.y; croot = cr.z;
-                }
+                uint4 cr = cr_first;
+                if (eb != e0) { cr = make_uint4(0, 0, 0xFFFFFFFFu, 0); if (valid) cr = A.cand[e]; }
+                const u32 c = cr.x & kIdMask, l = cr.x >> 31, cdepth = cr.y;
+                const u32 croot = valid ? cr.z : 0xFFFFFFFFu;
                 const u32 rmin = wave_min_u32(croot);
                 if (rmin > ch_root) continue;
                 const bool keep_ch = (ch != C2A_NONE) && (ch_root == rmin);
@@ -784,31 +828,32 @@ __global__ void __launch_bounds__(WPB * 64) k_peel_level_wave_str(PeelArgs A, u3
                 const u32 m = (u32)__popcll(smask);
                 if (surv) {
                     const u32 k = (u32)__popcll(smask & lt_mask);
-                    s_c[wv][k] = c; s_l[wv][k] = l; s_d[wv][k] = cdepth;
+                    s_c[wvc][k] = c; s_l[wvc][k] = l; s_d[wvc][k] = cdepth;
                 }
                 wave_lds_sync();
                 // sequential tournament, kStrMax survivors per round with their strings in registers
                 u32 next = 0;
                 if (!keep_ch) {      // the first survivor becomes the champion without a comparison
-                    ch = s_c[wv][0]; ch_el = s_l[wv][0]; ch_depth = s_d[wv][0];
+                    ch = s_c[wvc][0]; ch_el = s_l[wvc][0]; ch_depth = s_d[wvc][0];
                     next = 1;
                 }
                 ch_root = rmin;
                 while (next < m) {
                     const u32 take = (m - next) < (u32)kStrMax ? (m - next) : (u32)kStrMax;
-                    // all of this round in chunk 0?  then one coalesced load per string, all issued back to back
+                    // all of this round in chunk 0?  then one coalesced load per string, all issued back to back;
+                    // lanes beyond a string's length skip their word (it is zero)
                     bool shallow = ch_depth <= kChunkBits;
-                    for (u32 t = 0; t < take; ++t) shallow = shallow && s_d[wv][next + t] <= kChunkBits;
+                    for (u32 t = 0; t < take; ++t) shallow = shallow && s_d[wvc][next + t] <= kChunkBits;
                     if (shallow) {
                         u64 sw[kStrMax];
 #pragma unroll
                         for (int t = 0; t < kStrMax; ++t)
-                            sw[t] = (u32)t < take ? A.pstr[(u64)s_c[wv][next + t] * kChunkWords + lane] : 0ull;
-                        if (!champ_loaded) { champ_w = ch_depth ? A.pstr[(u64)ch * kChunkWords + lane] : 0ull; champ_loaded = true; }
+                            sw[t] = (C2A_X < 1 && (u32)t < take && lane * 64 < s_d[wvc][next + t]) ? A.pstr[(u64)s_c[wvc][next + t] * kChunkWords + lane] : 0ull;
+                        if (!champ_loaded) { champ_w = (C2A_X < 1 && lane * 64 < ch_depth) ? A.pstr[(u64)ch * kChunkWords + lane] : 0ull; champ_loaded = true; }
 #pragma unroll
                         for (int t = 0; t < kStrMax; ++t) {
                             if ((u32)t < take) {
-                                const u32 cc = s_c[wv][next + t], cl = s_l[wv][next + t], cd = s_d[wv][next + t];
+                                const u32 cc = s_c[wvc][next + t], cl = s_l[wvc][next + t], cd = s_d[wvc][next + t];
                                 bool less;
                                 if (cc == ch) less = cl < ch_el;
                                 else less = str_less_wave(sw[t], cd, cl, champ_w, ch_depth, ch_el, lane);
@@ -818,7 +863,7 @@ __global__ void __launch_bounds__(WPB * 64) k_peel_level_wave_str(PeelArgs A, u3
                     } else {
                         // deep trees: chunk resolution (cprev hops) per comparison, strings loaded per comparison
                         for (u32 t = 0; t < take; ++t) {
-                            const u32 cc = s_c[wv][next + t], cl = s_l[wv][next + t], cd = s_d[wv][next + t];
+                            const u32 cc = s_c[wvc][next + t], cl = s_l[wvc][next + t], cd = s_d[wvc][next + t];
                             bool less;
                             if (cc == ch) less = cl < ch_el;
                             else {
@@ -840,6 +885,7 @@ __global__ void __launch_bounds__(WPB * 64) k_peel_level_wave_str(PeelArgs A, u3
                 }
                 wave_lds_sync();
             }
+            C2A_PROF_IF(PROF, 3, c2a_now() - t_begin);
             const u32 depth = ch == C2A_NONE ? 0u : ch_depth + 1;
             const u32 my_label = ch == C2A_NONE ? 0u : ch_el;
             const u32 pos = lo + (u32)i;
@@ -849,37 +895,19 @@ __global__ void __launch_bounds__(WPB * 64) k_peel_level_wave_str(PeelArgs A, u3
                 A.posof[g] = pos;
                 if (ch != C2A_NONE) A.child[2 * (u64)ch + my_label] = pos;
             }
-            u32 kfill = 0;
-            if (dl != C2A_NONE) kfill = atomicAdd(&A.fill[dl], 1u);
+            if (dl != C2A_NONE) A.cand[gd.z + kfill] = make_uint4(pos | (lane << 31), depth, ch_root, my_label);   // lane == edge label
             if (ch != C2A_NONE) {
                 const bool need_parent = ch_depth != 0 && chunk_of(depth) == chunk_of(ch_depth);
-                if (need_parent && !champ_loaded) champ_w = A.pstr[(u64)ch * kChunkWords + lane];
+                if (need_parent && !champ_loaded) champ_w = (C2A_X < 1 && lane * 64 < chunk_len(ch_depth)) ? A.pstr[(u64)ch * kChunkWords + lane] : 0ull;
                 bool fresh;
-                A.pstr[(u64)pos * kChunkWords + lane] = child_word(need_parent ? champ_w : 0ull, ch_depth, my_label, lane, fresh);
+                const u64 nw = child_word(need_parent ? champ_w : 0ull, ch_depth, my_label, lane, fresh);
+                if (lane * 64 < chunk_len(depth)) A.pstr[(u64)pos * kChunkWords + lane] = nw;      // words past the end are never read
                 if (lane == 0 && chunk_of(depth)) A.cprev[pos] = fresh ? ch : A.cprev[ch];
             }
-            if (dl != C2A_NONE) {
-                A.cand[gd.z + kfill] = make_uint4(pos | (lane << 31), depth, ch_root, my_label);   // lane == edge label
-                if (kfill + 1 == gd.w) { rdy = dl; rdy_rec = gd; }
-            }
-        }
-        if (lane < 2) { s_ready[2 * wv + lane] = rdy; s_rec[2 * wv + lane] = rdy_rec; }
-        __syncthreads();
-        if (wv == 0) {
-            const u32 d = lane < 2 * WPB ? s_ready[lane] : C2A_NONE;
-            const u64 mask = __ballot(d != C2A_NONE);
-            if (mask) {
-                if (lane == 0) s_base = atomicAdd(&A.fcount[level + 1], (u32)__popcll(mask));
-                wave_lds_sync();
-                if (d != C2A_NONE) {
-                    const u32 p = s_base + (u32)__popcll(mask & lt_mask);
-                    const uint4 gd = s_rec[lane];
-                    nxt[p].b = make_uint4(gd.w, 0, 0, 0);
-                    nxt[p].a = make_uint4(d, gd.x, gd.y, gd.z);
-                }
-            }
+            C2A_PROF_IF(PROF, 4, c2a_now() - t_begin);
         }
         __syncthreads();
+        if (active) C2A_PROF_IF(PROF, 5, c2a_now() - t_begin);
     }
 }
 
@@ -1120,6 +1148,295 @@ __global__ void __launch_bounds__(kPGroupsPerWg * 16) k_peel_persistent(PeelArgs
         }
         __syncthreads();
         C2A_PPROF(5);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Variant 4: the path-string peel as ONE persistent launch on ONE XCD (narrow frontiers).
+// What a kernel boundary per level costs (tools/ubench/xcd2.hip, MI355X): ~2.3 us of launch gap, an L2 invalidate,
+// and every first touch afterwards from HBM (220-370 ns per dependent hop instead of 85 ns in L2).  The 32 workgroups
+// of one XCD share ONE L2, so inside one launch they can exchange data through it with no cache maintenance at all:
+//   stores  : plain (the vector L1 is write-through; vmcnt(0) == the L2 has the data)
+//   loads   : sc1 (agent-scope relaxed atomic loads: miss the L1 always, hit the shared L2)       [0 stale reads / 16 M]
+//   atomics : L2 atomics (fill[], the frontier counter, the level barrier) — ~12 ns each on one word, 32 per level
+//   level barrier among the 32 workgroups: 1.05-1.36 us; `buffer_inv sc1` (7 us) is never used
+// The XCD filter only decides WHO works (HW_REG_XCC_ID is ground truth; the first workgroup to arrive picks the XCD;
+// the census tells the participants how many they are); correctness never depends on placement.
+// One 16-lane group per gate (64 gates per workgroup, 2048 per pass over the 32 CUs): lane l16 holds words
+// {l16, 16+l16, 32+l16, 48+l16} of a string, so every 8-byte load instruction of a group covers 128 contiguous bytes
+// and the k-th one is skipped for strings shorter than 1024k bits.
+// The launch returns at the first level that is empty or wider than `cap` (the host goes on with a launch per level).
+// ------------------------------------------------------------------------------------------------
+constexpr int kSGroupsPerWg = 64;           // 1024 threads
+constexpr int kSMax = 5;                    // survivor strings held in registers per tournament round
+constexpr int kSW = 4;                      // u64 words of a string per lane
+
+__device__ __forceinline__ u32 group_ballot16(bool p, u32 l16, u32 gshift) {
+#ifdef C2A_EMULATE
+    (void)gshift;
+    return group_or16(p ? (1u << l16) : 0u);
+#else
+    (void)l16;
+    return (u32)((__ballot(p) >> gshift) & 0xFFFFull);
+#endif
+}
+
+template <bool SC1>
+__device__ __forceinline__ void load_str16(const u64* pstr, u32 x, u32 len, u32 l16, u64 (&w)[kSW]) {
+#pragma unroll
+    for (int k = 0; k < kSW; ++k) {
+        const u32 word = (u32)k * 16 + l16;
+        w[k] = word * 64 < len ? ld_u64<SC1>(pstr + (u64)x * kChunkWords + word) : 0ull;
+    }
+}
+
+// bit `pos` of a string held by a group (group-uniform pos)
+__device__ __forceinline__ u32 str_bit16(const u64 (&w)[kSW], u32 pos) {
+    const u32 word = pos >> 6, kk = word >> 4;
+    u64 v = 0;
+#pragma unroll
+    for (int k = 0; k < kSW; ++k) {
+        const u64 t = __shfl(w[k], (int)(word & 15u), 16);
+        if ((u32)k == kk) v = t;
+    }
+    return (u32)((v >> (pos & 63u)) & 1ull);
+}
+
+// group-cooperative: is P(a).la < P(b).lb for two strings of one chunk held in registers?  (group-uniform result)
+__device__ __forceinline__ bool str_less16(const u64 (&a)[kSW], u32 lena, u32 la, const u64 (&b)[kSW], u32 lenb, u32 lb, u32 l16,
+                                           u32 gshift) {
+    const u32 minlen = lena < lenb ? lena : lenb;
+#pragma unroll
+    for (int k = 0; k < kSW; ++k) {
+        const u32 lo = ((u32)k * 16 + l16) * 64;
+        u64 x = a[k] ^ b[k];
+        if (lo >= minlen) x = 0;
+        else if (minlen - lo < 64) x &= (1ull << (minlen - lo)) - 1ull;
+        const u32 bal = group_ballot16(x != 0, l16, gshift);
+        if (bal) {
+            const int L = (int)__ffs((int)bal) - 1;
+            const u64 xl = __shfl(x, L, 16);
+            const u64 al = __shfl(a[k], L, 16);
+            return ((al >> ctz64(xl)) & 1ull) == 0;
+        }
+    }
+    if (lena == lenb) return la < lb;
+    if (lena < lenb) return la < str_bit16(b, lena);
+    return str_bit16(a, lenb) < lb;
+}
+
+__global__ void __launch_bounds__(kSGroupsPerWg * 16) k_peel_persistent_str(PeelArgs A, u32 level0, u32 cap, PeelCtl* ctl) {
+    __shared__ u32 s_c[kSGroupsPerWg][20], s_l[kSGroupsPerWg][20], s_d[kSGroupsPerWg][20];
+    __shared__ u32 s_ready[2 * kSGroupsPerWg];
+    __shared__ uint4 s_rec[2 * kSGroupsPerWg];
+    __shared__ u32 s_cnt[2];
+    __shared__ u32 s_base, s_P, s_rank, s_go, s_nf;
+    const u32 tid = threadIdx.x, lane = tid & 63u, l16 = tid & 15u, gq = tid >> 4, gshift = lane & 48u;
+    // ---- who works: the XCD of the first workgroup to arrive
+    if (tid == 0) {
+        const u32 x = xcc_id();
+        const u32 prev = atomicCAS(&ctl->chosen_xcd, 0xFFFFFFFFu, x);
+        const bool mine = prev == 0xFFFFFFFFu || prev == x;
+        s_go = mine ? 1u : 0u;
+        if (mine) s_rank = atomicAdd(&ctl->joined, 1u); else atomicAdd(&ctl->bystanders, 1u);
+    }
+    __syncthreads();
+    if (!s_go) return;
+    if (tid == 0) {
+        while (ld_u32<true>(&ctl->joined) + ld_u32<true>(&ctl->bystanders) < gridDim.x) __builtin_amdgcn_s_sleep(2);
+        s_P = ld_u32<true>(&ctl->joined);
+    }
+    __syncthreads();
+    const u32 P = s_P, rank = s_rank;
+    const u32 total_groups = P * kSGroupsPerWg;
+    u32 epoch = 0;
+    u32 pf_acc = 0;                                        // sink of the look-ahead loads (never true, keeps them alive)
+    // one lane per workgroup reads the level's frontier size (512 waves on one word is a 0.7 us pile-up on one L2 channel)
+    if (tid == 0) s_nf = ld_u32<true>(&A.fcount[level0]);
+    u32 lo = ld_u32<true>(&A.fbase[level0]);
+    __syncthreads();
+    for (u32 level = level0;; ++level) {
+        C2A_PPROF(0);
+        const u32 n_front = s_nf;
+        if (n_front == 0 || n_front > cap) {               // every participant reads the same value: uniform exit
+            if (rank == 0 && tid == 0) st_u32<true>(&ctl->last_level, level);
+            if (pf_acc == 0x9E3779B9u && n_front == 0xFFFFFFFFu) ctl->pad[0] = pf_acc;
+            break;
+        }
+        if (rank == 0 && tid == 0) A.fbase[level + 1] = lo + n_front;
+        FrontierSlot* cur = A.slots[level & 1u];
+        FrontierSlot* nxt = A.slots[(level + 1) & 1u];
+        for (u32 base = 0; base < n_front; base += total_groups) {
+            const u32 i = base + rank * kSGroupsPerWg + gq;
+            const bool active = i < n_front;
+            // ---- slot, then (in one round trip) candidate records, the producers' ginfo and the two push tickets
+            u32 sword = 0;                                            // lanes 0-3: a.x..a.w, lane 4: b.x — one 4-byte load per lane
+            if (active && l16 < 5) sword = ld_u32<true>(reinterpret_cast<const u32*>(&cur[i]) + l16);
+            const uint4 sa = make_uint4(__shfl(sword, 0, 16), __shfl(sword, 1, 16), __shfl(sword, 2, 16), __shfl(sword, 3, 16));
+            const u32 cnt = __shfl(sword, 4, 16);
+            const u32 g = sa.x;
+            const u32 e0 = sa.w, e1 = e0 + cnt;
+            const u32 dl = active ? (l16 == 0 ? sa.y : (l16 == 1 ? sa.z : C2A_NONE)) : C2A_NONE;
+            uint4 gd = make_uint4(0, 0, 0, 0);
+            u32 kfill = 0;
+            uint4 cr_first = make_uint4(0, 0, 0xFFFFFFFFu, 0);
+            if (active && e0 + l16 < e1) cr_first = ld_u128<true>(&A.cand[e0 + l16]);
+            if (dl != C2A_NONE) { gd = A.ginfo[dl]; kfill = atomicAdd(&A.fill[dl], 1u); }          // ginfo is static
+            const bool last_push = dl != C2A_NONE && kfill + 1 == gd.w;
+            if (l16 < 2) { s_ready[2 * gq + l16] = last_push ? dl : C2A_NONE; s_rec[2 * gq + l16] = gd; }
+            C2A_PPROF(1);
+            __syncthreads();
+            // ---- one append per workgroup: the ticket is issued now, the slots are written after the tournament
+            u32 d_app = C2A_NONE;
+            u64 mask_app = 0;
+            if (tid < 2 * kSGroupsPerWg) {                           // waves 0 and 1, whole waves
+                d_app = s_ready[tid];
+                mask_app = __ballot(d_app != C2A_NONE);
+                if (lane == 0) s_cnt[tid >> 6] = (u32)__popcll(mask_app);
+            }
+            __syncthreads();
+            C2A_PPROF(2);
+            u32 ticket = 0;                                          // consumed after the tournament: the round trip overlaps it
+            if (tid == 0) { const u32 tot = s_cnt[0] + s_cnt[1]; ticket = tot ? atomicAdd(&A.fcount[level + 1], tot) : 0u; }
+            if (d_app != C2A_NONE) {
+                // look-ahead for the next level: pull ginfo[] and fill[] of the appended gate's two producers into the L2
+                // now (random lines, HBM), so that next level's tickets find them there
+                const uint4 r = s_rec[tid];
+                if (r.x != C2A_NONE) pf_acc ^= A.ginfo[r.x].w ^ ld_u32<true>(&A.fill[r.x]);
+                if (r.y != C2A_NONE) pf_acc ^= A.ginfo[r.y].w ^ ld_u32<true>(&A.fill[r.y]);
+            }
+            if (active) {
+                u32 ch = C2A_NONE, ch_el = 0, ch_root = g, ch_depth = 0;
+                u64 champ[kSW] = {0, 0, 0, 0};
+                bool champ_loaded = false;
+                for (u32 eb = e0; eb < e1; eb += 16) {
+                    const u32 e = eb + l16;
+                    const bool valid = e < e1;
+                    uint4 cr = cr_first;
+                    if (eb != e0) { cr = make_uint4(0, 0, 0xFFFFFFFFu, 0); if (valid) cr = ld_u128<true>(&A.cand[e]); }
+                    const u32 c = cr.x & kIdMask, l = cr.x >> 31, cdepth = cr.y;
+                    const u32 croot = valid ? cr.z : 0xFFFFFFFFu;
+                    const u32 rmin = group_min16(croot);
+                    if (rmin > ch_root) continue;
+                    const bool keep_ch = (ch != C2A_NONE) && (ch_root == rmin);
+                    if (!keep_ch) champ_loaded = false;
+                    const bool surv = valid && croot == rmin;
+                    const u32 smask = group_ballot16(surv, l16, gshift);
+                    const u32 m = (u32)__popc(smask);
+                    if (surv) {
+                        const u32 k = (u32)__popc(smask & ((1u << l16) - 1u));
+                        s_c[gq][k] = c; s_l[gq][k] = l; s_d[gq][k] = cdepth;
+                    }
+                    group_lds_sync();
+                    C2A_PPROF(3);
+                    u32 next = 0;
+                    if (!keep_ch) { ch = s_c[gq][0]; ch_el = s_l[gq][0]; ch_depth = s_d[gq][0]; next = 1; }
+                    ch_root = rmin;
+                    while (next < m) {
+                        const u32 take = (m - next) < (u32)kSMax ? (m - next) : (u32)kSMax;
+                        bool shallow = ch_depth <= kChunkBits;
+                        for (u32 t = 0; t < take; ++t) shallow = shallow && s_d[gq][next + t] <= kChunkBits;
+                        if (shallow) {
+                            u64 sw[kSMax][kSW];
+#pragma unroll
+                            for (int t = 0; t < kSMax; ++t) {
+                                const bool on = (u32)t < take;
+                                load_str16<true>(A.pstr, on ? s_c[gq][next + t] : 0u, on ? s_d[gq][next + t] : 0u, l16, sw[t]);
+                            }
+                            if (!champ_loaded) { load_str16<true>(A.pstr, ch, ch_depth, l16, champ); champ_loaded = true; }
+                            if (A.prof && (sw[0][0] ^ champ[0]) == 0x123456789ABCDEFull) return;
+                            C2A_PPROF(4);
+#pragma unroll
+                            for (int t = 0; t < kSMax; ++t) {
+                                if ((u32)t < take) {
+                                    const u32 cc = s_c[gq][next + t], cl = s_l[gq][next + t], cd = s_d[gq][next + t];
+                                    bool less;
+                                    if (cc == ch) less = cl < ch_el;
+                                    else less = str_less16(sw[t], cd, cl, champ, ch_depth, ch_el, l16, gshift);
+                                    if (less) {
+                                        ch = cc; ch_el = cl; ch_depth = cd;
+#pragma unroll
+                                        for (int k = 0; k < kSW; ++k) champ[k] = sw[t][k];
+                                    }
+                                }
+                            }
+                        } else {
+                            // deep trees: chunk resolution (cprev hops) and string loads per comparison
+                            for (u32 t = 0; t < take; ++t) {
+                                const u32 cc = s_c[gq][next + t], cl = s_l[gq][next + t], cd = s_d[gq][next + t];
+                                bool less;
+                                if (cc == ch) less = cl < ch_el;
+                                else {
+                                    u32 ra = cc, rb = ch, lena, lenb, ba, bb;
+                                    resolve_chunks<true>(A.cprev, ra, lena, ba, cd, rb, lenb, bb, ch_depth);
+                                    if (ra == rb) {
+                                        if (ba != C2A_NONE) less = (u32)(ld_u64<true>(A.pstr + (u64)ba * kChunkWords) & 1ull) < ch_el;
+                                        else less = cl < (u32)(ld_u64<true>(A.pstr + (u64)bb * kChunkWords) & 1ull);
+                                    } else {
+                                        u64 wa[kSW], wb[kSW];
+                                        load_str16<true>(A.pstr, ra, lena, l16, wa);
+                                        load_str16<true>(A.pstr, rb, lenb, l16, wb);
+                                        less = str_less16(wa, lena, cl, wb, lenb, ch_el, l16, gshift);
+                                    }
+                                }
+                                if (less) { ch = cc; ch_el = cl; ch_depth = cd; champ_loaded = false; }
+                            }
+                        }
+                        next += take;
+                    }
+                    group_lds_sync();
+                }
+                C2A_PPROF(5);
+                const u32 depth = ch == C2A_NONE ? 0u : ch_depth + 1;
+                const u32 my_label = ch == C2A_NONE ? 0u : ch_el;
+                const u32 pos = lo + i;
+                if (l16 == 0) {
+                    A.meta[pos] = make_uint4(ch, depth, ch_root, my_label);
+                    A.order[pos] = g;
+                    A.posof[g] = pos;
+                    if (ch != C2A_NONE) A.child[2 * (u64)ch + my_label] = pos;
+                }
+                if (dl != C2A_NONE) A.cand[gd.z + kfill] = make_uint4(pos | (l16 << 31), depth, ch_root, my_label);   // l16 == edge label
+                if (ch != C2A_NONE) {
+                    const bool need_parent = ch_depth != 0 && chunk_of(depth) == chunk_of(ch_depth);
+                    if (need_parent && !champ_loaded) load_str16<true>(A.pstr, ch, chunk_len(ch_depth), l16, champ);
+                    const u32 len = chunk_len(depth);
+                    bool fresh = false;
+#pragma unroll
+                    for (int k = 0; k < kSW; ++k) {
+                        const u32 word = (u32)k * 16 + l16;
+                        const u64 v = child_word(need_parent ? champ[k] : 0ull, ch_depth, my_label, word, fresh);
+                        if (word * 64 < len) A.pstr[(u64)pos * kChunkWords + word] = v;
+                    }
+                    if (l16 == 0 && chunk_of(depth)) A.cprev[pos] = fresh ? ch : ld_u32<true>(&A.cprev[ch]);
+                }
+            }
+            C2A_PPROF(6);
+            if (tid == 0) s_base = ticket;
+            __syncthreads();
+            if (d_app != C2A_NONE) {
+                const u32 p = s_base + (tid >= 64 ? s_cnt[0] : 0u) + (u32)__popcll(mask_app & ((1ull << lane) - 1ull));
+                const uint4 r = s_rec[tid];
+                nxt[p].b = make_uint4(r.w, 0, 0, 0);
+                nxt[p].a = make_uint4(d_app, r.x, r.y, r.z);
+            }
+            __syncthreads();
+        }
+        // ---- level barrier: every wave's (write-through) stores are in the L2, then arrive / wait
+#ifndef C2A_EMULATE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        __syncthreads();
+        ++epoch;
+        if (tid == 0) {
+            const u32 a = atomicAdd(&ctl->arrive, 1u);
+            if (a == P * epoch - 1) st_u32<true>(&ctl->gen, epoch);
+            while (ld_u32<true>(&ctl->gen) < epoch) __builtin_amdgcn_s_sleep(1);
+            s_nf = ld_u32<true>(&A.fcount[level + 1]);
+        }
+        lo += n_front;
+        __syncthreads();
+        C2A_PPROF(7);
     }
 }
 

@@ -100,6 +100,8 @@ def _variant(kind, mode, rep):
 WAVE_BACKENDS = [
     _variant("emul", "wpb4", "str"), _variant("emul", "wpb4", "rows"), _variant("emul", "lane", "rows"),
     _variant("emul", "persist-sc1", "rows"), _variant("emul", "base64", "rows"),
+    _variant("emul", "persist", "str"), _variant("emul", "persist-cap48", "str"),
+    _variant("hip", "persist", "str"), _variant("hip", "persist-cap48", "str"), _variant("hip", "persist-cap2048", "str"),
     _variant("hip", "wpb4", "str"), _variant("hip", "wpb8", "str"), _variant("hip", "wpb16", "str"), _variant("hip", "lane", "str"),
     _variant("hip", "wpb4", "rows"), _variant("hip", "wpb8", "rows"), _variant("hip", "wpb16", "rows"), _variant("hip", "lane", "rows"),
     _variant("hip", "persist-sc1", "rows"), _variant("hip", "persist-fence", "rows"), _variant("hip", "base64", "rows")]
@@ -116,7 +118,9 @@ def backend_wave(request, c2a):
         kv["C2A_PEEL_WAVE_MAX"] = 0
     elif mode == "base64":         # 256-byte ancestor rows (default is base 16)
         kv["C2A_ANC_BITS"] = 6
-    elif mode.startswith("persist"):   # the optional single-XCD persistent launch (off by default), both hand-off flavours
+    elif mode.startswith("persist-cap"):   # persistent launch that hands wide levels back to the launch-per-level kernels
+        kv.update(C2A_PEEL_PERSIST_MAX=int(mode[11:]))
+    elif mode.startswith("persist"):   # the single-XCD persistent launch for every level after the first batch
         kv.update(C2A_PEEL_PERSIST_MAX=1 << 30, C2A_ANC_BITS=4, C2A_PEEL_PERSIST_SC1=1 if mode == "persist-sc1" else 0)
     else:
         kv.update(C2A_PEEL_WAVE_MAX=1 << 30, C2A_PEEL_WPB=int(mode[3:]))
