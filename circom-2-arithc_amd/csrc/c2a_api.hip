@@ -41,18 +41,10 @@ struct c2a_ctx {
     int n_cu = 256;
     u32 peel_wave_max = 8192;      // frontier size up to which a level gets one wave per gate
     u32 bool_chunk = 256;          // arithmetic gates per k_boolify workgroup: 128, 256 (measured best) or 512
-    bool peel_persist_sc1 = true;  // persistent peel: bulk data by sc1 accesses (true) or plain accesses + fences (false)
-    u32 peel_persist_max = 0;      // frontier size below which the rest of the peel runs as ONE persistent single-XCD launch;
-                                   // 0 = never (default: measured 1.8x SLOWER than a launch per level)
-    u32 anc_bits = 4;              // log2(entries per ancestor row): 4 (64-B rows, default) or 6 (256-B rows: one hop fewer per
-                                   // lift/diverge/copy at depth < 4096 but measured 1.45x slower: 182 VGPRs, 32 loads per hop)
-    u32 peel_wpb = 8;              // gates (waves) per workgroup in wave mode: 4, 8 or 16 (8 measured best)
-    u32 peel_strings = 1;          // path representation: 1 = path bit-strings (512 B per node, one hop per comparison),
-                                   // 0 = base-16 ancestor rows (64 B per node and plane, <= 6 hops per comparison)
+    u32 peel_wpb = 16;             // waves per workgroup in wave mode incl. the append wave for 16: 4+1, 8+1 or 15+1 (15+1 measured best)
 
     // problem
     u32 n = 0, n_nodes = 0, n_in = 0, n_out = 0;
-    u32 planes = 0;
     // results (host copies of scalars)
     u32 wire_count = 0, n_mid = 0;
     c2a_stats stats{};
@@ -61,10 +53,10 @@ struct c2a_ctx {
 
     // device buffers
     DevBuf lh, rh, out, op, gate4, in_nodes, out_nodes;
-    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, fill, cand, meta, anc, pstr, cprev, fcount, fbase, order, posof, child, ginfo, slots0, slots1;
+    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, fill, cand, meta, pstr, cprev, fring, fbase, order, posof, child, ginfo, slots0, slots1;
     DevBuf rflag, ridx, rlist, next, owner, local, slist, snext, ssum, jnxt, jval, sorted;
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op;
-    DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof, peel_ctl;
+    DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof;
     DevBuf tsz, asz, goff, aoff, tmpl, tables, b_in0, b_in1, b_out, b_op;
     DevBuf ev_produced, ev_spos, ev_aval, ev_bval, cb_in0, cb_in1, cb_out, cb_op;
     bool bool_planned = false;
@@ -74,9 +66,9 @@ struct c2a_ctx {
 
     c2a_ctx() {
         all = {&lh, &rh, &out, &op, &gate4, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &fill, &cand,
-               &ginfo, &slots0, &slots1, &meta, &anc, &pstr, &cprev, &fcount, &fbase, &order, &posof, &child, &rflag, &ridx, &rlist, &next,
+               &ginfo, &slots0, &slots1, &meta, &pstr, &cprev, &fring, &fbase, &order, &posof, &child, &rflag, &ridx, &rlist, &next,
                &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
-               &node_wire, &e_in0, &e_in1, &e_out, &e_op, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &peel_ctl, &tsz, &asz, &goff,
+               &node_wire, &e_in0, &e_in1, &e_out, &e_op, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &tsz, &asz, &goff,
                &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &cb_in0, &cb_in1, &cb_out, &cb_op};
     }
 };
@@ -117,6 +109,8 @@ int ensure(c2a_ctx* c, DevBuf& b, size_t bytes) {
         if (_r) return _r;                                   \
     } while (0)
 
+// grids of the frontier kernels are multiples of the segment count
+inline u32 grid_seg(u32 blocks) { return (blocks + kSeg - 1) / kSeg * kSeg; }
 inline u32 grid_for(u64 items, u32 cap_blocks) {
     u64 b = (items + kThreads - 1) / kThreads;
     if (b < 1) b = 1;
@@ -173,14 +167,6 @@ int read_scalars(c2a_ctx* c, u32* host, int first, int count) {
     return C2A_OK;
 }
 
-u32 planes_for(u64 n, u32 bits) {
-    // tree depth < n, so (2^bits)^planes > n-1 is always enough
-    u32 p = 1;
-    u64 reach = 1ull << bits;
-    while (reach < n) { reach <<= bits; ++p; }
-    return p;
-}
-
 int do_prep(c2a_ctx* c) {
     const u32 n = c->n;
     hipStream_t s = c->stream;
@@ -188,7 +174,7 @@ int do_prep(c2a_ctx* c) {
     HIP_TRY(hipMemsetAsync(c->prod1.p, 0, (size_t)c->n_nodes * 4, s));
     HIP_TRY(hipMemsetAsync(c->cons_cnt.p, 0, (size_t)n * 4, s));
     HIP_TRY(hipMemsetAsync(c->fill.p, 0, (size_t)n * 4, s));
-    HIP_TRY(hipMemsetAsync(c->fcount.p, 0, ((size_t)n + 2) * 4, s));
+    HIP_TRY(hipMemsetAsync(c->fring.p, 0, (size_t)kRing * kSeg * 4, s));
     HIP_TRY(hipMemsetAsync(c->fbase.p, 0, 8, s));
     HIP_TRY(hipMemsetAsync(c->child.p, 0xFF, (size_t)n * 8, s));
     HIP_TRY(hipMemsetAsync(c->scalars.p, 0, SC_WORDS * 4, s));
@@ -199,47 +185,21 @@ int do_prep(c2a_ctx* c) {
     if (r) return r;
     C2A_LAUNCH_NOSYNC(k_ginfo, G, kThreads, s, n, c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_off.as<u32>(),
                       c->cons_cnt.as<u32>(), c->ginfo.as<uint4>());
-    C2A_LAUNCH(k_init_frontier, G, kThreads, s, n, (const uint4*)c->ginfo.as<uint4>(), c->slots0.as<FrontierSlot>(),
-               c->fcount.as<u32>());
+    C2A_LAUNCH(k_init_frontier, grid_seg(grid_for(n, 4096)), kThreads, s, n, seg_capacity(n), (const uint4*)c->ginfo.as<uint4>(),
+               c->slots0.as<FrontierSlot>(), c->fring.as<u32>());
     return C2A_OK;
 }
 
-int print_persistent_profile(c2a_ctx* c, u32 joined) {
-    std::vector<ull> hp(64 * 64 * 8);
-    HIP_TRY(hipMemcpy(hp.data(), c->peel_prof.p, hp.size() * sizeof(ull), hipMemcpyDeviceToHost));
-    double acc[8] = {0}, mean[8] = {0}; u32 used = 0;
-    for (u32 L = 8; L < 64; ++L) {
-        // per level: slowest workgroup's (and the mean) phase ends since that level's earliest start
-        ull t0 = ~0ull; ull mx[8] = {0}; double sm[8] = {0}; u32 cnt = 0;
-        for (u32 r = 0; r < joined && r < 64; ++r) { const ull* q = &hp[((size_t)L * 64 + r) * 8]; if (q[0]) t0 = std::min(t0, q[0]); }
-        if (t0 == ~0ull) continue;
-        for (u32 r = 0; r < joined && r < 64; ++r) {
-            const ull* q = &hp[((size_t)L * 64 + r) * 8];
-            if (!q[0]) continue;
-            ++cnt;
-            for (int k = 0; k < 8; ++k) if (q[k]) { mx[k] = std::max(mx[k], q[k] - t0); sm[k] += (double)(q[k] - t0); }
-        }
-        ++used;
-        for (int k = 0; k < 8; ++k) { acc[k] += (double)mx[k] * 10.0; mean[k] += sm[k] * 10.0 / cnt; }
-    }
-    if (used) {
-        std::fprintf(stderr, "[c2a persistent profile] %u levels, %u workgroups; phase ends in ns since the level's first workgroup started, max over workgroups (mean):", used, joined);
-        for (int k = 0; k < 8; ++k) std::fprintf(stderr, " p%d=%.0f(%.0f)", k, acc[k] / used, mean[k] / used);
-        std::fprintf(stderr, "\n");
-    }
-    return C2A_OK;
-}
-
-// Reverse Kahn peel: one launch per level, queued in batches; the host only looks at the frontier
-// counters between batches (to stop, and to size the next batch's grid).
+// Reverse Kahn peel: one launch per level, queued in batches; the host only looks at the level sizes between
+// batches (to stop, and to size the next batch's grid).
 int do_peel(c2a_ctx* c, u32* peeled_out) {
     const u32 n = c->n;
     hipStream_t s = c->stream;
     PeelArgs A;
-    A.n = n; A.ginfo = c->ginfo.as<uint4>();
+    A.n = n; A.seg_cap = seg_capacity(n); A.ginfo = c->ginfo.as<uint4>();
     A.slots[0] = c->slots0.as<FrontierSlot>(); A.slots[1] = c->slots1.as<FrontierSlot>();
     A.cand = c->cand.as<uint4>(); A.fill = c->fill.as<u32>();
-    A.meta = c->meta.as<uint4>(); A.anc = c->anc.as<u32>(); A.pstr = c->pstr.as<u64>(); A.cprev = c->cprev.as<u32>(); A.fcount = c->fcount.as<u32>(); A.fbase = c->fbase.as<u32>();
+    A.meta = c->meta.as<uint4>(); A.pstr = c->pstr.as<u64>(); A.cprev = c->cprev.as<u32>(); A.fring = c->fring.as<u32>(); A.fbase = c->fbase.as<u32>();
     A.order = c->order.as<u32>(); A.posof = c->posof.as<u32>(); A.child = c->child.as<u32>();
     A.prof = nullptr; A.prof_level0 = 256;
     const bool profiling = std::getenv("C2A_PEEL_PROFILE") != nullptr;
@@ -251,124 +211,56 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
     }
 
     u32 level = 0, launches = 0;
-    u32 f0 = 0;
-    HIP_TRY(hipMemcpyAsync(&f0, c->fcount.as<u32>(), 4, hipMemcpyDeviceToHost, s));
+    u32 seg0[kSeg];
+    HIP_TRY(hipMemcpyAsync(seg0, c->fring.as<u32>(), sizeof(seg0), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    u32 est = f0;                    // frontier size estimate for grid sizing
+    u32 est = 0;                     // frontier size estimate for grid sizing
+    for (u32 t = 0; t < kSeg; ++t) est += seg0[t];
     u32 batch = 8;
-    const u32 max_blocks = (u32)c->n_cu * 8;
+    const u32 max_blocks = (u32)c->n_cu * 8;         // a multiple of kSeg
     u32 peeled = 0;
-    bool profiling_done = false;
     while (true) {
         // narrow frontier -> one wave per gate (latency ~ one path comparison per level);
         // wide frontier   -> one lane per gate (throughput)
-        const bool wave_mode = est <= c->peel_wave_max;
+        const bool wave_mode = level > 0 && est <= c->peel_wave_max;
         const u32 wpb_sel = c->peel_wpb;
-        const u32 wpb = (c->peel_strings && wpb_sel == 16) ? 15u : wpb_sel;   // string kernel: one more (append) wave per workgroup
-        const u32 want = wave_mode ? (u32)(((u64)est * 5 / 4 + wpb - 1) / wpb) + 4
-                                   : (u32)(((u64)est * 2 + kThreads - 1) / kThreads);
-        const u32 blocks = std::max<u32>(8u, std::min<u32>(max_blocks, want));
+        const u32 wpb = wpb_sel == 16 ? 15u : wpb_sel;   // 16 waves per workgroup = 15 gate waves + the append wave
+        // per segment: ~est / kSeg gates (+25 % for growth inside the batch), WPB or 256 per workgroup
+        const u32 per_seg = wave_mode ? (u32)(((u64)est * 5 / 4 / kSeg + wpb - 1) / wpb) + 1
+                                      : (u32)(((u64)est * 2 / kSeg + kThreads - 1) / kThreads);
+        const u32 blocks = std::max<u32>(kSeg, std::min<u32>(max_blocks, per_seg * kSeg));
         for (u32 i = 0; i < batch; ++i) {
-            if (c->peel_strings) {
-                if (level == 0) C2A_LAUNCH_NOSYNC(k_peel_level_str, grid_for(f0, max_blocks), kThreads, s, A, level);
-                else if (!wave_mode) C2A_LAUNCH_NOSYNC(k_peel_level_str, blocks, kThreads, s, A, level);
-                else if (profiling) {
-                    if (wpb_sel == 16) C2A_LAUNCH((k_peel_level_wave_str<15, true>), blocks, 1024, s, A, level);
-                    else if (wpb_sel == 8) C2A_LAUNCH((k_peel_level_wave_str<8, true>), blocks, 576, s, A, level);
-                    else C2A_LAUNCH((k_peel_level_wave_str<4, true>), blocks, 320, s, A, level);
-                } else {
-                    if (wpb_sel == 16) C2A_LAUNCH((k_peel_level_wave_str<15, false>), blocks, 1024, s, A, level);
-                    else if (wpb_sel == 8) C2A_LAUNCH((k_peel_level_wave_str<8, false>), blocks, 576, s, A, level);
-                    else C2A_LAUNCH((k_peel_level_wave_str<4, false>), blocks, 320, s, A, level);
-                }
-            } else if (level == 0) {
-                // the very first launch sees the (possibly huge) level-0 frontier: sinks have no consumers
-                if (c->anc_bits == 6) C2A_LAUNCH_NOSYNC((k_peel_level<6>), grid_for(f0, max_blocks), kThreads, s, A, level);
-                else C2A_LAUNCH_NOSYNC((k_peel_level<4>), grid_for(f0, max_blocks), kThreads, s, A, level);
-            } else if (wave_mode) {
-                if (c->anc_bits == 6) {
-                    if (wpb_sel == 16) C2A_LAUNCH((k_peel_level_wave<16, 6>), blocks, 1024, s, A, level);
-                    else if (wpb_sel == 8) C2A_LAUNCH((k_peel_level_wave<8, 6>), blocks, 512, s, A, level);
-                    else C2A_LAUNCH((k_peel_level_wave<4, 6>), blocks, 256, s, A, level);
-                } else {
-                    if (wpb_sel == 16) C2A_LAUNCH((k_peel_level_wave<16, 4>), blocks, 1024, s, A, level);
-                    else if (wpb_sel == 8) C2A_LAUNCH((k_peel_level_wave<8, 4>), blocks, 512, s, A, level);
-                    else C2A_LAUNCH((k_peel_level_wave<4, 4>), blocks, 256, s, A, level);
-                }
+            if (!wave_mode) C2A_LAUNCH(k_peel_level_str, blocks, kThreads, s, A, level);
+            else if (profiling) {
+                if (wpb_sel == 16) C2A_LAUNCH((k_peel_level_wave_str<15, true>), blocks, 1024, s, A, level);
+                else if (wpb_sel == 8) C2A_LAUNCH((k_peel_level_wave_str<8, true>), blocks, 576, s, A, level);
+                else C2A_LAUNCH((k_peel_level_wave_str<4, true>), blocks, 320, s, A, level);
             } else {
-                if (c->anc_bits == 6) C2A_LAUNCH_NOSYNC((k_peel_level<6>), blocks, kThreads, s, A, level);
-                else C2A_LAUNCH_NOSYNC((k_peel_level<4>), blocks, kThreads, s, A, level);
+                if (wpb_sel == 16) C2A_LAUNCH((k_peel_level_wave_str<15, false>), blocks, 1024, s, A, level);
+                else if (wpb_sel == 8) C2A_LAUNCH((k_peel_level_wave_str<8, false>), blocks, 576, s, A, level);
+                else C2A_LAUNCH((k_peel_level_wave_str<4, false>), blocks, 320, s, A, level);
             }
             ++level; ++launches;
             if (level > n) break;
         }
-        // look at the last few frontier counters of the batch
-        u32 tail[9] = {0};
+        // sizes of the last few levels (from the level boundaries) and of the next one (its segment counters)
+        u32 tail[10] = {0};
+        u32 segs[kSeg] = {0};
         const u32 look = std::min<u32>(8u, level);
-        HIP_TRY(hipMemcpyAsync(tail, c->fcount.as<u32>() + (level - look), (look + 1) * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(tail, c->fbase.as<u32>() + (level - look), (look + 1) * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(segs, c->fring.as<u32>() + (level % kRing) * kSeg, sizeof(segs), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        const u32 next_cnt = tail[look];
+        u32 next_cnt = 0;
+        for (u32 t = 0; t < kSeg; ++t) next_cnt += segs[t];
         if (next_cnt == 0 || level > n) break;
         u32 mx = next_cnt;
-        for (u32 k = 0; k <= look; ++k) mx = std::max(mx, tail[k]);
+        for (u32 k = 0; k < look; ++k) mx = std::max(mx, tail[k + 1] - tail[k]);
         est = mx;
         batch = std::min<u32>(batch * 2, 512u);
-        if (c->peel_persist_max && c->peel_strings && next_cnt <= c->peel_persist_max) {
-            // narrow frontier: all following levels inside ONE launch on ONE XCD, until the frontier is empty or wide again
-            ENSURE(c->peel_ctl, sizeof(PeelCtl));
-            PeelCtl init;
-            std::memset(&init, 0, sizeof(init));
-            init.chosen_xcd = 0xFFFFFFFFu;
-            HIP_TRY(hipMemcpyAsync(c->peel_ctl.p, &init, sizeof(init), hipMemcpyHostToDevice, s));
-#ifdef C2A_EMULATE
-            const u32 wgs = 1;                       // the emulation runs workgroups one after the other
-#else
-            const u32 wgs = (u32)c->n_cu;            // one per CU: an XCD's worth of them takes part
-#endif
-            C2A_LAUNCH(k_peel_persistent_str, wgs, kSGroupsPerWg * 16, s, A, level, c->peel_persist_max, c->peel_ctl.as<PeelCtl>());
-            ++launches;
-            PeelCtl fin;
-            HIP_TRY(hipMemcpyAsync(&fin, c->peel_ctl.p, sizeof(fin), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            if (profiling) { int pr = print_persistent_profile(c, fin.joined); if (pr) return pr; profiling_done = true; }
-            c->stats.persistent_wgs = fin.joined;
-            level = fin.last_level;
-            u32 cnt_now = 0;
-            HIP_TRY(hipMemcpyAsync(&cnt_now, c->fcount.as<u32>() + level, 4, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            if (cnt_now == 0 || level > n) break;
-            est = cnt_now;                           // wide again: a few launches per level, then look again
-            batch = 8;
-            continue;
-        }
-        if (c->peel_persist_max && !c->peel_strings && c->anc_bits == 4 && est <= c->peel_persist_max) {      // the persistent kernel is base-16 only
-            // the frontier has narrowed: finish every remaining level inside one persistent launch
-            ENSURE(c->peel_ctl, sizeof(PeelCtl));
-            PeelCtl init;
-            std::memset(&init, 0, sizeof(init));
-            init.chosen_xcd = 0xFFFFFFFFu;
-            HIP_TRY(hipMemcpyAsync(c->peel_ctl.p, &init, sizeof(init), hipMemcpyHostToDevice, s));
-#ifdef C2A_EMULATE
-            const u32 wgs = 1;                       // the emulation runs workgroups one after the other
-#else
-            const u32 wgs = (u32)c->n_cu;            // one per CU: all resident, one XCD's worth takes part
-#endif
-            if (c->peel_persist_sc1) C2A_LAUNCH((k_peel_persistent<true>), wgs, kPGroupsPerWg * 16, s, A, level, c->peel_ctl.as<PeelCtl>());
-            else C2A_LAUNCH((k_peel_persistent<false>), wgs, kPGroupsPerWg * 16, s, A, level, c->peel_ctl.as<PeelCtl>());
-            ++launches;
-            PeelCtl fin;
-            HIP_TRY(hipMemcpyAsync(&fin, c->peel_ctl.p, sizeof(fin), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            if (profiling) { int pr = print_persistent_profile(c, fin.joined); if (pr) return pr; }
-            level = fin.last_level;
-            c->stats.persistent_wgs = fin.joined;
-            profiling_done = true;
-            break;
-        }
     }
     {
         u32* tot = c->scalars.as<u32>() + SC_PEELED;
-        C2A_LAUNCH(k_peel_totals, 1, kThreads, s, (const u32*)c->fcount.as<u32>(), level + 1, tot);
+        C2A_LAUNCH(k_peel_totals, 1, kThreads, s, (const u32*)c->fbase.as<u32>(), level, tot);
         u32 t2[2] = {0, 0};
         int r = read_scalars(c, t2, SC_PEELED, 2);
         if (r) return r;
@@ -377,7 +269,7 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
         c->n_levels_run = level;
     }
     c->stats.level_launches = launches;
-    if (profiling && !profiling_done) {   // diagnostics: mean over levels of the slowest wave's phase timestamps (ns since kernel entry)
+    if (profiling) {   // diagnostics: mean over levels of the slowest wave's phase timestamps (ns since kernel entry)
         std::vector<ull> hp((size_t)kProfLevels * kProfWaves * 8);
         HIP_TRY(hipMemcpy(hp.data(), c->peel_prof.p, hp.size() * sizeof(ull), hipMemcpyDeviceToHost));
         for (u32 L = 0; L < kProfLevels; L += 8) {
@@ -385,13 +277,40 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
             double mean[6] = {0}; ull mx[6] = {0}; u32 act = 0, slow = 0; ull slow_end = 0; u32 last_active = 0; ull tmin = ~0ull, tmax = 0, fin = 0;
             for (u32 w = 0; w < kProfWaves; ++w) {
                 const ull* r = &hp[((size_t)L * kProfWaves + w) * 8];
-                if (!r[5]) continue;
+                if (!r[4]) continue;
                 last_active = w;
                 if (!r[7]) continue;
                 ++act;
                 for (int k = 0; k < 6; ++k) { mean[k] += (double)r[k] * 10; mx[k] = std::max(mx[k], r[k] * 10); }
                 if (r[5] > slow_end) { slow_end = r[5]; slow = w; }
                 tmin = std::min(tmin, r[6]); tmax = std::max(tmax, r[6]); fin = std::max(fin, r[6] + r[5]);
+            }
+            {   // distribution of a wave's own finishing time (slot 4: stores issued) and of the tournament (slot 3 - slot 2), by candidate count
+                std::vector<ull> own; std::vector<ull> tour;
+                double by_c[5] = {0}, by_t[5] = {0}; u32 by_n[5] = {0};
+                for (u32 w = 0; w < kProfWaves; ++w) {
+                    const ull* q = &hp[((size_t)L * kProfWaves + w) * 8];
+                    if (!q[4] || !q[7]) continue;
+                    own.push_back(q[4] * 10); tour.push_back((q[3] - q[2]) * 10);
+                    const u32 cb = (u32)std::min<ull>(q[7] - 1000, 4);
+                    by_c[cb] += (double)q[4] * 10; by_t[cb] += (double)(q[3] - q[2]) * 10; by_n[cb]++;
+                }
+                {   // (C2A_PROF_STRINGS builds: slot 5 = strings arrived) split the tournament into load and compare
+                    double ld = 0, cmp = 0, nold = 0; u32 n_ld = 0, n_no = 0;
+                    for (u32 w = 0; w < kProfWaves; ++w) {
+                        const ull* q = &hp[((size_t)L * kProfWaves + w) * 8];
+                        if (!q[4] || !q[7]) continue;
+                        if (q[5] && q[5] >= q[2] && q[5] <= q[3]) { ld += (double)(q[5] - q[2]) * 10; cmp += (double)(q[3] - q[5]) * 10; ++n_ld; }
+                        else { nold += (double)(q[3] - q[2]) * 10; ++n_no; }
+                    }
+                    if (n_ld) std::fprintf(stderr, "[c2a peel profile]   tournaments with string loads: %u, until strings arrived %.0f ns, compare %.0f ns; without: %u, %.0f ns\n", n_ld, ld / n_ld, cmp / n_ld, n_no, n_no ? nold / n_no : 0.0);
+                }
+                std::sort(own.begin(), own.end()); std::sort(tour.begin(), tour.end());
+                auto pct = [](const std::vector<ull>& v, double f) { return v.empty() ? 0ull : v[(size_t)((v.size() - 1) * f)]; };
+                std::fprintf(stderr, "[c2a peel profile]   own finish ns p50=%llu p90=%llu p99=%llu max=%llu | tournament p50=%llu p90=%llu p99=%llu max=%llu | by candidates (n, own, tournament):",
+                             pct(own, .5), pct(own, .9), pct(own, .99), pct(own, 1.0), pct(tour, .5), pct(tour, .9), pct(tour, .99), pct(tour, 1.0));
+                for (int k = 0; k < 5; ++k) if (by_n[k]) std::fprintf(stderr, " c%d%s=(%u, %.0f, %.0f)", k, k == 4 ? "+" : "", by_n[k], by_c[k] / by_n[k], by_t[k] / by_n[k]);
+                std::fprintf(stderr, "\n");
             }
             if (!act) continue;
             const ull* r = &hp[((size_t)L * kProfWaves + slow) * 8];
@@ -473,7 +392,6 @@ int do_topo_sort(c2a_ctx* c, u64* cycle_at) {
     std::memset(c->ev_valid, 0, sizeof(c->ev_valid));
     c->stats = c2a_stats{};
     c->stats.n_gates = n;
-    c->stats.anc_planes = c->planes;
     if (cycle_at) *cycle_at = 0;
     if (n == 0) { c->stage = ST_SORTED; return C2A_OK; }
     rec(c, EV_PREP0);
@@ -604,10 +522,6 @@ int c2a_create(int device_id, c2a_ctx** out) {
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
         c->n_cu = prop.multiProcessorCount;
     if (const char* e = std::getenv("C2A_BOOL_CHUNK")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 128 || v == 256 || v == 512) c->bool_chunk = v; }
-    if (const char* e = std::getenv("C2A_PEEL_PERSIST_SC1")) c->peel_persist_sc1 = std::strtoul(e, nullptr, 10) != 0;
-    if (const char* e = std::getenv("C2A_PEEL_PERSIST_MAX")) c->peel_persist_max = (u32)std::strtoul(e, nullptr, 10);
-    if (const char* e = std::getenv("C2A_ANC_BITS")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 4 || v == 6) c->anc_bits = v; }
-    if (const char* e = std::getenv("C2A_PEEL_STRINGS")) c->peel_strings = std::strtoul(e, nullptr, 10) != 0;
     if (const char* e = std::getenv("C2A_PEEL_WPB")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 4 || v == 8 || v == 16) c->peel_wpb = v; }
     if (const char* e = std::getenv("C2A_PEEL_WAVE_MAX")) c->peel_wave_max = (u32)std::strtoul(e, nullptr, 10);   // tuning / test knob
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return C2A_ERR_HIP; }
@@ -651,18 +565,16 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
         if (output_nodes[i] >= n_nodes) return fail(c, C2A_ERR_ARG, "c2a_load_gates: output node id >= n_nodes");
     HIP_TRY(hipSetDevice(c->device));
     c->n = n; c->n_nodes = n_nodes; c->n_in = n_in; c->n_out = n_out;
-    c->planes = planes_for(n, c->anc_bits);
     const size_t n4 = (size_t)n * 4, nn4 = (size_t)n_nodes * 4;
     ENSURE(c->lh, n4); ENSURE(c->rh, n4); ENSURE(c->out, n4); ENSURE(c->op, n); ENSURE(c->gate4, (size_t)n * 16);
     ENSURE(c->in_nodes, (size_t)n_in * 4); ENSURE(c->out_nodes, (size_t)n_out * 4);
     ENSURE(c->prod1, nn4); ENSURE(c->dep0, n4); ENSURE(c->dep1, n4); ENSURE(c->cons_cnt, n4);
     ENSURE(c->cons_off, n4 + 4); ENSURE(c->fill, n4); ENSURE(c->cand, (size_t)n * 2 * 16);
     ENSURE(c->meta, (size_t)n * 16); ENSURE(c->ginfo, (size_t)n * 16);
-    ENSURE(c->slots0, ((size_t)n + 1 + kSlotPad) * sizeof(FrontierSlot)); ENSURE(c->slots1, ((size_t)n + 1 + kSlotPad) * sizeof(FrontierSlot));
+    ENSURE(c->slots0, (size_t)kSeg * seg_capacity(n) * sizeof(FrontierSlot)); ENSURE(c->slots1, (size_t)kSeg * seg_capacity(n) * sizeof(FrontierSlot));
 
-    if (c->peel_strings) { ENSURE(c->pstr, (size_t)n * kChunkWords * 8); ENSURE(c->cprev, (size_t)n * 4); }
-    else { ENSURE(c->anc, ((size_t)c->planes * n * 4) << c->anc_bits); }
-    ENSURE(c->fcount, n4 + 8); ENSURE(c->fbase, n4 + 8); ENSURE(c->order, n4); ENSURE(c->posof, n4); ENSURE(c->child, 2 * n4);
+    ENSURE(c->pstr, (size_t)n * kChunkWords * 8); ENSURE(c->cprev, (size_t)n * 4);
+    ENSURE(c->fring, (size_t)kRing * kSeg * 4); ENSURE(c->fbase, n4 + 8); ENSURE(c->order, n4); ENSURE(c->posof, n4); ENSURE(c->child, 2 * n4);
     ENSURE(c->rflag, n4); ENSURE(c->ridx, n4 + 4); ENSURE(c->rlist, n4);
     ENSURE(c->next, 2 * n4); ENSURE(c->owner, 2 * n4); ENSURE(c->local, 2 * n4); ENSURE(c->slist, 2 * n4);
     ENSURE(c->snext, 2 * n4); ENSURE(c->ssum, 2 * n4); ENSURE(c->jnxt, 2 * n4); ENSURE(c->jval, 2 * n4);
@@ -1033,6 +945,8 @@ int c2a_get_timings(c2a_ctx* c, c2a_timings* t) {
 int c2a_get_stats(c2a_ctx* c, c2a_stats* s) {
     if (!c || !s) return C2A_ERR_ARG;
     *s = c->stats;
+    s->frontier_segments = kSeg;
+    s->path_chunks = c->stats.max_depth ? (c->stats.max_depth - 1) / kChunkBits + 1 : 1;
     return C2A_OK;
 }
 

@@ -124,76 +124,86 @@ __global__ void k_ginfo(u32 n, const u32* __restrict__ dep0, const u32* __restri
     for (u64 g = gtid(); g < n; g += gstride()) ginfo[g] = make_uint4(dep0[g], dep1[g], cons_off[g], cons_cnt[g]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The frontier of the reverse Kahn peel.
 // Frontier slot: 32 bytes {gate, dep0, dep1, cons_off} {cons_cnt, -, -, -}.  Two slot arrays alternate by level
-// parity and slot i of level L is at a fixed address, so a level's first hop (the slot) does not wait for the
-// frontier size: fcount[L] is loaded alongside it.
+// parity, and a slot is at an address that does not depend on the level's size, so a level's first hop (the slot)
+// does not wait for the counts: both are loaded together.
+// The frontier is SEGMENTED: kSeg independent append counters and slot regions.  One counter for the whole level was
+// the peel's bottleneck at ~2 000 gates per level: ~290 workgroup tickets queue on one word at ~12 ns each (memory-side
+// atomics), ~3 us of an 8 us level.  With 16 segments a counter sees ~18 tickets.  A level's gates are the
+// concatenation of its segments (tree position = fbase[level] + segment prefix + index), every kernel recomputes the
+// 16-entry prefix from the counts.  Who appends where is chosen so that no segment can overflow n/8 + 1024 slots
+// whatever the graph: a workgroup class (1/16 of a level's gates, +- one workgroup) feeds one segment and a gate
+// appends at most two producers.  Counters live in a ring of kRing levels: level L reads row L % kRing, adds to
+// row (L+1) % kRing and clears row (L+2) % kRing; level sizes for later stages come from fbase[].
+// ------------------------------------------------------------------------------------------------
 struct FrontierSlot { uint4 a, b; };
+constexpr u32 kSeg = 16;
+constexpr u32 kRing = 4;
+constexpr u32 kSlotPad = 4096;             // slots past a segment's end that a speculative slot load may touch
+__host__ __device__ inline u32 seg_capacity(u32 n) { return n / 8 + 1024 + kSlotPad; }
 
-// level 0 of the reverse Kahn peel: gates nobody consumes.  fcount[0] must be zero.
-__global__ void __launch_bounds__(kThreads) k_init_frontier(u32 n, const uint4* __restrict__ ginfo, FrontierSlot* slots,
-                                                            u32* fcount) {
+// level 0: gates nobody consumes.  Ring row 0 must be zero.  gridDim.x % kSeg == 0.
+__global__ void __launch_bounds__(kThreads) k_init_frontier(u32 n, u32 seg_cap, const uint4* __restrict__ ginfo, FrontierSlot* slots,
+                                                            u32* fring) {
+    const u32 seg = blockIdx.x % kSeg;
+    FrontierSlot* out = slots + (u64)seg * seg_cap;
     for (u64 base = (u64)blockIdx.x * kThreads; base < n; base += (u64)gridDim.x * kThreads) {
         const u64 g = base + threadIdx.x;
         uint4 gi = make_uint4(0, 0, 0, 1);
         if (g < n) gi = ginfo[g];
         const bool sink = g < n && gi.w == 0;
-        const u32 p = block_append_slot(sink, &fcount[0]);
-        if (sink) { slots[p].a = make_uint4((u32)g, gi.x, gi.y, gi.z); slots[p].b = make_uint4(gi.w, 0, 0, 0); }
+        const u32 p = block_append_slot(sink, &fring[seg]);
+        if (sink) { out[p].a = make_uint4((u32)g, gi.x, gi.y, gi.z); out[p].b = make_uint4(gi.w, 0, 0, 0); }
     }
 }
 
-// totals after the peel: {gates peeled, non-empty levels}
-__global__ void k_peel_totals(const u32* __restrict__ fcount, u32 n_levels, u32* out2) {
-    __shared__ u32 s_sum[kThreads], s_lv[kThreads];
-    u32 sum = 0, lv = 0;
-    for (u32 i = threadIdx.x; i < n_levels; i += kThreads) { const u32 c = fcount[i]; sum += c; lv += c ? 1u : 0u; }
-    s_sum[threadIdx.x] = sum; s_lv[threadIdx.x] = lv;
+// totals after the peel: {gates peeled, non-empty levels} from the level boundaries
+__global__ void k_peel_totals(const u32* __restrict__ fbase, u32 n_levels, u32* out2) {
+    __shared__ u32 s_lv[kThreads];
+    u32 lv = 0;
+    for (u32 i = threadIdx.x; i < n_levels; i += kThreads) lv += fbase[i + 1] != fbase[i] ? 1u : 0u;
+    s_lv[threadIdx.x] = lv;
     __syncthreads();
     for (u32 off = kThreads / 2; off; off >>= 1) {
-        if (threadIdx.x < off) { s_sum[threadIdx.x] += s_sum[threadIdx.x + off]; s_lv[threadIdx.x] += s_lv[threadIdx.x + off]; }
+        if (threadIdx.x < off) s_lv[threadIdx.x] += s_lv[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0) { out2[0] = s_sum[0]; out2[1] = s_lv[0]; }
+    if (threadIdx.x == 0) { out2[0] = fbase[n_levels]; out2[1] = s_lv[0]; }
 }
 
 // ------------------------------------------------------------------------------------------------
 // peel one level + pick DFS-tree parents
 // ------------------------------------------------------------------------------------------------
-// Tree node == peel position (fbase[level] + slot index): nodes of recent levels are contiguous, which keeps
-// the short hops of a path comparison inside a few MB (at 10 M gates the tables span GBs and a scattered hop
-// costs ~2x a local one).  meta[pos] = {parent pos | NONE, depth, root gate id, label of the edge parent->node}.
-// anc plane j, row pos: 16 entries = ancestor at distance (d+1)*16^j, valid while <= depth, each entry
-// carrying that ancestor's own edge label in bit 31 (so a path comparison never has to fetch meta[]).
+// Tree node == peel position: nodes of recent levels are contiguous in every per-node table.
+// meta[pos] = {parent pos | NONE, depth, root gate id, label of the edge parent->node}.
 // Candidate lists are filled as consumers are peeled, AFTER their tournament, with everything a comparison
-// starts from: cand[cons_off[d] + k] = {consumer | edge label << 31, consumer depth, consumer root, consumer's
-// own edge label}; the push that completes d's list (k + 1 == cons_cnt[d]) writes d's frontier slot.
-// Dependent memory hops on a level's critical path: slot -> candidate records -> <= 3 (lift) + <= 3 (diverge)
-// ancestor rows -> max(<= 3 row copies, fill atomic + slot atomic).
+// starts from: cand[cons_off[d] + k] = {consumer pos | edge label << 31, consumer depth, consumer root, consumer's
+// own edge label}; the push that completes d's list (k + 1 == cons_cnt[d]) appends d to the next frontier.
 constexpr u32 kIdMask = 0x7FFFFFFFu;
 
 struct PeelArgs {
     u32 n;
+    u32 seg_cap;               // slots per frontier segment
     const uint4* ginfo;        // [n] {dep0, dep1, cons_off, cons_cnt}
-    FrontierSlot* slots[2];    // by level parity
+    FrontierSlot* slots[2];    // [kSeg][seg_cap] by level parity
     uint4* cand;               // [edges]
     u32* fill;                 // pushes so far per gate (zeroed)
     uint4* meta;               // [n] by position
-    u32* anc;                  // [planes][n][16] by position (ancestor-row representation)
-    u64* pstr;                 // [n][64] path strings by position (path-string representation)
+    u64* pstr;                 // [n][64] path strings by position
     u32* cprev;                // [n] ancestor at the start of the node's current chunk (only beyond depth 4096)
     u32* order;                // position -> gate
     u32* child;                // [2n] tree children by label: child[2*p + l] (written as each gate picks its parent)
     u32* posof;                // gate -> position
     u32* fbase;                // [levels+2] first position of each level
-    u32* fcount;               // [levels+2] frontier sizes (slot allocation + host monitoring)
+    u32* fring;                // [kRing][kSeg] frontier segment sizes
     ull* prof;                 // optional phase timestamps (diagnostics; nullptr normally)
     u32 prof_level0;           // first level recorded
 };
 
-// Two access flavours.  SC1 = false: plain loads/stores — data produced by EARLIER launches (the kernel
-// boundary publishes it).  SC1 = true: relaxed agent-scope atomics (global_load/store ... sc1: write-through
-// stores, L1-bypassing loads) — data exchanged between workgroups INSIDE one persistent launch; the only form
-// that handed off without stale reads in tools/ubench/xcd.hip (plain stores + nt or sc1 loads did not).
+// Two access flavours.  SC1 = false: plain loads/stores.  SC1 = true: relaxed agent-scope atomics
+// (global_load/store ... sc1), for words that other workgroups of the same launch may be writing.
 template <bool SC1> __device__ __forceinline__ u32 ld_u32(const u32* p) {
     if (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return *p;
@@ -202,187 +212,42 @@ template <bool SC1> __device__ __forceinline__ void st_u32(u32* p, u32 v) {
     if (SC1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
 }
-template <bool SC1> __device__ __forceinline__ u64 ld_u64(const u64* p) {
-    if (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return *p;
-}
-template <bool SC1> __device__ __forceinline__ uint4 ld_u128(const uint4* p) {
-    if (SC1) {
-        const u64* q = reinterpret_cast<const u64*>(p);
-        const u64 a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const u64 b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return make_uint4((u32)a, (u32)(a >> 32), (u32)b, (u32)(b >> 32));
-    }
-    return *p;
-}
-template <bool SC1> __device__ __forceinline__ void st_u128(uint4* p, const uint4& v) {
-    if (SC1) {
-        u64* q = reinterpret_cast<u64*>(p);
-        __hip_atomic_store(q, (u64)v.x | ((u64)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(q + 1, (u64)v.z | ((u64)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        *p = v;
-    }
-}
 
-// B = log2(entries per ancestor row): 4 -> base-16 rows of 64 B, 6 -> base-64 rows of 256 B.  A wider row costs
-// bytes (not the budget here) and removes dependent hops (the budget): at depth < 4096 a lift, a divergence search
-// and a row copy take <= 2 hops each with B = 6 instead of <= 3 with B = 4.
-template <bool SC1, int B>
-__device__ __forceinline__ u32 anc_entry(const u32* anc, u64 plane, int j, u32 x, u32 d) {
-    return ld_u32<SC1>(anc + (u64)j * plane + ((u64)x << B) + d);
+// stores of the per-level kernels (experiment switch C2A_ST: 0 plain, 1 nontemporal, 2 agent-scope write-through)
+#ifndef C2A_ST
+#define C2A_ST 0
+#endif
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_g(u32* p, u32 v) {
+#if defined(C2A_EMULATE) || C2A_ST == 0
+    *p = v;
+#elif C2A_ST == 1
+    __builtin_nontemporal_store(v, p);
+#else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
-
-template <bool SC1, int B>
-__device__ __forceinline__ void load_row(const u32* anc, u64 plane, int j, u32 x, u32 (&r)[1 << B]) {
-    const uint4* p = reinterpret_cast<const uint4*>(anc + (u64)j * plane + ((u64)x << B));
-#pragma unroll
-    for (int q = 0; q < (1 << B) / 4; ++q) {
-        const uint4 v = ld_u128<SC1>(p + q);
-        r[4 * q + 0] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
-    }
+__device__ __forceinline__ void st_g(u64* p, u64 v) {
+#if defined(C2A_EMULATE) || C2A_ST == 0
+    *p = v;
+#elif C2A_ST == 1
+    __builtin_nontemporal_store(v, p);
+#else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
-
-// Two lifts of the same node in one pass (their loads are independent and overlap): xe = ancestor at `dist`,
-// ye = ancestor at `dist - 1`, both as labelled entries.  dist >= 1; `self` = the node's own labelled entry.
-template <bool SC1, int B>
-__device__ __forceinline__ void lift2(const u32* anc, u64 plane, u32 self, u32 dist, u32& xe, u32& ye) {
-    u32 x = self, y = self;
-    u32 dx = dist, dy = dist - 1;
-    int j = 0;
-    while (dx | dy) {
-        const u32 ex = dx & ((1u << B) - 1u), ey = dy & ((1u << B) - 1u);
-        u32 nx = x, ny = y;
-        if (ex) nx = anc_entry<SC1, B>(anc, plane, j, x & kIdMask, ex - 1);
-        if (ey) ny = anc_entry<SC1, B>(anc, plane, j, y & kIdMask, ey - 1);
-        x = nx; y = ny;
-        dx >>= B; dy >>= B;
-        ++j;
-    }
-    xe = x; ye = y;
+__device__ __forceinline__ void st_g(uint4* p, const uint4& v) {
+#if defined(C2A_EMULATE) || C2A_ST == 0
+    *p = v;
+#elif C2A_ST == 1
+    v4u t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<v4u*>(p));
+#else
+    u64* q = reinterpret_cast<u64*>(p);
+    __hip_atomic_store(q, (u64)v.x | ((u64)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, (u64)v.z | ((u64)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
-
-// ae != be (ids) at equal depth D >= 1 under one root: walk both up to the children of their lowest common
-// ancestor, one 64-byte row per node per base-16 digit; entries keep their label bits.
-template <bool SC1, int B>
-__device__ __forceinline__ void diverge(const u32* anc, u64 plane, u32& ae, u32& be, u32 D) {
-    if (D == 0) return;
-    constexpr u32 R = 1u << B;
-    int j = (31 - __clz(D)) / B;
-    for (; j >= 0; --j) {
-        u32 m = D >> (B * j);
-        if (m == 0) continue;
-        if (m > R) m = R;
-        u32 ra[R], rb[R];
-        load_row<SC1, B>(anc, plane, j, ae & kIdMask, ra);
-        load_row<SC1, B>(anc, plane, j, be & kIdMask, rb);
-        u32 pa = ae, pb = be, pd = 0;
-#pragma unroll
-        for (u32 d = 0; d < R; ++d) {
-            if (d < m && ((ra[d] ^ rb[d]) & kIdMask)) { pa = ra[d]; pb = rb[d]; pd = d + 1; }
-        }
-        ae = pa; be = pb;
-        D -= pd << (B * j);
-    }
-}
-
-// A candidate = "the path to consumer c, then edge `el`".  ce = c | own edge label of c << 31.
-// is P(a).ela < P(b).elb ?  ids differ, same root.
-template <bool SC1, int B>
-__device__ __forceinline__ bool path_less(const u32* anc, u64 plane, u32 ae, u32 ela, u32 da, u32 be, u32 elb, u32 db) {
-    if (da > db) {
-        u32 up, below;
-        lift2<SC1, B>(anc, plane, ae, da - db, up, below);
-        if (((up ^ be) & kIdMask) == 0) return (below >> 31) < elb;      // b is an ancestor of a
-        ae = up;
-        diverge<SC1, B>(anc, plane, ae, be, db);
-    } else if (db > da) {
-        u32 up, below;
-        lift2<SC1, B>(anc, plane, be, db - da, up, below);
-        if (((up ^ ae) & kIdMask) == 0) return ela < (below >> 31);      // a is an ancestor of b
-        be = up;
-        diverge<SC1, B>(anc, plane, ae, be, da);
-    } else {
-        diverge<SC1, B>(anc, plane, ae, be, da);
-    }
-    return (ae >> 31) < (be >> 31);
-}
-
-// Variant 1: one lane per frontier gate, candidates compared one after the other.  Used while the frontier
-// is wide (the first levels); its latency per level is (largest fan-out) x (one path comparison).
-template <int B>
-__global__ void __launch_bounds__(kThreads) k_peel_level(PeelArgs A, u32 level) {
-    FrontierSlot* cur = A.slots[level & 1u];
-    FrontierSlot* nxt = A.slots[(level + 1) & 1u];
-    constexpr u32 R = 1u << B;
-    const u64 plane = (u64)A.n << B;
-    const u32 n_front = A.fcount[level];
-    const u32 lo = A.fbase[level];
-    if (gtid() == 0) A.fbase[level + 1] = lo + n_front;
-    for (u64 i = gtid(); i < n_front; i += gstride()) {
-        const uint4 sa = cur[i].a;
-        const u32 cnt = cur[i].b.x;
-        const u32 g = sa.x;
-        const u32 pos = lo + (u32)i;
-        // ---- tournament over the candidate paths: [g] (child of the virtual root) and P(c).l per consumer
-        u32 best = C2A_NONE, best_el = 0, best_root = g, best_depth = 0;     // best = labelled entry of the consumer
-        const u32 e0 = sa.w, e1 = e0 + cnt;
-        for (u32 e = e0; e < e1; ++e) {
-            const uint4 cr = A.cand[e];
-            const u32 ce = (cr.x & kIdMask) | (cr.w << 31), el = cr.x >> 31;
-            bool take;
-            if (best == C2A_NONE) take = cr.z < g;
-            else if (cr.z != best_root) take = cr.z < best_root;
-            else if (((ce ^ best) & kIdMask) == 0) take = el < best_el;
-            else take = path_less<false, B>(A.anc, plane, ce, el, cr.y, best, best_el, best_depth);
-            if (take) { best = ce; best_el = el; best_root = cr.z; best_depth = cr.y; }
-        }
-        const u32 depth = best == C2A_NONE ? 0u : best_depth + 1;
-        const u32 my_label = best == C2A_NONE ? 0u : best_el;
-        A.meta[pos] = make_uint4(best == C2A_NONE ? C2A_NONE : (best & kIdMask), depth, best_root, my_label);
-        A.order[pos] = g;
-        A.posof[g] = pos;
-        if (best != C2A_NONE) A.child[2 * (u64)(best & kIdMask) + my_label] = pos;
-        // ---- ancestor rows: row j = [q_j, row_j(q_j)[0..R-2]], q_0 = parent, q_{j+1} = my ancestor at R^(j+1)
-        if (depth) {
-            u32 q = best;                                   // labelled entry
-            u32 need = 1;                                   // R^j
-            for (int j = 0; need <= depth; ++j) {
-                u32 r[R];
-                load_row<false, B>(A.anc, plane, j, q & kIdMask, r);
-                uint4* dst = reinterpret_cast<uint4*>(A.anc + (u64)j * plane + ((u64)pos << B));
-                dst[0] = make_uint4(q, r[0], r[1], r[2]);
-#pragma unroll
-                for (u32 t = 1; t < R / 4; ++t) dst[t] = make_uint4(r[4 * t - 1], r[4 * t], r[4 * t + 1], r[4 * t + 2]);
-                q = r[R - 2];
-                if (need > (0xFFFFFFFFu >> B)) break;
-                need <<= B;
-            }
-        }
-        // ---- tell the producers; a producer joins the next frontier when its last consumer has been peeled
-        const u32 deps[2] = {sa.y, sa.z};
-#pragma unroll
-        for (u32 l = 0; l < 2; ++l) {
-            const u32 d = deps[l];
-            if (d == C2A_NONE) continue;
-            const uint4 gd = A.ginfo[d];
-            const u32 k = atomicAdd(&A.fill[d], 1u);
-            A.cand[gd.z + k] = make_uint4(pos | (l << 31), depth, best_root, my_label);
-            if (k + 1 == gd.w) {
-                const u32 p = atomicAdd(&A.fcount[level + 1], 1u);
-                nxt[p].b = make_uint4(gd.w, 0, 0, 0);
-                nxt[p].a = make_uint4(d, gd.x, gd.y, gd.z);
-            }
-        }
-    }
-}
-
-// Variant 2: one WAVE per frontier gate.  Lanes load the candidate records in parallel, candidates with a
-// larger DFS root are dropped by a wave-wide min, and the survivors play a one-round all-pairs tournament (one
-// path comparison per lane, <= 11 candidates = 55 pairs per round) — so the latency per level is about ONE path
-// comparison whatever the fan-out.  Ancestor rows are copied 16 lanes wide (one 64-byte line per plane) while
-// the producers' fill atomics and the workgroup's single frontier append are in flight.
-constexpr int kGroup = 11;                                // 11*10/2 = 55 pairs <= 64 lanes
 
 __device__ __forceinline__ u32 wave_min_u32(u32 v) {
 #pragma unroll
@@ -412,185 +277,43 @@ __device__ __forceinline__ ull c2a_now() {
     return wall_clock64();      // constant 100 MHz
 #endif
 }
-// diagnostics: every wave of levels [256, 288) stores its phase timestamps (slot 6 = start, 7 = candidates)
+// diagnostics (PROF instantiation only): every wave of kProfLevels levels stores its phase timestamps
 constexpr u32 kProfLevels = 32, kProfWaves = 32768;
-#define C2A_PROF_IF(on, slot, value) do { if (on) C2A_PROF(slot, value); } while (0)
 #define C2A_PROF(slot, value)                                                                                   \
     do {                                                                                                        \
-        if (A.prof && lane == 0 && level >= A.prof_level0 && level < A.prof_level0 + kProfLevels) {             \
+        if (PROF && A.prof && lane == 0 && level >= A.prof_level0 && level < A.prof_level0 + kProfLevels) {     \
             const u32 wg_ = blockIdx.x * WPB + wv;                                                              \
             if (wg_ < kProfWaves) A.prof[((u64)(level - A.prof_level0) * kProfWaves + wg_) * 8 + (slot)] = (value); \
         }                                                                                                       \
     } while (0)
 
-// WPB = waves (= gates per pass) per workgroup: 16 -> fewest appends on the frontier counter, 4/8 -> shorter
-// wait for the slowest wave of the group
-template <int WPB, int B>
-__global__ void __launch_bounds__(WPB * 64) k_peel_level_wave(PeelArgs A, u32 level) {
-    const ull t_begin = A.prof ? c2a_now() : 0;
-    __shared__ u32 s_c[WPB][72], s_l[WPB][72], s_d[WPB][72];
-    __shared__ u32 s_ready[2 * WPB];
-    __shared__ uint4 s_rec[2 * WPB];
-    __shared__ u32 s_base;
-    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    FrontierSlot* cur = A.slots[level & 1u];
-    FrontierSlot* nxt = A.slots[(level + 1) & 1u];
-    constexpr u32 R = 1u << B;
-    const u64 plane = (u64)A.n << B;
-    const u64 lt_mask = (1ull << lane) - 1ull;
-    // slot i sits at a fixed address: issue its load before the frontier size is known
-    uint4 sa0 = make_uint4(0, 0, 0, 0);
-    u32 cnt0 = 0;
-    {
-        const u64 i0 = (u64)blockIdx.x * WPB + wv;
-        if (i0 < A.n) { sa0 = cur[i0].a; cnt0 = cur[i0].b.x; }
+// This level's segment sizes -> exclusive prefix (lanes 0..kSeg-1 hold count and prefix of their segment).
+// Whole-wave call.  `total` is wave-uniform.
+__device__ __forceinline__ void level_segments(const u32* __restrict__ fring, u32 level, u32 lane, u32& my_cnt, u32& my_pre, u32& total) {
+    my_cnt = lane < kSeg ? fring[(level % kRing) * kSeg + lane] : 0u;
+    u32 inc = my_cnt;
+#pragma unroll
+    for (int off = 1; off < (int)kSeg; off <<= 1) {
+        const u32 o = __shfl_up(inc, off, 64);
+        if (lane >= (u32)off) inc += o;
     }
-    const u32 n_front = A.fcount[level];
-    const u32 lo = A.fbase[level];                       // only needed after the tournament
-    if (gtid() == 0) A.fbase[level + 1] = lo + n_front;
-    for (u32 chunk = blockIdx.x; (u64)chunk * WPB < n_front; chunk += gridDim.x) {
-        const u64 i = (u64)chunk * WPB + wv;
-        u32 rdy = C2A_NONE;                              // producer completed by this wave's gate (lanes 0 / 1)
-        uint4 rdy_rec = make_uint4(0, 0, 0, 0);
-        uint4 sa = sa0;
-        u32 cnt = cnt0;
-        if (chunk != blockIdx.x && i < n_front) { sa = cur[i].a; cnt = cur[i].b.x; }
-        if (i < n_front) {
-            const u32 g = sa.x;
-            const u32 e0 = sa.w, e1 = e0 + cnt;
-            // lanes 0/1 own the two producers: fetch their records now, off the critical path
-            const u32 dl = lane == 0 ? sa.y : (lane == 1 ? sa.z : C2A_NONE);
-            uint4 gd = make_uint4(0, 0, 0, 0);
-            if (dl != C2A_NONE) gd = A.ginfo[dl];
-            C2A_PROF(0, c2a_now() - t_begin);
-            C2A_PROF(6, t_begin);
-            C2A_PROF(7, (ull)cnt + 1000);
-            // champion so far (wave-uniform): labelled consumer entry; NONE = the virtual-root candidate [g]
-            u32 ch = C2A_NONE, ch_el = 0, ch_root = g, ch_depth = 0;
-            for (u32 eb = e0; eb < e1; eb += 64) {
-                const u32 e = eb + lane;
-                const bool valid = e < e1;
-                u32 c = 0, l = 0, cdepth = 0, croot = 0xFFFFFFFFu;
-                if (valid) {
-                    const uint4 cr = A.cand[e];
-                    c = (cr.x & kIdMask) | (cr.w << 31); l = cr.x >> 31;
-                    cdepth = cr.y; croot = cr.z;
-                }
-                const u32 rmin = wave_min_u32(croot);
-                C2A_PROF(1, c2a_now() - t_begin);
-                if (rmin > ch_root) continue;                       // the whole chunk starts from a later DFS root
-                const bool keep_ch = (ch != C2A_NONE) && (ch_root == rmin);
-                const bool surv = valid && croot == rmin;
-                const u64 smask = __ballot(surv);
-                u32 m = (u32)__popcll(smask);
-                if (surv) {
-                    const u32 k = (u32)__popcll(smask & lt_mask);
-                    s_c[wv][k] = c; s_l[wv][k] = l; s_d[wv][k] = cdepth;
-                }
-                if (keep_ch && lane == 0) { s_c[wv][m] = ch; s_l[wv][m] = ch_el; s_d[wv][m] = ch_depth; }
-                m += keep_ch ? 1u : 0u;
-                wave_lds_sync();
-                // all-pairs rounds over groups of <= kGroup candidates: [winner so far] + next candidates
-                u32 win = 0;        // index (in s_*) of the current winner
-                u32 next = 1;       // next unplayed candidate
-                while (next < m) {
-                    const u32 take = (m - next) < (u32)(kGroup - 1) ? (m - next) : (u32)(kGroup - 1);
-                    const u32 q = take + 1;                         // group: member 0 = win, member t = next+t-1
-                    const u32 P = q * (q - 1) / 2;
-                    u32 pi = 0, pj = 1;                             // lane -> pair (i<j), triangular enumeration
-                    {
-                        u32 rem = lane, row = 0, len = q - 1;
-                        while (len && rem >= len) { rem -= len; ++row; --len; }
-                        pi = row; pj = row + 1 + rem;
-                    }
-                    u32 loser = 0xFFFFFFFFu;
-                    if (lane < P) {
-                        const u32 xi = pi == 0 ? win : next + pi - 1, xj = next + pj - 1;
-                        const u32 ci = s_c[wv][xi], cj = s_c[wv][xj];
-                        const u32 li = s_l[wv][xi], lj = s_l[wv][xj];
-                        bool less;
-                        if (((ci ^ cj) & kIdMask) == 0) less = li < lj;
-                        else less = path_less<false, B>(A.anc, plane, ci, li, s_d[wv][xi], cj, lj, s_d[wv][xj]);
-                        loser = less ? pj : pi;
-                    }
-                    u32 w = 0;
-                    for (u32 t = 0; t < q; ++t) {
-                        const u64 lost = __ballot(loser == t);
-                        if (lost == 0) w = t;
-                    }
-                    win = w == 0 ? win : next + w - 1;
-                    next += take;
-                }
-                ch = s_c[wv][win]; ch_el = s_l[wv][win]; ch_depth = s_d[wv][win]; ch_root = rmin;
-                wave_lds_sync();
-            }
-            C2A_PROF(2, c2a_now() - t_begin);
-            const u32 depth = ch == C2A_NONE ? 0u : ch_depth + 1;
-            const u32 my_label = ch == C2A_NONE ? 0u : ch_el;
-            const u32 pos = lo + (u32)i;
-            if (lane == 0) {
-                A.meta[pos] = make_uint4(ch == C2A_NONE ? C2A_NONE : (ch & kIdMask), depth, ch_root, my_label);
-                A.order[pos] = g;
-                A.posof[g] = pos;
-                if (ch != C2A_NONE) A.child[2 * (u64)(ch & kIdMask) + my_label] = pos;
-            }
-            // push myself to the producers (lanes 0/1): the atomic's round trip overlaps the row copies below
-            u32 kfill = 0;
-            if (dl != C2A_NONE) kfill = atomicAdd(&A.fill[dl], 1u);
-            if (depth) {
-                u32 q = ch;                                 // labelled entry
-                u32 need = 1;
-                for (int j = 0; need <= depth; ++j) {
-                    u32 v = q;
-                    if (lane >= 1 && lane < R) v = anc_entry<false, B>(A.anc, plane, j, q & kIdMask, lane - 1);
-                    if (lane < R) A.anc[(u64)j * plane + ((u64)pos << B) + lane] = v;
-                    q = __shfl(v, (int)R - 1, 64);
-                    if (need > (0xFFFFFFFFu >> B)) break;
-                    need <<= B;
-                }
-            }
-            if (dl != C2A_NONE) {
-                A.cand[gd.z + kfill] = make_uint4(pos | (lane << 31), depth, ch_root, my_label);   // lane == edge label
-                if (kfill + 1 == gd.w) { rdy = dl; rdy_rec = gd; }
-            }
-            C2A_PROF(3, c2a_now() - t_begin);
-        }
-        // ---- one append per workgroup: a single counter takes ~12 ns per atomic, so per-gate appends would
-        // cost more than the whole level (MI355X_MICROARCH.md price list, row "fanin")
-        if (lane < 2) { s_ready[2 * wv + lane] = rdy; s_rec[2 * wv + lane] = rdy_rec; }
-        __syncthreads();
-        C2A_PROF(4, c2a_now() - t_begin);
-        if (wv == 0) {
-            const u32 d = lane < 2 * WPB ? s_ready[lane] : C2A_NONE;
-            const u64 mask = __ballot(d != C2A_NONE);
-            if (mask) {
-                if (lane == 0) s_base = atomicAdd(&A.fcount[level + 1], (u32)__popcll(mask));
-                wave_lds_sync();
-                if (d != C2A_NONE) {
-                    const u32 p = s_base + (u32)__popcll(mask & lt_mask);
-                    const uint4 gd = s_rec[lane];
-                    nxt[p].b = make_uint4(gd.w, 0, 0, 0);
-                    nxt[p].a = make_uint4(d, gd.x, gd.y, gd.z);
-                }
-            }
-        }
-        __syncthreads();
-        C2A_PROF(5, c2a_now() - t_begin);
-    }
+    my_pre = inc - my_cnt;
+    total = __shfl(inc, (int)kSeg - 1, 64);
 }
 
 // ================================================================================================
-// PATH STRINGS — the second representation of "the path from the DFS root to a tree node", built to cut the
-// dependent memory hops of a path comparison from <= 6 (lift + diverge over ancestor rows) to ONE.
+// PATH STRINGS — the representation of "the path from the DFS root to a tree node".
 // Every tree node stores the edge labels of its path as a bit string: bit j = label of the edge entering depth
 // j+1.  A string is held in chunks of kChunkBits = 4096 bits = 512 B = one coalesced 8-byte load per lane of a wave;
-// a node keeps only its CURRENT chunk (bits [ci*K, depth), zero padded) plus cprev = its ancestor at depth ci*K,
-// whose own string is the complete previous chunk — so storage is 512 B per node whatever the depth, and for trees
-// shallower than 4096 (the 10 M-gate headline config: 3 471) comparing two candidates is: load both strings (one
-// round trip, coalesced), XOR, ballot, count trailing zeros.  Deeper trees add one cprev hop per chunk level.
-// A new node's string = parent's string + one bit: ONE hop to build (three for the ancestor rows).
+// a node keeps only its CURRENT chunk (bits [ci*K, depth), words past the end unwritten and never read) plus
+// cprev = its ancestor at depth ci*K, whose own string is the complete previous chunk — so storage is 512 B per node
+// whatever the depth, and for trees shallower than 4096 (the 10 M-gate headline config: 3 471) comparing two
+// candidates is: load both strings (one round trip, coalesced), XOR, ballot, count trailing zeros.  Deeper trees
+// add one cprev hop per chunk level.  A new node's string = parent's string + one bit: ONE hop to build.
+// (Round-1 history: base-16 / base-64 ancestor rows with lift + diverge needed <= 6 dependent hops per comparison
+// and 3 per new node — peel 66 ms vs 44 ms at 10 M gates; a persistent single-XCD launch with L2-level hand-off
+// was correct but issue-bound on 32 CUs: 10.3 us per level vs 8.2.  Both are in the git history)
 // ================================================================================================
-constexpr u32 kSlotPad = 1u << 16;        // slots past the frontier that a speculative prefetch may touch
 constexpr u32 kChunkBits = 4096;
 constexpr u32 kChunkWords = kChunkBits / 64;
 
@@ -601,17 +324,16 @@ __device__ __forceinline__ u32 ctz64(u64 x) { return (u32)__ffsll((long long)x) 
 // Bring two distinct tree nodes under one root to the first chunk in which their paths can differ.
 // a/b: positions (in/out), lena/lenb: bits of that chunk (out); below_a/below_b: when a (b) had to climb, the
 // node of its chain one chunk below the returned one (its bit 0 is the label right after the returned chunk).
-template <bool SC1 = false>
-__device__ __forceinline__ void resolve_chunks(const u32* cprev, u32& a, u32& lena, u32& below_a, u32 da, u32& b,
+__device__ __forceinline__ void resolve_chunks(const u32* __restrict__ cprev, u32& a, u32& lena, u32& below_a, u32 da, u32& b,
                                                u32& lenb, u32& below_b, u32 db) {
     u32 ia = chunk_of(da), ib = chunk_of(db);
     lena = chunk_len(da); lenb = chunk_len(db);
     below_a = C2A_NONE; below_b = C2A_NONE;
     if ((ia | ib) == 0) return;
-    while (ia > ib) { below_a = a; a = ld_u32<SC1>(&cprev[a]); --ia; lena = kChunkBits; }
-    while (ib > ia) { below_b = b; b = ld_u32<SC1>(&cprev[b]); --ib; lenb = kChunkBits; }
+    while (ia > ib) { below_a = a; a = cprev[a]; --ia; lena = kChunkBits; }
+    while (ib > ia) { below_b = b; b = cprev[b]; --ib; lenb = kChunkBits; }
     while (ia > 0 && a != b) {
-        const u32 pa = ld_u32<SC1>(&cprev[a]), pb = ld_u32<SC1>(&cprev[b]);
+        const u32 pa = cprev[a], pb = cprev[b];
         if (pa == pb) break;
         below_a = a; below_b = b;
         a = pa; b = pb; --ia;
@@ -643,6 +365,16 @@ __device__ __forceinline__ bool str_less_lane(const u64* __restrict__ pstr, cons
     return ((sa[lenb >> 6] >> (lenb & 63u)) & 1ull) < lb;
 }
 
+// wave-uniform pick of one lane's value (v_readlane: a few cycles; ds_bpermute through __shfl costs ~100)
+__device__ __forceinline__ u32 rdlane(u32 v, u32 j) {
+#ifdef C2A_EMULATE
+    return __shfl(v, (int)j, 64);
+#else
+    return (u32)__builtin_amdgcn_readlane((int)v, (int)j);
+#endif
+}
+__device__ __forceinline__ u64 rdlane64(u64 v, u32 j) { return (u64)rdlane((u32)v, j) | ((u64)rdlane((u32)(v >> 32), j) << 32); }
+
 // wave-cooperative comparison of two strings already in registers (this lane's word of each): wave-uniform result
 __device__ __forceinline__ bool str_less_wave(u64 wa, u32 lena, u32 la, u64 wb, u32 lenb, u32 lb, u32 lane) {
     const u32 minlen = lena < lenb ? lena : lenb;
@@ -652,14 +384,14 @@ __device__ __forceinline__ bool str_less_wave(u64 wa, u32 lena, u32 la, u64 wb, 
     else if (minlen - lo < 64) x &= (1ull << (minlen - lo)) - 1ull;
     const u64 bal = __ballot(x != 0);
     if (bal) {
-        const int L = (int)ctz64(bal);
-        const u64 xl = __shfl(x, L, 64);
-        const u64 al = __shfl(wa, L, 64);
+        const u32 L = ctz64(bal);
+        const u64 xl = rdlane64(x, L);
+        const u64 al = rdlane64(wa, L);
         return ((al >> ctz64(xl)) & 1ull) == 0;
     }
     if (lena == lenb) return la < lb;
-    if (lena < lenb) return la < ((__shfl(wb, (int)(lena >> 6), 64) >> (lena & 63u)) & 1ull);
-    return ((__shfl(wa, (int)(lenb >> 6), 64) >> (lenb & 63u)) & 1ull) < lb;
+    if (lena < lenb) return la < ((rdlane64(wb, lena >> 6) >> (lena & 63u)) & 1ull);
+    return ((rdlane64(wa, lenb >> 6) >> (lenb & 63u)) & 1ull) < lb;
 }
 
 // the new node's string: parent's current chunk + one bit, or a fresh chunk when the parent filled its own
@@ -672,143 +404,183 @@ __device__ __forceinline__ u64 child_word(u64 parent_word, u32 parent_depth, u32
     return w;
 }
 
-// ---- one lane per gate (wide frontiers)
+// ---- one lane per gate (wide frontiers: throughput).  256 threads, gridDim.x % kSeg == 0.
+// A workgroup's appends go to segment blockIdx.x % kSeg, one ticket per wave and label.
 __global__ void __launch_bounds__(kThreads) k_peel_level_str(PeelArgs A, u32 level) {
-    FrontierSlot* cur = A.slots[level & 1u];
-    FrontierSlot* nxt = A.slots[(level + 1) & 1u];
-    const u32 n_front = A.fcount[level];
+    __shared__ u32 s_pre[kSeg + 1];
+    const u32 lane = threadIdx.x & 63u;
+    FrontierSlot* cur = (level & 1u) ? A.slots[1] : A.slots[0];
+    FrontierSlot* nxt = (level & 1u) ? A.slots[0] : A.slots[1];
+    u32 my_cnt, my_pre, n_front;
+    level_segments(A.fring, level, lane, my_cnt, my_pre, n_front);
     const u32 lo = A.fbase[level];
+    if (threadIdx.x < kSeg) s_pre[threadIdx.x] = my_pre;
+    if (threadIdx.x == 0) s_pre[kSeg] = n_front;
     if (gtid() == 0) A.fbase[level + 1] = lo + n_front;
-    for (u64 i = gtid(); i < n_front; i += gstride()) {
-        const uint4 sa = cur[i].a;
-        const u32 cnt = cur[i].b.x;
-        const u32 g = sa.x;
-        const u32 pos = lo + (u32)i;
-        u32 best = C2A_NONE, best_el = 0, best_root = g, best_depth = 0;
-        const u32 e0 = sa.w, e1 = e0 + cnt;
-        for (u32 e = e0; e < e1; ++e) {
-            const uint4 cr = A.cand[e];
-            const u32 pc = cr.x & kIdMask, el = cr.x >> 31;
-            bool take;
-            if (best == C2A_NONE) take = cr.z < g;
-            else if (cr.z != best_root) take = cr.z < best_root;
-            else if (pc == best) take = el < best_el;
-            else take = str_less_lane(A.pstr, A.cprev, pc, el, cr.y, best, best_el, best_depth);
-            if (take) { best = pc; best_el = el; best_root = cr.z; best_depth = cr.y; }
-        }
-        const u32 depth = best == C2A_NONE ? 0u : best_depth + 1;
-        const u32 my_label = best == C2A_NONE ? 0u : best_el;
-        A.meta[pos] = make_uint4(best, depth, best_root, my_label);
-        A.order[pos] = g;
-        A.posof[g] = pos;
-        if (best != C2A_NONE) {
-            A.child[2 * (u64)best + my_label] = pos;
-            u64* dst = A.pstr + (u64)pos * kChunkWords;
-            const u64* src = A.pstr + (u64)best * kChunkWords;
-            const u32 bit = (depth - 1) - chunk_of(depth) * kChunkBits;
-            const bool fresh_chunk = best_depth == 0 || chunk_of(depth) != chunk_of(best_depth);
-            // words past a string's end are never written and never read: the parent has `bit` bits, the child bit + 1
-            for (u32 w = 0; w * 64 <= bit; ++w) {
-                u64 v = (!fresh_chunk && w * 64 < bit) ? src[w] : 0ull;
-                if (w == (bit >> 6)) v |= (u64)my_label << (bit & 63u);
-                dst[w] = v;
+    if (gtid() < kSeg) A.fring[((level + 2) % kRing) * kSeg + (u32)gtid()] = 0u;
+    __syncthreads();
+    const u32 seg_out = blockIdx.x % kSeg;
+    u32* counter = &A.fring[((level + 1) % kRing) * kSeg + seg_out];
+    FrontierSlot* out = nxt + (u64)seg_out * A.seg_cap;
+    const u64 lt_mask = (1ull << lane) - 1ull;
+    for (u64 base = (u64)blockIdx.x * kThreads; base < n_front; base += gstride()) {
+        const u64 i = base + threadIdx.x;
+        const bool active = i < n_front;
+        u32 rdy[2] = {C2A_NONE, C2A_NONE};
+        uint4 rec[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+        if (active) {
+            u32 seg = 0;                                        // segment of flat index i: largest s with pre[s] <= i
+#pragma unroll
+            for (u32 step = kSeg / 2; step; step >>= 1) if (s_pre[seg + step] <= (u32)i) seg += step;
+            const FrontierSlot* sl = cur + (u64)seg * A.seg_cap + ((u32)i - s_pre[seg]);
+            const uint4 sa = sl->a;
+            const u32 cnt = sl->b.x;
+            const u32 g = sa.x;
+            const u32 pos = lo + (u32)i;
+            u32 best = C2A_NONE, best_el = 0, best_root = g, best_depth = 0;
+            const u32 e0 = sa.w, e1 = e0 + cnt;
+            for (u32 e = e0; e < e1; ++e) {
+                const uint4 cr = A.cand[e];
+                const u32 pc = cr.x & kIdMask, el = cr.x >> 31;
+                bool take;
+                if (best == C2A_NONE) take = cr.z < g;
+                else if (cr.z != best_root) take = cr.z < best_root;
+                else if (pc == best) take = el < best_el;
+                else take = str_less_lane(A.pstr, A.cprev, pc, el, cr.y, best, best_el, best_depth);
+                if (take) { best = pc; best_el = el; best_root = cr.z; best_depth = cr.y; }
             }
-            if (chunk_of(depth)) A.cprev[pos] = fresh_chunk ? best : A.cprev[best];
+            const u32 depth = best == C2A_NONE ? 0u : best_depth + 1;
+            const u32 my_label = best == C2A_NONE ? 0u : best_el;
+            A.meta[pos] = make_uint4(best, depth, best_root, my_label);
+            A.order[pos] = g;
+            A.posof[g] = pos;
+            if (best != C2A_NONE) {
+                A.child[2 * (u64)best + my_label] = pos;
+                u64* dst = A.pstr + (u64)pos * kChunkWords;
+                const u64* src = A.pstr + (u64)best * kChunkWords;
+                const u32 bit = (depth - 1) - chunk_of(depth) * kChunkBits;
+                const bool fresh_chunk = best_depth == 0 || chunk_of(depth) != chunk_of(best_depth);
+                // words past a string's end are never written and never read: the parent has `bit` bits, the child bit + 1
+                for (u32 w = 0; w * 64 <= bit; ++w) {
+                    u64 v = (!fresh_chunk && w * 64 < bit) ? src[w] : 0ull;
+                    if (w == (bit >> 6)) v |= (u64)my_label << (bit & 63u);
+                    dst[w] = v;
+                }
+                if (chunk_of(depth)) A.cprev[pos] = fresh_chunk ? best : A.cprev[best];
+            }
+            const u32 deps[2] = {sa.y, sa.z};
+#pragma unroll
+            for (u32 l = 0; l < 2; ++l) {
+                const u32 d = deps[l];
+                if (d == C2A_NONE) continue;
+                const uint4 gd = A.ginfo[d];
+                const u32 k = atomicAdd(&A.fill[d], 1u);
+                A.cand[gd.z + k] = make_uint4(pos | (l << 31), depth, best_root, my_label);
+                if (k + 1 == gd.w) { rdy[l] = d; rec[l] = gd; }
+            }
         }
-        const u32 deps[2] = {sa.y, sa.z};
+        // the wave's appends: one ticket per label (the loop bound is workgroup-uniform, so the wave is converged here)
 #pragma unroll
         for (u32 l = 0; l < 2; ++l) {
-            const u32 d = deps[l];
-            if (d == C2A_NONE) continue;
-            const uint4 gd = A.ginfo[d];
-            const u32 k = atomicAdd(&A.fill[d], 1u);
-            A.cand[gd.z + k] = make_uint4(pos | (l << 31), depth, best_root, my_label);
-            if (k + 1 == gd.w) {
-                const u32 p = atomicAdd(&A.fcount[level + 1], 1u);
-                nxt[p].b = make_uint4(gd.w, 0, 0, 0);
-                nxt[p].a = make_uint4(d, gd.x, gd.y, gd.z);
+            const u64 mask = __ballot(rdy[l] != C2A_NONE);
+            if (mask) {
+                u32 b = 0;
+                if (lane == (u32)ctz64(mask)) b = atomicAdd(counter, (u32)__popcll(mask));
+                b = __shfl(b, (int)ctz64(mask), 64);
+                if (rdy[l] != C2A_NONE) {
+                    const u32 p = b + (u32)__popcll(mask & lt_mask);
+                    out[p].b = make_uint4(rec[l].w, 0, 0, 0);
+                    out[p].a = make_uint4(rdy[l], rec[l].x, rec[l].y, rec[l].z);
+                }
             }
         }
     }
 }
 
-// ---- one wave per gate (narrow frontiers): survivor strings live in registers, the whole tournament costs ONE
-// round trip to memory when every survivor is shallower than a chunk
-constexpr int kStrMax = 12;               // survivor strings held in registers per round
-
-// Workgroup = WPB gate waves + ONE append wave.  Dependent memory round trips per level:
-//   1. frontier slot (fixed address, prefetched) + this level's count
+// ---- one wave per gate (narrow frontiers: latency): survivor strings live in registers, the whole tournament costs
+// ONE round trip to memory when every survivor is shallower than a chunk.
+// Workgroup = WPB gate waves + ONE append wave; gridDim.x % kSeg == 0; workgroup b serves segment b % kSeg, chunks
+// b / kSeg, + gridDim.x / kSeg, ... of WPB gates; the appends of chunk j of segment s go to segment (s + j) % kSeg.
+// Dependent memory round trips per level:
+//   1. frontier slot (fixed address, loaded before the counts are known) || this level's 16 segment counts
 //   2. candidate records  ||  ginfo of the two producers  ||  fill[] tickets of the two pushes
-//   3. survivor strings   ||  (append wave) next-level counter ticket -> next-level slots
+//   3. survivor strings   ||  (append wave) next-level segment ticket -> next-level slots
 //   then only stores (meta, order, child, the new string, the two candidate records).
-// The pushes' tickets need nothing from the tournament, so "am I the last consumer of this producer" — and with it the whole
-// next-level frontier — is known after round trip 2, and the append overlaps the tournament.
-#ifndef C2A_X
-#define C2A_X 0      // timing experiments: 1 = no string loads, 2 = + no candidate loads, 3 = + no tournament/stores (results wrong)
-#endif
+// The pushes' tickets need nothing from the tournament, so "am I the last consumer of this producer" — and with it the
+// whole next-level frontier — is known after round trip 2, and the append overlaps the tournament.
+constexpr int kStrMax = 4;                // survivor strings held in registers per round (rounds repeat for more)
+
 template <int WPB, bool PROF>
 __global__ void __launch_bounds__((WPB + 1) * 64) k_peel_level_wave_str(PeelArgs A, u32 level) {
     const ull t_begin = PROF ? c2a_now() : 0;
-    __shared__ u32 s_c[WPB][72], s_l[WPB][72], s_d[WPB][72];
     __shared__ u32 s_ready[2 * WPB];
     __shared__ uint4 s_rec[2 * WPB];
     const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const bool gate_wave = wv < (u32)WPB;
-    const u32 wvc = gate_wave ? wv : 0u;      // LDS row (the append wave never touches its row)
     // both pointers come with the one kernarg fetch; indexing the array by level would be a second, dependent scalar load
     FrontierSlot* cur = (level & 1u) ? A.slots[1] : A.slots[0];
     FrontierSlot* nxt = (level & 1u) ? A.slots[0] : A.slots[1];
+    const u32 seg = blockIdx.x % kSeg, j0 = blockIdx.x / kSeg, jstep = gridDim.x / kSeg;
+    const FrontierSlot* my_seg = cur + (u64)seg * A.seg_cap;
     const u64 lt_mask = (1ull << lane) - 1ull;
     uint4 sa0 = make_uint4(0, 0, 0, 0);
     u32 cnt0 = 0;
-    if (gate_wave) {
-        const u64 i0 = (u64)blockIdx.x * WPB + wv;
-        sa0 = cur[i0].a; cnt0 = cur[i0].b.x;      // speculative, before the level's count is known: the slot arrays are padded (kSlotPad)
+    if (gate_wave) {      // speculative, before the level's counts are known: the segments are padded (kSlotPad)
+        const FrontierSlot* sl = my_seg + (j0 * WPB + wv);
+        sa0 = sl->a; cnt0 = sl->b.x;
     }
-    const u32 n_front = A.fcount[level];
+    u32 my_cnt, my_pre, n_front;
+    level_segments(A.fring, level, lane, my_cnt, my_pre, n_front);
+    const u32 seg_cnt = __shfl(my_cnt, (int)seg, 64), seg_pre = __shfl(my_pre, (int)seg, 64);
     const u32 lo = A.fbase[level];
     if (gtid() == 0) A.fbase[level + 1] = lo + n_front;
-    if (gate_wave) { C2A_PROF_IF(PROF, 6, t_begin); C2A_PROF_IF(PROF, 0, c2a_now() - t_begin); }
-    for (u32 chunk = blockIdx.x; (u64)chunk * WPB < n_front; chunk += gridDim.x) {
-        const u64 i = (u64)chunk * WPB + wv;
-        const bool active = gate_wave && i < n_front;
+    if (gtid() < kSeg) A.fring[((level + 2) % kRing) * kSeg + (u32)gtid()] = 0u;
+    u32* next_row = &A.fring[((level + 1) % kRing) * kSeg];
+    C2A_PROF(6, t_begin); C2A_PROF(0, c2a_now() - t_begin);
+    for (u32 j = j0; j * WPB < seg_cnt; j += jstep) {
+        const u32 idx = j * WPB + wv;
+        const bool active = gate_wave && idx < seg_cnt;
         uint4 sa = sa0;
         u32 cnt = cnt0;
-        if (chunk != blockIdx.x && active) { sa = cur[i].a; cnt = cur[i].b.x; }
+        if (j != j0 && active) { sa = my_seg[idx].a; cnt = my_seg[idx].b.x; }
         // ---- round trip 2: producers' ginfo, fill tickets, first block of candidate records
         const u32 g = sa.x;
         const u32 e0 = sa.w, e1 = e0 + cnt;
         const u32 dl = active ? (lane == 0 ? sa.y : (lane == 1 ? sa.z : C2A_NONE)) : C2A_NONE;
-        uint4 gd = make_uint4(0, 0, 0, 0);
+        // the ticket first (it is the long one), then the two loads BRANCH-FREE (clamped index, result discarded by the
+        // lanes that have nothing to load): a predicated load is a branch, and the wait-count pass drains vmcnt at its join
         u32 kfill = 0;
-        uint4 cr_first = make_uint4(0, 0, 0xFFFFFFFFu, 0);
-#if C2A_X < 2
-        if (active && e0 + lane < e1) cr_first = A.cand[e0 + lane];
-#endif
-        if (dl != C2A_NONE) { gd = A.ginfo[dl]; kfill = atomicAdd(&A.fill[dl], 1u); }
+        if (dl != C2A_NONE) kfill = atomicAdd(&A.fill[dl], 1u);
+        const bool has_cand = active && e0 + lane < e1;
+        const uint4 cr_raw = A.cand[has_cand ? e0 + lane : 0u];
+        const uint4 gd_raw = A.ginfo[dl != C2A_NONE ? dl : 0u];
+        const uint4 cr_first = has_cand ? cr_raw : make_uint4(0, 0, 0xFFFFFFFFu, 0);
+        const uint4 gd = dl != C2A_NONE ? gd_raw : make_uint4(0, 0, 0, 0);
         const bool last_push = dl != C2A_NONE && kfill + 1 == gd.w;
         if (gate_wave && lane < 2) { s_ready[2 * wv + lane] = last_push ? dl : C2A_NONE; s_rec[2 * wv + lane] = gd; }
-        if (active) { C2A_PROF_IF(PROF, 7, 1000ull + cnt); C2A_PROF_IF(PROF, 1, c2a_now() - t_begin); }
+        if (active) { C2A_PROF(7, 1000ull + cnt); C2A_PROF(1, c2a_now() - t_begin); }
         __syncthreads();
-        if (active) C2A_PROF_IF(PROF, 2, c2a_now() - t_begin);
+        if (active) C2A_PROF(2, c2a_now() - t_begin);
         if (!gate_wave) {
-            // ---- append wave: one ticket on the next level's counter for the whole workgroup
+            // ---- append wave: one ticket on the target segment's counter for the whole workgroup
             const u32 d = lane < 2 * WPB ? s_ready[lane] : C2A_NONE;
             const u64 mask = __ballot(d != C2A_NONE);
             if (mask) {
+                const u32 seg_out = (seg + j) % kSeg;
                 u32 base = 0;
-                if (lane == 0) base = atomicAdd(&A.fcount[level + 1], (u32)__popcll(mask));
+                if (lane == 0) base = atomicAdd(&next_row[seg_out], (u32)__popcll(mask));
                 base = __shfl(base, 0, 64);
                 if (d != C2A_NONE) {
-                    const u32 p = base + (u32)__popcll(mask & lt_mask);
+                    FrontierSlot* out = nxt + (u64)seg_out * A.seg_cap + (base + (u32)__popcll(mask & lt_mask));
                     const uint4 r = s_rec[lane];
-                    nxt[p].b = make_uint4(r.w, 0, 0, 0);
-                    nxt[p].a = make_uint4(d, r.x, r.y, r.z);
+                    st_g(&out->b, make_uint4(r.w, 0, 0, 0));
+                    st_g(&out->a, make_uint4(d, r.x, r.y, r.z));
                 }
             }
-        } else if (active && C2A_X < 3) {
+        } else if (active) {
             // champion so far (wave-uniform); NONE = the virtual-root candidate [g].  champ_w = this lane's word of
-            // the champion's string when champ_loaded
+            // the champion's string when champ_loaded.  Everything wave-uniform lives in scalar registers: candidates
+            // are picked out of their lanes with v_readlane (a few cycles), never through LDS or ds_bpermute (~100).
             u32 ch = C2A_NONE, ch_el = 0, ch_root = g, ch_depth = 0;
             u64 champ_w = 0;
             bool champ_loaded = false;
@@ -819,624 +591,125 @@ __global__ void __launch_bounds__((WPB + 1) * 64) k_peel_level_wave_str(PeelArgs
                 if (eb != e0) { cr = make_uint4(0, 0, 0xFFFFFFFFu, 0); if (valid) cr = A.cand[e]; }
                 const u32 c = cr.x & kIdMask, l = cr.x >> 31, cdepth = cr.y;
                 const u32 croot = valid ? cr.z : 0xFFFFFFFFu;
-                const u32 rmin = wave_min_u32(croot);
-                if (rmin > ch_root) continue;
-                const bool keep_ch = (ch != C2A_NONE) && (ch_root == rmin);
-                if (!keep_ch) champ_loaded = false;
-                const bool surv = valid && croot == rmin;
-                const u64 smask = __ballot(surv);
-                const u32 m = (u32)__popcll(smask);
-                if (surv) {
-                    const u32 k = (u32)__popcll(smask & lt_mask);
-                    s_c[wvc][k] = c; s_l[wvc][k] = l; s_d[wvc][k] = cdepth;
+                const u64 vmask = __ballot(valid);
+                u32 rmin;
+                if (__popcll(vmask) <= 8) {                     // the usual case: a scalar loop over the few valid lanes
+                    rmin = 0xFFFFFFFFu;
+                    for (u64 mm = vmask; mm; mm &= mm - 1) { const u32 r = rdlane(croot, ctz64(mm)); rmin = r < rmin ? r : rmin; }
+                } else {
+                    rmin = wave_min_u32(croot);
                 }
-                wave_lds_sync();
-                // sequential tournament, kStrMax survivors per round with their strings in registers
-                u32 next = 0;
-                if (!keep_ch) {      // the first survivor becomes the champion without a comparison
-                    ch = s_c[wvc][0]; ch_el = s_l[wvc][0]; ch_depth = s_d[wvc][0];
-                    next = 1;
+                if (rmin > ch_root) continue;
+                if (!((ch != C2A_NONE) && (ch_root == rmin))) {   // new smallest root: the first survivor starts as champion
+                    champ_loaded = false;
+                    ch = C2A_NONE;
                 }
                 ch_root = rmin;
-                while (next < m) {
-                    const u32 take = (m - next) < (u32)kStrMax ? (m - next) : (u32)kStrMax;
-                    // all of this round in chunk 0?  then one coalesced load per string, all issued back to back;
-                    // lanes beyond a string's length skip their word (it is zero)
+                u64 smask = __ballot(valid && croot == rmin);
+                if (ch == C2A_NONE) {
+                    const u32 j = ctz64(smask);
+                    smask &= smask - 1;
+                    ch = rdlane(c, j); ch_el = rdlane(l, j); ch_depth = rdlane(cdepth, j);
+                }
+                // sequential tournament, kStrMax survivors per round with their strings in registers
+                while (smask) {
+                    u32 cc[kStrMax], cl[kStrMax], cd[kStrMax];
+                    u32 take = 0;
+#pragma unroll
+                    for (int t = 0; t < kStrMax; ++t) {
+                        if (smask) {
+                            const u32 j = ctz64(smask);
+                            smask &= smask - 1;
+                            cc[t] = rdlane(c, j); cl[t] = rdlane(l, j); cd[t] = rdlane(cdepth, j);
+                            take = (u32)t + 1;
+                        } else {
+                            cc[t] = ch; cl[t] = 0; cd[t] = 0;          // unused slot: length 0, loads word 0 of the champion
+                        }
+                    }
+                    // all of this round in chunk 0?  then one coalesced load per string
                     bool shallow = ch_depth <= kChunkBits;
-                    for (u32 t = 0; t < take; ++t) shallow = shallow && s_d[wvc][next + t] <= kChunkBits;
+#pragma unroll
+                    for (int t = 0; t < kStrMax; ++t) shallow = shallow && cd[t] <= kChunkBits;
+#ifdef C2A_PROF_PRELOAD
+                    if (PROF) C2A_PROF(5, c2a_now() - t_begin);
+#endif
                     if (shallow) {
+                        // the loads back to back, BRANCH-FREE: a load under a lane predicate is a branch, and the
+                        // compiler's wait-count pass then drains vmcnt before the next one (measured: +0.65 us per candidate).
+                        // Lanes past a string's end (and unused slots, length 0) read word 0 of the string and discard it.
                         u64 sw[kStrMax];
 #pragma unroll
-                        for (int t = 0; t < kStrMax; ++t)
-                            sw[t] = (C2A_X < 1 && (u32)t < take && lane * 64 < s_d[wvc][next + t]) ? A.pstr[(u64)s_c[wvc][next + t] * kChunkWords + lane] : 0ull;
-                        if (!champ_loaded) { champ_w = (C2A_X < 1 && lane * 64 < ch_depth) ? A.pstr[(u64)ch * kChunkWords + lane] : 0ull; champ_loaded = true; }
+                        for (int t = 0; t < kStrMax; ++t) {
+                            const bool on = lane * 64 < cd[t];
+                            const u64 v = A.pstr[(u64)cc[t] * kChunkWords + (on ? lane : 0u)];
+                            sw[t] = on ? v : 0ull;
+                        }
+                        if (!champ_loaded) {
+                            const bool on = lane * 64 < ch_depth;
+                            const u64 v = A.pstr[(u64)ch * kChunkWords + (on ? lane : 0u)];
+                            champ_w = on ? v : 0ull;
+                            champ_loaded = true;
+                        }
+#ifdef C2A_PROF_STRINGS
+                        if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); C2A_PROF(5, c2a_now() - t_begin); }
+#endif
 #pragma unroll
                         for (int t = 0; t < kStrMax; ++t) {
                             if ((u32)t < take) {
-                                const u32 cc = s_c[wvc][next + t], cl = s_l[wvc][next + t], cd = s_d[wvc][next + t];
                                 bool less;
-                                if (cc == ch) less = cl < ch_el;
-                                else less = str_less_wave(sw[t], cd, cl, champ_w, ch_depth, ch_el, lane);
-                                if (less) { ch = cc; ch_el = cl; ch_depth = cd; champ_w = sw[t]; }
+                                if (cc[t] == ch) less = cl[t] < ch_el;
+                                else less = str_less_wave(sw[t], cd[t], cl[t], champ_w, ch_depth, ch_el, lane);
+                                if (less) { ch = cc[t]; ch_el = cl[t]; ch_depth = cd[t]; champ_w = sw[t]; }
                             }
                         }
                     } else {
                         // deep trees: chunk resolution (cprev hops) per comparison, strings loaded per comparison
                         for (u32 t = 0; t < take; ++t) {
-                            const u32 cc = s_c[wvc][next + t], cl = s_l[wvc][next + t], cd = s_d[wvc][next + t];
+                            const u32 cct = cc[t], clt = cl[t], cdt = cd[t];
                             bool less;
-                            if (cc == ch) less = cl < ch_el;
+                            if (cct == ch) less = clt < ch_el;
                             else {
-                                u32 ra = cc, rb = ch, lena, lenb, ba, bb;
-                                resolve_chunks(A.cprev, ra, lena, ba, cd, rb, lenb, bb, ch_depth);
+                                u32 ra = cct, rb = ch, lena, lenb, ba, bb;
+                                resolve_chunks(A.cprev, ra, lena, ba, cdt, rb, lenb, bb, ch_depth);
                                 if (ra == rb) {
                                     if (ba != C2A_NONE) less = (A.pstr[(u64)ba * kChunkWords] & 1ull) < ch_el;
-                                    else less = cl < (A.pstr[(u64)bb * kChunkWords] & 1ull);
+                                    else less = clt < (A.pstr[(u64)bb * kChunkWords] & 1ull);
                                 } else {
-                                    const u64 wa = lena ? A.pstr[(u64)ra * kChunkWords + lane] : 0ull;
-                                    const u64 wb = lenb ? A.pstr[(u64)rb * kChunkWords + lane] : 0ull;
-                                    less = str_less_wave(wa, lena, cl, wb, lenb, ch_el, lane);
+                                    const u64 wa = lane * 64 < lena ? A.pstr[(u64)ra * kChunkWords + lane] : 0ull;
+                                    const u64 wb = lane * 64 < lenb ? A.pstr[(u64)rb * kChunkWords + lane] : 0ull;
+                                    less = str_less_wave(wa, lena, clt, wb, lenb, ch_el, lane);
                                 }
                             }
-                            if (less) { ch = cc; ch_el = cl; ch_depth = cd; champ_loaded = false; }
+                            if (less) { ch = cct; ch_el = clt; ch_depth = cdt; champ_loaded = false; }
                         }
                     }
-                    next += take;
                 }
-                wave_lds_sync();
             }
-            C2A_PROF_IF(PROF, 3, c2a_now() - t_begin);
+            C2A_PROF(3, c2a_now() - t_begin);
             const u32 depth = ch == C2A_NONE ? 0u : ch_depth + 1;
             const u32 my_label = ch == C2A_NONE ? 0u : ch_el;
-            const u32 pos = lo + (u32)i;
+            const u32 pos = lo + seg_pre + idx;
             if (lane == 0) {
-                A.meta[pos] = make_uint4(ch, depth, ch_root, my_label);
-                A.order[pos] = g;
-                A.posof[g] = pos;
-                if (ch != C2A_NONE) A.child[2 * (u64)ch + my_label] = pos;
+                st_g(&A.meta[pos], make_uint4(ch, depth, ch_root, my_label));
+                st_g(&A.order[pos], g);
+                st_g(&A.posof[g], pos);
+                if (ch != C2A_NONE) st_g(&A.child[2 * (u64)ch + my_label], pos);
             }
-            if (dl != C2A_NONE) A.cand[gd.z + kfill] = make_uint4(pos | (lane << 31), depth, ch_root, my_label);   // lane == edge label
+            if (dl != C2A_NONE) st_g(&A.cand[gd.z + kfill], make_uint4(pos | (lane << 31), depth, ch_root, my_label));   // lane == edge label
             if (ch != C2A_NONE) {
                 const bool need_parent = ch_depth != 0 && chunk_of(depth) == chunk_of(ch_depth);
-                if (need_parent && !champ_loaded) champ_w = (C2A_X < 1 && lane * 64 < chunk_len(ch_depth)) ? A.pstr[(u64)ch * kChunkWords + lane] : 0ull;
+                if (need_parent && !champ_loaded) champ_w = lane * 64 < chunk_len(ch_depth) ? A.pstr[(u64)ch * kChunkWords + lane] : 0ull;
                 bool fresh;
                 const u64 nw = child_word(need_parent ? champ_w : 0ull, ch_depth, my_label, lane, fresh);
-                if (lane * 64 < chunk_len(depth)) A.pstr[(u64)pos * kChunkWords + lane] = nw;      // words past the end are never read
-                if (lane == 0 && chunk_of(depth)) A.cprev[pos] = fresh ? ch : A.cprev[ch];
+                if (lane * 64 < chunk_len(depth)) st_g(&A.pstr[(u64)pos * kChunkWords + lane], nw);      // words past the end are never read
+                if (lane == 0 && chunk_of(depth)) st_g(&A.cprev[pos], fresh ? ch : A.cprev[ch]);
             }
-            C2A_PROF_IF(PROF, 4, c2a_now() - t_begin);
+            C2A_PROF(4, c2a_now() - t_begin);
         }
         __syncthreads();
-        if (active) C2A_PROF_IF(PROF, 5, c2a_now() - t_begin);
-    }
-}
-
-// Variant 3: ONE persistent launch for all remaining (narrow) levels, confined to one XCD.
-// A kernel boundary per level costs ~13 us here (cold caches after every boundary: ~0.6 us per dependent hop,
-// plus launch/teardown).  Inside one launch the level step is a workgroup-aggregated append + a counter barrier:
-// measured 1.7 us per produce/barrier/consume iteration for the 32 workgroups of one XCD (tools/ubench/xcd.hip).
-// Rules (cdna_hip_programming.md §6 G16): every word exchanged between workgroups in the launch is accessed with
-// agent-scope relaxed atomics (sc1), every storing wave drains vmcnt before the barrier, correctness never
-// depends on placement — the XCD filter only decides WHO works (HW_REG_XCC_ID is ground truth, the first
-// workgroup to arrive picks the XCD), the census tells the participants how many they are, and they are all
-// resident by then (they have all reported).  One 16-lane group per gate, four gates per wave:
-// candidates in chunks of 16, all-pairs rounds of <= 6 candidates (15 pairs), all cross-lane traffic by
-// width-16 shuffles (group-uniform control flow).
-struct PeelCtl {
-    u32 chosen_xcd;     // 0xFFFFFFFF until the first workgroup arrives
-    u32 joined, bystanders;
-    u32 arrive, gen;    // barrier
-    u32 last_level;     // first empty level (out)
-    u32 pad[10];
-};
-
-constexpr int kPGroupsPerWg = 64;           // 1024 threads
-constexpr int kPGroup = 6;                  // 6*5/2 = 15 pairs <= 16 lanes
-
-__device__ __forceinline__ u32 xcc_id() {
-#ifdef C2A_EMULATE
-    return 0;
-#else
-    return __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 0xFu;      // HW_REG_XCC_ID[3:0]
+#if !defined(C2A_PROF_STRINGS) && !defined(C2A_PROF_PRELOAD)
+        if (active) C2A_PROF(5, c2a_now() - t_begin);
 #endif
-}
-
-// LDS hand-off between the lanes of one 16-lane group (group-uniform control flow): DS ops of a wave execute in
-// order, so only the compiler has to be stopped; the emulation needs a real rendezvous of the group's fibers
-__device__ __forceinline__ void group_lds_sync() {
-#ifdef C2A_EMULATE
-    (void)__shfl(0u, 0, 16);
-#else
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#endif
-}
-
-__device__ __forceinline__ u32 group_or16(u32 v) {
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) v |= __shfl_xor(v, off, 16);
-    return v;
-}
-__device__ __forceinline__ u32 group_min16(u32 v) {
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) { const u32 o = __shfl_xor(v, off, 16); v = o < v ? o : v; }
-    return v;
-}
-
-// DS = true: bulk data (slots, candidate records, meta, ancestor rows) by sc1 accesses, no fences.
-// DS = false: bulk data by plain accesses + one agent-scope release and acquire per workgroup per level (G16 recipe).
-template <bool DS>
-__global__ void __launch_bounds__(kPGroupsPerWg * 16) k_peel_persistent(PeelArgs A, u32 level0, PeelCtl* ctl) {
-    __shared__ u32 s_c[kPGroupsPerWg][20], s_l[kPGroupsPerWg][20], s_d[kPGroupsPerWg][20];
-    __shared__ u32 s_ready[2 * kPGroupsPerWg];
-    __shared__ uint4 s_rec[2 * kPGroupsPerWg];
-    __shared__ u32 s_cnt[2];
-    __shared__ u32 s_base, s_P, s_rank, s_go;
-    const u32 tid = threadIdx.x, lane = tid & 63u, l16 = tid & 15u, gq = tid >> 4;
-    // ---- who works: the XCD of the first workgroup to arrive
-    if (tid == 0) {
-        const u32 x = xcc_id();
-        const u32 prev = atomicCAS(&ctl->chosen_xcd, 0xFFFFFFFFu, x);
-        const bool mine = prev == 0xFFFFFFFFu || prev == x;
-        s_go = mine ? 1u : 0u;
-        if (mine) s_rank = atomicAdd(&ctl->joined, 1u); else atomicAdd(&ctl->bystanders, 1u);
-    }
-    __syncthreads();
-    if (!s_go) return;
-    if (tid == 0) {
-        while (ld_u32<true>(&ctl->joined) + ld_u32<true>(&ctl->bystanders) < gridDim.x) __builtin_amdgcn_s_sleep(2);
-        s_P = ld_u32<true>(&ctl->joined);
-    }
-    __syncthreads();
-    const u32 P = s_P, rank = s_rank;
-    const u32 total_groups = P * kPGroupsPerWg;
-    const u64 plane = (u64)A.n * 16;
-    u32 epoch = 0;
-    // diagnostics: per workgroup, per level (first 64 levels of the launch), wall-clock ticks (10 ns) at the phase ends
-#define C2A_PPROF(slot)                                                                                        \
-    do {                                                                                                       \
-        if (A.prof && tid == 0 && level >= A.prof_level0 && level - A.prof_level0 < 64) A.prof[(((u64)(level - A.prof_level0)) * 64 + rank) * 8 + (slot)] = c2a_now(); \
-    } while (0)
-    for (u32 level = level0;; ++level) {
-        C2A_PPROF(0);
-        const u32 n_front = ld_u32<true>(&A.fcount[level]);
-        if (A.prof && tid == 0 && rank == 0 && level >= A.prof_level0 && level - A.prof_level0 < 64) A.prof[(((u64)(level - A.prof_level0)) * 64 + 63) * 8 + 7] = n_front;
-        if (n_front == 0) {                               // every participant reads the same value: uniform exit
-            if (rank == 0 && tid == 0) st_u32<true>(&ctl->last_level, level);
-            break;
-        }
-        const u32 lo = ld_u32<true>(&A.fbase[level]);
-        if (rank == 0 && tid == 0) st_u32<true>(&A.fbase[level + 1], lo + n_front);
-        FrontierSlot* cur = A.slots[level & 1u];
-        FrontierSlot* nxt = A.slots[(level + 1) & 1u];
-        for (u32 base = 0; base < n_front; base += total_groups) {
-            const u32 i = base + rank * kPGroupsPerWg + gq;
-            u32 rdy = C2A_NONE;
-            uint4 rdy_rec = make_uint4(0, 0, 0, 0);
-            if (i < n_front) {
-                const uint4 sa = ld_u128<DS>(&cur[i].a);
-                const u32 cnt = ld_u32<DS>(&cur[i].b.x);
-                const u32 g = sa.x;
-                const u32 e0 = sa.w, e1 = e0 + cnt;
-                const u32 dl = l16 == 0 ? sa.y : (l16 == 1 ? sa.z : C2A_NONE);
-                uint4 gd = make_uint4(0, 0, 0, 0);
-                if (dl != C2A_NONE) gd = A.ginfo[dl];                 // static (written before this launch)
-                u32 ch = C2A_NONE, ch_el = 0, ch_root = g, ch_depth = 0;
-                for (u32 eb = e0; eb < e1; eb += 16) {
-                    const u32 e = eb + l16;
-                    const bool valid = e < e1;
-                    u32 c = 0, l = 0, cdepth = 0, croot = 0xFFFFFFFFu;
-                    if (valid) {
-                        const uint4 cr = ld_u128<DS>(&A.cand[e]);
-                        c = (cr.x & kIdMask) | (cr.w << 31); l = cr.x >> 31;
-                        cdepth = cr.y; croot = cr.z;
-                    }
-                    const u32 rmin = group_min16(croot);
-                    if (rmin > ch_root) continue;
-                    const bool keep_ch = (ch != C2A_NONE) && (ch_root == rmin);
-                    const bool surv = valid && croot == rmin;
-                    const u32 smask = group_or16(surv ? (1u << l16) : 0u);
-                    u32 m = (u32)__popc(smask);
-                    if (surv) {
-                        const u32 k = (u32)__popc(smask & ((1u << l16) - 1u));
-                        s_c[gq][k] = c; s_l[gq][k] = l; s_d[gq][k] = cdepth;
-                    }
-                    if (keep_ch && l16 == 0) { s_c[gq][m] = ch; s_l[gq][m] = ch_el; s_d[gq][m] = ch_depth; }
-                    m += keep_ch ? 1u : 0u;
-                    group_lds_sync();
-                    u32 win = 0, next = 1;
-                    while (next < m) {
-                        const u32 take = (m - next) < (u32)(kPGroup - 1) ? (m - next) : (u32)(kPGroup - 1);
-                        const u32 q = take + 1;
-                        const u32 NP = q * (q - 1) / 2;
-                        u32 pi = 0, pj = 1;
-                        {
-                            u32 rem = l16, row = 0, len = q - 1;
-                            while (len && rem >= len) { rem -= len; ++row; --len; }
-                            pi = row; pj = row + 1 + rem;
-                        }
-                        u32 lost_bit = 0;
-                        if (l16 < NP) {
-                            const u32 xi = pi == 0 ? win : next + pi - 1, xj = next + pj - 1;
-                            const u32 ci = s_c[gq][xi], cj = s_c[gq][xj];
-                            const u32 li = s_l[gq][xi], lj = s_l[gq][xj];
-                            bool less;
-                            if (((ci ^ cj) & kIdMask) == 0) less = li < lj;
-                            else less = path_less<DS, 4>(A.anc, plane, ci, li, s_d[gq][xi], cj, lj, s_d[gq][xj]);
-                            lost_bit = 1u << (less ? pj : pi);
-                        }
-                        const u32 lost = group_or16(lost_bit);
-                        const u32 w = (u32)__ffs((int)(~lost & ((1u << q) - 1u))) - 1u;    // the one member that never lost
-                        win = w == 0 ? win : next + w - 1;
-                        next += take;
-                    }
-                    ch = s_c[gq][win]; ch_el = s_l[gq][win]; ch_depth = s_d[gq][win]; ch_root = rmin;
-                    group_lds_sync();
-                }
-                const u32 depth = ch == C2A_NONE ? 0u : ch_depth + 1;
-                const u32 my_label = ch == C2A_NONE ? 0u : ch_el;
-                const u32 pos = lo + i;
-                if (l16 == 0) {
-                    st_u128<DS>(&A.meta[pos], make_uint4(ch == C2A_NONE ? C2A_NONE : (ch & kIdMask), depth, ch_root, my_label));
-                    st_u32<DS>(&A.order[pos], g);
-                    st_u32<DS>(&A.posof[g], pos);
-                    if (ch != C2A_NONE) st_u32<DS>(&A.child[2 * (u64)(ch & kIdMask) + my_label], pos);
-                }
-                u32 kfill = 0;
-                if (dl != C2A_NONE) kfill = atomicAdd(&A.fill[dl], 1u);
-                if (depth) {
-                    u32 q = ch, need = 1;
-                    for (int j = 0; need <= depth; ++j) {
-                        u32 v = q;
-                        if (l16 >= 1) v = anc_entry<DS, 4>(A.anc, plane, j, q & kIdMask, l16 - 1);
-                        st_u32<DS>(&A.anc[(u64)j * plane + (u64)pos * 16 + l16], v);
-                        q = __shfl(v, 15, 16);
-                        if (need > (0xFFFFFFFFu >> 4)) break;
-                        need <<= 4;
-                    }
-                }
-                if (dl != C2A_NONE) {
-                    st_u128<DS>(&A.cand[gd.z + kfill], make_uint4(pos | (l16 << 31), depth, ch_root, my_label));   // l16 == edge label
-                    if (kfill + 1 == gd.w) { rdy = dl; rdy_rec = gd; }
-                }
-            }
-            C2A_PPROF(1);
-            // ---- one append per workgroup
-            if (l16 < 2) { s_ready[2 * gq + l16] = rdy; s_rec[2 * gq + l16] = rdy_rec; }
-            __syncthreads();
-            C2A_PPROF(2);
-            u32 d = C2A_NONE;
-            u64 mask = 0;
-            if (tid < 2 * kPGroupsPerWg) {                           // waves 0 and 1, whole waves
-                d = s_ready[tid];
-                mask = __ballot(d != C2A_NONE);
-                if (lane == 0) s_cnt[tid >> 6] = (u32)__popcll(mask);
-            }
-            __syncthreads();
-            if (tid == 0) { const u32 tot = s_cnt[0] + s_cnt[1]; s_base = tot ? atomicAdd(&A.fcount[level + 1], tot) : 0u; }
-            __syncthreads();
-            if (d != C2A_NONE) {
-                const u32 p = s_base + (tid >= 64 ? s_cnt[0] : 0u) + (u32)__popcll(mask & ((1ull << lane) - 1ull));
-                const uint4 gd = s_rec[tid];
-                st_u32<DS>(&nxt[p].b.x, gd.w);
-                st_u128<DS>(&nxt[p].a, make_uint4(d, gd.x, gd.y, gd.z));
-            }
-            __syncthreads();
-            C2A_PPROF(3);
-        }
-        // ---- level barrier: drain every wave's write-through stores, then arrive / wait
-#ifndef C2A_EMULATE
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        __syncthreads();
-        C2A_PPROF(4);
-        ++epoch;
-        if (tid == 0) {
-#ifndef C2A_EMULATE
-            if (!DS) {      // publish this workgroup's plain stores (the asm wait restates the post-wbl2 wait: G16 pitfall 12)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-#endif
-            const u32 a = atomicAdd(&ctl->arrive, 1u);
-            if (a == P * epoch - 1) st_u32<true>(&ctl->gen, epoch);
-            while (ld_u32<true>(&ctl->gen) < epoch) __builtin_amdgcn_s_sleep(1);
-#ifndef C2A_EMULATE
-            if (!DS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // one lane's acquire + the barrier below covers the workgroup
-#endif
-        }
-        __syncthreads();
-        C2A_PPROF(5);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Variant 4: the path-string peel as ONE persistent launch on ONE XCD (narrow frontiers).
-// What a kernel boundary per level costs (tools/ubench/xcd2.hip, MI355X): ~2.3 us of launch gap, an L2 invalidate,
-// and every first touch afterwards from HBM (220-370 ns per dependent hop instead of 85 ns in L2).  The 32 workgroups
-// of one XCD share ONE L2, so inside one launch they can exchange data through it with no cache maintenance at all:
-//   stores  : plain (the vector L1 is write-through; vmcnt(0) == the L2 has the data)
-//   loads   : sc1 (agent-scope relaxed atomic loads: miss the L1 always, hit the shared L2)       [0 stale reads / 16 M]
-//   atomics : L2 atomics (fill[], the frontier counter, the level barrier) — ~12 ns each on one word, 32 per level
-//   level barrier among the 32 workgroups: 1.05-1.36 us; `buffer_inv sc1` (7 us) is never used
-// The XCD filter only decides WHO works (HW_REG_XCC_ID is ground truth; the first workgroup to arrive picks the XCD;
-// the census tells the participants how many they are); correctness never depends on placement.
-// One 16-lane group per gate (64 gates per workgroup, 2048 per pass over the 32 CUs): lane l16 holds words
-// {l16, 16+l16, 32+l16, 48+l16} of a string, so every 8-byte load instruction of a group covers 128 contiguous bytes
-// and the k-th one is skipped for strings shorter than 1024k bits.
-// The launch returns at the first level that is empty or wider than `cap` (the host goes on with a launch per level).
-// ------------------------------------------------------------------------------------------------
-constexpr int kSGroupsPerWg = 64;           // 1024 threads
-constexpr int kSMax = 5;                    // survivor strings held in registers per tournament round
-constexpr int kSW = 4;                      // u64 words of a string per lane
-
-__device__ __forceinline__ u32 group_ballot16(bool p, u32 l16, u32 gshift) {
-#ifdef C2A_EMULATE
-    (void)gshift;
-    return group_or16(p ? (1u << l16) : 0u);
-#else
-    (void)l16;
-    return (u32)((__ballot(p) >> gshift) & 0xFFFFull);
-#endif
-}
-
-template <bool SC1>
-__device__ __forceinline__ void load_str16(const u64* pstr, u32 x, u32 len, u32 l16, u64 (&w)[kSW]) {
-#pragma unroll
-    for (int k = 0; k < kSW; ++k) {
-        const u32 word = (u32)k * 16 + l16;
-        w[k] = word * 64 < len ? ld_u64<SC1>(pstr + (u64)x * kChunkWords + word) : 0ull;
-    }
-}
-
-// bit `pos` of a string held by a group (group-uniform pos)
-__device__ __forceinline__ u32 str_bit16(const u64 (&w)[kSW], u32 pos) {
-    const u32 word = pos >> 6, kk = word >> 4;
-    u64 v = 0;
-#pragma unroll
-    for (int k = 0; k < kSW; ++k) {
-        const u64 t = __shfl(w[k], (int)(word & 15u), 16);
-        if ((u32)k == kk) v = t;
-    }
-    return (u32)((v >> (pos & 63u)) & 1ull);
-}
-
-// group-cooperative: is P(a).la < P(b).lb for two strings of one chunk held in registers?  (group-uniform result)
-__device__ __forceinline__ bool str_less16(const u64 (&a)[kSW], u32 lena, u32 la, const u64 (&b)[kSW], u32 lenb, u32 lb, u32 l16,
-                                           u32 gshift) {
-    const u32 minlen = lena < lenb ? lena : lenb;
-#pragma unroll
-    for (int k = 0; k < kSW; ++k) {
-        const u32 lo = ((u32)k * 16 + l16) * 64;
-        u64 x = a[k] ^ b[k];
-        if (lo >= minlen) x = 0;
-        else if (minlen - lo < 64) x &= (1ull << (minlen - lo)) - 1ull;
-        const u32 bal = group_ballot16(x != 0, l16, gshift);
-        if (bal) {
-            const int L = (int)__ffs((int)bal) - 1;
-            const u64 xl = __shfl(x, L, 16);
-            const u64 al = __shfl(a[k], L, 16);
-            return ((al >> ctz64(xl)) & 1ull) == 0;
-        }
-    }
-    if (lena == lenb) return la < lb;
-    if (lena < lenb) return la < str_bit16(b, lena);
-    return str_bit16(a, lenb) < lb;
-}
-
-__global__ void __launch_bounds__(kSGroupsPerWg * 16) k_peel_persistent_str(PeelArgs A, u32 level0, u32 cap, PeelCtl* ctl) {
-    __shared__ u32 s_c[kSGroupsPerWg][20], s_l[kSGroupsPerWg][20], s_d[kSGroupsPerWg][20];
-    __shared__ u32 s_ready[2 * kSGroupsPerWg];
-    __shared__ uint4 s_rec[2 * kSGroupsPerWg];
-    __shared__ u32 s_cnt[2];
-    __shared__ u32 s_base, s_P, s_rank, s_go, s_nf;
-    const u32 tid = threadIdx.x, lane = tid & 63u, l16 = tid & 15u, gq = tid >> 4, gshift = lane & 48u;
-    // ---- who works: the XCD of the first workgroup to arrive
-    if (tid == 0) {
-        const u32 x = xcc_id();
-        const u32 prev = atomicCAS(&ctl->chosen_xcd, 0xFFFFFFFFu, x);
-        const bool mine = prev == 0xFFFFFFFFu || prev == x;
-        s_go = mine ? 1u : 0u;
-        if (mine) s_rank = atomicAdd(&ctl->joined, 1u); else atomicAdd(&ctl->bystanders, 1u);
-    }
-    __syncthreads();
-    if (!s_go) return;
-    if (tid == 0) {
-        while (ld_u32<true>(&ctl->joined) + ld_u32<true>(&ctl->bystanders) < gridDim.x) __builtin_amdgcn_s_sleep(2);
-        s_P = ld_u32<true>(&ctl->joined);
-    }
-    __syncthreads();
-    const u32 P = s_P, rank = s_rank;
-    const u32 total_groups = P * kSGroupsPerWg;
-    u32 epoch = 0;
-    u32 pf_acc = 0;                                        // sink of the look-ahead loads (never true, keeps them alive)
-    // one lane per workgroup reads the level's frontier size (512 waves on one word is a 0.7 us pile-up on one L2 channel)
-    if (tid == 0) s_nf = ld_u32<true>(&A.fcount[level0]);
-    u32 lo = ld_u32<true>(&A.fbase[level0]);
-    __syncthreads();
-    for (u32 level = level0;; ++level) {
-        C2A_PPROF(0);
-        const u32 n_front = s_nf;
-        if (n_front == 0 || n_front > cap) {               // every participant reads the same value: uniform exit
-            if (rank == 0 && tid == 0) st_u32<true>(&ctl->last_level, level);
-            if (pf_acc == 0x9E3779B9u && n_front == 0xFFFFFFFFu) ctl->pad[0] = pf_acc;
-            break;
-        }
-        if (rank == 0 && tid == 0) A.fbase[level + 1] = lo + n_front;
-        FrontierSlot* cur = A.slots[level & 1u];
-        FrontierSlot* nxt = A.slots[(level + 1) & 1u];
-        for (u32 base = 0; base < n_front; base += total_groups) {
-            const u32 i = base + rank * kSGroupsPerWg + gq;
-            const bool active = i < n_front;
-            // ---- slot, then (in one round trip) candidate records, the producers' ginfo and the two push tickets
-            u32 sword = 0;                                            // lanes 0-3: a.x..a.w, lane 4: b.x — one 4-byte load per lane
-            if (active && l16 < 5) sword = ld_u32<true>(reinterpret_cast<const u32*>(&cur[i]) + l16);
-            const uint4 sa = make_uint4(__shfl(sword, 0, 16), __shfl(sword, 1, 16), __shfl(sword, 2, 16), __shfl(sword, 3, 16));
-            const u32 cnt = __shfl(sword, 4, 16);
-            const u32 g = sa.x;
-            const u32 e0 = sa.w, e1 = e0 + cnt;
-            const u32 dl = active ? (l16 == 0 ? sa.y : (l16 == 1 ? sa.z : C2A_NONE)) : C2A_NONE;
-            uint4 gd = make_uint4(0, 0, 0, 0);
-            u32 kfill = 0;
-            uint4 cr_first = make_uint4(0, 0, 0xFFFFFFFFu, 0);
-            if (active && e0 + l16 < e1) cr_first = ld_u128<true>(&A.cand[e0 + l16]);
-            if (dl != C2A_NONE) { gd = A.ginfo[dl]; kfill = atomicAdd(&A.fill[dl], 1u); }          // ginfo is static
-            const bool last_push = dl != C2A_NONE && kfill + 1 == gd.w;
-            if (l16 < 2) { s_ready[2 * gq + l16] = last_push ? dl : C2A_NONE; s_rec[2 * gq + l16] = gd; }
-            C2A_PPROF(1);
-            __syncthreads();
-            // ---- one append per workgroup: the ticket is issued now, the slots are written after the tournament
-            u32 d_app = C2A_NONE;
-            u64 mask_app = 0;
-            if (tid < 2 * kSGroupsPerWg) {                           // waves 0 and 1, whole waves
-                d_app = s_ready[tid];
-                mask_app = __ballot(d_app != C2A_NONE);
-                if (lane == 0) s_cnt[tid >> 6] = (u32)__popcll(mask_app);
-            }
-            __syncthreads();
-            C2A_PPROF(2);
-            u32 ticket = 0;                                          // consumed after the tournament: the round trip overlaps it
-            if (tid == 0) { const u32 tot = s_cnt[0] + s_cnt[1]; ticket = tot ? atomicAdd(&A.fcount[level + 1], tot) : 0u; }
-            if (d_app != C2A_NONE) {
-                // look-ahead for the next level: pull ginfo[] and fill[] of the appended gate's two producers into the L2
-                // now (random lines, HBM), so that next level's tickets find them there
-                const uint4 r = s_rec[tid];
-                if (r.x != C2A_NONE) pf_acc ^= A.ginfo[r.x].w ^ ld_u32<true>(&A.fill[r.x]);
-                if (r.y != C2A_NONE) pf_acc ^= A.ginfo[r.y].w ^ ld_u32<true>(&A.fill[r.y]);
-            }
-            if (active) {
-                u32 ch = C2A_NONE, ch_el = 0, ch_root = g, ch_depth = 0;
-                u64 champ[kSW] = {0, 0, 0, 0};
-                bool champ_loaded = false;
-                for (u32 eb = e0; eb < e1; eb += 16) {
-                    const u32 e = eb + l16;
-                    const bool valid = e < e1;
-                    uint4 cr = cr_first;
-                    if (eb != e0) { cr = make_uint4(0, 0, 0xFFFFFFFFu, 0); if (valid) cr = ld_u128<true>(&A.cand[e]); }
-                    const u32 c = cr.x & kIdMask, l = cr.x >> 31, cdepth = cr.y;
-                    const u32 croot = valid ? cr.z : 0xFFFFFFFFu;
-                    const u32 rmin = group_min16(croot);
-                    if (rmin > ch_root) continue;
-                    const bool keep_ch = (ch != C2A_NONE) && (ch_root == rmin);
-                    if (!keep_ch) champ_loaded = false;
-                    const bool surv = valid && croot == rmin;
-                    const u32 smask = group_ballot16(surv, l16, gshift);
-                    const u32 m = (u32)__popc(smask);
-                    if (surv) {
-                        const u32 k = (u32)__popc(smask & ((1u << l16) - 1u));
-                        s_c[gq][k] = c; s_l[gq][k] = l; s_d[gq][k] = cdepth;
-                    }
-                    group_lds_sync();
-                    C2A_PPROF(3);
-                    u32 next = 0;
-                    if (!keep_ch) { ch = s_c[gq][0]; ch_el = s_l[gq][0]; ch_depth = s_d[gq][0]; next = 1; }
-                    ch_root = rmin;
-                    while (next < m) {
-                        const u32 take = (m - next) < (u32)kSMax ? (m - next) : (u32)kSMax;
-                        bool shallow = ch_depth <= kChunkBits;
-                        for (u32 t = 0; t < take; ++t) shallow = shallow && s_d[gq][next + t] <= kChunkBits;
-                        if (shallow) {
-                            u64 sw[kSMax][kSW];
-#pragma unroll
-                            for (int t = 0; t < kSMax; ++t) {
-                                const bool on = (u32)t < take;
-                                load_str16<true>(A.pstr, on ? s_c[gq][next + t] : 0u, on ? s_d[gq][next + t] : 0u, l16, sw[t]);
-                            }
-                            if (!champ_loaded) { load_str16<true>(A.pstr, ch, ch_depth, l16, champ); champ_loaded = true; }
-                            if (A.prof && (sw[0][0] ^ champ[0]) == 0x123456789ABCDEFull) return;
-                            C2A_PPROF(4);
-#pragma unroll
-                            for (int t = 0; t < kSMax; ++t) {
-                                if ((u32)t < take) {
-                                    const u32 cc = s_c[gq][next + t], cl = s_l[gq][next + t], cd = s_d[gq][next + t];
-                                    bool less;
-                                    if (cc == ch) less = cl < ch_el;
-                                    else less = str_less16(sw[t], cd, cl, champ, ch_depth, ch_el, l16, gshift);
-                                    if (less) {
-                                        ch = cc; ch_el = cl; ch_depth = cd;
-#pragma unroll
-                                        for (int k = 0; k < kSW; ++k) champ[k] = sw[t][k];
-                                    }
-                                }
-                            }
-                        } else {
-                            // deep trees: chunk resolution (cprev hops) and string loads per comparison
-                            for (u32 t = 0; t < take; ++t) {
-                                const u32 cc = s_c[gq][next + t], cl = s_l[gq][next + t], cd = s_d[gq][next + t];
-                                bool less;
-                                if (cc == ch) less = cl < ch_el;
-                                else {
-                                    u32 ra = cc, rb = ch, lena, lenb, ba, bb;
-                                    resolve_chunks<true>(A.cprev, ra, lena, ba, cd, rb, lenb, bb, ch_depth);
-                                    if (ra == rb) {
-                                        if (ba != C2A_NONE) less = (u32)(ld_u64<true>(A.pstr + (u64)ba * kChunkWords) & 1ull) < ch_el;
-                                        else less = cl < (u32)(ld_u64<true>(A.pstr + (u64)bb * kChunkWords) & 1ull);
-                                    } else {
-                                        u64 wa[kSW], wb[kSW];
-                                        load_str16<true>(A.pstr, ra, lena, l16, wa);
-                                        load_str16<true>(A.pstr, rb, lenb, l16, wb);
-                                        less = str_less16(wa, lena, cl, wb, lenb, ch_el, l16, gshift);
-                                    }
-                                }
-                                if (less) { ch = cc; ch_el = cl; ch_depth = cd; champ_loaded = false; }
-                            }
-                        }
-                        next += take;
-                    }
-                    group_lds_sync();
-                }
-                C2A_PPROF(5);
-                const u32 depth = ch == C2A_NONE ? 0u : ch_depth + 1;
-                const u32 my_label = ch == C2A_NONE ? 0u : ch_el;
-                const u32 pos = lo + i;
-                if (l16 == 0) {
-                    A.meta[pos] = make_uint4(ch, depth, ch_root, my_label);
-                    A.order[pos] = g;
-                    A.posof[g] = pos;
-                    if (ch != C2A_NONE) A.child[2 * (u64)ch + my_label] = pos;
-                }
-                if (dl != C2A_NONE) A.cand[gd.z + kfill] = make_uint4(pos | (l16 << 31), depth, ch_root, my_label);   // l16 == edge label
-                if (ch != C2A_NONE) {
-                    const bool need_parent = ch_depth != 0 && chunk_of(depth) == chunk_of(ch_depth);
-                    if (need_parent && !champ_loaded) load_str16<true>(A.pstr, ch, chunk_len(ch_depth), l16, champ);
-                    const u32 len = chunk_len(depth);
-                    bool fresh = false;
-#pragma unroll
-                    for (int k = 0; k < kSW; ++k) {
-                        const u32 word = (u32)k * 16 + l16;
-                        const u64 v = child_word(need_parent ? champ[k] : 0ull, ch_depth, my_label, word, fresh);
-                        if (word * 64 < len) A.pstr[(u64)pos * kChunkWords + word] = v;
-                    }
-                    if (l16 == 0 && chunk_of(depth)) A.cprev[pos] = fresh ? ch : ld_u32<true>(&A.cprev[ch]);
-                }
-            }
-            C2A_PPROF(6);
-            if (tid == 0) s_base = ticket;
-            __syncthreads();
-            if (d_app != C2A_NONE) {
-                const u32 p = s_base + (tid >= 64 ? s_cnt[0] : 0u) + (u32)__popcll(mask_app & ((1ull << lane) - 1ull));
-                const uint4 r = s_rec[tid];
-                nxt[p].b = make_uint4(r.w, 0, 0, 0);
-                nxt[p].a = make_uint4(d_app, r.x, r.y, r.z);
-            }
-            __syncthreads();
-        }
-        // ---- level barrier: every wave's (write-through) stores are in the L2, then arrive / wait
-#ifndef C2A_EMULATE
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        __syncthreads();
-        ++epoch;
-        if (tid == 0) {
-            const u32 a = atomicAdd(&ctl->arrive, 1u);
-            if (a == P * epoch - 1) st_u32<true>(&ctl->gen, epoch);
-            while (ld_u32<true>(&ctl->gen) < epoch) __builtin_amdgcn_s_sleep(1);
-            s_nf = ld_u32<true>(&A.fcount[level + 1]);
-        }
-        lo += n_front;
-        __syncthreads();
-        C2A_PPROF(7);
     }
 }
 

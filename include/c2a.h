@@ -77,9 +77,9 @@ typedef struct c2a_stats {
     uint32_t max_depth;          /* depth of the DFS tree */
     uint32_t n_roots;            /* DFS roots (children of the virtual root) */
     uint32_t n_splitters;        /* list-ranking sublists */
-    uint32_t level_launches;     /* peel kernel launches (incl. empty tail launches and the persistent one) */
-    uint32_t anc_planes;
-    uint32_t persistent_wgs;     /* workgroups that took part in the persistent peel launch (0 = not used) */
+    uint32_t level_launches;     /* peel kernel launches (incl. empty tail launches) */
+    uint32_t frontier_segments;  /* independent append counters / slot regions of the peel frontier */
+    uint32_t path_chunks;        /* 4096-bit path-string chunks the deepest DFS path spans (1 = every comparison is one round trip) */
     uint32_t reserved;
 } c2a_stats;
 

@@ -90,40 +90,22 @@ def backend(request, c2a):
     be.close()
 
 
-def _variant(kind, mode, rep):
+def _variant(kind, mode):
     marks = [pytest.mark.gpu] if kind == "hip" else []
-    return pytest.param((kind, mode, rep), id=f"{kind}-{rep}-{mode}", marks=marks)
+    return pytest.param((kind, mode), id=f"{kind}-{mode}", marks=marks)
 
 
-# (library build, kernel shape, path representation).  "str" = path bit-strings (library default), "rows" = base-16 /
-# base-64 ancestor rows.  The persistent single-XCD launch and the 256-byte rows exist for the rows representation only.
-WAVE_BACKENDS = [
-    _variant("emul", "wpb4", "str"), _variant("emul", "wpb4", "rows"), _variant("emul", "lane", "rows"),
-    _variant("emul", "persist-sc1", "rows"), _variant("emul", "base64", "rows"),
-    _variant("emul", "persist", "str"), _variant("emul", "persist-cap48", "str"),
-    _variant("hip", "persist", "str"), _variant("hip", "persist-cap48", "str"), _variant("hip", "persist-cap2048", "str"),
-    _variant("hip", "wpb4", "str"), _variant("hip", "wpb8", "str"), _variant("hip", "wpb16", "str"), _variant("hip", "lane", "str"),
-    _variant("hip", "wpb4", "rows"), _variant("hip", "wpb8", "rows"), _variant("hip", "wpb16", "rows"), _variant("hip", "lane", "rows"),
-    _variant("hip", "persist-sc1", "rows"), _variant("hip", "persist-fence", "rows"), _variant("hip", "base64", "rows")]
+# (library build, kernel shape of the per-level peel)
+WAVE_BACKENDS = [_variant("emul", "wpb4"), _variant("emul", "lane"),
+                 _variant("hip", "wpb4"), _variant("hip", "wpb8"), _variant("hip", "wpb16"), _variant("hip", "lane")]
 
 
 @pytest.fixture(params=WAVE_BACKENDS)
 def backend_wave(request, c2a):
-    """Every level (however wide) through the wave-per-gate kernel, at each workgroup shape; every level through the
-    lane-per-gate kernel; and everything after the first batch through the persistent single-XCD kernel — for both
-    representations of tree paths."""
-    kind, mode, rep = request.param
-    kv = {"C2A_PEEL_STRINGS": 1 if rep == "str" else 0}
-    if mode == "lane":
-        kv["C2A_PEEL_WAVE_MAX"] = 0
-    elif mode == "base64":         # 256-byte ancestor rows (default is base 16)
-        kv["C2A_ANC_BITS"] = 6
-    elif mode.startswith("persist-cap"):   # persistent launch that hands wide levels back to the launch-per-level kernels
-        kv.update(C2A_PEEL_PERSIST_MAX=int(mode[11:]))
-    elif mode.startswith("persist"):   # the single-XCD persistent launch for every level after the first batch
-        kv.update(C2A_PEEL_PERSIST_MAX=1 << 30, C2A_ANC_BITS=4, C2A_PEEL_PERSIST_SC1=1 if mode == "persist-sc1" else 0)
-    else:
-        kv.update(C2A_PEEL_WAVE_MAX=1 << 30, C2A_PEEL_WPB=int(mode[3:]))
+    """Every level (however wide) through the wave-per-gate kernel, at each workgroup shape, and every level through the
+    lane-per-gate kernel."""
+    kind, mode = request.param
+    kv = {"C2A_PEEL_WAVE_MAX": 0} if mode == "lane" else {"C2A_PEEL_WAVE_MAX": 1 << 30, "C2A_PEEL_WPB": int(mode[3:])}
     with _Env(**kv):
         be = c2a.Backend(0, lib_path=request.getfixturevalue("emul_lib")) if kind == "emul" else c2a.Backend(0)
     yield be

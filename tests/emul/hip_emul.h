@@ -5,11 +5,14 @@
 // through the same C ABI by the `-m "not gpu"` tests.  The product library (libc2a_hip.so) never
 // includes this file and the Python host layer never loads the emulated library.
 //
-// Model: one OS thread; a launch runs blocks sequentially; the threads of a block are ucontext fibers
-// that run round-robin between __syncthreads() calls.  Atomics are plain read-modify-writes.
+// Model: one OS thread; a launch runs blocks sequentially; the threads of a block are fibers (a 12-instruction
+// x86-64 stack switch: glibc's swapcontext makes a sigprocmask system call per switch) that run round-robin
+// between __syncthreads() calls.  Atomics are plain read-modify-writes.
 // Wave-level intrinsics (__ballot, __shfl*, __any, __all) rendezvous the 64 fibers of a wave.
 #pragma once
-#include <ucontext.h>
+#if !defined(__x86_64__)
+#error "hip_emul.h: the fiber switch is written for x86-64"
+#endif
 
 #include <algorithm>
 #include <chrono>
@@ -36,9 +39,35 @@ struct uint2 { unsigned x, y; };
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 
+// void hipemu_switch(void** save_sp, void* load_sp): park the caller (callee-saved registers on its stack, stack
+// pointer in *save_sp) and resume the context whose stack pointer is load_sp
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+__asm__(R"(
+.text
+.weak hipemu_switch
+.type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size hipemu_switch,.-hipemu_switch
+)");
+
 namespace hipemu {
 struct Fiber {
-    ucontext_t ctx;
+    void* sp = nullptr;
     char* stack = nullptr;
     dim3 tid;
     bool done = false;
@@ -47,7 +76,7 @@ struct Fiber {
 struct State {
     dim3 tid, bid, bdim, gdim;
     Fiber* cur = nullptr;
-    ucontext_t sched;
+    void* sched_sp = nullptr;
     std::function<void()> body;
     // wave rendezvous scratch
     unsigned long long wave_vals[64];
@@ -59,15 +88,22 @@ inline void trampoline() {
     State& s = st();
     s.body();
     s.cur->done = true;
-    swapcontext(&s.cur->ctx, &s.sched);
+    hipemu_switch(&s.cur->sp, s.sched_sp);
+    std::abort();      // a finished fiber is never resumed
 }
 inline void yield(int kind) {
     State& s = st();
     if (!s.cur) { std::fprintf(stderr, "hip_emul: sync primitive used in a NOSYNC launch\n"); std::abort(); }
     s.cur->wait_kind = kind;
-    swapcontext(&s.cur->ctx, &s.sched);
+    hipemu_switch(&s.cur->sp, s.sched_sp);
 }
 constexpr size_t kStack = 256 * 1024;
+// fiber stacks are reused by every launch (a 256 KB malloc is an mmap + page faults each time)
+inline char* stack_pool(unsigned t) {
+    static std::vector<char*> pool;
+    while (pool.size() <= t) pool.push_back((char*)std::malloc(kStack));
+    return pool[t];
+}
 
 template <class F>
 void run_block_fibers(unsigned nthreads, dim3 bdim, F&& per_thread) {
@@ -75,13 +111,14 @@ void run_block_fibers(unsigned nthreads, dim3 bdim, F&& per_thread) {
     std::vector<Fiber> fibers(nthreads);
     for (unsigned t = 0; t < nthreads; ++t) {
         Fiber& f = fibers[t];
-        f.stack = (char*)std::malloc(kStack);
+        f.stack = stack_pool(t);
         f.tid = dim3(t % bdim.x, (t / bdim.x) % bdim.y, t / (bdim.x * bdim.y));
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = f.stack;
-        f.ctx.uc_stack.ss_size = kStack;
-        f.ctx.uc_link = &s.sched;
-        makecontext(&f.ctx, (void (*)())trampoline, 0);
+        // first switch "returns" into trampoline with the stack aligned as after a call
+        void** top = reinterpret_cast<void**>((reinterpret_cast<uintptr_t>(f.stack) + kStack) & ~uintptr_t(15));
+        top[-1] = nullptr;                                   // trampoline's (unused) return address
+        top[-2] = reinterpret_cast<void*>(&trampoline);
+        for (int r = 3; r <= 8; ++r) top[-r] = nullptr;      // rbp rbx r12 r13 r14 r15
+        f.sp = top - 8;
     }
     s.body = per_thread;
     // Waves are scheduled as units so that wave rendezvous complete: run each wave's fibers round-robin
@@ -98,7 +135,7 @@ void run_block_fibers(unsigned nthreads, dim3 bdim, F&& per_thread) {
                     if (f.done || f.wait_kind == 1) continue;
                     f.wait_kind = 0;
                     s.cur = &f; s.tid = f.tid;
-                    swapcontext(&s.sched, &f.ctx);
+                    hipemu_switch(&s.sched_sp, f.sp);
                     progressed = true;
                 }
                 bool all_parked = true;
@@ -111,7 +148,6 @@ void run_block_fibers(unsigned nthreads, dim3 bdim, F&& per_thread) {
         if (!any_alive) break;
     }
     s.cur = nullptr;
-    for (auto& f : fibers) std::free(f.stack);
 }
 }  // namespace hipemu
 

@@ -115,7 +115,7 @@ def test_layered_dags(backend, orc, c2a, layers, width, window):
     assert st["levels"] >= layers
 
 
-def test_deep_chain_exercises_upper_ancestor_planes(backend, orc):
+def test_deep_chain_exercises_path_string_chunks(backend, orc):
     """A 9000-deep dependency chain with side branches: tree depth > 16^3, so all four base-16 digit planes
     of the ancestor table and the long level-ancestor jumps are used."""
     rng = np.random.default_rng(5)
