@@ -41,7 +41,10 @@ struct c2a_ctx {
     int n_cu = 256;
     u32 peel_wave_max = 8192;      // frontier size up to which a level gets one wave per gate
     u32 bool_chunk = 256;          // arithmetic gates per k_boolify workgroup: 128, 256 (measured best) or 512
-    u32 peel_wpb = 16;             // waves per workgroup in wave mode incl. the append wave for 16: 4+1, 8+1 or 15+1 (15+1 measured best)
+    u32 peel_async_waves = 6;      // dataflow launch: waves per CU
+    u32 peel_async = 1;            // 1: the whole peel as ONE dataflow launch (k_peel_async), 0: one launch per reverse Kahn level
+    u32 peel_wpb = 16;             // waves per workgroup in wave mode (one of them is the append wave): 4, 8, 12 or 16
+    u32 peel_slack_pct = 125;      // wave-mode grid = this % of the largest recent frontier (growth inside a batch of launches)
 
     // problem
     u32 n = 0, n_nodes = 0, n_in = 0, n_out = 0;
@@ -53,30 +56,28 @@ struct c2a_ctx {
 
     // device buffers
     DevBuf lh, rh, out, op, gate4, in_nodes, out_nodes;
-    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, fill, cand, meta, pstr, cprev, fring, fbase, order, posof, child, ginfo, slots0, slots1;
+    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, eslot, link, aq_ht, aq_items, aq_idle, fill, cand, meta, pstr, cprev, fring, fbase, order, posof, child, ginfo, slots0, slots1;
     DevBuf rflag, ridx, rlist, next, owner, local, slist, snext, ssum, jnxt, jval, sorted;
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op;
     DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof;
     DevBuf tsz, asz, goff, aoff, tmpl, tables, b_in0, b_in1, b_out, b_op;
-    DevBuf ev_produced, ev_spos, ev_aval, ev_bval, cb_in0, cb_in1, cb_out, cb_op;
+    DevBuf ev_produced, ev_spos, ev_aval, ev_bval, ev_lcount, ev_lbase, ev_lorder, cb_in0, cb_in1, cb_out, cb_op;
     bool bool_planned = false;
-    std::vector<u32> h_fbase;      // level boundaries of the last peel (host copy)
-    u32 n_levels_run = 0;
     std::vector<DevBuf*> all;
 
     c2a_ctx() {
-        all = {&lh, &rh, &out, &op, &gate4, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &fill, &cand,
+        all = {&lh, &rh, &out, &op, &gate4, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &link, &aq_ht, &aq_items, &aq_idle, &fill, &cand,
                &ginfo, &slots0, &slots1, &meta, &pstr, &cprev, &fring, &fbase, &order, &posof, &child, &rflag, &ridx, &rlist, &next,
                &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
                &node_wire, &e_in0, &e_in1, &e_out, &e_op, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &tsz, &asz, &goff,
-               &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &cb_in0, &cb_in1, &cb_out, &cb_op};
+               &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &ev_lcount, &ev_lbase, &ev_lorder, &cb_in0, &cb_in1, &cb_out, &cb_op};
     }
 };
 
 namespace {
 
 // scalars block layout (u32 words unless noted)
-enum Scalar { SC_MAXDEPTH = 0, SC_SCOUNT = 1, SC_ERR = 2, SC_NMID = 3, SC_NROOTS = 4, SC_LEVELS = 5, SC_PEELED = 6 /*2 words*/, SC_DFS = 8 /*3 words*/,
+enum Scalar { SC_MAXDEPTH = 0, SC_SCOUNT = 1, SC_ERR = 2, SC_NMID = 3, SC_NROOTS = 4, SC_LEVELS = 5, SC_PEELED = 6 /*2 words*/, SC_DFS = 8 /*3 words*/, SC_ASYNC = 48 /*3 words*/,
               SC_TOTAL64 = 16 /* u64 slots from here: 16..31 */, SC_WORDS = 64 };
 
 int fail(c2a_ctx* c, int code, const std::string& msg) {
@@ -180,13 +181,51 @@ int do_prep(c2a_ctx* c) {
     HIP_TRY(hipMemsetAsync(c->scalars.p, 0, SC_WORDS * 4, s));
     C2A_LAUNCH_NOSYNC(k_producer, G, kThreads, s, n, c->out.as<u32>(), c->prod1.as<u32>());
     C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->prod1.as<u32>(), c->dep0.as<u32>(),
-                      c->dep1.as<u32>(), c->cons_cnt.as<u32>());
+                      c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>());
     int r = scan_exclusive<u32>(c, c->cons_cnt.as<u32>(), c->cons_off.as<u32>(), n);
     if (r) return r;
     C2A_LAUNCH_NOSYNC(k_ginfo, G, kThreads, s, n, c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_off.as<u32>(),
                       c->cons_cnt.as<u32>(), c->ginfo.as<uint4>());
-    C2A_LAUNCH(k_init_frontier, grid_seg(grid_for(n, 4096)), kThreads, s, n, seg_capacity(n), (const uint4*)c->ginfo.as<uint4>(),
-               c->slots0.as<FrontierSlot>(), c->fring.as<u32>());
+    if (!c->peel_async)
+        C2A_LAUNCH(k_init_frontier, grid_seg(grid_for(n, 4096)), kThreads, s, n, seg_capacity(n), (const uint4*)c->ginfo.as<uint4>(),
+                   c->slots0.as<FrontierSlot>(), c->fring.as<u32>());
+    return C2A_OK;
+}
+
+// The whole peel as one dataflow launch (+ one grid-stride launch for the sinks): see k_peel_async.
+int do_peel_async(c2a_ctx* c, u32* peeled_out) {
+    const u32 n = c->n;
+    hipStream_t s = c->stream;
+    AsyncArgs A;
+    A.n = n; A.seg_cap = seg_capacity(n); A.ginfo = c->ginfo.as<uint4>(); A.eslot = c->eslot.as<u32>();
+    A.seeds = c->slots0.as<FrontierSlot>(); A.seed_cnt = c->fring.as<u32>();
+    A.cand = c->cand.as<uint4>(); A.fill = c->fill.as<u32>(); A.meta = c->meta.as<uint4>(); A.pstr = c->pstr.as<u64>();
+    A.cprev = c->cprev.as<u32>(); A.child = c->child.as<u32>(); A.link = c->link.as<u32>();
+    A.totals = c->scalars.as<u32>() + SC_ASYNC;
+#ifdef C2A_EMULATE
+    const u32 waves = kSeg;                          // the emulation runs them one after the other
+#else
+    const u32 waves = grid_seg((u32)c->n_cu * c->peel_async_waves);
+#endif
+    // hand-off queues: every entry is used once per run (no wrap-around); a wave spreads its pushes round robin, so
+    // a queue receives at most pushes / n_queues + waves entries
+    A.n_queues = std::max<u32>(1u, waves / 4);
+    A.q_cap = n / A.n_queues + waves + 64;
+    ENSURE(c->aq_ht, (size_t)A.n_queues * kQStride * 8); ENSURE(c->aq_items, (size_t)A.n_queues * A.q_cap * 4); ENSURE(c->aq_idle, (size_t)kIdleCounters * 64);
+    HIP_TRY(hipMemsetAsync(c->aq_ht.p, 0, (size_t)A.n_queues * kQStride * 8, s));
+    HIP_TRY(hipMemsetAsync(c->aq_items.p, 0, (size_t)A.n_queues * A.q_cap * 4, s));
+    HIP_TRY(hipMemsetAsync(c->aq_idle.p, 0, (size_t)kIdleCounters * 64, s));
+    A.q_ht = c->aq_ht.as<u64>(); A.q_items = c->aq_items.as<u32>(); A.idle = c->aq_idle.as<u32>();
+    C2A_LAUNCH(k_async_sinks, grid_seg(grid_for(n, 4096)), kThreads, s, A);
+    C2A_LAUNCH(k_peel_async, waves, 64, s, A);
+    C2A_LAUNCH_NOSYNC(k_identity, grid_for(n, 4096), kThreads, s, n, c->order.as<u32>(), c->posof.as<u32>());
+    u32 t2[3] = {0, 0, 0};
+    int r = read_scalars(c, t2, SC_ASYNC, 3);
+    if (r) return r;
+    if (t2[2]) return fail(c, C2A_ERR_HIP, "dataflow peel: watchdog tripped (" + std::to_string(t2[2]) + " waves gave up waiting)");
+    *peeled_out = t2[0];
+    c->stats.levels = t2[0] ? t2[1] + 1 : 0;
+    c->stats.level_launches = 2;
     return C2A_OK;
 }
 
@@ -223,22 +262,24 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
         // narrow frontier -> one wave per gate (latency ~ one path comparison per level);
         // wide frontier   -> one lane per gate (throughput)
         const bool wave_mode = level > 0 && est <= c->peel_wave_max;
-        const u32 wpb_sel = c->peel_wpb;
-        const u32 wpb = wpb_sel == 16 ? 15u : wpb_sel;   // 16 waves per workgroup = 15 gate waves + the append wave
-        // per segment: ~est / kSeg gates (+25 % for growth inside the batch), WPB or 256 per workgroup
-        const u32 per_seg = wave_mode ? (u32)(((u64)est * 5 / 4 / kSeg + wpb - 1) / wpb) + 1
+        const u32 wg_waves = c->peel_wpb;                // waves per workgroup: wg_waves - 1 gate waves + the append wave
+        const u32 wpb = wg_waves - 1;
+        // per segment: ~est / kSeg gates (+ slack for growth inside the batch), WPB or 256 per workgroup
+        const u32 per_seg = wave_mode ? (u32)(((u64)est * c->peel_slack_pct / 100 / kSeg + wpb - 1) / wpb) + 1
                                       : (u32)(((u64)est * 2 / kSeg + kThreads - 1) / kThreads);
         const u32 blocks = std::max<u32>(kSeg, std::min<u32>(max_blocks, per_seg * kSeg));
         for (u32 i = 0; i < batch; ++i) {
             if (!wave_mode) C2A_LAUNCH(k_peel_level_str, blocks, kThreads, s, A, level);
             else if (profiling) {
-                if (wpb_sel == 16) C2A_LAUNCH((k_peel_level_wave_str<15, true>), blocks, 1024, s, A, level);
-                else if (wpb_sel == 8) C2A_LAUNCH((k_peel_level_wave_str<8, true>), blocks, 576, s, A, level);
-                else C2A_LAUNCH((k_peel_level_wave_str<4, true>), blocks, 320, s, A, level);
+                if (wg_waves == 16) C2A_LAUNCH((k_peel_level_wave_str<15, true>), blocks, 1024, s, A, level);
+                else if (wg_waves == 12) C2A_LAUNCH((k_peel_level_wave_str<11, true>), blocks, 768, s, A, level);
+                else if (wg_waves == 8) C2A_LAUNCH((k_peel_level_wave_str<7, true>), blocks, 512, s, A, level);
+                else C2A_LAUNCH((k_peel_level_wave_str<3, true>), blocks, 256, s, A, level);
             } else {
-                if (wpb_sel == 16) C2A_LAUNCH((k_peel_level_wave_str<15, false>), blocks, 1024, s, A, level);
-                else if (wpb_sel == 8) C2A_LAUNCH((k_peel_level_wave_str<8, false>), blocks, 576, s, A, level);
-                else C2A_LAUNCH((k_peel_level_wave_str<4, false>), blocks, 320, s, A, level);
+                if (wg_waves == 16) C2A_LAUNCH((k_peel_level_wave_str<15, false>), blocks, 1024, s, A, level);
+                else if (wg_waves == 12) C2A_LAUNCH((k_peel_level_wave_str<11, false>), blocks, 768, s, A, level);
+                else if (wg_waves == 8) C2A_LAUNCH((k_peel_level_wave_str<7, false>), blocks, 512, s, A, level);
+                else C2A_LAUNCH((k_peel_level_wave_str<3, false>), blocks, 256, s, A, level);
             }
             ++level; ++launches;
             if (level > n) break;
@@ -266,7 +307,6 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
         if (r) return r;
         peeled = t2[0];
         c->stats.levels = t2[1];
-        c->n_levels_run = level;
     }
     c->stats.level_launches = launches;
     if (profiling) {   // diagnostics: mean over levels of the slowest wave's phase timestamps (ns since kernel entry)
@@ -399,7 +439,7 @@ int do_topo_sort(c2a_ctx* c, u64* cycle_at) {
     if (r) return r;
     rec(c, EV_PREP1);
     u32 peeled = 0;
-    r = do_peel(c, &peeled);
+    r = c->peel_async ? do_peel_async(c, &peeled) : do_peel(c, &peeled);
     if (r) return r;
     rec(c, EV_PEEL1);
     {
@@ -522,7 +562,10 @@ int c2a_create(int device_id, c2a_ctx** out) {
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
         c->n_cu = prop.multiProcessorCount;
     if (const char* e = std::getenv("C2A_BOOL_CHUNK")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 128 || v == 256 || v == 512) c->bool_chunk = v; }
-    if (const char* e = std::getenv("C2A_PEEL_WPB")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 4 || v == 8 || v == 16) c->peel_wpb = v; }
+    if (const char* e = std::getenv("C2A_PEEL_ASYNC")) c->peel_async = std::strtoul(e, nullptr, 10) != 0;
+    if (const char* e = std::getenv("C2A_PEEL_ASYNC_WAVES")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 32) c->peel_async_waves = v; }
+    if (const char* e = std::getenv("C2A_PEEL_WPB")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 4 || v == 8 || v == 12 || v == 16) c->peel_wpb = v; }
+    if (const char* e = std::getenv("C2A_PEEL_SLACK")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 100 && v <= 400) c->peel_slack_pct = v; }
     if (const char* e = std::getenv("C2A_PEEL_WAVE_MAX")) c->peel_wave_max = (u32)std::strtoul(e, nullptr, 10);   // tuning / test knob
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return C2A_ERR_HIP; }
     for (int i = 0; i < EV_COUNT; ++i)
@@ -569,7 +612,7 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     ENSURE(c->lh, n4); ENSURE(c->rh, n4); ENSURE(c->out, n4); ENSURE(c->op, n); ENSURE(c->gate4, (size_t)n * 16);
     ENSURE(c->in_nodes, (size_t)n_in * 4); ENSURE(c->out_nodes, (size_t)n_out * 4);
     ENSURE(c->prod1, nn4); ENSURE(c->dep0, n4); ENSURE(c->dep1, n4); ENSURE(c->cons_cnt, n4);
-    ENSURE(c->cons_off, n4 + 4); ENSURE(c->fill, n4); ENSURE(c->cand, (size_t)n * 2 * 16);
+    ENSURE(c->cons_off, n4 + 4); ENSURE(c->eslot, 2 * n4); ENSURE(c->link, n4); ENSURE(c->fill, n4); ENSURE(c->cand, (size_t)n * 2 * 16);
     ENSURE(c->meta, (size_t)n * 16); ENSURE(c->ginfo, (size_t)n * 16);
     ENSURE(c->slots0, (size_t)kSeg * seg_capacity(n) * sizeof(FrontierSlot)); ENSURE(c->slots1, (size_t)kSeg * seg_capacity(n) * sizeof(FrontierSlot));
 
@@ -624,7 +667,7 @@ int c2a_topo_sort_serial(c2a_ctx* c, uint32_t* sorted, uint64_t* cycle_at) {
     const u32 G = grid_for(c->n, 4096);
     C2A_LAUNCH_NOSYNC(k_producer, G, kThreads, c->stream, c->n, c->out.as<u32>(), c->prod1.as<u32>());
     C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, c->stream, c->n, c->lh.as<u32>(), c->rh.as<u32>(), c->prod1.as<u32>(),
-                      c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_cnt.as<u32>());
+                      c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>());
     u32 status = 0;
     u64 at = 0;
     int r = run_serial_dfs(c, &status, &at);
@@ -890,21 +933,29 @@ int c2a_verify_boolify(c2a_ctx* c, uint64_t seed, uint64_t* n_checked, uint64_t*
     if (wc)
         C2A_LAUNCH_NOSYNC(k_eval_init, grid_for((u64)wc * 64, 8192), kThreads, s, wc, width, M, out_base, (u64)seed,
                           (const u8*)c->ev_produced.as<u8>(), c->ev_aval.as<u64>(), c->ev_bval.as<u64>());
-    // the peel's level lists, last level first: producers before consumers, gates of one level independent
-    const u32 L = c->n_levels_run;
-    std::vector<u32> fb((size_t)L + 1, 0);               // fbase[k+1] is written by the launch of level k: valid up to index L
+    // level lists (gates of one reverse Kahn level are independent), last level first: producers before consumers
+    const u32 L = c->stats.levels;
+    std::vector<u32> fb((size_t)L + 1, 0);
     if (n) {
-        HIP_TRY(hipMemcpyAsync(fb.data(), c->fbase.p, ((size_t)L + 1) * 4, hipMemcpyDeviceToHost, s));
+        ENSURE(c->ev_lcount, ((size_t)L + 1) * 4); ENSURE(c->ev_lbase, ((size_t)L + 2) * 4); ENSURE(c->ev_lorder, (size_t)n * 4);
+        HIP_TRY(hipMemsetAsync(c->ev_lcount.p, 0, ((size_t)L + 1) * 4, s));
+        C2A_LAUNCH_NOSYNC(k_level_hist, grid_for(n, 4096), kThreads, s, n, (const uint4*)c->meta.as<uint4>(), c->ev_lcount.as<u32>());
+        int r = scan_exclusive<u32>(c, c->ev_lcount.as<u32>(), c->ev_lbase.as<u32>(), L);
+        if (r) return r;
+        HIP_TRY(hipMemsetAsync(c->ev_lcount.p, 0, ((size_t)L + 1) * 4, s));
+        C2A_LAUNCH_NOSYNC(k_level_scatter, grid_for(n, 4096), kThreads, s, n, (const uint4*)c->meta.as<uint4>(), (const u32*)c->order.as<u32>(),
+                          (const u32*)c->ev_lbase.as<u32>(), c->ev_lcount.as<u32>(), c->ev_lorder.as<u32>());
+        HIP_TRY(hipMemcpyAsync(fb.data(), c->ev_lbase.p, ((size_t)L + 1) * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
     for (u32 lv = L; n && lv-- > 0;) {
         const u32 lo = fb[lv], hi = fb[lv + 1];
         if (hi <= lo || hi > n) continue;
         const u32 cnt = hi - lo;
-        C2A_LAUNCH_NOSYNC(k_eval_level_arith, grid_for((u64)cnt * 64, 4096), kThreads, s, lo, cnt, width, c->order.as<u32>(),
+        C2A_LAUNCH_NOSYNC(k_eval_level_arith, grid_for((u64)cnt * 64, 4096), kThreads, s, lo, cnt, width, c->ev_lorder.as<u32>(),
                           c->ev_spos.as<u32>(), c->e_in0.as<u32>(), c->e_in1.as<u32>(), c->e_out.as<u32>(), c->e_op.as<u8>(),
                           c->ev_aval.as<u64>());
-        C2A_LAUNCH_NOSYNC(k_eval_level_bool, grid_for(cnt, 4096), kThreads, s, lo, cnt, c->order.as<u32>(), c->ev_spos.as<u32>(),
+        C2A_LAUNCH_NOSYNC(k_eval_level_bool, grid_for(cnt, 4096), kThreads, s, lo, cnt, c->ev_lorder.as<u32>(), c->ev_spos.as<u32>(),
                           (const u64*)c->goff.as<u64>(), c->b_in0.as<u32>(), c->b_in1.as<u32>(), c->b_out.as<u32>(),
                           c->b_op.as<u8>(), c->ev_bval.as<u64>());
     }

@@ -84,7 +84,7 @@ __global__ void k_producer(u32 n, const u32* __restrict__ out, u32* prod1) {
 // deps closure (compiler.rs:408-421) + consumer counts.  dep1 is dropped when equal to dep0: a second
 // visit of the same gate is a no-op in the DFS (topological_sort.rs:30-32).
 __global__ void k_deps(u32 n, const u32* __restrict__ lh, const u32* __restrict__ rh, const u32* __restrict__ prod1,
-                       u32* dep0, u32* dep1, u32* cons_cnt) {
+                       u32* dep0, u32* dep1, u32* cons_cnt, u32* eslot) {
     for (u64 g = gtid(); g < n; g += gstride()) {
         const u32 p0 = prod1[lh[g]], p1 = prod1[rh[g]];
         const u32 d0 = p0 ? p0 - 1 : C2A_NONE;
@@ -92,8 +92,9 @@ __global__ void k_deps(u32 n, const u32* __restrict__ lh, const u32* __restrict_
         if (d1 == d0) d1 = C2A_NONE;
         dep0[g] = d0;
         dep1[g] = d1;
-        if (d0 != C2A_NONE) atomicAdd(&cons_cnt[d0], 1u);
-        if (d1 != C2A_NONE) atomicAdd(&cons_cnt[d1], 1u);
+        // eslot[2g + l] = index of the edge (g, l) in its producer's consumer list: a static home for the candidate record
+        eslot[2 * g] = d0 != C2A_NONE ? atomicAdd(&cons_cnt[d0], 1u) : 0u;
+        eslot[2 * g + 1] = d1 != C2A_NONE ? atomicAdd(&cons_cnt[d1], 1u) : 0u;
     }
 }
 
@@ -177,7 +178,7 @@ __global__ void k_peel_totals(const u32* __restrict__ fbase, u32 n_levels, u32* 
 // peel one level + pick DFS-tree parents
 // ------------------------------------------------------------------------------------------------
 // Tree node == peel position: nodes of recent levels are contiguous in every per-node table.
-// meta[pos] = {parent pos | NONE, depth, root gate id, label of the edge parent->node}.
+// meta[pos] = {parent pos | NONE, depth, root gate id, label of the edge parent->node | reverse Kahn level << 1}.
 // Candidate lists are filled as consumers are peeled, AFTER their tournament, with everything a comparison
 // starts from: cand[cons_off[d] + k] = {consumer pos | edge label << 31, consumer depth, consumer root, consumer's
 // own edge label}; the push that completes d's list (k + 1 == cons_cnt[d]) appends d to the next frontier.
@@ -324,16 +325,17 @@ __device__ __forceinline__ u32 ctz64(u64 x) { return (u32)__ffsll((long long)x) 
 // Bring two distinct tree nodes under one root to the first chunk in which their paths can differ.
 // a/b: positions (in/out), lena/lenb: bits of that chunk (out); below_a/below_b: when a (b) had to climb, the
 // node of its chain one chunk below the returned one (its bit 0 is the label right after the returned chunk).
-__device__ __forceinline__ void resolve_chunks(const u32* __restrict__ cprev, u32& a, u32& lena, u32& below_a, u32 da, u32& b,
+template <bool SC1 = false>
+__device__ __forceinline__ void resolve_chunks(const u32* cprev, u32& a, u32& lena, u32& below_a, u32 da, u32& b,
                                                u32& lenb, u32& below_b, u32 db) {
     u32 ia = chunk_of(da), ib = chunk_of(db);
     lena = chunk_len(da); lenb = chunk_len(db);
     below_a = C2A_NONE; below_b = C2A_NONE;
     if ((ia | ib) == 0) return;
-    while (ia > ib) { below_a = a; a = cprev[a]; --ia; lena = kChunkBits; }
-    while (ib > ia) { below_b = b; b = cprev[b]; --ib; lenb = kChunkBits; }
+    while (ia > ib) { below_a = a; a = ld_u32<SC1>(&cprev[a]); --ia; lena = kChunkBits; }
+    while (ib > ia) { below_b = b; b = ld_u32<SC1>(&cprev[b]); --ib; lenb = kChunkBits; }
     while (ia > 0 && a != b) {
-        const u32 pa = cprev[a], pb = cprev[b];
+        const u32 pa = ld_u32<SC1>(&cprev[a]), pb = ld_u32<SC1>(&cprev[b]);
         if (pa == pb) break;
         below_a = a; below_b = b;
         a = pa; b = pb; --ia;
@@ -451,7 +453,7 @@ __global__ void __launch_bounds__(kThreads) k_peel_level_str(PeelArgs A, u32 lev
             }
             const u32 depth = best == C2A_NONE ? 0u : best_depth + 1;
             const u32 my_label = best == C2A_NONE ? 0u : best_el;
-            A.meta[pos] = make_uint4(best, depth, best_root, my_label);
+            A.meta[pos] = make_uint4(best, depth, best_root, my_label | (level << 1));
             A.order[pos] = g;
             A.posof[g] = pos;
             if (best != C2A_NONE) {
@@ -690,7 +692,7 @@ __global__ void __launch_bounds__((WPB + 1) * 64) k_peel_level_wave_str(PeelArgs
             const u32 my_label = ch == C2A_NONE ? 0u : ch_el;
             const u32 pos = lo + seg_pre + idx;
             if (lane == 0) {
-                st_g(&A.meta[pos], make_uint4(ch, depth, ch_root, my_label));
+                st_g(&A.meta[pos], make_uint4(ch, depth, ch_root, my_label | (level << 1)));
                 st_g(&A.order[pos], g);
                 st_g(&A.posof[g], pos);
                 if (ch != C2A_NONE) st_g(&A.child[2 * (u64)ch + my_label], pos);
@@ -711,6 +713,380 @@ __global__ void __launch_bounds__((WPB + 1) * 64) k_peel_level_wave_str(PeelArgs
         if (active) C2A_PROF(5, c2a_now() - t_begin);
 #endif
     }
+}
+
+// ================================================================================================
+// ASYNCHRONOUS PEEL — the same tournament per gate, but no level barrier at all.
+// A launch per level costs ~7 us per level at ~2 000 gates per level whatever is done inside (dispatch + three dependent
+// round trips + the slowest of ~2 000 waves), and the graph is ~5 000 levels deep.  Here ONE launch runs the whole peel
+// as a dataflow: the wave whose push completes a producer's consumer list goes on with that producer at once, so the
+// critical path is a chain of (candidate records -> survivor strings -> stores acknowledged -> commit ticket) steps,
+// ~2 us each, with no launch, no frontier and no counters in between.  No wave ever waits for another one (nothing
+// spins, nothing can deadlock; the host emulation runs the workgroups one after the other): a gate is processed by
+// exactly the wave that completed it, work found beyond the one gate a wave can continue with goes on a wave-private
+// intrusive stack (link[]), and a wave that runs out of work exits.
+// Data exchanged between waves inside the launch: candidate records, path strings, cprev — written with agent-scope
+// write-through stores, drained (vmcnt 0) BEFORE the commit ticket, read with agent-scope loads AFTER the ticket that
+// completes the list (verified hand-off: tools/ubench/xcd2.hip, sc1 store -> atomic -> sc1 load, 0 stale reads).
+// A candidate record's home is static (cand[cons_off[d] + eslot[2g+l]], the edge's index from k_deps), so a push
+// needs ONE ticket and that ticket is the commit.  Tree node identity = gate id (order/posof are the identity).
+// The sinks (gates nobody consumes: 17 % of the headline graph) are peeled by a plain grid-stride kernel first; the
+// producers they complete seed the dataflow launch.
+// ================================================================================================
+struct AsyncArgs {
+    u32 n;
+    u32 seg_cap;
+    const uint4* ginfo;        // [n] {dep0, dep1, cons_off, cons_cnt}
+    const u32* eslot;          // [2n] index of edge (g, l) in its producer's candidate list
+    FrontierSlot* seeds;       // [kSeg][seg_cap] gates completed by the sinks
+    u32* seed_cnt;             // [kSeg]
+    uint4* cand;
+    u32* fill;
+    uint4* meta;               // by gate id
+    u64* pstr;
+    u32* cprev;
+    u32* child;
+    u32* link;                 // [n] wave-private stacks (used when a hand-off queue is full — never in practice)
+    u32* totals;               // [0] gates processed by the dataflow launch + sinks, [1] max level, [2] watchdog trips
+    // hand-off of completed producers a wave cannot continue with: n_queues ticket queues of q_cap entries each
+    u32 n_queues, q_cap;
+    u64* q_ht;                 // [n_queues * kQStride] head (low word) | tail (high word), one queue per 128-byte line
+    u32* q_items;              // [n_queues][q_cap] gate + 1, 0 = not written yet (zeroed per run, every entry used once)
+    u32* idle;                 // [kIdleCounters * 16] waves with nothing to do (one counter per 64-byte line)
+};
+constexpr u32 kIdleCounters = 64;
+constexpr u32 kQStride = 16;               // u64 words between two queues' head/tail words
+constexpr u32 kWatchdogPolls = 1u << 22;   // ~2 s of polling: give up instead of hanging the GPU (reported as an error)
+
+template <bool SC1> __device__ __forceinline__ uint4 ld_rec(const uint4* p) {
+    if (SC1) {
+        const u64* q = reinterpret_cast<const u64*>(p);
+        const u64 a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_uint4((u32)a, (u32)(a >> 32), (u32)b, (u32)(b >> 32));
+    }
+    return *p;
+}
+__device__ __forceinline__ void st_rec_sc1(uint4* p, const uint4& v) {
+    u64* q = reinterpret_cast<u64*>(p);
+    __hip_atomic_store(q, (u64)v.x | ((u64)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, (u64)v.z | ((u64)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 ld_str(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_str(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// sinks: roots of depth 0 without candidates; their pushes are published by the kernel boundary.  256 threads,
+// gridDim.x % kSeg == 0; the producers completed here are appended to seed segment blockIdx.x % kSeg.
+__global__ void __launch_bounds__(kThreads) k_async_sinks(AsyncArgs A) {
+    const u32 lane = threadIdx.x & 63u;
+    const u32 seg_out = blockIdx.x % kSeg;
+    FrontierSlot* out = A.seeds + (u64)seg_out * A.seg_cap;
+    const u64 lt_mask = (1ull << lane) - 1ull;
+    u32 done = 0;
+    for (u64 base = (u64)blockIdx.x * kThreads; base < A.n; base += gstride()) {
+        const u64 g = base + threadIdx.x;
+        u32 rdy[2] = {C2A_NONE, C2A_NONE};
+        uint4 rec[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+        if (g < A.n) {
+            const uint4 gi = A.ginfo[g];
+            if (gi.w == 0) {
+                ++done;
+                A.meta[g] = make_uint4(C2A_NONE, 0u, (u32)g, 0u);
+                const u32 deps[2] = {gi.x, gi.y};
+#pragma unroll
+                for (u32 l = 0; l < 2; ++l) {
+                    const u32 d = deps[l];
+                    if (d == C2A_NONE) continue;
+                    const uint4 gd = A.ginfo[d];
+                    A.cand[gd.z + A.eslot[2 * g + l]] = make_uint4((u32)g | (l << 31), 0u, (u32)g, 0u);
+                    const u32 k = atomicAdd(&A.fill[d], 1u);
+                    if (k + 1 == gd.w) { rdy[l] = d; rec[l] = gd; }
+                }
+            }
+        }
+#pragma unroll
+        for (u32 l = 0; l < 2; ++l) {
+            const u64 mask = __ballot(rdy[l] != C2A_NONE);
+            if (mask) {
+                u32 b = 0;
+                if (lane == (u32)ctz64(mask)) b = atomicAdd(&A.seed_cnt[seg_out], (u32)__popcll(mask));
+                b = __shfl(b, (int)ctz64(mask), 64);
+                if (rdy[l] != C2A_NONE) {
+                    const u32 p = b + (u32)__popcll(mask & lt_mask);
+                    out[p].b = make_uint4(rec[l].w, 0, 0, 0);
+                    out[p].a = make_uint4(rdy[l], rec[l].x, rec[l].y, rec[l].z);
+                }
+            }
+        }
+    }
+    // one counter update per wave
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) done += __shfl_xor(done, off, 64);
+    if (lane == 0 && done) atomicAdd(&A.totals[0], done);
+}
+
+// the dataflow launch: 64-thread workgroups (one wave each), gridDim.x % kSeg == 0
+__global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
+    const u32 lane = threadIdx.x;
+    const u32 seg = blockIdx.x % kSeg, jstep = gridDim.x / kSeg;
+    u32 idx = blockIdx.x / kSeg;
+    const u32 seg_cnt = A.seed_cnt[seg];
+    const FrontierSlot* my_seeds = A.seeds + (u64)seg * A.seg_cap;
+    u32 head = C2A_NONE;                     // wave-private stack (overflow of the hand-off queues)
+    u32 processed = 0, max_level = 0;
+    const u32 W = gridDim.x, me = blockIdx.x;
+    const u32 home_q = me % A.n_queues;
+    u32* head_w = reinterpret_cast<u32*>(A.q_ht);            // head of queue q = word 2 q kQStride, tail = the next word
+    u32 push_rr = me;                        // round-robin cursor of this wave's pushes
+    u32 roam = me * 0x9E3779B1u;             // pseudo-random walk over the other queues
+    bool registered = false;                 // counted in idle[]
+    for (;;) {
+        // ---- next piece of work: own stack, own share of the seeds, then the hand-off queues
+        u32 g = C2A_NONE;
+        uint4 gi = make_uint4(0, 0, 0, 0);
+        if (head != C2A_NONE) {
+            g = head;
+            head = ld_u32<true>(&A.link[g]);
+            gi = A.ginfo[g];
+        } else if (idx < seg_cnt) {
+            const FrontierSlot* sl = my_seeds + idx;
+            idx += jstep;
+            const uint4 a = sl->a;
+            g = a.x;
+            gi = make_uint4(a.y, a.z, a.w, sl->b.x);
+        } else {
+            // poll: home queue, then a roaming one; a wave counts as idle from its first empty-handed poll until the
+            // moment BEFORE it tries to claim an entry, so "all waves idle" implies that nothing is queued or in flight
+            u32 polls = 0;
+            u32 hint = C2A_NONE;                                 // a queue seen non-empty by the termination check
+            for (;;) {
+#ifdef C2A_EMULATE
+                const u32 q = (home_q + polls) % A.n_queues;     // workgroups run one after the other: scan every queue once
+#else
+                u32 q = (polls & 1u) ? (roam = roam * 1664525u + 1013904223u, (roam >> 8) % A.n_queues) : home_q;
+                if (hint != C2A_NONE) { q = hint; hint = C2A_NONE; }
+#endif
+                // one lane looks, everybody acts on what it saw (wave-uniform by construction, also for the host emulation
+                // where the lanes of a wave run one after the other)
+                u64 ht = 0;
+                if (lane == 0) ht = __hip_atomic_load(&A.q_ht[(u64)q * kQStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ht = rdlane64(ht, 0);
+                const u32 qh = (u32)ht, qt = (u32)(ht >> 32);
+                if (qh < qt) {
+                    if (registered) { if (lane == 0) atomicAdd(&A.idle[(me % kIdleCounters) * 16], 0xFFFFFFFFu); registered = false; }
+                    u32 old = 0;
+                    if (lane == 0) old = atomicCAS(&head_w[2 * (u64)q * kQStride], qh, qh + 1);
+                    old = rdlane(old, 0);
+                    if (old == qh) {
+                        u32 v = 0, spins = 0;
+                        do {
+                            if (lane == 0) v = ld_u32<true>(&A.q_items[(u64)q * A.q_cap + qh]);
+                            v = rdlane(v, 0);
+                        } while (v == 0 && ++spins < kWatchdogPolls);
+                        if (v) { g = v - 1; gi = A.ginfo[g]; }
+                        else if (lane == 0) atomicAdd(&A.totals[2], 1u);
+                        break;
+                    }
+                    hint = q;                                    // lost the race: look at the same queue again at once
+                    continue;
+                }
+#ifdef C2A_EMULATE
+                if (++polls >= A.n_queues) break;                // nothing left for this workgroup
+#else
+                if (!registered) { if (lane == 0) atomicAdd(&A.idle[(me % kIdleCounters) * 16], 1u); registered = true; }
+                ++polls;
+                if ((polls & 31u) == 0) {
+                    u32 cnt = lane < kIdleCounters ? ld_u32<true>(&A.idle[lane * 16]) : 0u;
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+                    if (cnt >= W) {
+                        // every wave is idle or gone, so nobody pushes any more: finished unless an entry is still queued
+                        u32 found = C2A_NONE;
+                        for (u32 qq = lane; qq < A.n_queues; qq += 64) {
+                            const u64 x = __hip_atomic_load(&A.q_ht[(u64)qq * kQStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((u32)x < (u32)(x >> 32)) found = qq;
+                        }
+                        const u64 fm = __ballot(found != C2A_NONE);
+                        if (fm == 0) break;
+                        hint = rdlane(found, ctz64(fm));
+                        continue;
+                    }
+                }
+                if (polls >= kWatchdogPolls) { if (lane == 0) atomicAdd(&A.totals[2], 1u); break; }
+                // back off: the longer nothing turns up, the less often this wave asks (64 clocks per unit, <= ~3 us)
+                if (polls < 8) __builtin_amdgcn_s_sleep(4); else if (polls < 64) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(64);
+#endif
+            }
+            if (g == C2A_NONE) break;
+        }
+        // ---- follow the chain from g
+        for (;;) {
+            const u32 e0 = gi.z, e1 = e0 + gi.w;
+            const u32 dl = lane == 0 ? gi.x : (lane == 1 ? gi.y : C2A_NONE);
+            // static data of the pushes, fetched while the tournament runs
+            const uint4 gd_raw = A.ginfo[dl != C2A_NONE ? dl : 0u];
+            const u32 es = A.eslot[2 * (u64)g + (lane & 1u)];
+            u32 ch = C2A_NONE, ch_el = 0, ch_root = g, ch_depth = 0, level = 0;
+            u64 champ_w = 0;
+            bool champ_loaded = false;
+            for (u32 eb = e0; eb < e1; eb += 64) {
+                const u32 e = eb + lane;
+                const bool valid = e < e1;
+                const uint4 cr_raw = ld_rec<true>(&A.cand[valid ? e : e0]);
+                const u32 c = cr_raw.x & kIdMask, l = cr_raw.x >> 31, cdepth = cr_raw.y;
+                const u32 croot = valid ? cr_raw.z : 0xFFFFFFFFu;
+                const u32 clevel = valid ? (cr_raw.w >> 1) + 1u : 0u;
+                const u64 vmask = __ballot(valid);
+                u32 rmin = 0xFFFFFFFFu;
+                if (__popcll(vmask) <= 8) {
+                    for (u64 mm = vmask; mm; mm &= mm - 1) {
+                        const u32 j = ctz64(mm);
+                        const u32 r = rdlane(croot, j), lv = rdlane(clevel, j);
+                        rmin = r < rmin ? r : rmin;
+                        level = lv > level ? lv : level;
+                    }
+                } else {
+                    rmin = wave_min_u32(croot);
+                    u32 lv = clevel;
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) { const u32 o = __shfl_xor(lv, off, 64); lv = o > lv ? o : lv; }
+                    level = lv > level ? lv : level;
+                }
+                if (rmin > ch_root) continue;
+                if (!((ch != C2A_NONE) && (ch_root == rmin))) { champ_loaded = false; ch = C2A_NONE; }
+                ch_root = rmin;
+                u64 smask = __ballot(valid && croot == rmin);
+                if (ch == C2A_NONE) {
+                    const u32 j = ctz64(smask);
+                    smask &= smask - 1;
+                    ch = rdlane(c, j); ch_el = rdlane(l, j); ch_depth = rdlane(cdepth, j);
+                }
+                while (smask) {
+                    u32 cc[kStrMax], cl[kStrMax], cd[kStrMax];
+                    u32 take = 0;
+#pragma unroll
+                    for (int t = 0; t < kStrMax; ++t) {
+                        if (smask) {
+                            const u32 j = ctz64(smask);
+                            smask &= smask - 1;
+                            cc[t] = rdlane(c, j); cl[t] = rdlane(l, j); cd[t] = rdlane(cdepth, j);
+                            take = (u32)t + 1;
+                        } else {
+                            cc[t] = ch; cl[t] = 0; cd[t] = 0;
+                        }
+                    }
+                    bool shallow = ch_depth <= kChunkBits;
+#pragma unroll
+                    for (int t = 0; t < kStrMax; ++t) shallow = shallow && cd[t] <= kChunkBits;
+                    if (shallow) {
+                        u64 sw[kStrMax];
+#pragma unroll
+                        for (int t = 0; t < kStrMax; ++t) {
+                            const bool on = lane * 64 < cd[t];
+                            const u64 v = ld_str(&A.pstr[(u64)cc[t] * kChunkWords + (on ? lane : 0u)]);
+                            sw[t] = on ? v : 0ull;
+                        }
+                        if (!champ_loaded) {
+                            const bool on = lane * 64 < ch_depth;
+                            const u64 v = ld_str(&A.pstr[(u64)ch * kChunkWords + (on ? lane : 0u)]);
+                            champ_w = on ? v : 0ull;
+                            champ_loaded = true;
+                        }
+#pragma unroll
+                        for (int t = 0; t < kStrMax; ++t) {
+                            if ((u32)t < take) {
+                                bool less;
+                                if (cc[t] == ch) less = cl[t] < ch_el;
+                                else less = str_less_wave(sw[t], cd[t], cl[t], champ_w, ch_depth, ch_el, lane);
+                                if (less) { ch = cc[t]; ch_el = cl[t]; ch_depth = cd[t]; champ_w = sw[t]; }
+                            }
+                        }
+                    } else {
+                        for (u32 t = 0; t < take; ++t) {
+                            const u32 cct = cc[t], clt = cl[t], cdt = cd[t];
+                            bool less;
+                            if (cct == ch) less = clt < ch_el;
+                            else {
+                                u32 ra = cct, rb = ch, lena, lenb, ba, bb;
+                                resolve_chunks<true>(A.cprev, ra, lena, ba, cdt, rb, lenb, bb, ch_depth);
+                                if (ra == rb) {
+                                    if (ba != C2A_NONE) less = (u32)(ld_str(&A.pstr[(u64)ba * kChunkWords]) & 1ull) < ch_el;
+                                    else less = clt < (u32)(ld_str(&A.pstr[(u64)bb * kChunkWords]) & 1ull);
+                                } else {
+                                    const u64 wa = lane * 64 < lena ? ld_str(&A.pstr[(u64)ra * kChunkWords + lane]) : 0ull;
+                                    const u64 wb = lane * 64 < lenb ? ld_str(&A.pstr[(u64)rb * kChunkWords + lane]) : 0ull;
+                                    less = str_less_wave(wa, lena, clt, wb, lenb, ch_el, lane);
+                                }
+                            }
+                            if (less) { ch = cct; ch_el = clt; ch_depth = cdt; champ_loaded = false; }
+                        }
+                    }
+                }
+            }
+            // ---- the node: meta / child are read after the launch only (plain), the string and cprev by other waves
+            const u32 depth = ch == C2A_NONE ? 0u : ch_depth + 1;
+            const u32 my_label = ch == C2A_NONE ? 0u : ch_el;
+            const u32 tag = my_label | (level << 1);
+            max_level = level > max_level ? level : max_level;
+            ++processed;
+            if (lane == 0) {
+                A.meta[g] = make_uint4(ch, depth, ch_root, tag);
+                if (ch != C2A_NONE) A.child[2 * (u64)ch + my_label] = g;
+            }
+            if (ch != C2A_NONE) {
+                const bool need_parent = ch_depth != 0 && chunk_of(depth) == chunk_of(ch_depth);
+                if (need_parent && !champ_loaded) {
+                    const bool on = lane * 64 < chunk_len(ch_depth);
+                    const u64 v = ld_str(&A.pstr[(u64)ch * kChunkWords + (on ? lane : 0u)]);
+                    champ_w = on ? v : 0ull;
+                }
+                bool fresh;
+                const u64 nw = child_word(need_parent ? champ_w : 0ull, ch_depth, my_label, lane, fresh);
+                if (lane * 64 < chunk_len(depth)) st_str(&A.pstr[(u64)g * kChunkWords + lane], nw);
+                if (lane == 0 && chunk_of(depth)) st_u32<true>(&A.cprev[g], fresh ? ch : ld_u32<true>(&A.cprev[ch]));
+            }
+            // ---- pushes: record to its static home, everything acknowledged, then the commit ticket
+            const uint4 gd = dl != C2A_NONE ? gd_raw : make_uint4(0, 0, 0, 0);
+            if (dl != C2A_NONE) st_rec_sc1(&A.cand[gd.z + es], make_uint4(g | (lane << 31), depth, ch_root, tag));     // lane == edge label
+#ifndef C2A_EMULATE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            u32 kfill = 0;
+            if (dl != C2A_NONE) kfill = atomicAdd(&A.fill[dl], 1u);
+            const bool last_push = dl != C2A_NONE && kfill + 1 == gd.w;
+            const u64 rmask = __ballot(last_push);
+            if (rmask == 0) break;                                  // the chain ends here
+            // continue with the first completed producer; a second one goes on the stack
+            const u32 j0 = ctz64(rmask);
+            const u32 nxt = rdlane(dl, j0);
+            const uint4 ngi = make_uint4(rdlane(gd.x, j0), rdlane(gd.y, j0), rdlane(gd.z, j0), rdlane(gd.w, j0));
+            if (rmask & (rmask - 1)) {
+                // hand the second one to whoever is idle: ticket on a queue (round robin over all queues), then the entry
+                const u32 other = rdlane(dl, 1);
+                const u32 q = (push_rr++) % A.n_queues;
+                u32 t = 0;
+                if (lane == 0) t = atomicAdd(&head_w[2 * (u64)q * kQStride + 1], 1u);
+                t = rdlane(t, 0);
+                if (t < A.q_cap) {
+                    if (lane == 0) st_u32<true>(&A.q_items[(u64)q * A.q_cap + t], other + 1u);
+                } else {                                           // cannot happen with q_cap >= n / n_queues + waves (see host)
+                    if (lane == 0) st_u32<true>(&A.link[other], head);
+                    head = other;
+                }
+            }
+            g = nxt; gi = ngi;
+        }
+    }
+    if (lane == 0) {
+        if (!registered) atomicAdd(&A.idle[(me % kIdleCounters) * 16], 1u);      // a wave that has left counts as idle for good
+        if (processed) atomicAdd(&A.totals[0], processed);
+        if (max_level) atomicMax(&A.totals[1], max_level);
+    }
+}
+
+// tree node == gate id in the asynchronous peel
+__global__ void k_identity(u32 n, u32* a, u32* b) {
+    for (u64 i = gtid(); i < n; i += gstride()) { a[i] = (u32)i; b[i] = (u32)i; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -757,7 +1133,7 @@ __global__ void k_euler_next(u32 n, const uint4* __restrict__ meta, const u32* _
             const u32 k = ridx[order[x]];
             nx = k + 1 < n_roots ? 2 * rlist[k + 1] : C2A_NONE;
         } else {
-            const u32 s1 = m.w == 0 ? child[2 * (u64)m.x + 1] : C2A_NONE;
+            const u32 s1 = (m.w & 1u) == 0 ? child[2 * (u64)m.x + 1] : C2A_NONE;
             nx = s1 != C2A_NONE ? 2 * s1 : 2 * m.x + 1;
         }
         next[2 * i + 1] = nx;
@@ -1166,6 +1542,18 @@ __global__ void k_eval_init(u32 wire_count, u32 width, u32 M, u64 out_base, u64 
 }
 
 // one level: lane per (gate, vector) for the arithmetic side, lane per gate for its boolean template
+// level lists for the level-parallel evaluation: counting sort of the tree nodes by reverse Kahn level (meta.w >> 1)
+__global__ void k_level_hist(u32 n, const uint4* __restrict__ meta, u32* lcount) {
+    for (u64 i = gtid(); i < n; i += gstride()) atomicAdd(&lcount[meta[i].w >> 1], 1u);
+}
+__global__ void k_level_scatter(u32 n, const uint4* __restrict__ meta, const u32* __restrict__ order, const u32* __restrict__ lbase,
+                                u32* cursor, u32* lorder) {
+    for (u64 i = gtid(); i < n; i += gstride()) {
+        const u32 lv = meta[i].w >> 1;
+        lorder[lbase[lv] + atomicAdd(&cursor[lv], 1u)] = order[i];
+    }
+}
+
 __global__ void k_eval_level_arith(u32 lo, u32 cnt, u32 width, const u32* __restrict__ order, const u32* __restrict__ spos,
                                    const u32* __restrict__ e_in0, const u32* __restrict__ e_in1, const u32* __restrict__ e_out,
                                    const u8* __restrict__ e_op, u64* aval) {

@@ -96,16 +96,21 @@ def _variant(kind, mode):
 
 
 # (library build, kernel shape of the per-level peel)
-WAVE_BACKENDS = [_variant("emul", "wpb4"), _variant("emul", "lane"),
-                 _variant("hip", "wpb4"), _variant("hip", "wpb8"), _variant("hip", "wpb16"), _variant("hip", "lane")]
+WAVE_BACKENDS = [_variant("emul", "async"), _variant("emul", "wpb4"), _variant("emul", "lane"), _variant("hip", "async"),
+                 _variant("hip", "wpb4"), _variant("hip", "wpb8"), _variant("hip", "wpb12"), _variant("hip", "wpb16"), _variant("hip", "lane")]
 
 
 @pytest.fixture(params=WAVE_BACKENDS)
 def backend_wave(request, c2a):
-    """Every level (however wide) through the wave-per-gate kernel, at each workgroup shape, and every level through the
-    lane-per-gate kernel."""
+    """The dataflow (single-launch) peel, and the launch-per-level peel with every level (however wide) through the
+    wave-per-gate kernel at each workgroup shape / through the lane-per-gate kernel."""
     kind, mode = request.param
-    kv = {"C2A_PEEL_WAVE_MAX": 0} if mode == "lane" else {"C2A_PEEL_WAVE_MAX": 1 << 30, "C2A_PEEL_WPB": int(mode[3:])}
+    if mode == "async":
+        kv = {"C2A_PEEL_ASYNC": 1}
+    elif mode == "lane":
+        kv = {"C2A_PEEL_ASYNC": 0, "C2A_PEEL_WAVE_MAX": 0}
+    else:
+        kv = {"C2A_PEEL_ASYNC": 0, "C2A_PEEL_WAVE_MAX": 1 << 30, "C2A_PEEL_WPB": int(mode[3:])}
     with _Env(**kv):
         be = c2a.Backend(0, lib_path=request.getfixturevalue("emul_lib")) if kind == "emul" else c2a.Backend(0)
     yield be
