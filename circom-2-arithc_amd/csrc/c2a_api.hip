@@ -41,7 +41,8 @@ struct c2a_ctx {
     int n_cu = 256;
     u32 peel_wave_max = 8192;      // frontier size up to which a level gets one wave per gate
     u32 bool_chunk = 256;          // arithmetic gates per k_boolify workgroup: 128, 256 (measured best) or 512
-    u32 peel_async_waves = 6;      // dataflow launch: waves per CU
+    u32 peel_sinks_blocks = 4096;  // grid cap of the sinks pass (latency-bound per thread: two dependent round trips per sink)
+    u32 peel_async_waves = 8;      // dataflow launch: waves per CU
     u32 peel_async = 1;            // 1: the whole peel as ONE dataflow launch (k_peel_async), 0: one launch per reverse Kahn level
     u32 peel_wpb = 16;             // waves per workgroup in wave mode (one of them is the append wave): 4, 8, 12 or 16
     u32 peel_slack_pct = 125;      // wave-mode grid = this % of the largest recent frontier (growth inside a batch of launches)
@@ -56,7 +57,7 @@ struct c2a_ctx {
 
     // device buffers
     DevBuf lh, rh, out, op, gate4, in_nodes, out_nodes;
-    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, eslot, link, aq_ht, aq_items, aq_idle, fill, cand, meta, pstr, cprev, fring, fbase, order, posof, child, ginfo, slots0, slots1;
+    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, eslot, link, aq_ht, aq_items, aq_idle, aq_seeds, aq_seed_cnt, fill, cand, meta, pstr, cprev, fring, fbase, order, posof, child, ginfo, slots0, slots1;
     DevBuf rflag, ridx, rlist, next, owner, local, slist, snext, ssum, jnxt, jval, sorted;
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op;
     DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof;
@@ -66,7 +67,7 @@ struct c2a_ctx {
     std::vector<DevBuf*> all;
 
     c2a_ctx() {
-        all = {&lh, &rh, &out, &op, &gate4, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &link, &aq_ht, &aq_items, &aq_idle, &fill, &cand,
+        all = {&lh, &rh, &out, &op, &gate4, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &link, &aq_ht, &aq_items, &aq_idle, &aq_seeds, &aq_seed_cnt, &fill, &cand,
                &ginfo, &slots0, &slots1, &meta, &pstr, &cprev, &fring, &fbase, &order, &posof, &child, &rflag, &ridx, &rlist, &next,
                &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
                &node_wire, &e_in0, &e_in1, &e_out, &e_op, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &tsz, &asz, &goff,
@@ -198,7 +199,6 @@ int do_peel_async(c2a_ctx* c, u32* peeled_out) {
     hipStream_t s = c->stream;
     AsyncArgs A;
     A.n = n; A.seg_cap = seg_capacity(n); A.ginfo = c->ginfo.as<uint4>(); A.eslot = c->eslot.as<u32>();
-    A.seeds = c->slots0.as<FrontierSlot>(); A.seed_cnt = c->fring.as<u32>();
     A.cand = c->cand.as<uint4>(); A.fill = c->fill.as<u32>(); A.meta = c->meta.as<uint4>(); A.pstr = c->pstr.as<u64>();
     A.cprev = c->cprev.as<u32>(); A.child = c->child.as<u32>(); A.link = c->link.as<u32>();
     A.totals = c->scalars.as<u32>() + SC_ASYNC;
@@ -216,12 +216,28 @@ int do_peel_async(c2a_ctx* c, u32* peeled_out) {
     HIP_TRY(hipMemsetAsync(c->aq_items.p, 0, (size_t)A.n_queues * A.q_cap * 4, s));
     HIP_TRY(hipMemsetAsync(c->aq_idle.p, 0, (size_t)kIdleCounters * 64, s));
     A.q_ht = c->aq_ht.as<u64>(); A.q_items = c->aq_items.as<u32>(); A.idle = c->aq_idle.as<u32>();
-    C2A_LAUNCH(k_async_sinks, grid_seg(grid_for(n, 4096)), kThreads, s, A);
+    const bool want_stats = std::getenv("C2A_ASYNC_STATS") != nullptr;
+    A.stats = nullptr;
+    if (want_stats) { ENSURE(c->peel_prof, 64); HIP_TRY(hipMemsetAsync(c->peel_prof.p, 0, 64, s)); A.stats = c->peel_prof.as<ull>(); }
+    // seed regions: one per workgroup of the sinks pass; a workgroup sees at most gates_per_block gates, each completes <= 2 producers
+    const u32 sink_blocks = grid_for(n, c->peel_sinks_blocks);
+    const u64 gates_per_block = ((u64)n + (u64)sink_blocks * kThreads - 1) / ((u64)sink_blocks * kThreads) * kThreads;
+    A.n_regions = sink_blocks; A.region_cap = (u32)(2 * gates_per_block);
+    ENSURE(c->aq_seeds, (size_t)A.n_regions * A.region_cap * sizeof(FrontierSlot)); ENSURE(c->aq_seed_cnt, (size_t)A.n_regions * 4);
+    HIP_TRY(hipMemsetAsync(c->aq_seed_cnt.p, 0, (size_t)A.n_regions * 4, s));
+    A.seeds = c->aq_seeds.as<FrontierSlot>(); A.seed_cnt = c->aq_seed_cnt.as<u32>();
+    C2A_LAUNCH(k_async_sinks, sink_blocks, kThreads, s, A);
     C2A_LAUNCH(k_peel_async, waves, 64, s, A);
     C2A_LAUNCH_NOSYNC(k_identity, grid_for(n, 4096), kThreads, s, n, c->order.as<u32>(), c->posof.as<u32>());
     u32 t2[3] = {0, 0, 0};
     int r = read_scalars(c, t2, SC_ASYNC, 3);
     if (r) return r;
+    if (want_stats) {
+        ull st[8];
+        HIP_TRY(hipMemcpy(st, c->peel_prof.p, 64, hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[c2a async stats] waves %u queues %u | seeds %llu, popped %llu, pushed %llu, processed %llu, polls %llu | busy %.1f ms-waves, idle %.1f ms-waves, longest busy wave %.2f ms\n", waves, A.n_queues,
+                     st[5], st[0], st[2], st[6], st[1], st[3] / 1e5, st[4] / 1e5, st[7] / 1e5);
+    }
     if (t2[2]) return fail(c, C2A_ERR_HIP, "dataflow peel: watchdog tripped (" + std::to_string(t2[2]) + " waves gave up waiting)");
     *peeled_out = t2[0];
     c->stats.levels = t2[0] ? t2[1] + 1 : 0;
@@ -563,6 +579,7 @@ int c2a_create(int device_id, c2a_ctx** out) {
         c->n_cu = prop.multiProcessorCount;
     if (const char* e = std::getenv("C2A_BOOL_CHUNK")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 128 || v == 256 || v == 512) c->bool_chunk = v; }
     if (const char* e = std::getenv("C2A_PEEL_ASYNC")) c->peel_async = std::strtoul(e, nullptr, 10) != 0;
+    if (const char* e = std::getenv("C2A_PEEL_SINKS_BLOCKS")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 16) c->peel_sinks_blocks = v; }
     if (const char* e = std::getenv("C2A_PEEL_ASYNC_WAVES")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 32) c->peel_async_waves = v; }
     if (const char* e = std::getenv("C2A_PEEL_WPB")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 4 || v == 8 || v == 12 || v == 16) c->peel_wpb = v; }
     if (const char* e = std::getenv("C2A_PEEL_SLACK")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 100 && v <= 400) c->peel_slack_pct = v; }

@@ -738,8 +738,9 @@ struct AsyncArgs {
     u32 seg_cap;
     const uint4* ginfo;        // [n] {dep0, dep1, cons_off, cons_cnt}
     const u32* eslot;          // [2n] index of edge (g, l) in its producer's candidate list
-    FrontierSlot* seeds;       // [kSeg][seg_cap] gates completed by the sinks
-    u32* seed_cnt;             // [kSeg]
+    FrontierSlot* seeds;       // [n_regions][region_cap] gates completed by the sinks, one region per workgroup of k_async_sinks
+    u32* seed_cnt;             // [n_regions]
+    u32 n_regions, region_cap;
     uint4* cand;
     u32* fill;
     uint4* meta;               // by gate id
@@ -753,6 +754,7 @@ struct AsyncArgs {
     u64* q_ht;                 // [n_queues * kQStride] head (low word) | tail (high word), one queue per 128-byte line
     u32* q_items;              // [n_queues][q_cap] gate + 1, 0 = not written yet (zeroed per run, every entry used once)
     u32* idle;                 // [kIdleCounters * 16] waves with nothing to do (one counter per 64-byte line)
+    ull* stats;                // optional diagnostics (8 words), nullptr normally
 };
 constexpr u32 kIdleCounters = 64;
 constexpr u32 kQStride = 16;               // u64 words between two queues' head/tail words
@@ -777,10 +779,15 @@ __device__ __forceinline__ void st_str(u64* p, u64 v) { __hip_atomic_store(p, v,
 
 // sinks: roots of depth 0 without candidates; their pushes are published by the kernel boundary.  256 threads,
 // gridDim.x % kSeg == 0; the producers completed here are appended to seed segment blockIdx.x % kSeg.
+// sinks: roots of depth 0 without candidates; their pushes are published by the kernel boundary.  256 threads.
+// The producers completed here seed the dataflow launch.  No shared counter anywhere: workgroup b appends to its own
+// region seeds[b * region_cap ...] under its own counter (a block handles at most region_cap / 2 gates, a gate completes
+// at most two producers); the dataflow waves share the regions out statically.
 __global__ void __launch_bounds__(kThreads) k_async_sinks(AsyncArgs A) {
+    __shared__ u32 s_done[kThreads / 64];
     const u32 lane = threadIdx.x & 63u;
-    const u32 seg_out = blockIdx.x % kSeg;
-    FrontierSlot* out = A.seeds + (u64)seg_out * A.seg_cap;
+    FrontierSlot* out = A.seeds + (u64)blockIdx.x * A.region_cap;
+    u32* counter = &A.seed_cnt[blockIdx.x];
     const u64 lt_mask = (1ull << lane) - 1ull;
     u32 done = 0;
     for (u64 base = (u64)blockIdx.x * kThreads; base < A.n; base += gstride()) {
@@ -809,7 +816,7 @@ __global__ void __launch_bounds__(kThreads) k_async_sinks(AsyncArgs A) {
             const u64 mask = __ballot(rdy[l] != C2A_NONE);
             if (mask) {
                 u32 b = 0;
-                if (lane == (u32)ctz64(mask)) b = atomicAdd(&A.seed_cnt[seg_out], (u32)__popcll(mask));
+                if (lane == (u32)ctz64(mask)) b = atomicAdd(counter, (u32)__popcll(mask));      // this workgroup's own counter
                 b = __shfl(b, (int)ctz64(mask), 64);
                 if (rdy[l] != C2A_NONE) {
                     const u32 p = b + (u32)__popcll(mask & lt_mask);
@@ -819,19 +826,34 @@ __global__ void __launch_bounds__(kThreads) k_async_sinks(AsyncArgs A) {
             }
         }
     }
-    // one counter update per wave
+    // one update of the global count per workgroup
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) done += __shfl_xor(done, off, 64);
-    if (lane == 0 && done) atomicAdd(&A.totals[0], done);
+    if (lane == 0) s_done[threadIdx.x >> 6] = done;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 t = 0;
+        for (int w = 0; w < kThreads / 64; ++w) t += s_done[w];
+        if (t) atomicAdd(&A.totals[0], t);
+    }
 }
 
-// the dataflow launch: 64-thread workgroups (one wave each), gridDim.x % kSeg == 0
+// advance (region, idx) to this wave's next seed; false when its share is exhausted
+__device__ __forceinline__ bool next_seed(const AsyncArgs& A, u32& region, u32& idx, u32& region_cnt) {
+    while (region < A.n_regions) {
+        if (idx < region_cnt) return true;
+        region += gridDim.x;
+        idx = 0;
+        region_cnt = region < A.n_regions ? A.seed_cnt[region] : 0u;
+    }
+    return false;
+}
+
+// the dataflow launch: 64-thread workgroups (one wave each)
 __global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
     const u32 lane = threadIdx.x;
-    const u32 seg = blockIdx.x % kSeg, jstep = gridDim.x / kSeg;
-    u32 idx = blockIdx.x / kSeg;
-    const u32 seg_cnt = A.seed_cnt[seg];
-    const FrontierSlot* my_seeds = A.seeds + (u64)seg * A.seg_cap;
+    u32 region = blockIdx.x, idx = 0;               // this wave's share of the seeds: regions me, me + waves, ...
+    u32 region_cnt = region < A.n_regions ? A.seed_cnt[region] : 0u;
     u32 head = C2A_NONE;                     // wave-private stack (overflow of the hand-off queues)
     u32 processed = 0, max_level = 0;
     const u32 W = gridDim.x, me = blockIdx.x;
@@ -840,6 +862,8 @@ __global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
     u32 push_rr = me;                        // round-robin cursor of this wave's pushes
     u32 roam = me * 0x9E3779B1u;             // pseudo-random walk over the other queues
     bool registered = false;                 // counted in idle[]
+    u32 st_pops = 0, st_polls = 0, st_push = 0, st_seeds = 0;      // diagnostics (C2A_ASYNC_STATS)
+    ull st_busy = 0, st_idle = 0, st_t0 = c2a_now();
     for (;;) {
         // ---- next piece of work: own stack, own share of the seeds, then the hand-off queues
         u32 g = C2A_NONE;
@@ -848,13 +872,15 @@ __global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
             g = head;
             head = ld_u32<true>(&A.link[g]);
             gi = A.ginfo[g];
-        } else if (idx < seg_cnt) {
-            const FrontierSlot* sl = my_seeds + idx;
-            idx += jstep;
+        } else if (next_seed(A, region, idx, region_cnt)) {
+            const FrontierSlot* sl = A.seeds + (u64)region * A.region_cap + idx;
+            ++idx;
+            ++st_seeds;
             const uint4 a = sl->a;
             g = a.x;
             gi = make_uint4(a.y, a.z, a.w, sl->b.x);
         } else {
+            { const ull t = c2a_now(); st_busy += t - st_t0; st_t0 = t; }
             // poll: home queue, then a roaming one; a wave counts as idle from its first empty-handed poll until the
             // moment BEFORE it tries to claim an entry, so "all waves idle" implies that nothing is queued or in flight
             u32 polls = 0;
@@ -883,7 +909,7 @@ __global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
                             if (lane == 0) v = ld_u32<true>(&A.q_items[(u64)q * A.q_cap + qh]);
                             v = rdlane(v, 0);
                         } while (v == 0 && ++spins < kWatchdogPolls);
-                        if (v) { g = v - 1; gi = A.ginfo[g]; }
+                        if (v) { g = v - 1; gi = A.ginfo[g]; ++st_pops; }
                         else if (lane == 0) atomicAdd(&A.totals[2], 1u);
                         break;
                     }
@@ -917,6 +943,8 @@ __global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
                 if (polls < 8) __builtin_amdgcn_s_sleep(4); else if (polls < 64) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(64);
 #endif
             }
+            st_polls += polls;
+            { const ull t = c2a_now(); st_idle += t - st_t0; st_t0 = t; }
             if (g == C2A_NONE) break;
         }
         // ---- follow the chain from g
@@ -1064,6 +1092,7 @@ __global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
                 // hand the second one to whoever is idle: ticket on a queue (round robin over all queues), then the entry
                 const u32 other = rdlane(dl, 1);
                 const u32 q = (push_rr++) % A.n_queues;
+                ++st_push;
                 u32 t = 0;
                 if (lane == 0) t = atomicAdd(&head_w[2 * (u64)q * kQStride + 1], 1u);
                 t = rdlane(t, 0);
@@ -1081,6 +1110,11 @@ __global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
         if (!registered) atomicAdd(&A.idle[(me % kIdleCounters) * 16], 1u);      // a wave that has left counts as idle for good
         if (processed) atomicAdd(&A.totals[0], processed);
         if (max_level) atomicMax(&A.totals[1], max_level);
+        if (A.stats) {
+            atomicAdd(&A.stats[0], (ull)st_pops); atomicAdd(&A.stats[1], (ull)st_polls); atomicAdd(&A.stats[2], (ull)st_push);
+            atomicAdd(&A.stats[3], st_busy); atomicAdd(&A.stats[4], st_idle); atomicAdd(&A.stats[5], (ull)st_seeds); atomicAdd(&A.stats[6], (ull)processed);
+            atomicMax(&A.stats[7], st_busy);
+        }
     }
 }
 
