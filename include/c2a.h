@@ -60,7 +60,7 @@ typedef struct c2a_bool_info {
 
 typedef struct c2a_timings {     /* milliseconds, HIP events on the context's stream, last run */
     float prep;                  /* producer map, deps, consumer CSR, level-0 frontier */
-    float peel;                  /* reverse Kahn peel + DFS-tree parent selection (all levels) */
+    float peel;                  /* reverse Kahn peel + DFS-tree parent selection (dataflow launch, or all levels) */
     float order;                 /* Euler tour + list ranking -> sorted_gate_ids */
     float wires;                 /* first-seen wire numbering */
     float emit;                  /* gate emission */
@@ -77,8 +77,8 @@ typedef struct c2a_stats {
     uint32_t max_depth;          /* depth of the DFS tree */
     uint32_t n_roots;            /* DFS roots (children of the virtual root) */
     uint32_t n_splitters;        /* list-ranking sublists */
-    uint32_t level_launches;     /* peel kernel launches (incl. empty tail launches) */
-    uint32_t frontier_segments;  /* independent append counters / slot regions of the peel frontier */
+    uint32_t level_launches;     /* peel kernel launches: 2 for the dataflow peel (sinks + one launch), else one per level */
+    uint32_t frontier_segments;  /* launch-per-level variant: independent append counters / slot regions of the frontier */
     uint32_t path_chunks;        /* 4096-bit path-string chunks the deepest DFS path spans (1 = every comparison is one round trip) */
     uint32_t reserved;
 } c2a_stats;
