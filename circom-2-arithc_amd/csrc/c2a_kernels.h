@@ -1006,7 +1006,23 @@ __global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
                     bool shallow = ch_depth <= kChunkBits;
 #pragma unroll
                     for (int t = 0; t < kStrMax; ++t) shallow = shallow && cd[t] <= kChunkBits;
-                    if (shallow) {
+                    if (shallow && take == 1) {
+                        // the usual case, two survivors: exactly two loads (every request counts — the launch is bound by
+                        // the memory side's request rate, not by bytes)
+                        const bool on0 = lane * 64 < cd[0];
+                        const u64 v0 = ld_str(&A.pstr[(u64)cc[0] * kChunkWords + (on0 ? lane : 0u)]);
+                        if (!champ_loaded) {
+                            const bool on = lane * 64 < ch_depth;
+                            const u64 v = ld_str(&A.pstr[(u64)ch * kChunkWords + (on ? lane : 0u)]);
+                            champ_w = on ? v : 0ull;
+                            champ_loaded = true;
+                        }
+                        const u64 s0 = on0 ? v0 : 0ull;
+                        bool less;
+                        if (cc[0] == ch) less = cl[0] < ch_el;
+                        else less = str_less_wave(s0, cd[0], cl[0], champ_w, ch_depth, ch_el, lane);
+                        if (less) { ch = cc[0]; ch_el = cl[0]; ch_depth = cd[0]; champ_w = s0; }
+                    } else if (shallow) {
                         u64 sw[kStrMax];
 #pragma unroll
                         for (int t = 0; t < kStrMax; ++t) {
