@@ -210,6 +210,7 @@ int do_peel_async(c2a_ctx* c, u32* peeled_out) {
     // hand-off queues: every entry is used once per run (no wrap-around); a wave spreads its pushes round robin, so
     // a queue receives at most pushes / n_queues + waves entries
     A.n_queues = std::max<u32>(1u, waves / 4);
+    if (const char* e = std::getenv("C2A_PEEL_QUEUES")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= waves) A.n_queues = v; }
     A.q_cap = n / A.n_queues + waves + 64;
     ENSURE(c->aq_ht, (size_t)A.n_queues * kQStride * 8); ENSURE(c->aq_items, (size_t)A.n_queues * A.q_cap * 4); ENSURE(c->aq_idle, (size_t)kIdleCounters * 64);
     HIP_TRY(hipMemsetAsync(c->aq_ht.p, 0, (size_t)A.n_queues * kQStride * 8, s));

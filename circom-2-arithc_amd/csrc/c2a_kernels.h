@@ -8,12 +8,13 @@
 //   wires + emit    : first-seen wire numbering, gate emission   src/compiler.rs:423-464
 //   boolify         : boolify(&circuit, width)                   src/main.rs:30-32 (crate absent: frozen spec)
 //
-// The exact DFS post-order is reproduced level-synchronously: the DFS tree parent of a
-// gate is the consumer that reaches it by the lexicographically smallest path from a virtual root
-// (children = gates in id order; edge labels 0 = lh producer, 1 = rh producer).  Gates are peeled in
-// reverse Kahn levels from the sinks; each peeled gate picks its parent by comparing consumer paths with
-// base-16 ancestor tables (64-byte rows: one cache line per hop), then the post-order index of every
-// gate comes from an Euler tour + list ranking — no per-level sweep for the numbering.
+// The exact DFS post-order is reproduced without a DFS: the DFS tree parent of a gate is the
+// consumer that reaches it by the lexicographically smallest path from a virtual root (children = gates in id
+// order; edge labels 0 = lh producer, 1 = rh producer).  A gate picks its parent once all its consumers have picked
+// theirs (reverse Kahn order from the sinks) by comparing the consumers' paths, held as 512-byte bit strings (one
+// memory round trip per comparison).  By default the whole peel is ONE dataflow launch (k_peel_async: a wave goes on
+// with the producer its ticket completed, ticket queues hand over the rest, no level barrier); a launch-per-level
+// variant is kept for A/B.  The post-order index of every gate then comes from an Euler tour + list ranking.
 #pragma once
 #include "c2a_platform.h"
 

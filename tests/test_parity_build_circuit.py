@@ -116,8 +116,8 @@ def test_layered_dags(backend, orc, c2a, layers, width, window):
 
 
 def test_deep_chain_exercises_path_string_chunks(backend, orc):
-    """A 9000-deep dependency chain with side branches: tree depth > 16^3, so all four base-16 digit planes
-    of the ancestor table and the long level-ancestor jumps are used."""
+    """A 9000-deep dependency chain with side branches: tree depth > 4096, so path strings span three chunks and
+    comparisons go through the chunk links (cprev), including the chunk-boundary ancestor cases."""
     rng = np.random.default_rng(5)
     depth = 9000
     # chain gate k (ids permuted) : out = node 10+k, lh = node 10+k-1 ; side gates hang off random chain nodes
@@ -142,7 +142,7 @@ def test_deep_chain_exercises_path_string_chunks(backend, orc):
 
 
 def test_wave_per_gate_kernel_small_graphs(backend_wave, orc):
-    """k_peel_level_wave (all-pairs tournament, workgroup-aggregated appends) on adversarial small graphs."""
+    """Every peel variant (dataflow launch, wave-per-gate and lane-per-gate launch-per-level) on adversarial small graphs."""
     rng = np.random.default_rng(4242)
     seen = {"ok": 0, "cyclic": 0, "inconsistent": 0, "cyclic-and-inconsistent": 0}
     for trial in range(40):
@@ -154,8 +154,8 @@ def test_wave_per_gate_kernel_small_graphs(backend_wave, orc):
 
 
 def test_wave_per_gate_kernel_high_fanout(backend_wave, orc):
-    """One producer read by 150 consumers spread over several DFS roots: chunks of 64 candidates, groups of 11,
-    champion carried across chunks."""
+    """One producer read by 150 consumers spread over several DFS roots: blocks of 64 candidate records, rounds of 4
+    survivor strings, champion carried across blocks."""
     rng = np.random.default_rng(77)
     n_cons = 150
     chain = 40
@@ -177,3 +177,53 @@ def test_wave_per_gate_kernel_high_fanout(backend_wave, orc):
     p = dict(lh=lh, rh=rh, out=out, op=rng.integers(0, 20, n).astype(np.uint8), n_nodes=11 + n + 2,
              input_nodes=np.array([1, 2], np.uint32), output_nodes=np.array([11 + n_cons + chain - 1], np.uint32))
     assert _compare(backend_wave, orc, p, check_serial=False) == "ok"
+
+
+@pytest.mark.parametrize("shape", ["in-tree", "wide-shallow", "two-chains", "fan-in-star"])
+def test_dataflow_peel_shapes(backend, orc, shape):
+    """Graph shapes that stress the hand-off and termination logic of the one-launch peel: a complete binary in-tree
+    (every gate completes two producers: maximal queue traffic), a wide shallow graph (seeds >> waves), two long
+    independent chains (almost every wave idle almost all the time), a star of consumers on one producer."""
+    rng = np.random.default_rng(99)
+    if shape == "in-tree":
+        # gate k consumes the outputs of gates 2k+1 and 2k+2 (heap layout), leaves read inputs; ids permuted
+        n = 2047
+        perm = rng.permutation(n)
+        lh = np.empty(n, np.uint32); rh = np.empty(n, np.uint32); out = np.empty(n, np.uint32)
+        for k in range(n):
+            g = perm[k]
+            out[g] = 100 + k
+            a, b = 2 * k + 1, 2 * k + 2
+            lh[g] = 100 + a if a < n else 1 + (k % 7)
+            rh[g] = 100 + b if b < n else 10 + (k % 5)
+        p = dict(lh=lh, rh=rh, out=out, op=rng.integers(0, 20, n).astype(np.uint8), n_nodes=100 + n + 1,
+                 input_nodes=np.arange(1, 16, dtype=np.uint32), output_nodes=np.array([100], np.uint32))
+    elif shape == "wide-shallow":
+        n = 6000
+        lh = np.empty(n, np.uint32); rh = np.empty(n, np.uint32); out = (1000 + np.arange(n)).astype(np.uint32)
+        lh[:2000] = rng.integers(1, 50, 2000); rh[:2000] = rng.integers(1, 50, 2000)
+        lh[2000:4000] = 1000 + rng.integers(0, 2000, 2000); rh[2000:4000] = 1000 + rng.integers(0, 2000, 2000)
+        lh[4000:] = 1000 + rng.integers(2000, 4000, 2000); rh[4000:] = 1000 + rng.integers(0, 4000, 2000)
+        perm = rng.permutation(n)
+        p = dict(lh=lh[perm], rh=rh[perm], out=out[perm], op=rng.integers(0, 20, n).astype(np.uint8), n_nodes=1000 + n + 1,
+                 input_nodes=np.arange(1, 50, dtype=np.uint32), output_nodes=(1000 + np.arange(5990, 6000)).astype(np.uint32))
+    elif shape == "two-chains":
+        n = 3000
+        lh = np.empty(n, np.uint32); rh = np.empty(n, np.uint32); out = (10 + np.arange(n)).astype(np.uint32)
+        for k in range(n):
+            prev = k - 2                                   # chain A = even k, chain B = odd k
+            lh[k] = 10 + prev if prev >= 0 else 1
+            rh[k] = 2
+        perm = rng.permutation(n)
+        p = dict(lh=lh[perm], rh=rh[perm], out=out[perm], op=rng.integers(0, 20, n).astype(np.uint8), n_nodes=10 + n + 1,
+                 input_nodes=np.array([1, 2], np.uint32), output_nodes=np.array([10 + n - 1, 10 + n - 2], np.uint32))
+    else:
+        n = 1200
+        lh = np.empty(n, np.uint32); rh = np.empty(n, np.uint32); out = (10 + np.arange(n)).astype(np.uint32)
+        lh[0], rh[0] = 1, 2                                # gate 0 feeds everybody
+        for k in range(1, n):
+            lh[k] = 10 if k % 3 else 10 + int(rng.integers(0, k))
+            rh[k] = 10 + int(rng.integers(0, k))
+        p = dict(lh=lh, rh=rh, out=out, op=rng.integers(0, 20, n).astype(np.uint8), n_nodes=10 + n + 1,
+                 input_nodes=np.array([1, 2], np.uint32), output_nodes=np.array([10 + n - 1], np.uint32))
+    assert _compare(backend, orc, p, check_serial=False) == "ok"
