@@ -219,7 +219,12 @@ int do_peel_async(c2a_ctx* c, u32* peeled_out) {
     A.q_ht = c->aq_ht.as<u64>(); A.q_items = c->aq_items.as<u32>(); A.idle = c->aq_idle.as<u32>();
     const bool want_stats = std::getenv("C2A_ASYNC_STATS") != nullptr;
     A.stats = nullptr;
-    if (want_stats) { ENSURE(c->peel_prof, 64); HIP_TRY(hipMemsetAsync(c->peel_prof.p, 0, 64, s)); A.stats = c->peel_prof.as<ull>(); }
+    A.q_time = nullptr;
+    if (want_stats) {
+        ENSURE(c->peel_prof, 128 + (size_t)A.n_queues * A.q_cap * 8);
+        HIP_TRY(hipMemsetAsync(c->peel_prof.p, 0, 128, s));
+        A.stats = c->peel_prof.as<ull>(); A.q_time = c->peel_prof.as<ull>() + 16;
+    }
     // seed regions: one per workgroup of the sinks pass; a workgroup sees at most gates_per_block gates, each completes <= 2 producers
     const u32 sink_blocks = grid_for(n, c->peel_sinks_blocks);
     const u64 gates_per_block = ((u64)n + (u64)sink_blocks * kThreads - 1) / ((u64)sink_blocks * kThreads) * kThreads;
@@ -234,10 +239,12 @@ int do_peel_async(c2a_ctx* c, u32* peeled_out) {
     int r = read_scalars(c, t2, SC_ASYNC, 3);
     if (r) return r;
     if (want_stats) {
-        ull st[8];
-        HIP_TRY(hipMemcpy(st, c->peel_prof.p, 64, hipMemcpyDeviceToHost));
+        ull st[16];
+        HIP_TRY(hipMemcpy(st, c->peel_prof.p, 128, hipMemcpyDeviceToHost));
         std::fprintf(stderr, "[c2a async stats] waves %u queues %u | seeds %llu, popped %llu, pushed %llu, processed %llu, polls %llu | busy %.1f ms-waves, idle %.1f ms-waves, longest busy wave %.2f ms\n", waves, A.n_queues,
                      st[5], st[0], st[2], st[6], st[1], st[3] / 1e5, st[4] / 1e5, st[7] / 1e5);
+        if (st[0]) std::fprintf(stderr, "[c2a async stats] hand-off: mean %.0f ns from push to pop; final idle (waiting for the end) %.1f ms-waves of the idle time\n", st[8] * 10.0 / st[0], st[9] / 1e5);
+        std::fprintf(stderr, "[c2a async stats] hand-off latency histogram: <1us %llu, 1-2us %llu, 2-4us %llu, 4-8us %llu, 8-16us %llu, >=16us %llu\n", st[10], st[11], st[12], st[13], st[14], st[15]);
     }
     if (t2[2]) return fail(c, C2A_ERR_HIP, "dataflow peel: watchdog tripped (" + std::to_string(t2[2]) + " waves gave up waiting)");
     *peeled_out = t2[0];

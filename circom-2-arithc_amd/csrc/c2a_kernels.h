@@ -755,7 +755,8 @@ struct AsyncArgs {
     u64* q_ht;                 // [n_queues * kQStride] head (low word) | tail (high word), one queue per 128-byte line
     u32* q_items;              // [n_queues][q_cap] gate + 1, 0 = not written yet (zeroed per run, every entry used once)
     u32* idle;                 // [kIdleCounters * 16] waves with nothing to do (one counter per 64-byte line)
-    ull* stats;                // optional diagnostics (8 words), nullptr normally
+    ull* stats;                // optional diagnostics (16 words), nullptr normally
+    ull* q_time;               // with stats: push time of every queue entry
 };
 constexpr u32 kIdleCounters = 64;
 constexpr u32 kQStride = 16;               // u64 words between two queues' head/tail words
@@ -864,7 +865,7 @@ __global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
     u32 roam = me * 0x9E3779B1u;             // pseudo-random walk over the other queues
     bool registered = false;                 // counted in idle[]
     u32 st_pops = 0, st_polls = 0, st_push = 0, st_seeds = 0;      // diagnostics (C2A_ASYNC_STATS)
-    ull st_busy = 0, st_idle = 0, st_t0 = c2a_now();
+    ull st_busy = 0, st_idle = 0, st_t0 = c2a_now(), st_hand = 0, st_final = 0;
     for (;;) {
         // ---- next piece of work: own stack, own share of the seeds, then the hand-off queues
         u32 g = C2A_NONE;
@@ -910,7 +911,7 @@ __global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
                             if (lane == 0) v = ld_u32<true>(&A.q_items[(u64)q * A.q_cap + qh]);
                             v = rdlane(v, 0);
                         } while (v == 0 && ++spins < kWatchdogPolls);
-                        if (v) { g = v - 1; gi = A.ginfo[g]; ++st_pops; }
+                        if (v) { g = v - 1; gi = A.ginfo[g]; ++st_pops; if (A.stats) { const ull tp = __hip_atomic_load(&A.q_time[(u64)q * A.q_cap + qh], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (tp) { const ull dt = c2a_now() - tp; st_hand += dt; const u32 b = dt < 100 ? 0 : dt < 200 ? 1 : dt < 400 ? 2 : dt < 800 ? 3 : dt < 1600 ? 4 : 5; if (lane == 0) atomicAdd(&A.stats[10 + b], 1ull); } } }
                         else if (lane == 0) atomicAdd(&A.totals[2], 1u);
                         break;
                     }
@@ -945,7 +946,7 @@ __global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
 #endif
             }
             st_polls += polls;
-            { const ull t = c2a_now(); st_idle += t - st_t0; st_t0 = t; }
+            { const ull t = c2a_now(); st_idle += t - st_t0; if (g == C2A_NONE) st_final = t - st_t0; st_t0 = t; }
             if (g == C2A_NONE) break;
         }
         // ---- follow the chain from g
@@ -1114,6 +1115,7 @@ __global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
                 if (lane == 0) t = atomicAdd(&head_w[2 * (u64)q * kQStride + 1], 1u);
                 t = rdlane(t, 0);
                 if (t < A.q_cap) {
+                    if (A.stats && lane == 0) __hip_atomic_store(&A.q_time[(u64)q * A.q_cap + t], c2a_now(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (lane == 0) st_u32<true>(&A.q_items[(u64)q * A.q_cap + t], other + 1u);
                 } else {                                           // cannot happen with q_cap >= n / n_queues + waves (see host)
                     if (lane == 0) st_u32<true>(&A.link[other], head);
@@ -1131,6 +1133,7 @@ __global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
             atomicAdd(&A.stats[0], (ull)st_pops); atomicAdd(&A.stats[1], (ull)st_polls); atomicAdd(&A.stats[2], (ull)st_push);
             atomicAdd(&A.stats[3], st_busy); atomicAdd(&A.stats[4], st_idle); atomicAdd(&A.stats[5], (ull)st_seeds); atomicAdd(&A.stats[6], (ull)processed);
             atomicMax(&A.stats[7], st_busy);
+            atomicAdd(&A.stats[8], st_hand); atomicAdd(&A.stats[9], st_final);
         }
     }
 }
