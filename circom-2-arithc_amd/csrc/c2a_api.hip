@@ -78,7 +78,7 @@ struct c2a_ctx {
 namespace {
 
 // scalars block layout (u32 words unless noted)
-enum Scalar { SC_MAXDEPTH = 0, SC_SCOUNT = 1, SC_ERR = 2, SC_NMID = 3, SC_NROOTS = 4, SC_LEVELS = 5, SC_PEELED = 6 /*2 words*/, SC_DFS = 8 /*3 words*/, SC_ASYNC = 48 /*3 words*/,
+enum Scalar { SC_MAXDEPTH = 0, SC_SCOUNT = 1, SC_ERR = 2, SC_NMID = 3, SC_NROOTS = 4, SC_LEVELS = 5, SC_PEELED = 6 /*2 words*/, SC_DFS = 8 /*3 words*/, SC_ASYNC = 48 /*3 words*/, SC_DUP = 52,
               SC_TOTAL64 = 16 /* u64 slots from here: 16..31 */, SC_WORDS = 64 };
 
 int fail(c2a_ctx* c, int code, const std::string& msg) {
@@ -180,7 +180,7 @@ int do_prep(c2a_ctx* c) {
     HIP_TRY(hipMemsetAsync(c->fbase.p, 0, 8, s));
     HIP_TRY(hipMemsetAsync(c->child.p, 0xFF, (size_t)n * 8, s));
     HIP_TRY(hipMemsetAsync(c->scalars.p, 0, SC_WORDS * 4, s));
-    C2A_LAUNCH_NOSYNC(k_producer, G, kThreads, s, n, c->out.as<u32>(), c->prod1.as<u32>());
+    C2A_LAUNCH_NOSYNC(k_producer, G, kThreads, s, n, c->out.as<u32>(), c->prod1.as<u32>(), c->scalars.as<u32>() + SC_DUP);
     C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->prod1.as<u32>(), c->dep0.as<u32>(),
                       c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>());
     int r = scan_exclusive<u32>(c, c->cons_cnt.as<u32>(), c->cons_off.as<u32>(), n);
@@ -508,9 +508,10 @@ int do_assign_wires(c2a_ctx* c) {
     if (n) {
         const u32 G = grid_for(n, 4096);
         C2A_LAUNCH_NOSYNC(k_first_seen, G, kThreads, s, n, c->sorted.as<u32>(), (const uint4*)c->gate4.as<uint4>(),
-                          c->first.as<u32>());
+                          (const u32*)c->prod1.as<u32>(), (const u32*)(c->scalars.as<u32>() + SC_DUP), c->first.as<u32>());
         C2A_LAUNCH_NOSYNC(k_new_wire_flags, G, kThreads, s, n, c->sorted.as<u32>(), (const uint4*)c->gate4.as<uint4>(),
-                          c->first.as<u32>(), c->nflag.as<u8>(), c->wflag.as<u32>());
+                          c->first.as<u32>(), c->nflag.as<u8>(), (const u32*)c->prod1.as<u32>(),
+                          (const u32*)(c->scalars.as<u32>() + SC_DUP), c->wflag.as<u32>());
     }
     int r = scan_exclusive<u32>(c, c->wflag.as<u32>(), c->widx.as<u32>(), m);
     if (r) return r;
@@ -690,7 +691,7 @@ int c2a_topo_sort_serial(c2a_ctx* c, uint32_t* sorted, uint64_t* cycle_at) {
     HIP_TRY(hipMemsetAsync(c->cons_cnt.p, 0, (size_t)c->n * 4, c->stream));
     HIP_TRY(hipMemsetAsync(c->scalars.p, 0, SC_WORDS * 4, c->stream));
     const u32 G = grid_for(c->n, 4096);
-    C2A_LAUNCH_NOSYNC(k_producer, G, kThreads, c->stream, c->n, c->out.as<u32>(), c->prod1.as<u32>());
+    C2A_LAUNCH_NOSYNC(k_producer, G, kThreads, c->stream, c->n, c->out.as<u32>(), c->prod1.as<u32>(), c->scalars.as<u32>() + SC_DUP);
     C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, c->stream, c->n, c->lh.as<u32>(), c->rh.as<u32>(), c->prod1.as<u32>(),
                       c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>());
     u32 status = 0;

@@ -78,8 +78,11 @@ __global__ void k_scan_total(TOut* out_n, const TOut* total) {
 // ------------------------------------------------------------------------------------------------
 // producer[node] = last gate writing it (compiler.rs:403-406: later insert overwrites) -> max gate id.
 // prod1 holds gate id + 1 (0 = no producer); must be zeroed.
-__global__ void k_producer(u32 n, const u32* __restrict__ out, u32* prod1) {
-    for (u64 g = gtid(); g < n; g += gstride()) atomicMax(&prod1[out[g]], (u32)g + 1);
+// *dup is raised when two gates write one node (the reference keeps the last writer, compiler.rs:403-406): the wire
+// numbering then takes its general path (first-seen by atomicMin over every reference)
+__global__ void k_producer(u32 n, const u32* __restrict__ out, u32* prod1, u32* dup) {
+    for (u64 g = gtid(); g < n; g += gstride())
+        if (atomicMax(&prod1[out[g]], (u32)g + 1) != 0) *dup = 1u;
 }
 
 // deps closure (compiler.rs:408-421) + consumer counts.  dep1 is dropped when equal to dep0: a second
@@ -1347,24 +1350,43 @@ __global__ void k_pack_gates(u32 n, const u32* __restrict__ lh, const u32* __res
 
 // One lane per sorted position handles its three walk entries [lh, rh, out] (compiler.rs:427-430): walk index 3*pos+k.
 // first[node] = first index in the walk
-__global__ void k_first_seen(u32 n, const u32* __restrict__ sorted, const uint4* __restrict__ gate4, u32* first) {
+// first[node] = index of the node's first appearance in the walk `for gate in sorted: [lh, rh, out]` (compiler.rs:427-430).
+// Every node has one writer (*dup == 0, the normal case): the sorted order is topological, so a produced node is first
+// seen as its producer's `out` — nothing to compute — and only references to un-produced nodes (inputs, constants) need
+// the atomicMin.  Otherwise: atomicMin over all 3n references.
+__global__ void k_first_seen(u32 n, const u32* __restrict__ sorted, const uint4* __restrict__ gate4, const u32* __restrict__ prod1,
+                             const u32* __restrict__ dup, u32* first) {
+    const bool general = *dup != 0;
     for (u64 pos = gtid(); pos < n; pos += gstride()) {
         const uint4 g = gate4[sorted[pos]];
         const u32 i = 3u * (u32)pos;
-        atomicMin(&first[g.x], i);
-        atomicMin(&first[g.y], i + 1);
-        atomicMin(&first[g.z], i + 2);
+        if (general) {
+            atomicMin(&first[g.x], i);
+            atomicMin(&first[g.y], i + 1);
+            atomicMin(&first[g.z], i + 2);
+        } else {
+            if (prod1[g.x] == 0) atomicMin(&first[g.x], i);
+            if (prod1[g.y] == 0) atomicMin(&first[g.y], i + 1);
+        }
     }
 }
 
 __global__ void k_new_wire_flags(u32 n, const u32* __restrict__ sorted, const uint4* __restrict__ gate4,
-                                 const u32* __restrict__ first, const u8* __restrict__ nflag, u32* flag) {
+                                 const u32* __restrict__ first, const u8* __restrict__ nflag, const u32* __restrict__ prod1,
+                                 const u32* __restrict__ dup, u32* flag) {
+    const bool general = *dup != 0;
     for (u64 pos = gtid(); pos < n; pos += gstride()) {
         const uint4 g = gate4[sorted[pos]];
         const u32 i = 3u * (u32)pos;
-        flag[i] = (first[g.x] == i && nflag[g.x] == 0) ? 1u : 0u;                 // :431-438
-        flag[i + 1] = (first[g.y] == i + 1 && nflag[g.y] == 0) ? 1u : 0u;
-        flag[i + 2] = (first[g.z] == i + 2 && nflag[g.z] == 0) ? 1u : 0u;
+        if (general) {
+            flag[i] = (first[g.x] == i && nflag[g.x] == 0) ? 1u : 0u;                 // :431-438
+            flag[i + 1] = (first[g.y] == i + 1 && nflag[g.y] == 0) ? 1u : 0u;
+            flag[i + 2] = (first[g.z] == i + 2 && nflag[g.z] == 0) ? 1u : 0u;
+        } else {
+            flag[i] = (prod1[g.x] == 0 && first[g.x] == i && nflag[g.x] == 0) ? 1u : 0u;
+            flag[i + 1] = (prod1[g.y] == 0 && first[g.y] == i + 1 && nflag[g.y] == 0) ? 1u : 0u;
+            flag[i + 2] = nflag[g.z] == 0 ? 1u : 0u;                                  // first seen here: its only writer
+        }
     }
 }
 
