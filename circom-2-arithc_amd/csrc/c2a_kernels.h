@@ -1197,7 +1197,10 @@ __global__ void k_euler_next(u32 n, const uint4* __restrict__ meta, const u32* _
     }
 }
 
-__device__ __forceinline__ bool is_splitter(u32 e, u32 head) { return e == head || ((e * 0x9E3779B1u) >> 26) == 0u; }
+#ifndef C2A_SPLIT_SHIFT
+#define C2A_SPLIT_SHIFT 26      // one splitter per 2^(32 - shift) tour elements
+#endif
+__device__ __forceinline__ bool is_splitter(u32 e, u32 head) { return e == head || ((e * 0x9E3779B1u) >> C2A_SPLIT_SHIFT) == 0u; }
 
 // splitter compaction, 8 elements per lane: one atomic and three barriers per 2048 elements
 __global__ void __launch_bounds__(kThreads) k_rank_mark(u32 m, const u32* __restrict__ rlist, u32* scount, u32* slist,
