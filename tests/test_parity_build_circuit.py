@@ -227,3 +227,17 @@ def test_dataflow_peel_shapes(backend, orc, shape):
         p = dict(lh=lh, rh=rh, out=out, op=rng.integers(0, 20, n).astype(np.uint8), n_nodes=10 + n + 1,
                  input_nodes=np.array([1, 2], np.uint32), output_nodes=np.array([10 + n - 1], np.uint32))
     assert _compare(backend, orc, p, check_serial=False) == "ok"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layers,width,window,seed", [(1500, 200, 8, 11), (300, 1000, 64, 12), (6000, 50, 2, 13), (60, 5000, 30, 14)])
+def test_dataflow_peel_mid_size_full_compare(hip_backend, orc, c2a, layers, width, window, seed):
+    """300 K-gate graphs of four aspect ratios through the shipped configuration (all 2 048 waves of the dataflow launch
+    in play, real concurrency), every output array compared with the oracle element by element, three runs each
+    (same buffers: stale data from the previous run must not leak into the next)."""
+    fg = c2a.synth.layered_dag(layers, width, n_in=256, n_const=16, window=window, mix=c2a.synth.MIX_ALL, seed=seed)
+    p = dict(lh=fg.lh, rh=fg.rh, out=fg.out, op=fg.op, n_nodes=fg.n_nodes, input_nodes=fg.input_nodes,
+             output_nodes=fg.output_nodes)
+    for _ in range(3):
+        assert _compare(hip_backend, orc, p, check_serial=False) == "ok"
+    assert hip_backend.stats()["levels"] >= layers
