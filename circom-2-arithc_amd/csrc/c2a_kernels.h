@@ -734,7 +734,7 @@ __global__ void __launch_bounds__((WPB + 1) * 64) k_peel_level_wave_str(PeelArgs
 // completes the list (verified hand-off: tools/ubench/xcd2.hip, sc1 store -> atomic -> sc1 load, 0 stale reads).
 // A candidate record's home is static (cand[cons_off[d] + eslot[2g+l]], the edge's index from k_deps), so a push
 // needs ONE ticket and that ticket is the commit.  Tree node identity = gate id (order/posof are the identity).
-// The sinks (gates nobody consumes: 17 % of the headline graph) are peeled by a plain grid-stride kernel first; the
+// The sinks (gates nobody consumes: 14 % of the headline graph) are peeled by a plain grid-stride kernel first; the
 // producers they complete seed the dataflow launch.
 // ================================================================================================
 struct AsyncArgs {
