@@ -952,7 +952,11 @@ __global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
             { const ull t = c2a_now(); st_idle += t - st_t0; if (g == C2A_NONE) st_final = t - st_t0; st_t0 = t; }
             if (g == C2A_NONE) break;
         }
-        // ---- follow the chain from g
+        // ---- follow the chain from g.  When the chain goes on from gate p to its producer g, p's own record and string
+        // are still in registers: if p is g's ONLY consumer the whole tournament needs no load at all.
+        bool own_valid = false;
+        u32 own_node = 0, own_label = 0, own_depth = 0, own_root = 0, own_level = 0;
+        u64 own_str = 0;
         for (;;) {
             const u32 e0 = gi.z, e1 = e0 + gi.w;
             const u32 dl = lane == 0 ? gi.x : (lane == 1 ? gi.y : C2A_NONE);
@@ -962,7 +966,14 @@ __global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
             u32 ch = C2A_NONE, ch_el = 0, ch_root = g, ch_depth = 0, level = 0;
             u64 champ_w = 0;
             bool champ_loaded = false;
-            for (u32 eb = e0; eb < e1; eb += 64) {
+            const bool only_me = own_valid && gi.w == 1;
+            if (only_me) {
+                // the single candidate is the gate this wave just finished: same rules as below (a larger DFS root loses to
+                // [g] itself), no round trip
+                level = own_level + 1;
+                if (own_root < g) { ch = own_node; ch_el = own_label; ch_depth = own_depth; ch_root = own_root; champ_w = own_str; champ_loaded = true; }
+            }
+            for (u32 eb = e0; eb < (only_me ? e0 : e1); eb += 64) {
                 const u32 e = eb + lane;
                 const bool valid = e < e1;
                 const uint4 cr_raw = ld_rec<true>(&A.cand[valid ? e : e0]);
@@ -1082,6 +1093,7 @@ __global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
                 A.meta[g] = make_uint4(ch, depth, ch_root, tag);
                 if (ch != C2A_NONE) A.child[2 * (u64)ch + my_label] = g;
             }
+            u64 own_word = 0;
             if (ch != C2A_NONE) {
                 const bool need_parent = ch_depth != 0 && chunk_of(depth) == chunk_of(ch_depth);
                 if (need_parent && !champ_loaded) {
@@ -1091,7 +1103,7 @@ __global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
                 }
                 bool fresh;
                 const u64 nw = child_word(need_parent ? champ_w : 0ull, ch_depth, my_label, lane, fresh);
-                if (lane * 64 < chunk_len(depth)) st_str(&A.pstr[(u64)g * kChunkWords + lane], nw);
+                if (lane * 64 < chunk_len(depth)) { st_str(&A.pstr[(u64)g * kChunkWords + lane], nw); own_word = nw; }
                 if (lane == 0 && chunk_of(depth)) st_u32<true>(&A.cprev[g], fresh ? ch : ld_u32<true>(&A.cprev[ch]));
             }
             // ---- pushes: record to its static home, everything acknowledged, then the commit ticket
@@ -1125,6 +1137,9 @@ __global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
                     head = other;
                 }
             }
+            // what the next step may reuse: this gate as a candidate of nxt
+            own_valid = true; own_node = g; own_label = j0; own_depth = depth; own_root = ch_root; own_level = level;
+            own_str = own_word;
             g = nxt; gi = ngi;
         }
     }
