@@ -233,7 +233,8 @@ int do_peel_async(c2a_ctx* c, u32* peeled_out) {
     HIP_TRY(hipMemsetAsync(c->aq_seed_cnt.p, 0, (size_t)A.n_regions * 4, s));
     A.seeds = c->aq_seeds.as<FrontierSlot>(); A.seed_cnt = c->aq_seed_cnt.as<u32>();
     C2A_LAUNCH(k_async_sinks, sink_blocks, kThreads, s, A);
-    C2A_LAUNCH(k_peel_async, waves, 64, s, A);
+    if (want_stats) C2A_LAUNCH((k_peel_async<true>), waves, 64, s, A);
+    else C2A_LAUNCH((k_peel_async<false>), waves, 64, s, A);
     C2A_LAUNCH_NOSYNC(k_identity, grid_for(n, 4096), kThreads, s, n, c->order.as<u32>(), c->posof.as<u32>());
     u32 t2[3] = {0, 0, 0};
     int r = read_scalars(c, t2, SC_ASYNC, 3);

@@ -855,6 +855,7 @@ __device__ __forceinline__ bool next_seed(const AsyncArgs& A, u32& region, u32& 
 }
 
 // the dataflow launch: 64-thread workgroups (one wave each)
+template <bool STATS>
 __global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
     const u32 lane = threadIdx.x;
     u32 region = blockIdx.x, idx = 0;               // this wave's share of the seeds: regions me, me + waves, ...
@@ -868,7 +869,7 @@ __global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
     u32 roam = me * 0x9E3779B1u;             // pseudo-random walk over the other queues
     bool registered = false;                 // counted in idle[]
     u32 st_pops = 0, st_polls = 0, st_push = 0, st_seeds = 0;      // diagnostics (C2A_ASYNC_STATS)
-    ull st_busy = 0, st_idle = 0, st_t0 = c2a_now(), st_hand = 0, st_final = 0;
+    ull st_busy = 0, st_idle = 0, st_t0 = STATS ? c2a_now() : 0, st_hand = 0, st_final = 0;
     for (;;) {
         // ---- next piece of work: own stack, own share of the seeds, then the hand-off queues
         u32 g = C2A_NONE;
@@ -885,7 +886,7 @@ __global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
             g = a.x;
             gi = make_uint4(a.y, a.z, a.w, sl->b.x);
         } else {
-            { const ull t = c2a_now(); st_busy += t - st_t0; st_t0 = t; }
+            if (STATS) { const ull t = c2a_now(); st_busy += t - st_t0; st_t0 = t; }
             // poll: home queue, then a roaming one; a wave counts as idle from its first empty-handed poll until the
             // moment BEFORE it tries to claim an entry, so "all waves idle" implies that nothing is queued or in flight
             u32 polls = 0;
@@ -914,7 +915,7 @@ __global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
                             if (lane == 0) v = ld_u32<true>(&A.q_items[(u64)q * A.q_cap + qh]);
                             v = rdlane(v, 0);
                         } while (v == 0 && ++spins < kWatchdogPolls);
-                        if (v) { g = v - 1; gi = A.ginfo[g]; ++st_pops; if (A.stats) { const ull tp = __hip_atomic_load(&A.q_time[(u64)q * A.q_cap + qh], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (tp) { const ull dt = c2a_now() - tp; st_hand += dt; const u32 b = dt < 100 ? 0 : dt < 200 ? 1 : dt < 400 ? 2 : dt < 800 ? 3 : dt < 1600 ? 4 : 5; if (lane == 0) atomicAdd(&A.stats[10 + b], 1ull); } } }
+                        if (v) { g = v - 1; gi = A.ginfo[g]; ++st_pops; if (STATS) { const ull tp = __hip_atomic_load(&A.q_time[(u64)q * A.q_cap + qh], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (tp) { const ull dt = c2a_now() - tp; st_hand += dt; const u32 b = dt < 100 ? 0 : dt < 200 ? 1 : dt < 400 ? 2 : dt < 800 ? 3 : dt < 1600 ? 4 : 5; if (lane == 0) atomicAdd(&A.stats[10 + b], 1ull); } } }
                         else if (lane == 0) atomicAdd(&A.totals[2], 1u);
                         break;
                     }
@@ -949,7 +950,7 @@ __global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
 #endif
             }
             st_polls += polls;
-            { const ull t = c2a_now(); st_idle += t - st_t0; if (g == C2A_NONE) st_final = t - st_t0; st_t0 = t; }
+            if (STATS) { const ull t = c2a_now(); st_idle += t - st_t0; if (g == C2A_NONE) st_final = t - st_t0; st_t0 = t; }
             if (g == C2A_NONE) break;
         }
         // ---- follow the chain from g.  When the chain goes on from gate p to its producer g, p's own record and string
@@ -1130,7 +1131,7 @@ __global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
                 if (lane == 0) t = atomicAdd(&head_w[2 * (u64)q * kQStride + 1], 1u);
                 t = rdlane(t, 0);
                 if (t < A.q_cap) {
-                    if (A.stats && lane == 0) __hip_atomic_store(&A.q_time[(u64)q * A.q_cap + t], c2a_now(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (STATS && lane == 0) __hip_atomic_store(&A.q_time[(u64)q * A.q_cap + t], c2a_now(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (lane == 0) st_u32<true>(&A.q_items[(u64)q * A.q_cap + t], other + 1u);
                 } else {                                           // cannot happen with q_cap >= n / n_queues + waves (see host)
                     if (lane == 0) st_u32<true>(&A.link[other], head);
@@ -1147,7 +1148,7 @@ __global__ void __launch_bounds__(64) k_peel_async(AsyncArgs A) {
         if (!registered) atomicAdd(&A.idle[(me % kIdleCounters) * 16], 1u);      // a wave that has left counts as idle for good
         if (processed) atomicAdd(&A.totals[0], processed);
         if (max_level) atomicMax(&A.totals[1], max_level);
-        if (A.stats) {
+        if (STATS) {
             atomicAdd(&A.stats[0], (ull)st_pops); atomicAdd(&A.stats[1], (ull)st_polls); atomicAdd(&A.stats[2], (ull)st_push);
             atomicAdd(&A.stats[3], st_busy); atomicAdd(&A.stats[4], st_idle); atomicAdd(&A.stats[5], (ull)st_seeds); atomicAdd(&A.stats[6], (ull)processed);
             atomicMax(&A.stats[7], st_busy);
