@@ -64,8 +64,8 @@ class _Timings(ctypes.Structure):
 class _Stats(ctypes.Structure):
     _fields_ = [("n_gates", ctypes.c_uint64), ("n_edges", ctypes.c_uint64), ("levels", ctypes.c_uint32),
                 ("max_depth", ctypes.c_uint32), ("n_roots", ctypes.c_uint32), ("n_splitters", ctypes.c_uint32),
-                ("level_launches", ctypes.c_uint32), ("frontier_segments", ctypes.c_uint32),
-                ("path_chunks", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+                ("level_launches", ctypes.c_uint32), ("peel_waves", ctypes.c_uint32),
+                ("path_chunks", ctypes.c_uint32), ("peel_rereads", ctypes.c_uint32)]
 
 
 @dataclass

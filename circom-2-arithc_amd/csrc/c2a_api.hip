@@ -39,13 +39,11 @@ struct c2a_ctx {
     std::string err;
     Stage stage = ST_EMPTY;
     int n_cu = 256;
-    u32 peel_wave_max = 8192;      // frontier size up to which a level gets one wave per gate
     u32 bool_chunk = 256;          // arithmetic gates per k_boolify workgroup: 128, 256 (measured best) or 512
     u32 peel_sinks_blocks = 4096;  // grid cap of the sinks pass (latency-bound per thread: two dependent round trips per sink)
-    u32 peel_async_waves = 8;      // dataflow launch: waves per CU
-    u32 peel_async = 1;            // 1: the whole peel as ONE dataflow launch (k_peel_async), 0: one launch per reverse Kahn level
-    u32 peel_wpb = 16;             // waves per workgroup in wave mode (one of them is the append wave): 4, 8, 12 or 16
-    u32 peel_slack_pct = 125;      // wave-mode grid = this % of the largest recent frontier (growth inside a batch of launches)
+    u32 peel_waves = 8;            // dataflow launch: single-wave workgroups per CU (clamped by the occupancy query)
+    u32 peel_epoch = 0;            // tag of the node words written by the last run (alternates; restarts after a clear)
+    bool node_clear = true;        // node records must be zeroed before the next run (new graph, or a run that failed)
 
     // problem
     u32 n = 0, n_nodes = 0, n_in = 0, n_out = 0;
@@ -57,7 +55,7 @@ struct c2a_ctx {
 
     // device buffers
     DevBuf lh, rh, out, op, gate4, in_nodes, out_nodes;
-    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, eslot, link, aq_ht, aq_items, aq_idle, aq_seeds, aq_seed_cnt, fill, cand, meta, pstr, cprev, fring, fbase, order, posof, child, ginfo, slots0, slots1;
+    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, eslot, link, aq_ht, aq_items, aq_idle, aq_seeds, aq_seed_cnt, fill, meta, node, child, ginfo, ginfo2, clist, pctl;
     DevBuf rflag, ridx, rlist, next, owner, local, slist, snext, ssum, jnxt, jval, sorted;
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op;
     DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof;
@@ -67,8 +65,8 @@ struct c2a_ctx {
     std::vector<DevBuf*> all;
 
     c2a_ctx() {
-        all = {&lh, &rh, &out, &op, &gate4, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &link, &aq_ht, &aq_items, &aq_idle, &aq_seeds, &aq_seed_cnt, &fill, &cand,
-               &ginfo, &slots0, &slots1, &meta, &pstr, &cprev, &fring, &fbase, &order, &posof, &child, &rflag, &ridx, &rlist, &next,
+        all = {&lh, &rh, &out, &op, &gate4, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &link, &aq_ht, &aq_items, &aq_idle, &aq_seeds, &aq_seed_cnt, &fill,
+               &ginfo, &ginfo2, &clist, &pctl, &meta, &node, &child, &rflag, &ridx, &rlist, &next,
                &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
                &node_wire, &e_in0, &e_in1, &e_out, &e_op, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &tsz, &asz, &goff,
                &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &ev_lcount, &ev_lbase, &ev_lorder, &cb_in0, &cb_in1, &cb_out, &cb_op};
@@ -78,7 +76,7 @@ struct c2a_ctx {
 namespace {
 
 // scalars block layout (u32 words unless noted)
-enum Scalar { SC_MAXDEPTH = 0, SC_SCOUNT = 1, SC_ERR = 2, SC_NMID = 3, SC_NROOTS = 4, SC_LEVELS = 5, SC_PEELED = 6 /*2 words*/, SC_DFS = 8 /*3 words*/, SC_ASYNC = 48 /*3 words*/, SC_DUP = 52,
+enum Scalar { SC_MAXDEPTH = 0, SC_SCOUNT = 1, SC_ERR = 2, SC_NMID = 3, SC_NROOTS = 4, SC_LEVELS = 5, SC_DFS = 8 /*3 words*/, SC_DUP = 52,
               SC_TOTAL64 = 16 /* u64 slots from here: 16..31 */, SC_WORDS = 64 };
 
 int fail(c2a_ctx* c, int code, const std::string& msg) {
@@ -111,8 +109,6 @@ int ensure(c2a_ctx* c, DevBuf& b, size_t bytes) {
         if (_r) return _r;                                   \
     } while (0)
 
-// grids of the frontier kernels are multiples of the segment count
-inline u32 grid_seg(u32 blocks) { return (blocks + kSeg - 1) / kSeg * kSeg; }
 inline u32 grid_for(u64 items, u32 cap_blocks) {
     u64 b = (items + kThreads - 1) / kThreads;
     if (b < 1) b = 1;
@@ -176,8 +172,6 @@ int do_prep(c2a_ctx* c) {
     HIP_TRY(hipMemsetAsync(c->prod1.p, 0, (size_t)c->n_nodes * 4, s));
     HIP_TRY(hipMemsetAsync(c->cons_cnt.p, 0, (size_t)n * 4, s));
     HIP_TRY(hipMemsetAsync(c->fill.p, 0, (size_t)n * 4, s));
-    HIP_TRY(hipMemsetAsync(c->fring.p, 0, (size_t)kRing * kSeg * 4, s));
-    HIP_TRY(hipMemsetAsync(c->fbase.p, 0, 8, s));
     HIP_TRY(hipMemsetAsync(c->child.p, 0xFF, (size_t)n * 8, s));
     HIP_TRY(hipMemsetAsync(c->scalars.p, 0, SC_WORDS * 4, s));
     C2A_LAUNCH_NOSYNC(k_producer, G, kThreads, s, n, c->out.as<u32>(), c->prod1.as<u32>(), c->scalars.as<u32>() + SC_DUP);
@@ -186,207 +180,91 @@ int do_prep(c2a_ctx* c) {
     int r = scan_exclusive<u32>(c, c->cons_cnt.as<u32>(), c->cons_off.as<u32>(), n);
     if (r) return r;
     C2A_LAUNCH_NOSYNC(k_ginfo, G, kThreads, s, n, c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_off.as<u32>(),
-                      c->cons_cnt.as<u32>(), c->ginfo.as<uint4>());
-    if (!c->peel_async)
-        C2A_LAUNCH(k_init_frontier, grid_seg(grid_for(n, 4096)), kThreads, s, n, seg_capacity(n), (const uint4*)c->ginfo.as<uint4>(),
-                   c->slots0.as<FrontierSlot>(), c->fring.as<u32>());
+                      c->cons_cnt.as<u32>(), c->eslot.as<u32>(), c->ginfo.as<uint4>(), c->ginfo2.as<uint4>(), c->clist.as<u32>());
     return C2A_OK;
 }
 
-// The whole peel as one dataflow launch (+ one grid-stride launch for the sinks): see k_peel_async.
-int do_peel_async(c2a_ctx* c, u32* peeled_out) {
-    const u32 n = c->n;
-    hipStream_t s = c->stream;
-    AsyncArgs A;
-    A.n = n; A.seg_cap = seg_capacity(n); A.ginfo = c->ginfo.as<uint4>(); A.eslot = c->eslot.as<u32>();
-    A.cand = c->cand.as<uint4>(); A.fill = c->fill.as<u32>(); A.meta = c->meta.as<uint4>(); A.pstr = c->pstr.as<u64>();
-    A.cprev = c->cprev.as<u32>(); A.child = c->child.as<u32>(); A.link = c->link.as<u32>();
-    A.totals = c->scalars.as<u32>() + SC_ASYNC;
+// how many single-wave workgroups of the dataflow launch fit the device at once (the launch is CORRECT with any
+// grid — termination counts the waves that have started — but waves beyond residency only queue up behind it)
+u32 peel_grid(c2a_ctx* c, bool stats) {
 #ifdef C2A_EMULATE
-    const u32 waves = kSeg;                          // the emulation runs them one after the other
+    (void)stats;
+    return 16;                                      // the emulation runs them one after the other
 #else
-    const u32 waves = grid_seg((u32)c->n_cu * c->peel_async_waves);
+    int per_cu = 0;
+    hipError_t e = stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_peel<true>, 64, 0)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_peel<false>, 64, 0);
+    if (e != hipSuccess || per_cu < 1) per_cu = 1;
+    const u32 w = std::min<u32>(c->peel_waves, (u32)per_cu);
+    return std::max<u32>(1u, (u32)c->n_cu * w);
 #endif
-    // hand-off queues: every entry is used once per run (no wrap-around); a wave spreads its pushes round robin, so
-    // a queue receives at most pushes / n_queues + waves entries
-    A.n_queues = std::max<u32>(1u, waves / 4);
-    if (const char* e = std::getenv("C2A_PEEL_QUEUES")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= waves) A.n_queues = v; }
-    A.q_cap = n / A.n_queues + waves + 64;
-    ENSURE(c->aq_ht, (size_t)A.n_queues * kQStride * 8); ENSURE(c->aq_items, (size_t)A.n_queues * A.q_cap * 4); ENSURE(c->aq_idle, (size_t)kIdleCounters * 64);
-    HIP_TRY(hipMemsetAsync(c->aq_ht.p, 0, (size_t)A.n_queues * kQStride * 8, s));
-    HIP_TRY(hipMemsetAsync(c->aq_items.p, 0, (size_t)A.n_queues * A.q_cap * 4, s));
-    HIP_TRY(hipMemsetAsync(c->aq_idle.p, 0, (size_t)kIdleCounters * 64, s));
-    A.q_ht = c->aq_ht.as<u64>(); A.q_items = c->aq_items.as<u32>(); A.idle = c->aq_idle.as<u32>();
-    const bool want_stats = std::getenv("C2A_ASYNC_STATS") != nullptr;
-    A.stats = nullptr;
-    A.q_time = nullptr;
-    if (want_stats) {
-        ENSURE(c->peel_prof, 128 + (size_t)A.n_queues * A.q_cap * 8);
-        HIP_TRY(hipMemsetAsync(c->peel_prof.p, 0, 128, s));
-        A.stats = c->peel_prof.as<ull>(); A.q_time = c->peel_prof.as<ull>() + 16;
-    }
-    // seed regions: one per workgroup of the sinks pass; a workgroup sees at most gates_per_block gates, each completes <= 2 producers
-    const u32 sink_blocks = grid_for(n, c->peel_sinks_blocks);
-    const u64 gates_per_block = ((u64)n + (u64)sink_blocks * kThreads - 1) / ((u64)sink_blocks * kThreads) * kThreads;
-    A.n_regions = sink_blocks; A.region_cap = (u32)(2 * gates_per_block);
-    ENSURE(c->aq_seeds, (size_t)A.n_regions * A.region_cap * sizeof(FrontierSlot)); ENSURE(c->aq_seed_cnt, (size_t)A.n_regions * 4);
-    HIP_TRY(hipMemsetAsync(c->aq_seed_cnt.p, 0, (size_t)A.n_regions * 4, s));
-    A.seeds = c->aq_seeds.as<FrontierSlot>(); A.seed_cnt = c->aq_seed_cnt.as<u32>();
-    C2A_LAUNCH(k_async_sinks, sink_blocks, kThreads, s, A);
-    if (want_stats) C2A_LAUNCH((k_peel_async<true>), waves, 64, s, A);
-    else C2A_LAUNCH((k_peel_async<false>), waves, 64, s, A);
-    C2A_LAUNCH_NOSYNC(k_identity, grid_for(n, 4096), kThreads, s, n, c->order.as<u32>(), c->posof.as<u32>());
-    u32 t2[3] = {0, 0, 0};
-    int r = read_scalars(c, t2, SC_ASYNC, 3);
-    if (r) return r;
-    if (want_stats) {
-        ull st[16];
-        HIP_TRY(hipMemcpy(st, c->peel_prof.p, 128, hipMemcpyDeviceToHost));
-        std::fprintf(stderr, "[c2a async stats] waves %u queues %u | seeds %llu, popped %llu, pushed %llu, processed %llu, polls %llu | busy %.1f ms-waves, idle %.1f ms-waves, longest busy wave %.2f ms\n", waves, A.n_queues,
-                     st[5], st[0], st[2], st[6], st[1], st[3] / 1e5, st[4] / 1e5, st[7] / 1e5);
-        if (st[0]) std::fprintf(stderr, "[c2a async stats] hand-off: mean %.0f ns from push to pop; final idle (waiting for the end) %.1f ms-waves of the idle time\n", st[8] * 10.0 / st[0], st[9] / 1e5);
-        std::fprintf(stderr, "[c2a async stats] hand-off latency histogram: <1us %llu, 1-2us %llu, 2-4us %llu, 4-8us %llu, 8-16us %llu, >=16us %llu\n", st[10], st[11], st[12], st[13], st[14], st[15]);
-    }
-    if (t2[2]) return fail(c, C2A_ERR_HIP, "dataflow peel: watchdog tripped (" + std::to_string(t2[2]) + " waves gave up waiting)");
-    *peeled_out = t2[0];
-    c->stats.levels = t2[0] ? t2[1] + 1 : 0;
-    c->stats.level_launches = 2;
-    return C2A_OK;
 }
 
-// Reverse Kahn peel: one launch per level, queued in batches; the host only looks at the level sizes between
-// batches (to stop, and to size the next batch's grid).
+// The whole peel as one dataflow launch (+ one grid-stride launch for the sinks): see c2a_peel.h.
 int do_peel(c2a_ctx* c, u32* peeled_out) {
     const u32 n = c->n;
     hipStream_t s = c->stream;
+    const bool want_stats = std::getenv("C2A_PEEL_STATS") != nullptr;
     PeelArgs A;
-    A.n = n; A.seg_cap = seg_capacity(n); A.ginfo = c->ginfo.as<uint4>();
-    A.slots[0] = c->slots0.as<FrontierSlot>(); A.slots[1] = c->slots1.as<FrontierSlot>();
-    A.cand = c->cand.as<uint4>(); A.fill = c->fill.as<u32>();
-    A.meta = c->meta.as<uint4>(); A.pstr = c->pstr.as<u64>(); A.cprev = c->cprev.as<u32>(); A.fring = c->fring.as<u32>(); A.fbase = c->fbase.as<u32>();
-    A.order = c->order.as<u32>(); A.posof = c->posof.as<u32>(); A.child = c->child.as<u32>();
-    A.prof = nullptr; A.prof_level0 = 256;
-    const bool profiling = std::getenv("C2A_PEEL_PROFILE") != nullptr;
-    if (profiling) {
-        ENSURE(c->peel_prof, (size_t)kProfLevels * kProfWaves * 8 * sizeof(ull));
-        HIP_TRY(hipMemsetAsync(c->peel_prof.p, 0, (size_t)kProfLevels * kProfWaves * 8 * sizeof(ull), s));
-        A.prof = c->peel_prof.as<ull>();
-        A.prof_level0 = (u32)std::strtoul(std::getenv("C2A_PEEL_PROFILE"), nullptr, 10);
+    A.n = n; A.ginfo = c->ginfo.as<uint4>(); A.ginfo2 = c->ginfo2.as<uint4>(); A.clist = c->clist.as<u32>();
+    A.node = c->node.as<u64>(); A.fill = c->fill.as<u32>(); A.meta = c->meta.as<uint4>(); A.child = c->child.as<u32>();
+    A.link = c->link.as<u32>();
+    // node words carry the tag of the run that wrote them: zeroed memory first sees tag 1, then the tag alternates (a word
+    // left over from two runs ago holds the same value: the peel of one loaded graph is deterministic)
+    if (c->node_clear) {
+        HIP_TRY(hipMemsetAsync(c->node.p, 0, (size_t)n * kNodeWords * 8, s));
+        c->peel_epoch = 0;
     }
-
-    u32 level = 0, launches = 0;
-    u32 seg0[kSeg];
-    HIP_TRY(hipMemcpyAsync(seg0, c->fring.as<u32>(), sizeof(seg0), hipMemcpyDeviceToHost, s));
+    c->peel_epoch ^= 1u;
+    c->node_clear = true;                            // until this run has finished cleanly
+    A.epoch = c->peel_epoch;
+    const u32 waves = peel_grid(c, want_stats);
+    // hand-off queues: every entry is used once per run (no wrap-around); a wave spreads its pushes round robin, so a
+    // queue receives at most pushes / n_queues + waves entries
+    A.n_queues = std::max<u32>(1u, waves / 4);
+    if (const char* e = std::getenv("C2A_PEEL_QUEUES")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= waves) A.n_queues = v; }
+    A.q_cap = n / A.n_queues + waves + 64;
+    ENSURE(c->aq_ht, (size_t)A.n_queues * kQStride * 8); ENSURE(c->aq_items, (size_t)A.n_queues * A.q_cap * 8); ENSURE(c->aq_idle, (size_t)kIdleCounters * 64);
+    ENSURE(c->pctl, (size_t)CTL_WORDS * 4);
+    HIP_TRY(hipMemsetAsync(c->aq_ht.p, 0, (size_t)A.n_queues * kQStride * 8, s));
+    HIP_TRY(hipMemsetAsync(c->aq_items.p, 0, (size_t)A.n_queues * A.q_cap * 8, s));
+    HIP_TRY(hipMemsetAsync(c->aq_idle.p, 0, (size_t)kIdleCounters * 64, s));
+    HIP_TRY(hipMemsetAsync(c->pctl.p, 0, (size_t)CTL_WORDS * 4, s));
+    A.q_ht = c->aq_ht.as<u64>(); A.q_items = c->aq_items.as<u64>(); A.idle = c->aq_idle.as<u32>(); A.ctl = c->pctl.as<u32>();
+    A.stats = nullptr;
+    if (want_stats) {
+        ENSURE(c->peel_prof, 128);
+        HIP_TRY(hipMemsetAsync(c->peel_prof.p, 0, 128, s));
+        A.stats = c->peel_prof.as<ull>();
+    }
+    // seed regions: one per workgroup of the sinks pass; a workgroup sees at most gates_per_block gates, each claims <= 2 producers
+    const u32 sink_blocks = grid_for(n, c->peel_sinks_blocks);
+    const u64 gates_per_block = ((u64)n + (u64)sink_blocks * kThreads - 1) / ((u64)sink_blocks * kThreads) * kThreads;
+    A.n_regions = sink_blocks; A.region_cap = (u32)(2 * gates_per_block);
+    ENSURE(c->aq_seeds, (size_t)A.n_regions * A.region_cap * 4); ENSURE(c->aq_seed_cnt, (size_t)A.n_regions * 4);
+    HIP_TRY(hipMemsetAsync(c->aq_seed_cnt.p, 0, (size_t)A.n_regions * 4, s));
+    A.seeds = c->aq_seeds.as<u32>(); A.seed_cnt = c->aq_seed_cnt.as<u32>();
+    C2A_LAUNCH(k_peel_sinks, sink_blocks, kThreads, s, A);
+    if (want_stats) C2A_LAUNCH((k_peel<true>), waves, 64, s, A);
+    else C2A_LAUNCH((k_peel<false>), waves, 64, s, A);
+    u32 t4[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(t4, c->pctl.p, sizeof(t4), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    u32 est = 0;                     // frontier size estimate for grid sizing
-    for (u32 t = 0; t < kSeg; ++t) est += seg0[t];
-    u32 batch = 8;
-    const u32 max_blocks = (u32)c->n_cu * 8;         // a multiple of kSeg
-    u32 peeled = 0;
-    while (true) {
-        // narrow frontier -> one wave per gate (latency ~ one path comparison per level);
-        // wide frontier   -> one lane per gate (throughput)
-        const bool wave_mode = level > 0 && est <= c->peel_wave_max;
-        const u32 wg_waves = c->peel_wpb;                // waves per workgroup: wg_waves - 1 gate waves + the append wave
-        const u32 wpb = wg_waves - 1;
-        // per segment: ~est / kSeg gates (+ slack for growth inside the batch), WPB or 256 per workgroup
-        const u32 per_seg = wave_mode ? (u32)(((u64)est * c->peel_slack_pct / 100 / kSeg + wpb - 1) / wpb) + 1
-                                      : (u32)(((u64)est * 2 / kSeg + kThreads - 1) / kThreads);
-        const u32 blocks = std::max<u32>(kSeg, std::min<u32>(max_blocks, per_seg * kSeg));
-        for (u32 i = 0; i < batch; ++i) {
-            if (!wave_mode) C2A_LAUNCH(k_peel_level_str, blocks, kThreads, s, A, level);
-            else if (profiling) {
-                if (wg_waves == 16) C2A_LAUNCH((k_peel_level_wave_str<15, true>), blocks, 1024, s, A, level);
-                else if (wg_waves == 12) C2A_LAUNCH((k_peel_level_wave_str<11, true>), blocks, 768, s, A, level);
-                else if (wg_waves == 8) C2A_LAUNCH((k_peel_level_wave_str<7, true>), blocks, 512, s, A, level);
-                else C2A_LAUNCH((k_peel_level_wave_str<3, true>), blocks, 256, s, A, level);
-            } else {
-                if (wg_waves == 16) C2A_LAUNCH((k_peel_level_wave_str<15, false>), blocks, 1024, s, A, level);
-                else if (wg_waves == 12) C2A_LAUNCH((k_peel_level_wave_str<11, false>), blocks, 768, s, A, level);
-                else if (wg_waves == 8) C2A_LAUNCH((k_peel_level_wave_str<7, false>), blocks, 512, s, A, level);
-                else C2A_LAUNCH((k_peel_level_wave_str<3, false>), blocks, 256, s, A, level);
-            }
-            ++level; ++launches;
-            if (level > n) break;
-        }
-        // sizes of the last few levels (from the level boundaries) and of the next one (its segment counters)
-        u32 tail[10] = {0};
-        u32 segs[kSeg] = {0};
-        const u32 look = std::min<u32>(8u, level);
-        HIP_TRY(hipMemcpyAsync(tail, c->fbase.as<u32>() + (level - look), (look + 1) * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(segs, c->fring.as<u32>() + (level % kRing) * kSeg, sizeof(segs), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        u32 next_cnt = 0;
-        for (u32 t = 0; t < kSeg; ++t) next_cnt += segs[t];
-        if (next_cnt == 0 || level > n) break;
-        u32 mx = next_cnt;
-        for (u32 k = 0; k < look; ++k) mx = std::max(mx, tail[k + 1] - tail[k]);
-        est = mx;
-        batch = std::min<u32>(batch * 2, 512u);
+    if (want_stats) {
+        ull st[16];
+        HIP_TRY(hipMemcpy(st, c->peel_prof.p, 128, hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[c2a peel stats] waves %u queues %u | seeds %llu, popped %llu, pushed %llu, processed %llu, idle polls %llu, record re-reads %llu | busy %.1f ms-waves, idle %.1f ms-waves, longest busy wave %.2f ms\n",
+                     waves, A.n_queues, st[5], st[0], st[2], st[6], st[1], st[8], st[3] / 1e5, st[4] / 1e5, st[7] / 1e5);
+        if (st[13]) std::fprintf(stderr, "[c2a peel stats] per chain step (ns): until the records are in %.0f, tournament %.0f, tickets + static data of the producers %.0f, stores + hand-over %.0f | steps without a load %.1f %% | chain start (static loads) %.0f ns per chain\n",
+                     st[9] * 10.0 / st[13], st[10] * 10.0 / st[13], st[11] * 10.0 / st[13], st[12] * 10.0 / st[13], 100.0 * st[14] / st[13], st[15] * 10.0 / (st[5] + st[0] + 1));
     }
-    {
-        u32* tot = c->scalars.as<u32>() + SC_PEELED;
-        C2A_LAUNCH(k_peel_totals, 1, kThreads, s, (const u32*)c->fbase.as<u32>(), level, tot);
-        u32 t2[2] = {0, 0};
-        int r = read_scalars(c, t2, SC_PEELED, 2);
-        if (r) return r;
-        peeled = t2[0];
-        c->stats.levels = t2[1];
-    }
-    c->stats.level_launches = launches;
-    if (profiling) {   // diagnostics: mean over levels of the slowest wave's phase timestamps (ns since kernel entry)
-        std::vector<ull> hp((size_t)kProfLevels * kProfWaves * 8);
-        HIP_TRY(hipMemcpy(hp.data(), c->peel_prof.p, hp.size() * sizeof(ull), hipMemcpyDeviceToHost));
-        for (u32 L = 0; L < kProfLevels; L += 8) {
-            // per level: number of active waves, mean/max of each phase, and the slowest wave's record
-            double mean[6] = {0}; ull mx[6] = {0}; u32 act = 0, slow = 0; ull slow_end = 0; u32 last_active = 0; ull tmin = ~0ull, tmax = 0, fin = 0;
-            for (u32 w = 0; w < kProfWaves; ++w) {
-                const ull* r = &hp[((size_t)L * kProfWaves + w) * 8];
-                if (!r[4]) continue;
-                last_active = w;
-                if (!r[7]) continue;
-                ++act;
-                for (int k = 0; k < 6; ++k) { mean[k] += (double)r[k] * 10; mx[k] = std::max(mx[k], r[k] * 10); }
-                if (r[5] > slow_end) { slow_end = r[5]; slow = w; }
-                tmin = std::min(tmin, r[6]); tmax = std::max(tmax, r[6]); fin = std::max(fin, r[6] + r[5]);
-            }
-            {   // distribution of a wave's own finishing time (slot 4: stores issued) and of the tournament (slot 3 - slot 2), by candidate count
-                std::vector<ull> own; std::vector<ull> tour;
-                double by_c[5] = {0}, by_t[5] = {0}; u32 by_n[5] = {0};
-                for (u32 w = 0; w < kProfWaves; ++w) {
-                    const ull* q = &hp[((size_t)L * kProfWaves + w) * 8];
-                    if (!q[4] || !q[7]) continue;
-                    own.push_back(q[4] * 10); tour.push_back((q[3] - q[2]) * 10);
-                    const u32 cb = (u32)std::min<ull>(q[7] - 1000, 4);
-                    by_c[cb] += (double)q[4] * 10; by_t[cb] += (double)(q[3] - q[2]) * 10; by_n[cb]++;
-                }
-                {   // (C2A_PROF_STRINGS builds: slot 5 = strings arrived) split the tournament into load and compare
-                    double ld = 0, cmp = 0, nold = 0; u32 n_ld = 0, n_no = 0;
-                    for (u32 w = 0; w < kProfWaves; ++w) {
-                        const ull* q = &hp[((size_t)L * kProfWaves + w) * 8];
-                        if (!q[4] || !q[7]) continue;
-                        if (q[5] && q[5] >= q[2] && q[5] <= q[3]) { ld += (double)(q[5] - q[2]) * 10; cmp += (double)(q[3] - q[5]) * 10; ++n_ld; }
-                        else { nold += (double)(q[3] - q[2]) * 10; ++n_no; }
-                    }
-                    if (n_ld) std::fprintf(stderr, "[c2a peel profile]   tournaments with string loads: %u, until strings arrived %.0f ns, compare %.0f ns; without: %u, %.0f ns\n", n_ld, ld / n_ld, cmp / n_ld, n_no, n_no ? nold / n_no : 0.0);
-                }
-                std::sort(own.begin(), own.end()); std::sort(tour.begin(), tour.end());
-                auto pct = [](const std::vector<ull>& v, double f) { return v.empty() ? 0ull : v[(size_t)((v.size() - 1) * f)]; };
-                std::fprintf(stderr, "[c2a peel profile]   own finish ns p50=%llu p90=%llu p99=%llu max=%llu | tournament p50=%llu p90=%llu p99=%llu max=%llu | by candidates (n, own, tournament):",
-                             pct(own, .5), pct(own, .9), pct(own, .99), pct(own, 1.0), pct(tour, .5), pct(tour, .9), pct(tour, .99), pct(tour, 1.0));
-                for (int k = 0; k < 5; ++k) if (by_n[k]) std::fprintf(stderr, " c%d%s=(%u, %.0f, %.0f)", k, k == 4 ? "+" : "", by_n[k], by_c[k] / by_n[k], by_t[k] / by_n[k]);
-                std::fprintf(stderr, "\n");
-            }
-            if (!act) continue;
-            const ull* r = &hp[((size_t)L * kProfWaves + slow) * 8];
-            std::fprintf(stderr, "[c2a peel profile] level %u: %u gate-waves (last wave id with a record %u); mean ns p0=%.0f p1=%.0f p2=%.0f p3=%.0f p4=%.0f end=%.0f | "
-                         "max end=%llu start-skew=%llu first-start->last-finish=%llu | slowest wave %u: %llu %llu %llu %llu %llu %llu cands=%llu\n", L + A.prof_level0, act, last_active,
-                         mean[0] / act, mean[1] / act, mean[2] / act, mean[3] / act, mean[4] / act, mean[5] / act, (unsigned long long)mx[5], (unsigned long long)(tmax - tmin) * 10, (unsigned long long)(fin - tmin) * 10, slow,
-                         (unsigned long long)r[0] * 10, (unsigned long long)r[1] * 10, (unsigned long long)r[2] * 10, (unsigned long long)r[3] * 10,
-                         (unsigned long long)r[4] * 10, (unsigned long long)r[5] * 10, (unsigned long long)(r[7] - 1000));
-        }
-    }
-    *peeled_out = peeled;
+    if (t4[CTL_ABORT]) return fail(c, C2A_ERR_HIP, "dataflow peel: watchdog tripped (" + std::to_string(t4[CTL_ABORT]) + " waves gave up waiting)");
+    c->node_clear = false;
+    *peeled_out = t4[CTL_PROCESSED];
+    c->stats.levels = t4[CTL_PROCESSED] ? t4[CTL_MAXLEVEL] + 1 : 0;
+    c->stats.level_launches = 2;
+    c->stats.peel_waves = waves;
+    c->stats.peel_rereads = t4[CTL_REREADS];
     return C2A_OK;
 }
 
@@ -394,17 +272,16 @@ int do_order(c2a_ctx* c) {
     const u32 n = c->n;
     hipStream_t s = c->stream;
     const u32 G = grid_for(n, 4096);
-    C2A_LAUNCH(k_rootflag, grid_for(n, 1024), kThreads, s, n, c->meta.as<uint4>(), c->posof.as<u32>(), c->rflag.as<u32>(),
+    C2A_LAUNCH(k_rootflag, grid_for(n, 1024), kThreads, s, n, c->meta.as<uint4>(), c->rflag.as<u32>(),
                c->scalars.as<u32>() + SC_MAXDEPTH);
     int r = scan_exclusive<u32>(c, c->rflag.as<u32>(), c->ridx.as<u32>(), n);
     if (r) return r;
-    C2A_LAUNCH_NOSYNC(k_rootlist, G, kThreads, s, n, c->rflag.as<u32>(), c->ridx.as<u32>(), c->posof.as<u32>(),
-                      c->rlist.as<u32>());
+    C2A_LAUNCH_NOSYNC(k_rootlist, G, kThreads, s, n, c->rflag.as<u32>(), c->ridx.as<u32>(), c->rlist.as<u32>());
     u32 n_roots = 0;
     HIP_TRY(hipMemcpyAsync(&n_roots, c->ridx.as<u32>() + n, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     c->stats.n_roots = n_roots;
-    C2A_LAUNCH_NOSYNC(k_euler_next, G, kThreads, s, n, c->meta.as<uint4>(), c->order.as<u32>(), c->child.as<u32>(),
+    C2A_LAUNCH_NOSYNC(k_euler_next, G, kThreads, s, n, c->meta.as<uint4>(), c->child.as<u32>(),
                       c->ridx.as<u32>(), c->rlist.as<u32>(), n_roots, c->next.as<u32>());
     const u32 m = 2 * n;
     u32* scount = c->scalars.as<u32>() + SC_SCOUNT;
@@ -428,7 +305,7 @@ int do_order(c2a_ctx* c) {
         std::swap(nx_a, nx_b);
         std::swap(vl_a, vl_b);
     }
-    C2A_LAUNCH_NOSYNC(k_rank_final, G, kThreads, s, n, c->order.as<u32>(), c->owner.as<u32>(), c->local.as<u32>(),
+    C2A_LAUNCH_NOSYNC(k_rank_final, G, kThreads, s, n, c->owner.as<u32>(), c->local.as<u32>(),
                       (const u32*)vl_a, c->sorted.as<u32>());
     return C2A_OK;
 }
@@ -464,7 +341,7 @@ int do_topo_sort(c2a_ctx* c, u64* cycle_at) {
     if (r) return r;
     rec(c, EV_PREP1);
     u32 peeled = 0;
-    r = c->peel_async ? do_peel_async(c, &peeled) : do_peel(c, &peeled);
+    r = do_peel(c, &peeled);
     if (r) return r;
     rec(c, EV_PEEL1);
     {
@@ -588,12 +465,8 @@ int c2a_create(int device_id, c2a_ctx** out) {
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
         c->n_cu = prop.multiProcessorCount;
     if (const char* e = std::getenv("C2A_BOOL_CHUNK")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 128 || v == 256 || v == 512) c->bool_chunk = v; }
-    if (const char* e = std::getenv("C2A_PEEL_ASYNC")) c->peel_async = std::strtoul(e, nullptr, 10) != 0;
     if (const char* e = std::getenv("C2A_PEEL_SINKS_BLOCKS")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 16) c->peel_sinks_blocks = v; }
-    if (const char* e = std::getenv("C2A_PEEL_ASYNC_WAVES")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 32) c->peel_async_waves = v; }
-    if (const char* e = std::getenv("C2A_PEEL_WPB")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 4 || v == 8 || v == 12 || v == 16) c->peel_wpb = v; }
-    if (const char* e = std::getenv("C2A_PEEL_SLACK")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 100 && v <= 400) c->peel_slack_pct = v; }
-    if (const char* e = std::getenv("C2A_PEEL_WAVE_MAX")) c->peel_wave_max = (u32)std::strtoul(e, nullptr, 10);   // tuning / test knob
+    if (const char* e = std::getenv("C2A_PEEL_WAVES")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 32) c->peel_waves = v; }
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return C2A_ERR_HIP; }
     for (int i = 0; i < EV_COUNT; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return C2A_ERR_HIP; }
@@ -639,12 +512,10 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     ENSURE(c->lh, n4); ENSURE(c->rh, n4); ENSURE(c->out, n4); ENSURE(c->op, n); ENSURE(c->gate4, (size_t)n * 16);
     ENSURE(c->in_nodes, (size_t)n_in * 4); ENSURE(c->out_nodes, (size_t)n_out * 4);
     ENSURE(c->prod1, nn4); ENSURE(c->dep0, n4); ENSURE(c->dep1, n4); ENSURE(c->cons_cnt, n4);
-    ENSURE(c->cons_off, n4 + 4); ENSURE(c->eslot, 2 * n4); ENSURE(c->link, n4); ENSURE(c->fill, n4); ENSURE(c->cand, (size_t)n * 2 * 16);
-    ENSURE(c->meta, (size_t)n * 16); ENSURE(c->ginfo, (size_t)n * 16);
-    ENSURE(c->slots0, (size_t)kSeg * seg_capacity(n) * sizeof(FrontierSlot)); ENSURE(c->slots1, (size_t)kSeg * seg_capacity(n) * sizeof(FrontierSlot));
-
-    ENSURE(c->pstr, (size_t)n * kChunkWords * 8); ENSURE(c->cprev, (size_t)n * 4);
-    ENSURE(c->fring, (size_t)kRing * kSeg * 4); ENSURE(c->fbase, n4 + 8); ENSURE(c->order, n4); ENSURE(c->posof, n4); ENSURE(c->child, 2 * n4);
+    ENSURE(c->cons_off, n4 + 4); ENSURE(c->eslot, 2 * n4); ENSURE(c->link, n4); ENSURE(c->fill, n4);
+    ENSURE(c->meta, (size_t)n * 16); ENSURE(c->ginfo, (size_t)n * 16); ENSURE(c->ginfo2, (size_t)n * 16); ENSURE(c->clist, 2 * n4 + 64 * 4);
+    ENSURE(c->node, (size_t)n * kNodeWords * 8); ENSURE(c->child, 2 * n4);
+    c->node_clear = true;
     ENSURE(c->rflag, n4); ENSURE(c->ridx, n4 + 4); ENSURE(c->rlist, n4);
     ENSURE(c->next, 2 * n4); ENSURE(c->owner, 2 * n4); ENSURE(c->local, 2 * n4); ENSURE(c->slist, 2 * n4);
     ENSURE(c->snext, 2 * n4); ENSURE(c->ssum, 2 * n4); ENSURE(c->jnxt, 2 * n4); ENSURE(c->jval, 2 * n4);
@@ -970,7 +841,7 @@ int c2a_verify_boolify(c2a_ctx* c, uint64_t seed, uint64_t* n_checked, uint64_t*
         int r = scan_exclusive<u32>(c, c->ev_lcount.as<u32>(), c->ev_lbase.as<u32>(), L);
         if (r) return r;
         HIP_TRY(hipMemsetAsync(c->ev_lcount.p, 0, ((size_t)L + 1) * 4, s));
-        C2A_LAUNCH_NOSYNC(k_level_scatter, grid_for(n, 4096), kThreads, s, n, (const uint4*)c->meta.as<uint4>(), (const u32*)c->order.as<u32>(),
+        C2A_LAUNCH_NOSYNC(k_level_scatter, grid_for(n, 4096), kThreads, s, n, (const uint4*)c->meta.as<uint4>(),
                           (const u32*)c->ev_lbase.as<u32>(), c->ev_lcount.as<u32>(), c->ev_lorder.as<u32>());
         HIP_TRY(hipMemcpyAsync(fb.data(), c->ev_lbase.p, ((size_t)L + 1) * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -1023,7 +894,6 @@ int c2a_get_timings(c2a_ctx* c, c2a_timings* t) {
 int c2a_get_stats(c2a_ctx* c, c2a_stats* s) {
     if (!c || !s) return C2A_ERR_ARG;
     *s = c->stats;
-    s->frontier_segments = kSeg;
     s->path_chunks = c->stats.max_depth ? (c->stats.max_depth - 1) / kChunkBits + 1 : 1;
     return C2A_OK;
 }

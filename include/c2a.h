@@ -59,7 +59,7 @@ typedef struct c2a_bool_info {
 } c2a_bool_info;
 
 typedef struct c2a_timings {     /* milliseconds, HIP events on the context's stream, last run */
-    float prep;                  /* producer map, deps, consumer CSR, level-0 frontier */
+    float prep;                  /* producer map, deps, consumer lists */
     float peel;                  /* reverse Kahn peel + DFS-tree parent selection (dataflow launch, or all levels) */
     float order;                 /* Euler tour + list ranking -> sorted_gate_ids */
     float wires;                 /* first-seen wire numbering */
@@ -77,10 +77,10 @@ typedef struct c2a_stats {
     uint32_t max_depth;          /* depth of the DFS tree */
     uint32_t n_roots;            /* DFS roots (children of the virtual root) */
     uint32_t n_splitters;        /* list-ranking sublists */
-    uint32_t level_launches;     /* peel kernel launches: 2 for the dataflow peel (sinks + one launch), else one per level */
-    uint32_t frontier_segments;  /* launch-per-level variant: independent append counters / slot regions of the frontier */
-    uint32_t path_chunks;        /* 4096-bit path-string chunks the deepest DFS path spans (1 = every comparison is one round trip) */
-    uint32_t reserved;
+    uint32_t level_launches;     /* peel kernel launches: 2 (the sinks pass + the one dataflow launch) */
+    uint32_t peel_waves;         /* single-wave workgroups of the dataflow launch (CUs x min(knob, occupancy query)) */
+    uint32_t path_chunks;        /* 3906-bit path-string chunks the deepest DFS path spans (1 = every tournament is one round trip) */
+    uint32_t peel_rereads;       /* times a wave read a candidate record again because a word of it had not arrived yet */
 } c2a_stats;
 
 /* Create a context on HIP device `device_id` (>= 0).  Fails with C2A_ERR_HIP when no device / runtime. */

@@ -47,7 +47,7 @@ def orc():
 @pytest.fixture(scope="session")
 def emul_lib():
     srcs = [os.path.join(ROOT, "circom-2-arithc_amd", "csrc", f) for f in
-            ("c2a_api.hip", "c2a_kernels.h", "c2a_templates.h", "c2a_platform.h")] + [
+            ("c2a_api.hip", "c2a_kernels.h", "c2a_peel.h", "c2a_templates.h", "c2a_platform.h")] + [
         os.path.join(EMUL_DIR, "hip_emul.h"), os.path.join(ROOT, "include", "c2a.h")]
     if (not os.path.exists(EMUL_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(EMUL_LIB) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", EMUL_DIR])
@@ -77,12 +77,9 @@ class _Env:
 
 @pytest.fixture(params=BACKENDS)
 def backend(request, c2a):
-    """Emulated build: the per-level kernel is forced to its one-lane-per-gate variant (the wave-per-gate
-    variant costs ~1000 fibers per workgroup under emulation; it has its own tests through `backend_wave`).
-    Real GPU: library defaults (wave-per-gate on narrow frontiers)."""
+    """Emulated build (kernel sources compiled for the host) or the product library on a real GPU."""
     if request.param == "emul":
-        with _Env(C2A_PEEL_WAVE_MAX=0):
-            be = c2a.Backend(0, lib_path=request.getfixturevalue("emul_lib"))
+        be = c2a.Backend(0, lib_path=request.getfixturevalue("emul_lib"))
     else:
         be = c2a.Backend(0)
         assert "hip" in be.version
@@ -95,23 +92,15 @@ def _variant(kind, mode):
     return pytest.param((kind, mode), id=f"{kind}-{mode}", marks=marks)
 
 
-# (library build, kernel shape of the per-level peel)
-WAVE_BACKENDS = [_variant("emul", "async"), _variant("emul", "wpb4"), _variant("emul", "lane"), _variant("hip", "async"),
-                 _variant("hip", "wpb4"), _variant("hip", "wpb8"), _variant("hip", "wpb12"), _variant("hip", "wpb16"), _variant("hip", "lane")]
+# (library build, waves per CU of the dataflow peel: the default, a starved launch, an oversubscribed one)
+WAVE_BACKENDS = [_variant("emul", "w8"), _variant("hip", "w8"), _variant("hip", "w1"), _variant("hip", "w32")]
 
 
 @pytest.fixture(params=WAVE_BACKENDS)
 def backend_wave(request, c2a):
-    """The dataflow (single-launch) peel, and the launch-per-level peel with every level (however wide) through the
-    wave-per-gate kernel at each workgroup shape / through the lane-per-gate kernel."""
+    """The dataflow peel at several launch sizes: termination must not depend on how many waves are resident."""
     kind, mode = request.param
-    if mode == "async":
-        kv = {"C2A_PEEL_ASYNC": 1}
-    elif mode == "lane":
-        kv = {"C2A_PEEL_ASYNC": 0, "C2A_PEEL_WAVE_MAX": 0}
-    else:
-        kv = {"C2A_PEEL_ASYNC": 0, "C2A_PEEL_WAVE_MAX": 1 << 30, "C2A_PEEL_WPB": int(mode[3:])}
-    with _Env(**kv):
+    with _Env(C2A_PEEL_WAVES=int(mode[1:])):
         be = c2a.Backend(0, lib_path=request.getfixturevalue("emul_lib")) if kind == "emul" else c2a.Backend(0)
     yield be
     be.close()

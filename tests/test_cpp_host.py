@@ -35,7 +35,7 @@ KINDS = [pytest.param("emul", id="emul"), pytest.param("hip", id="hip", marks=py
 @pytest.mark.parametrize("kind", KINDS)
 def test_reference_integration_tests_in_cpp(kind, tmp_path, request):
     exes = _build(tmp_path, kind, request.getfixturevalue("emul_lib") if kind == "emul" else None)
-    env = dict(os.environ, C2A_PEEL_WAVE_MAX="0") if kind == "emul" else dict(os.environ)
+    env = dict(os.environ)
     res = subprocess.run([exes["integration"]], capture_output=True, text=True, env=env, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "all checks passed" in res.stdout
@@ -44,7 +44,7 @@ def test_reference_integration_tests_in_cpp(kind, tmp_path, request):
 @pytest.mark.parametrize("kind", KINDS)
 def test_cli_writes_the_reference_artefacts(kind, tmp_path, request):
     exes = _build(tmp_path, kind, request.getfixturevalue("emul_lib") if kind == "emul" else None)
-    env = dict(os.environ, C2A_PEEL_WAVE_MAX="0") if kind == "emul" else dict(os.environ)
+    env = dict(os.environ)
     fx = FX["infixOps"]
     calls = tmp_path / "calls.txt"
     with open(calls, "w") as f:
