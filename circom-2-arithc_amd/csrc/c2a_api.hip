@@ -55,7 +55,7 @@ struct c2a_ctx {
 
     // device buffers
     DevBuf lh, rh, out, op, gate4, in_nodes, out_nodes;
-    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, eslot, link, aq_ht, aq_items, aq_idle, aq_seeds, aq_seed_cnt, fill, meta, node, child, ginfo, ginfo2, clist, pctl;
+    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, eslot, link, aq_ht, aq_items, aq_idle, aq_seeds, aq_seed_cnt, fill, meta, node, child, gstat, clist, pctl, pcold;
     DevBuf rflag, ridx, rlist, next, owner, local, slist, snext, ssum, jnxt, jval, sorted;
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op;
     DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof;
@@ -66,7 +66,7 @@ struct c2a_ctx {
 
     c2a_ctx() {
         all = {&lh, &rh, &out, &op, &gate4, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &link, &aq_ht, &aq_items, &aq_idle, &aq_seeds, &aq_seed_cnt, &fill,
-               &ginfo, &ginfo2, &clist, &pctl, &meta, &node, &child, &rflag, &ridx, &rlist, &next,
+               &gstat, &clist, &pctl, &pcold, &meta, &node, &child, &rflag, &ridx, &rlist, &next,
                &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
                &node_wire, &e_in0, &e_in1, &e_out, &e_op, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &tsz, &asz, &goff,
                &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &ev_lcount, &ev_lbase, &ev_lorder, &cb_in0, &cb_in1, &cb_out, &cb_op};
@@ -179,8 +179,8 @@ int do_prep(c2a_ctx* c) {
                       c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>());
     int r = scan_exclusive<u32>(c, c->cons_cnt.as<u32>(), c->cons_off.as<u32>(), n);
     if (r) return r;
-    C2A_LAUNCH_NOSYNC(k_ginfo, G, kThreads, s, n, c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_off.as<u32>(),
-                      c->cons_cnt.as<u32>(), c->eslot.as<u32>(), c->ginfo.as<uint4>(), c->ginfo2.as<uint4>(), c->clist.as<u32>());
+    C2A_LAUNCH_NOSYNC(k_gstat, G, kThreads, s, n, c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_off.as<u32>(),
+                      c->cons_cnt.as<u32>(), c->eslot.as<u32>(), c->gstat.as<uint4>(), c->clist.as<u32>());
     return C2A_OK;
 }
 
@@ -206,8 +206,9 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
     hipStream_t s = c->stream;
     const bool want_stats = std::getenv("C2A_PEEL_STATS") != nullptr;
     PeelArgs A;
-    A.n = n; A.ginfo = c->ginfo.as<uint4>(); A.ginfo2 = c->ginfo2.as<uint4>(); A.clist = c->clist.as<u32>();
+    A.n = n; A.gstat = c->gstat.as<uint4>(); A.clist = c->clist.as<u32>();
     A.node = c->node.as<u64>(); A.fill = c->fill.as<u32>(); A.meta = c->meta.as<uint4>(); A.child = c->child.as<u32>();
+    PeelCold cold;
     A.link = c->link.as<u32>();
     // node words carry the tag of the run that wrote them: zeroed memory first sees tag 1, then the tag alternates (a word
     // left over from two runs ago holds the same value: the peel of one loaded graph is deterministic)
@@ -231,19 +232,25 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
     HIP_TRY(hipMemsetAsync(c->aq_idle.p, 0, (size_t)kIdleCounters * 64, s));
     HIP_TRY(hipMemsetAsync(c->pctl.p, 0, (size_t)CTL_WORDS * 4, s));
     A.q_ht = c->aq_ht.as<u64>(); A.q_items = c->aq_items.as<u64>(); A.idle = c->aq_idle.as<u32>(); A.ctl = c->pctl.as<u32>();
-    A.stats = nullptr;
+    cold.stats = nullptr;
     if (want_stats) {
-        ENSURE(c->peel_prof, 128);
-        HIP_TRY(hipMemsetAsync(c->peel_prof.p, 0, 128, s));
-        A.stats = c->peel_prof.as<ull>();
+        ENSURE(c->peel_prof, 256);
+        HIP_TRY(hipMemsetAsync(c->peel_prof.p, 0, 256, s));
+        cold.stats = c->peel_prof.as<ull>();
     }
     // seed regions: one per workgroup of the sinks pass; a workgroup sees at most gates_per_block gates, each claims <= 2 producers
     const u32 sink_blocks = grid_for(n, c->peel_sinks_blocks);
     const u64 gates_per_block = ((u64)n + (u64)sink_blocks * kThreads - 1) / ((u64)sink_blocks * kThreads) * kThreads;
-    A.n_regions = sink_blocks; A.region_cap = (u32)(2 * gates_per_block);
-    ENSURE(c->aq_seeds, (size_t)A.n_regions * A.region_cap * 4); ENSURE(c->aq_seed_cnt, (size_t)A.n_regions * 4);
-    HIP_TRY(hipMemsetAsync(c->aq_seed_cnt.p, 0, (size_t)A.n_regions * 4, s));
-    A.seeds = c->aq_seeds.as<u32>(); A.seed_cnt = c->aq_seed_cnt.as<u32>();
+    cold.n_regions = sink_blocks; cold.region_cap = (u32)(2 * gates_per_block);
+    ENSURE(c->aq_seeds, (size_t)cold.n_regions * cold.region_cap * 4); ENSURE(c->aq_seed_cnt, (size_t)cold.n_regions * 4);
+    HIP_TRY(hipMemsetAsync(c->aq_seed_cnt.p, 0, (size_t)cold.n_regions * 4, s));
+    cold.seeds = c->aq_seeds.as<u32>(); cold.seed_cnt = c->aq_seed_cnt.as<u32>();
+    A.seeds_w = c->aq_seeds.as<u32>(); A.seed_cnt_w = c->aq_seed_cnt.as<u32>(); A.region_cap = cold.region_cap;
+    // what only the edges of the launch touch travels as one small block in HBM (keeps the kernel's scalar registers free)
+    ENSURE(c->pcold, sizeof(PeelCold));
+    HIP_TRY(hipMemcpyAsync(c->pcold.p, &cold, sizeof(PeelCold), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));                // `cold` is a stack object
+    A.cold = c->pcold.as<PeelCold>();
     C2A_LAUNCH(k_peel_sinks, sink_blocks, kThreads, s, A);
     if (want_stats) C2A_LAUNCH((k_peel<true>), waves, 64, s, A);
     else C2A_LAUNCH((k_peel<false>), waves, 64, s, A);
@@ -251,11 +258,13 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
     HIP_TRY(hipMemcpyAsync(t4, c->pctl.p, sizeof(t4), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (want_stats) {
-        ull st[16];
-        HIP_TRY(hipMemcpy(st, c->peel_prof.p, 128, hipMemcpyDeviceToHost));
-        std::fprintf(stderr, "[c2a peel stats] waves %u queues %u | seeds %llu, popped %llu, pushed %llu, processed %llu, idle polls %llu, record re-reads %llu | busy %.1f ms-waves, idle %.1f ms-waves, longest busy wave %.2f ms\n",
-                     waves, A.n_queues, st[5], st[0], st[2], st[6], st[1], st[8], st[3] / 1e5, st[4] / 1e5, st[7] / 1e5);
-        if (st[13]) std::fprintf(stderr, "[c2a peel stats] per chain step (ns): until the records are in %.0f, tournament %.0f, tickets + static data of the producers %.0f, stores + hand-over %.0f | steps without a load %.1f %% | chain start (static loads) %.0f ns per chain\n",
+        ull st[32];
+        HIP_TRY(hipMemcpy(st, c->peel_prof.p, 256, hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[c2a peel stats] waves %u queues %u | seeds %llu, popped %llu, pushed %llu, processed %llu, idle polls %llu, record re-reads %llu | busy %.1f ms-waves, idle %.1f ms-waves\n",
+                     waves, A.n_queues, st[5], st[0], st[2], st[6], st[1], st[8], st[3] / 1e5, st[4] / 1e5);
+        if (st[13]) std::fprintf(stderr, "[c2a peel stats] wait at the top of a step (ns): ticket %.0f, then static data %.0f, then records %.0f\n",
+                     (double)(st[7] & 0xFFFFFFFFull) * 10.0 / st[13], (double)(st[7] >> 32) * 10.0 / st[13], st[16] * 10.0 / st[13]);
+        if (st[13]) std::fprintf(stderr, "[c2a peel stats] per chain step (ns): wait for tickets/static data/records %.0f, issue of the next step %.0f, tournament %.0f, record + stores %.0f | steps without a load %.1f %% | chain start (static loads) %.0f ns per chain\n",
                      st[9] * 10.0 / st[13], st[10] * 10.0 / st[13], st[11] * 10.0 / st[13], st[12] * 10.0 / st[13], 100.0 * st[14] / st[13], st[15] * 10.0 / (st[5] + st[0] + 1));
     }
     if (t4[CTL_ABORT]) return fail(c, C2A_ERR_HIP, "dataflow peel: watchdog tripped (" + std::to_string(t4[CTL_ABORT]) + " waves gave up waiting)");
@@ -513,7 +522,7 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     ENSURE(c->in_nodes, (size_t)n_in * 4); ENSURE(c->out_nodes, (size_t)n_out * 4);
     ENSURE(c->prod1, nn4); ENSURE(c->dep0, n4); ENSURE(c->dep1, n4); ENSURE(c->cons_cnt, n4);
     ENSURE(c->cons_off, n4 + 4); ENSURE(c->eslot, 2 * n4); ENSURE(c->link, n4); ENSURE(c->fill, n4);
-    ENSURE(c->meta, (size_t)n * 16); ENSURE(c->ginfo, (size_t)n * 16); ENSURE(c->ginfo2, (size_t)n * 16); ENSURE(c->clist, 2 * n4 + 64 * 4);
+    ENSURE(c->meta, (size_t)n * 16); ENSURE(c->gstat, (size_t)n * 32); ENSURE(c->clist, 2 * n4 + 64 * 4);
     ENSURE(c->node, (size_t)n * kNodeWords * 8); ENSURE(c->child, 2 * n4);
     c->node_clear = true;
     ENSURE(c->rflag, n4); ENSURE(c->ridx, n4 + 4); ENSURE(c->rlist, n4);

@@ -12,20 +12,26 @@
 // tag simply reads again — no flag, no fence, no acknowledgement wait anywhere on the path):
 //   word 0      root gate id << 32 | depth in the DFS tree
 //   word 1      reverse Kahn level << 32 | cprev (ancestor at the start of the node's current chunk; deep trees only)
-//   words 2..63 the node's path string: 63 payload bits per word, bit j = label of the edge entering depth j+1
-// A string is held in chunks of kChunkBits = 62 x 63 = 3906 bits; a node keeps its CURRENT chunk only, so comparing two
-// candidates shallower than a chunk (the 10 M-gate headline graph: depth 3 471) is ONE coalesced load per candidate,
-// XOR, ballot, count trailing zeros.  Deeper trees add one cprev hop per chunk level.
+//   word 2      where a child's edge label goes in the string: word index << 8 | bit (no division on the hot path)
+//   words 3..63 the node's path string, ZERO-PADDED: 63 payload bits per word, bit j = label of the edge entering depth j+1
+// A string is held in chunks of kChunkBits = 61 x 63 = 3843 bits; a node keeps its CURRENT chunk only.  Comparing two
+// candidates P(a).la and P(b).lb that are shallower than a chunk (the 10 M-gate headline graph: depth 3 471): append
+// each label to its string, XOR, ballot, count trailing zeros — neither path can be a prefix of the other (that would be
+// a cycle), so the first differing bit decides and the zero padding needs no length masks.  A new node's string is its
+// parent's string with the label appended: exactly the register the comparison already built.  Deeper trees add one
+// cprev hop per chunk level (out of line).
 //
-// DATAFLOW.  The consumer list of every gate is static (clist, built by k_ginfo from the deps closure), so nothing but
+// DATAFLOW.  The consumer list of every gate is static (clist, built by k_gstat from the deps closure), so nothing but
 // the node records is exchanged between waves.  A gate g is CLAIMED by the wave that takes the last ticket on fill[g];
 // tickets are taken when a consumer is claimed, NOT when it is finished, so the ticket round trip overlaps the
 // consumer's own tournament and the claiming wave goes on with g right after finishing the consumer: its own record is
 // still in registers, the other consumers' records are loaded in one round trip (and read again if a word is not there
 // yet).  A single-consumer producer needs no ticket at all.  A second producer completed by the same gate is handed to a
-// ticket queue; idle waves pop.  No deadlock: a ticket is only ever taken by a wave at the START of a step that it then
-// runs to the end, so when a gate is claimed every one of its candidates is in a step that is running (or done) on some
-// resident wave; a wave only ever waits for such a record, the graph is acyclic, so every wait ends.
+// ticket queue; idle waves pop.  The chain loop is SOFTWARE-PIPELINED: the loads and tickets of the next step are issued
+// as soon as this step's tickets say where the chain goes on, before this step's own tournament and stores.
+// No deadlock: a ticket is only ever taken by a wave for a step that it then runs to the end, so when a gate is claimed
+// every one of its candidates is in a step that is running (or done) on some resident wave; a wave only ever waits for
+// such a record, the graph is acyclic, so every wait ends.
 // Termination: a wave counts as idle from its first empty-handed poll until the moment BEFORE it tries to claim an
 // entry; when the idle count reaches the number of waves that have STARTED, nobody can push any more and the peel is
 // over once every queue is seen empty — co-residency of the whole grid is not required (a wave that starts late finds
@@ -38,15 +44,15 @@ namespace c2a {
 
 constexpr u32 kIdMask = 0x7FFFFFFFu;
 constexpr u32 kNodeWords = 64;
-constexpr u32 kHdrWords = 2;
+constexpr u32 kHdrWords = 3;
+constexpr u32 kStrWords = kNodeWords - kHdrWords;                     // 61
 constexpr u32 kWordBits = 63;
-constexpr u32 kChunkBits = (kNodeWords - kHdrWords) * kWordBits;      // 3906
+constexpr u32 kChunkBits = kStrWords * kWordBits;                     // 3843
 constexpr u64 kTagBit = 1ull << 63;
 constexpr u64 kPayload = kTagBit - 1ull;
 
 constexpr u32 kIdleCounters = 64;
 constexpr u32 kQStride = 16;                // u64 words between two queues' head/tail words (one queue per 128-byte line)
-constexpr int kStrMax = 4;                  // candidate records held in registers per round
 #ifdef C2A_EMULATE
 constexpr u32 kPollLimit = 1;               // steps are atomic there: a missing record is a bug, fail at once
 #else
@@ -56,31 +62,36 @@ constexpr u32 kWatchdogChecks = 1u << 15;   // idle-side checks (one per 32 poll
 // control block (u32 words; every hot word on its own 64-byte line)
 enum PeelCtl { CTL_PROCESSED = 0, CTL_MAXLEVEL = 1, CTL_ABORT = 2, CTL_REREADS = 3, CTL_HEARTBEAT = 16, CTL_STARTED = 32, CTL_SEEDNEXT = 48, CTL_WORDS = 64 };
 
+// what only the edges of the launch touch (kept out of the kernel's scalar registers)
+struct PeelCold {
+    const u32* seeds;          // [n_regions][region_cap] producers claimed by the sinks pass
+    const u32* seed_cnt;       // [n_regions]
+    u32 n_regions, region_cap;
+    ull* stats;                // optional diagnostics (16 words), nullptr normally
+};
+
 struct PeelArgs {
-    u32 n;
     u32 epoch;                 // tag (0/1) of this run's node words
-    const uint4* ginfo;        // [n] {dep0, dep1, cons_off, cons_cnt}
-    const uint4* ginfo2;       // [n] {cons_off[dep0], cons_cnt[dep0], cons_off[dep1], cons_cnt[dep1]}
+    u32 n_queues, q_cap;
+    u32 n;
+    const uint4* gstat;        // [2n] {dep0, dep1, cons_off, cons_cnt} {cons_off[dep0], cons_cnt[dep0], cons_off[dep1], cons_cnt[dep1]}
     const u32* clist;          // [edges + 64] consumer | edge label << 31, grouped by producer
     u64* node;                 // [n][64] node records
     u32* fill;                 // [n] claim tickets taken so far (zeroed per run)
     uint4* meta;               // [n] {parent | NONE, depth, root, label | level << 1}: read by later launches only
     u32* child;                // [2n] tree children by label (0xFF-filled per run)
-    u32* seeds;                // [n_regions][region_cap] producers claimed by the sinks pass
-    u32* seed_cnt;             // [n_regions]
-    u32 n_regions, region_cap;
-    u32 n_queues, q_cap;
     u64* q_ht;                 // [n_queues * kQStride] head (low word) | tail (high word)
     u64* q_items;              // [n_queues][q_cap] (gate + 1) | cons_off << 32; 0 = not written yet
-    u32* link;                 // [n] wave-private overflow stacks (queue full — never in practice)
     u32* idle;                 // [kIdleCounters * 16]
     u32* ctl;                  // [CTL_WORDS]
-    ull* stats;                // optional diagnostics (16 words), nullptr normally
+    u32* link;                 // [n] wave-private overflow stacks (queue full — never in practice)
+    const PeelCold* cold;
+    // the sinks pass only
+    u32* seeds_w; u32* seed_cnt_w; u32 region_cap;
 };
 
 __device__ __forceinline__ u32 chunk_of(u32 depth) { return depth ? (depth - 1) / kChunkBits : 0u; }
 __device__ __forceinline__ u32 chunk_len(u32 depth) { return depth - chunk_of(depth) * kChunkBits; }
-__device__ __forceinline__ u32 str_words(u32 len) { return (len + kWordBits - 1) / kWordBits; }
 __device__ __forceinline__ u32 ctz64(u64 x) { return (u32)__ffsll((long long)x) - 1u; }
 
 __device__ __forceinline__ u64 ld_nw(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -120,25 +131,52 @@ __device__ __forceinline__ void peel_sleep(int units) {
     (void)units;
 #endif
 }
+// Where one lane does something and the wave then LEAVES a loop (break / return), the lanes must be seen to meet again
+// first: otherwise the compiler threads the jump into both sides of the `if (lane == 0)`, the loop exit becomes a join of
+// a divergent branch, and every value carried around that loop is handled as divergent (vector registers, masked code).
+__device__ __forceinline__ void wave_join() {
+#ifndef C2A_EMULATE
+    __builtin_amdgcn_wave_barrier();
+#endif
+}
+// the compiler must treat v as used (and redefined) here: pins the wait for a pending load to this point
+#ifdef C2A_EMULATE
+#define C2A_PIN(v) ((void)0)
+#else
+#define C2A_PIN(v) asm volatile("" : "+v"(v) :: "memory")
+#endif
 
 __device__ __forceinline__ u64 hdr0_word(u32 root, u32 depth) { return ((u64)(root & kIdMask) << 32) | depth; }
 __device__ __forceinline__ u64 hdr1_word(u32 level, u32 cprev) { return ((u64)(level & kIdMask) << 32) | cprev; }
 __device__ __forceinline__ u32 hdr_hi(u64 w) { return (u32)(w >> 32) & kIdMask; }
 
-// Is this record (one word per lane) completely there?  Header first, then as many string words as its depth needs.
-__device__ __forceinline__ bool rec_valid(u64 w, u32 lane, u32 epoch) {
-    const u64 h0 = rdlane64(w, 0), h1 = rdlane64(w, 1);
-    if ((u32)(h0 >> 63) != epoch || (u32)(h1 >> 63) != epoch) return false;
-    const u32 nw = str_words(chunk_len((u32)h0));
-    return __ballot(lane >= kHdrWords && lane < kHdrWords + nw && (u32)(w >> 63) != epoch) == 0ull;
+// ---- out-of-line pieces of the deep-tree comparison (cold; plain by-value arguments so that the kernel's argument
+// block is never dragged into memory) ----
+__device__ __forceinline__ u64 ld_word_wait(const u64* p, u32 epoch, u32* ctl) {
+    u64 v = ld_nw(p);
+    u32 spins = 0;
+    while ((u32)(v >> 63) != epoch) {
+        if (++spins > (1u << 22)) { atomicAdd(&ctl[CTL_ABORT], 1u); break; }
+        peel_sleep(4);
+        v = ld_nw(p);
+    }
+    return v;
 }
-
+__device__ __forceinline__ u64 ld_rec_wait(const u64* node_base, u32 epoch, u32* ctl, u32 node, u32 lane) {
+    const u64* p = node_base + (u64)node * kNodeWords + lane;
+    u64 v = ld_nw(p);
+    u32 spins = 0;
+    while (__ballot((u32)(v >> 63) != epoch) != 0ull) {
+        if (++spins > (1u << 22)) { if (lane == 0) atomicAdd(&ctl[CTL_ABORT], 1u); break; }
+        peel_sleep(4);
+        v = ld_nw(p);
+    }
+    return v;
+}
 // bit j of the string chunk held one word per lane
 __device__ __forceinline__ u32 str_bit(u64 w, u32 j) { return (u32)(rdlane64(w, kHdrWords + j / kWordBits) >> (j % kWordBits)) & 1u; }
-
-// P(a).la < P(b).lb ?  wa / wb: this lane's word of the records holding the chunk in which the two paths can first
-// differ, lena / lenb: bits of that chunk.  Wave-uniform result.
-__device__ __forceinline__ bool str_less_wave(u64 wa, u32 lena, u32 la, u64 wb, u32 lenb, u32 lb, u32 lane) {
+// P(a).la < P(b).lb by lengths (general form: chunks of any fill)
+__device__ __forceinline__ bool str_less_len(u64 wa, u32 lena, u32 la, u64 wb, u32 lenb, u32 lb, u32 lane) {
     const u32 minlen = lena < lenb ? lena : lenb;
     const u32 lo = (lane - kHdrWords) * kWordBits;
     u64 x = (wa ^ wb) & kPayload;
@@ -155,35 +193,8 @@ __device__ __forceinline__ bool str_less_wave(u64 wa, u32 lena, u32 la, u64 wb, 
     if (lena < lenb) return la < str_bit(wb, lena);
     return str_bit(wa, lenb) < lb;
 }
-
-// a word another wave wrote some time ago (an ancestor's): read until its tag is this run's
-__device__ __forceinline__ u64 ld_word_wait(const u64* p, u32 epoch, u32* ctl) {
-    u64 v = ld_nw(p);
-    u32 spins = 0;
-    while ((u32)(v >> 63) != epoch) {
-        if (++spins > (1u << 22)) { atomicAdd(&ctl[CTL_ABORT], 1u); break; }
-        peel_sleep(4);
-        v = ld_nw(p);
-    }
-    return v;
-}
-// whole record of a finished node, one word per lane (lanes past its string read word 0 again)
-__device__ __forceinline__ u64 ld_rec_wait(const u64* node_base, u32 epoch, u32* ctl, u32 node, u32 len, u32 lane) {
-    const u32 nw = kHdrWords + str_words(len);
-    const u64* p = node_base + (u64)node * kNodeWords + (lane < nw ? lane : 0u);
-    u64 v = ld_nw(p);
-    u32 spins = 0;
-    while (__ballot((u32)(v >> 63) != epoch) != 0ull) {
-        if (++spins > (1u << 22)) { if (lane == 0) atomicAdd(&ctl[CTL_ABORT], 1u); break; }
-        peel_sleep(4);
-        v = ld_nw(p);
-    }
-    return v;
-}
-
 // Trees deeper than one chunk: bring the two nodes to the first chunk in which their paths can differ (cprev hops),
-// then compare that chunk.  wa_in / wb_in: the two nodes' own records (already in registers).  Out of line and with
-// plain by-value arguments: it must not drag the kernel's argument block into memory.
+// then compare that chunk.  wa_in / wb_in: the two nodes' own records (already in registers).
 __device__ __attribute__((noinline)) bool deep_less(const u64* node_base, u32 epoch, u32* ctl, u32 a, u32 la, u32 da, u64 wa_in,
                                                     u32 b, u32 lb, u32 db, u64 wb_in, u32 lane) {
 #define C2A_CPREV(x) ((u32)ld_word_wait(node_base + (u64)(x) * kNodeWords + 1, epoch, ctl))
@@ -206,38 +217,39 @@ __device__ __attribute__((noinline)) bool deep_less(const u64* node_base, u32 ep
         if (below_a != C2A_NONE) return C2A_BIT0(below_a) < lb;
         return la < C2A_BIT0(below_b);
     }
-    const u64 wa = a_own ? wa_in : ld_rec_wait(node_base, epoch, ctl, a, lena, lane);
-    const u64 wb = b_own ? wb_in : ld_rec_wait(node_base, epoch, ctl, b, lenb, lane);
-    return str_less_wave(wa, lena, la, wb, lenb, lb, lane);
+    const u64 wa = a_own ? wa_in : ld_rec_wait(node_base, epoch, ctl, a, lane);
+    const u64 wb = b_own ? wb_in : ld_rec_wait(node_base, epoch, ctl, b, lane);
+    return str_less_len(wa, lena, la, wb, lenb, lb, lane);
 #undef C2A_CPREV
 #undef C2A_BIT0
 }
 
 // ------------------------------------------------------------------------------------------------
 // static per-gate data of the dataflow launch (after the consumer counts have been scanned):
-// ginfo, ginfo2 and the consumer lists (eslot[2g + l] = index of edge (g, l) in its producer's list, from k_deps)
+// gstat and the consumer lists (eslot[2g + l] = index of edge (g, l) in its producer's list, from k_deps)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_ginfo(u32 n, const u32* __restrict__ dep0, const u32* __restrict__ dep1, const u32* __restrict__ cons_off,
-                        const u32* __restrict__ cons_cnt, const u32* __restrict__ eslot, uint4* ginfo, uint4* ginfo2, u32* clist) {
+__global__ void k_gstat(u32 n, const u32* __restrict__ dep0, const u32* __restrict__ dep1, const u32* __restrict__ cons_off,
+                        const u32* __restrict__ cons_cnt, const u32* __restrict__ eslot, uint4* gstat, u32* clist) {
     for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (u64)gridDim.x * blockDim.x) {
         const u32 d0 = dep0[g], d1 = dep1[g];
-        ginfo[g] = make_uint4(d0, d1, cons_off[g], cons_cnt[g]);
+        gstat[2 * g] = make_uint4(d0, d1, cons_off[g], cons_cnt[g]);
         uint4 g2 = make_uint4(0, 0, 0, 0);
         if (d0 != C2A_NONE) { g2.x = cons_off[d0]; g2.y = cons_cnt[d0]; clist[g2.x + eslot[2 * g]] = (u32)g; }
         if (d1 != C2A_NONE) { g2.z = cons_off[d1]; g2.w = cons_cnt[d1]; clist[g2.z + eslot[2 * g + 1]] = (u32)g | 0x80000000u; }
-        ginfo2[g] = g2;
+        gstat[2 * g + 1] = g2;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // sinks (gates nobody consumes: DFS roots of depth 0, no candidates) — a plain grid-stride pass; the producers they
 // claim seed the dataflow launch.  No shared counter: workgroup b appends to its own region under its own counter.
+// A sink writes the three header words of its record only (its string is empty; readers treat depth 0 so).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_peel_sinks(PeelArgs A) {
     __shared__ u32 s_done[4];
     const u32 lane = threadIdx.x & 63u;
-    u32* out = A.seeds + (u64)blockIdx.x * A.region_cap;
-    u32* counter = &A.seed_cnt[blockIdx.x];
+    u32* out = A.seeds_w + (u64)blockIdx.x * A.region_cap;
+    u32* counter = &A.seed_cnt_w[blockIdx.x];
     const u64 lt_mask = (1ull << lane) - 1ull;
     const u64 tag = A.epoch ? kTagBit : 0ull;
     u32 done = 0;
@@ -245,13 +257,14 @@ __global__ void __launch_bounds__(256) k_peel_sinks(PeelArgs A) {
         const u64 g = base + threadIdx.x;
         u32 rdy[2] = {C2A_NONE, C2A_NONE};
         if (g < A.n) {
-            const uint4 gi = A.ginfo[g];
+            const uint4 gi = A.gstat[2 * g];
             if (gi.w == 0) {
                 ++done;
                 A.meta[g] = make_uint4(C2A_NONE, 0u, (u32)g, 0u);
                 A.node[g * kNodeWords] = tag | hdr0_word((u32)g, 0u);
                 A.node[g * kNodeWords + 1] = tag | hdr1_word(0u, C2A_NONE);
-                const uint4 g2 = A.ginfo2[g];
+                A.node[g * kNodeWords + 2] = tag;
+                const uint4 g2 = A.gstat[2 * g + 1];
                 const u32 deps[2] = {gi.x, gi.y}, cnts[2] = {g2.y, g2.w};
 #pragma unroll
                 for (u32 l = 0; l < 2; ++l) {
@@ -282,25 +295,26 @@ __global__ void __launch_bounds__(256) k_peel_sinks(PeelArgs A) {
     }
 }
 
-// hand a claimed gate to whoever is idle: ticket on a queue (round robin over all queues), then the entry.
-// false = the queue is full (cannot happen with the host's q_cap unless requeues pile up)
-__device__ __forceinline__ bool peel_push(const PeelArgs& A, u32& push_rr, u32 lane, u32 gate, u32 cons_off) {
-    u32* head_w = reinterpret_cast<u32*>(A.q_ht);
-    const u32 q = (push_rr++) % A.n_queues;
-    u32 t = 0;
-    if (lane == 0) t = atomicAdd(&head_w[2 * (u64)q * kQStride + 1], 1u);
-    t = rdlane(t, 0);
-    if (t >= A.q_cap) return false;
-    if (lane == 0) st_nw(&A.q_items[(u64)q * A.q_cap + t], (u64)(gate + 1u) | ((u64)cons_off << 32));
-    return true;
-}
+// everything issued for one gate at the top of its step; two of these swap roles (nothing is ever copied: a register
+// copy of a value still in flight is a use, and its wait would drain the step that was just issued)
+struct StepIO {
+    u32 kfill;                 // lane l < 2: ticket taken on producer l
+    uint4 ga, gb;              // lane l < 2: the two gstat records of producer l
+    u32 clp;                   // lanes 0..31: producer 0's consumers, 32..63: producer 1's
+    u32 cl;                    // this gate's consumers (its first block), one per lane from lane cbase on
+    u32 cbase, ccap;           // first lane / lanes of that block
+    u64 rest;                  // lanes of cl whose records are not loaded yet
+    u32 e0, e1, take;          // consumer | label << 31 of the (up to two) records in flight
+    u64 w0, w1;                // this lane's word of those records
+};
 
 // the dataflow launch: 64-thread workgroups (one wave each)
 template <bool STATS>
 __global__ void __launch_bounds__(64) k_peel(PeelArgs A) {
     const u32 lane = threadIdx.x;
     const u32 me = blockIdx.x;
-    const u64 tag = A.epoch ? kTagBit : 0ull;
+    const u32 epoch = A.epoch;
+    const u64 tag = epoch ? kTagBit : 0ull;
     u32* head_w = reinterpret_cast<u32*>(A.q_ht);            // head of queue q = word 2 q kQStride, tail = the next word
     const u32 home_q = me % A.n_queues;
     u32 push_rr = me;                        // round-robin cursor of this wave's pushes
@@ -312,25 +326,29 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A) {
     u32 processed = 0, max_level = 0, iters = 0;
     u32 st_pops = 0, st_polls = 0, st_push = 0, st_seeds = 0, st_rpolls = 0;
     ull st_busy = 0, st_idle = 0, st_t0 = STATS ? c2a_now() : 0;
+    ull ph_w1 = 0, ph_w2 = 0, ph_w3 = 0;
     ull ph_a = 0, ph_b = 0, ph_c = 0, ph_d = 0, ph_steps = 0, ph_noload = 0, ph_start = 0;      // STATS: phase times of the chain step
-    if (lane == 0) atomicAdd(&A.ctl[CTL_STARTED], 1u);
+    if (lane == 0) atomicAdd(&A.ctl[CTL_STARTED], 1u); wave_join();
     for (;;) {
         // ---- next piece of work: own stack, the seed pool, then the hand-off queues
         u32 g = C2A_NONE;
         u32 coff = C2A_NONE;                 // cons_off of g when the entry carried it
         if (head != C2A_NONE) {
             g = head;
-            head = ld_a32(&A.link[g]);
+            head = uniform(ld_a32(&A.link[g]));
         } else {
             if (seeds_left) {
+                // (pointers read from memory are generic pointers, and a load through one counts as divergent: every value
+                // read through A.cold is declared wave-uniform by hand)
+                const PeelCold* C = A.cold;
                 while (idx >= region_cnt) {
                     u32 r = 0;
-                    if (lane == 0) r = atomicAdd(&A.ctl[CTL_SEEDNEXT], 1u);
+                    if (lane == 0) r = atomicAdd(&A.ctl[CTL_SEEDNEXT], 1u); wave_join();
                     r = rdlane(r, 0);
-                    if (r >= A.n_regions) { seeds_left = false; break; }
-                    region = r; idx = 0; region_cnt = A.seed_cnt[r];
+                    if (r >= uniform(C->n_regions)) { seeds_left = false; break; }
+                    region = r; idx = 0; region_cnt = uniform(C->seed_cnt[r]);
                 }
-                if (seeds_left) { g = A.seeds[(u64)region * A.region_cap + idx]; ++idx; ++st_seeds; }
+                if (seeds_left) { g = uniform(C->seeds[(u64)region * uniform(C->region_cap) + idx]); ++idx; ++st_seeds; }
             }
             if (g == C2A_NONE) {
                 if (STATS) { const ull t = c2a_now(); st_busy += t - st_t0; st_t0 = t; }
@@ -343,38 +361,42 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A) {
 #endif
                     if (hint != C2A_NONE) { q = hint; hint = C2A_NONE; }
                     u64 ht = 0;
-                    if (lane == 0) ht = ld_nw(&A.q_ht[(u64)q * kQStride]);
+                    if (lane == 0) ht = ld_nw(&A.q_ht[(u64)q * kQStride]); wave_join();
                     ht = rdlane64(ht, 0);
                     const u32 qh = (u32)ht, qt_raw = (u32)(ht >> 32);
                     const u32 qt = qt_raw < A.q_cap ? qt_raw : A.q_cap;
                     if (qh < qt) {
-                        if (registered) { if (lane == 0) atomicAdd(&A.idle[(me % kIdleCounters) * 16], 0xFFFFFFFFu); registered = false; }
+                        if (registered) { if (lane == 0) atomicAdd(&A.idle[(me % kIdleCounters) * 16], 0xFFFFFFFFu); wave_join(); registered = false; }
+                        // claim the head entry and read it in the same round trip (lane 1 reads what lane 0 claims)
                         u32 old = 0;
-                        if (lane == 0) old = atomicCAS(&head_w[2 * (u64)q * kQStride], qh, qh + 1);
+                        u64 v = 0;
+                        if (lane == 0) old = atomicCAS(&head_w[2 * (u64)q * kQStride], qh, qh + 1); wave_join();
+                        if (lane == 1) v = ld_nw(&A.q_items[(u64)q * A.q_cap + qh]); wave_join();
                         old = rdlane(old, 0);
+                        v = rdlane64(v, 1);
                         if (old == qh) {
-                            u64 v = 0;
                             u32 spins = 0;
-                            do {
-                                if (lane == 0) v = ld_nw(&A.q_items[(u64)q * A.q_cap + qh]);
+                            while (v == 0 && ++spins < (1u << 22)) {
+                                if (lane == 0) v = ld_nw(&A.q_items[(u64)q * A.q_cap + qh]); wave_join();
                                 v = rdlane64(v, 0);
-                            } while (v == 0 && ++spins < (1u << 22));
+                            }
                             if (v) {
                                 g = (u32)v - 1u;
                                 coff = (u32)(v >> 32);
                                 ++st_pops;
-                            } else if (lane == 0) atomicAdd(&A.ctl[CTL_ABORT], 1u);
+                            } else { if (lane == 0) atomicAdd(&A.ctl[CTL_ABORT], 1u); wave_join(); }
                             break;
                         }
                         hint = q;                                    // lost the race: look at the same queue again at once
                         continue;
                     }
-                    if (!registered) { if (lane == 0) atomicAdd(&A.idle[(me % kIdleCounters) * 16], 1u); registered = true; }
+                    if (!registered) { if (lane == 0) atomicAdd(&A.idle[(me % kIdleCounters) * 16], 1u); wave_join(); registered = true; }
                     ++polls;
                     if ((polls & 31u) == 0) {
                         u32 cnt = lane < kIdleCounters ? ld_a32(&A.idle[lane * 16]) : 0u;
 #pragma unroll
                         for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+                        cnt = uniform(cnt);          // (a shuffle result counts as divergent: the branches below must not)
                         // the number of started waves is read AFTER the idle counters (a wave registers as started first)
                         u32 c3 = 0;
                         if (cnt != 0xFFFFFFFFu && lane < 3) c3 = ld_a32(&A.ctl[lane == 0 ? CTL_STARTED : (lane == 1 ? CTL_ABORT : CTL_HEARTBEAT)]);
@@ -394,194 +416,253 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A) {
                             continue;
                         }
                         if (hb != hb_seen) { hb_seen = hb; hb_checks = 0; }
-                        else if (++hb_checks > kWatchdogChecks) { if (lane == 0) atomicAdd(&A.ctl[CTL_ABORT], 1u); break; }
+                        else if (++hb_checks > kWatchdogChecks) { if (lane == 0) atomicAdd(&A.ctl[CTL_ABORT], 1u); wave_join(); break; }
                     }
                     // back off: the longer nothing turns up, the less often this wave asks (64 clocks per unit, <= ~3 us)
-                    peel_sleep(polls < 8 ? 4 : (polls < 64 ? 16 : 64));
+                    peel_sleep(polls < 16 ? 4 : 16);
                 }
                 st_polls += polls;
                 if (STATS) { const ull t = c2a_now(); st_idle += t - st_t0; st_t0 = t; }
                 if (g == C2A_NONE) break;
             }
         }
+        // (wave-uniform by construction — say so: one value the compiler takes for divergent here, and every value of the
+        // chain loop that depends on the gate id moves to vector registers and is handled as divergent code)
+        g = uniform(g); coff = uniform(coff);
         const ull ph_s0 = STATS ? c2a_now() : 0;
-        // ---- static data of g (a chain step gets all of this prefetched by the step before)
-        // (all of it consumed HERE, in scalar registers where wave-uniform: a load still pending at the loop header would
-        // make every chain step wait for the previous step's stores)
-        uint4 gi = uniform4(A.ginfo[g]);
-        uint4 gi2 = uniform4(A.ginfo2[g]);
+        // ---- static data of g (a chain step gets all of this prefetched by the step before); consumed HERE, in scalar
+        // registers where wave-uniform: a load still pending at the loop header would cost every chain step a wait
+        uint4 gi = uniform4(A.gstat[2 * (u64)g]);
+        uint4 gi2 = uniform4(A.gstat[2 * (u64)g + 1]);
         if (coff == C2A_NONE) coff = gi.z;
-        u32 cl = A.clist[coff + lane];                                   // clist is padded by 64 entries
-#ifndef C2A_EMULATE
-        asm volatile("" : "+v"(cl) :: "memory");
-#endif
-        // ---- follow the chain from g.  When the chain goes on from gate p to its producer g, p's own record is still in
-        // registers: if p is g's ONLY consumer the whole step needs no load and no ticket at all.
+        u32 cl0 = A.clist[coff + lane];                                  // clist is padded by 64 entries
+        C2A_PIN(cl0);
         if (STATS) ph_start += c2a_now() - ph_s0;
-        bool own_valid = false;
-        u32 own_node = 0, own_label = 0, own_depth = 0, own_root = 0, own_level = 0;
-        u64 own_w = 0;
-        for (;;) {
-            const ull ph0 = STATS ? c2a_now() : 0;
-            ull ph1 = 0;
-            const u32 cnt = gi.w;
-            const u32 dl = lane == 0 ? gi.x : (lane == 1 ? gi.y : C2A_NONE);
-            const u32 dcnt = lane == 0 ? gi2.y : (lane == 1 ? gi2.w : 0u);
-            // claim tickets on the producers (nothing of this gate's tournament is needed for them)
-            u32 kfill = 0;
-            if (dl != C2A_NONE && dcnt > 1u) kfill = atomicAdd(&A.fill[dl], 1u);
+
+        // issue everything the step of a gate needs from memory
+        auto issue = [&](StepIO& S, u32 dep0, u32 dep1, u32 n_cons, u32 off0, u32 cnt0, u32 off1, u32 cnt1, u32 scl, u32 cbase, u32 ccap,
+                         bool have_own, u32 own_id) {
+            const u32 dl = lane == 0 ? dep0 : (lane == 1 ? dep1 : C2A_NONE);
+            const u32 dcnt = lane == 0 ? cnt0 : (lane == 1 ? cnt1 : 0u);
+            S.kfill = 0;
+            if (dl != C2A_NONE && dcnt > 1u) S.kfill = atomicAdd(&A.fill[dl], 1u);
             // static data of both producers, BRANCH-FREE (clamped index, result discarded by lanes with nothing to load)
             const u32 dl_c = dl != C2A_NONE ? dl : 0u;
-            const uint4 gd_raw = A.ginfo[dl_c];
-            const uint4 gd2_raw = A.ginfo2[dl_c];
-            u32 clp;                                                     // lanes 0..31: dep0's consumers, 32..63: dep1's
+            S.ga = A.gstat[2 * (u64)dl_c];
+            S.gb = A.gstat[2 * (u64)dl_c + 1];
             {
                 const u32 half = lane >> 5, i = lane & 31u;
-                const u32 poff = half ? gi2.z : gi2.x, pcnt = half ? gi2.w : gi2.y;
-                clp = A.clist[poff + (i < pcnt ? i : 0u)];
+                const u32 poff = half ? off1 : off0, pcnt = half ? cnt1 : cnt0;
+                S.clp = A.clist[poff + (i < pcnt ? i : 0u)];
             }
-            // ---- tournament.  Champion so far (wave-uniform); NONE = the virtual-root candidate [g]
-            u32 ch = C2A_NONE, ch_el = 0, ch_root = g, ch_depth = 0, level = 0;
-            u64 ch_w = 0;
+            const u32 n_here = n_cons < ccap ? n_cons : ccap;
+            S.cl = scl; S.cbase = cbase; S.ccap = ccap;
+            u64 smask = __ballot(lane - cbase < n_here && !(have_own && (scl & kIdMask) == own_id));
+            S.take = 0; S.e0 = 0; S.e1 = 0;
+            if (smask) {
+                S.e0 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 1;
+                if (smask) { S.e1 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 2; }
+            }
+            S.rest = smask;
+            // the records (slots that are not loaded stay UNDEFINED on purpose: merging a loaded value with a constant is
+            // a register copy, a copy is a use, and its wait would land right behind the load)
+            if (S.take >= 1) S.w0 = ld_nw(&A.node[(u64)(S.e0 & kIdMask) * kNodeWords + lane]);
+            if (S.take >= 2) S.w1 = ld_nw(&A.node[(u64)(S.e1 & kIdMask) * kNodeWords + lane]);
+        };
+        StepIO S0, S1;
+        issue(S0, gi.x, gi.y, gi.w, gi2.x, gi2.y, gi2.z, gi2.w, cl0, 0u, 64u, false, 0u);
+        // the gate just finished stays in registers as a candidate of the next one
+        bool own_valid = false;
+        u32 own_node = 0, own_label = 0, own_depth = 0, own_root = 0, own_level = 0, own_pos = 0;
+        u64 own_w = 0, own_x = 0;            // its record, and its string with own_label appended
+        // a second claimed producer's queue ticket is taken at the top of a step and its entry written one step later
+        // (the ticket is back by then: nothing in between may wait for memory)
+        bool push_pending = false;
+        u32 push_q = 0, push_t = 0, push_gate = 0, push_off = 0;
+        auto write_entry = [&](u32 q, u32 t, u32 gate, u32 off) {
+            if (t < A.q_cap) { if (lane == 0) st_nw(&A.q_items[(u64)q * A.q_cap + t], (u64)(gate + 1u) | ((u64)off << 32)); wave_join(); }
+            else { if (lane == 0) st_a32(&A.link[gate], head); wave_join(); head = gate; }      // queue full: cannot happen with the host's q_cap
+        };
+
+        // one step: `cur` is in hand (issued one step ago), `nx` receives the next one.  true = the chain ends (or abort)
+        auto step = [&](StepIO& cur, StepIO& nx) -> bool {
+            const ull ph0 = STATS ? c2a_now() : 0;
+            // ---- everything of THIS step (issued one step ago) is needed now, and is pinned HERE: a register of `cur` that
+            // the compiler still counts as in flight further down would put its wait behind the issue of the next step
+            C2A_PIN(cur.kfill);
+            const ull ph0a = STATS ? c2a_now() : 0;
+            C2A_PIN(cur.ga.x); C2A_PIN(cur.ga.y); C2A_PIN(cur.ga.z); C2A_PIN(cur.ga.w);
+            C2A_PIN(cur.gb.x); C2A_PIN(cur.gb.y); C2A_PIN(cur.gb.z); C2A_PIN(cur.gb.w);
+            C2A_PIN(cur.clp);
+            const ull ph0b = STATS ? c2a_now() : 0;
+            C2A_PIN(cur.w0); C2A_PIN(cur.w1);
+            if (STATS) { const ull ph0c = c2a_now(); ph_w1 += ph0a - ph0; ph_w2 += ph0b - ph0a; ph_w3 += ph0c - ph0b; }
+            const bool old_pending = push_pending;
+            const u32 old_q = push_q, old_t = old_pending ? rdlane(push_t, 0) : 0u, old_gate = push_gate, old_off = push_off;
+            push_pending = false;
+            const u32 g_dep0 = gi.x, g_dep1 = gi.y, g_off = gi.z, g_cnt = gi.w, g_dcnt0 = gi2.y, g_dcnt1 = gi2.w;
+            const u32 dl = lane == 0 ? g_dep0 : (lane == 1 ? g_dep1 : C2A_NONE);
+            const u32 dcnt = lane == 0 ? g_dcnt0 : (lane == 1 ? g_dcnt1 : 0u);
+            const bool last = dl != C2A_NONE && (dcnt == 1u || cur.kfill + 1u == dcnt);
+            const u32 rmask = (u32)__ballot(last) & 3u;
+            const ull ph1 = STATS ? c2a_now() : 0;
+            // ---- go on with the first claimed producer: issue its step now; a second one goes to whoever is idle
+            u32 nxt = C2A_NONE, nxt_label = 0;
+            uint4 ngi = make_uint4(0, 0, 0, 0), ngi2 = make_uint4(0, 0, 0, 0);
+            if (rmask) {
+                const u32 j0 = (rmask & 1u) ? 0u : 1u;
+                nxt = j0 ? g_dep1 : g_dep0; nxt_label = j0;
+                ngi = make_uint4(rdlane(cur.ga.x, j0), rdlane(cur.ga.y, j0), rdlane(cur.ga.z, j0), rdlane(cur.ga.w, j0));
+                ngi2 = make_uint4(rdlane(cur.gb.x, j0), rdlane(cur.gb.y, j0), rdlane(cur.gb.z, j0), rdlane(cur.gb.w, j0));
+                if (rmask == 3u) {
+                    push_pending = true;
+                    push_gate = g_dep1; push_off = rdlane(cur.ga.z, 1);
+                    push_q = (push_rr++) % A.n_queues;
+                    ++st_push;
+                    push_t = 0;
+                    if (lane == 0) push_t = atomicAdd(&head_w[2 * (u64)push_q * kQStride + 1], 1u); wave_join();
+                }
+                // the consumers of nxt are already here (lanes 32 j0 ... of the prefetched lists) unless it has more than 32
+                // of them: then none is loaded ahead and the cold loop below reads the list itself
+                issue(nx, ngi.x, ngi.y, ngi.w, ngi2.x, ngi2.y, ngi2.z, ngi2.w, cur.clp, 32u * j0, ngi.w <= 32u ? 32u : 0u, true, g);
+            }
+            if (old_pending) write_entry(old_q, old_t, old_gate, old_off);
+            const ull ph2 = STATS ? c2a_now() : 0;
+            // ---- tournament of THIS gate.  Champion so far (wave-uniform); NONE = the virtual-root candidate [g]
+            u32 ch = C2A_NONE, ch_el = 0, ch_root = g, ch_depth = 0, ch_pos = 0, level = 0;
+            u64 ch_w = 0, ch_x = 0;              // the champion's record / its string with the edge label appended
             if (own_valid) {
                 level = own_level + 1;
-                if (own_root < g) { ch = own_node; ch_el = own_label; ch_root = own_root; ch_depth = own_depth; ch_w = own_w; }
+                if (own_root < g) { ch = own_node; ch_el = own_label; ch_root = own_root; ch_depth = own_depth; ch_pos = own_pos; ch_w = own_w; ch_x = own_x; }
             }
             bool gave_up = false;
-            // one block of <= 64 consumers (one per lane)
-            auto tournament_block = [&](u32 ce, u32 n_here) {
-                const bool valid = lane < n_here;
-                const u32 c = ce & kIdMask, l = ce >> 31;
-                u64 smask = __ballot(valid && !(own_valid && c == own_node));
-                while (smask) {
-                    u32 cc[kStrMax], cel[kStrMax];
-                    u32 take = 0;
-#pragma unroll
-                    for (int t = 0; t < kStrMax; ++t) {
-                        if (smask) {
-                            const u32 j = ctz64(smask);
-                            smask &= smask - 1;
-                            cc[t] = rdlane(c, j); cel[t] = rdlane(l, j);
-                            take = (u32)t + 1;
-                        } else { cc[t] = cc[0]; cel[t] = 0; }
-                    }
-                    // the records back to back, BRANCH-FREE (unused slots read the first candidate again)
-                    u64 sw[kStrMax];
-                    if (take == 1) {
-                        sw[0] = ld_nw(&A.node[(u64)cc[0] * kNodeWords + lane]);
-#pragma unroll
-                        for (int t = 1; t < kStrMax; ++t) sw[t] = 0;
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < kStrMax; ++t) sw[t] = ld_nw(&A.node[(u64)cc[t] * kNodeWords + lane]);
-                    }
-                    // all there?  A record still being written is read again
+            // one candidate: its record must be all there (else read it again: cold), then it meets the champion
+            auto candidate = [&](u64 w, u32 e) {
+                const u32 c = e & kIdMask, el = e >> 31;
+                u64 badm = __ballot((u32)(w >> 63) != epoch);
+                if (badm) {
+                    // a sink's record has header words only; anything else is still being written
                     u32 polls = 0;
                     for (;;) {
-                        u32 bad = 0;
-#pragma unroll
-                        for (int t = 0; t < kStrMax; ++t)
-                            if ((u32)t < take && !rec_valid(sw[t], lane, A.epoch)) bad |= 1u << t;
-                        if (STATS && ph1 == 0) ph1 = c2a_now();
-                        if (!bad) break;
-                        if (++polls > kPollLimit) { gave_up = true; break; }
+                        if ((badm & 7ull) == 0 && (u32)rdlane64(w, 0) == 0u) { if (lane >= kHdrWords) w = tag; break; }
+                        if (++polls > kPollLimit) { gave_up = true; return; }
                         peel_sleep(polls < 8 ? 4 : 16);
-#pragma unroll
-                        for (int t = 0; t < kStrMax; ++t)
-                            if (bad & (1u << t)) sw[t] = ld_nw(&A.node[(u64)cc[t] * kNodeWords + lane]);
+                        w = ld_nw(&A.node[(u64)c * kNodeWords + lane]);
+                        badm = __ballot((u32)(w >> 63) != epoch);
+                        if (!badm) break;
                     }
                     st_rpolls += polls;
-                    if (gave_up) return;
-#pragma unroll
-                    for (int t = 0; t < kStrMax; ++t) {
-                        if ((u32)t < take) {
-                            const u64 h0 = rdlane64(sw[t], 0), h1 = rdlane64(sw[t], 1);
-                            const u32 croot = hdr_hi(h0), cdepth = (u32)h0, clevel = hdr_hi(h1) + 1u;
-                            level = clevel > level ? clevel : level;
-                            bool less;
-                            if (croot != ch_root) less = croot < ch_root;          // a larger DFS root loses at once (also to [g] itself)
-                            else if (ch == C2A_NONE) less = false;                 // (root == g: impossible in a DAG)
-                            else if (cc[t] == ch) less = cel[t] < ch_el;
-                            else if (cdepth <= kChunkBits && ch_depth <= kChunkBits)
-                                less = str_less_wave(sw[t], cdepth, cel[t], ch_w, ch_depth, ch_el, lane);
-                            else less = deep_less(A.node, A.epoch, A.ctl, cc[t], cel[t], cdepth, sw[t], ch, ch_el, ch_depth, ch_w, lane);
-                            if (less) { ch = cc[t]; ch_el = cel[t]; ch_root = croot; ch_depth = cdepth; ch_w = sw[t]; }
-                        }
-                    }
                 }
+                const u64 h0 = rdlane64(w, 0);
+                const u32 croot = hdr_hi(h0), cdepth = (u32)h0;
+                const u32 clevel = (rdlane((u32)(w >> 32), 1) & kIdMask) + 1u;
+                const u32 cpos = rdlane((u32)w, 2);
+                level = clevel > level ? clevel : level;
+                // the candidate's string with its edge label appended (meaningful while the chunk has room: cpos < kStrWords << 8)
+                u64 x = w & kPayload;
+                if (lane == kHdrWords + (cpos >> 8)) x |= (u64)el << (cpos & 255u);
+                bool less;
+                if (croot != ch_root) less = croot < ch_root;              // a larger DFS root loses at once (also to [g] itself)
+                else if (ch == C2A_NONE) less = false;                     // (root == g: impossible in a DAG)
+                else if (c == ch) less = el < ch_el;
+                else if (cdepth < kChunkBits && ch_depth < kChunkBits) {
+                    // neither path is a prefix of the other (that would be a cycle): the first differing bit decides
+                    const u64 d = x ^ ch_x;
+                    const u64 bal = __ballot(d != 0) & ~7ull;
+                    const u32 L = ctz64(bal);
+                    less = ((rdlane64(x, L) >> ctz64(rdlane64(d, L))) & 1ull) == 0;
+                } else {
+                    // (the result of an out-of-line call counts as divergent; left like that, every value that depends on the
+                    // champion would move to vector registers and the whole tournament would be compiled as divergent code)
+                    less = uniform(deep_less(A.node, epoch, A.ctl, c, el, cdepth, w, ch, ch_el, ch_depth, ch_w, lane) ? 1u : 0u) != 0u;
+                }
+                if (less) { ch = c; ch_el = el; ch_root = croot; ch_depth = cdepth; ch_pos = cpos; ch_w = w; ch_x = x; }
             };
-            // the first block's consumers are already in registers: NO load (and so no wait for the tickets, the static
-            // prefetches and the previous step's stores) stands between the top of the step and the record loads
-            tournament_block(cl, cnt < 64u ? cnt : 64u);
-            for (u32 eb = 64; eb < cnt && !gave_up; eb += 64)
-                tournament_block(A.clist[gi.z + eb + lane], cnt - eb < 64u ? cnt - eb : 64u);
-            const ull ph2 = STATS ? c2a_now() : 0;
-            // who claimed the producers (the tickets came back with the records: vmcnt returns in order)
-            const uint4 gd = dl != C2A_NONE ? gd_raw : make_uint4(0, 0, 0, 0);
-            const uint4 gd2 = dl != C2A_NONE ? gd2_raw : make_uint4(0, 0, 0, 0);
-            // (the empty asm is the ticket's first use as far as the compiler can tell: it keeps the wait for the returning
-            // atomic — which would otherwise be pulled up to the top of the step — down here)
-#ifndef C2A_EMULATE
-            asm volatile("" : "+v"(kfill) :: "memory");
-#endif
-            const bool last = dl != C2A_NONE && (dcnt == 1u || kfill + 1u == dcnt);
-            const u64 rmask = __ballot(last);
-            if (gave_up) { if (lane == 0) atomicAdd(&A.ctl[CTL_ABORT], 1u); break; }      // a record never arrived: fail loudly
+            // the (up to two) records loaded ahead, then — cold — whatever else the consumer list holds, one at a time:
+            // more than two other consumers (cur.rest), or a list that was not prefetched (cur.ccap < 64: blocks from eb on)
+            {
+                u32 k = 0, blk = cur.cl, eb = cur.ccap == 64u ? 64u : 0u;
+                u64 smask = cur.rest;
+                const bool more_blocks = g_cnt > cur.ccap;
+                for (;;) {
+                    u64 w;
+                    u32 e;
+                    if (k < cur.take) {
+                        w = k ? cur.w1 : cur.w0; e = k ? cur.e1 : cur.e0;
+                    } else {
+                        if (smask == 0) {
+                            if (!more_blocks || eb >= g_cnt) break;
+                            blk = A.clist[g_off + eb + lane];
+                            C2A_PIN(blk);                        // (consumed here, like w below)
+                            smask = __ballot(eb + lane < g_cnt && !(own_valid && (blk & kIdMask) == own_node));
+                            eb += 64;
+                            if (smask == 0) continue;
+                        }
+                        e = rdlane(blk, ctz64(smask));
+                        smask &= smask - 1;
+                        w = ld_nw(&A.node[(u64)(e & kIdMask) * kNodeWords + lane]);
+                        C2A_PIN(w);                              // (consumed here: pending at the join it would cost the hot path a wait)
+                    }
+                    candidate(w, e);
+                    if (gave_up) break;
+                    ++k;
+                }
+            }
+            if (gave_up) { if (lane == 0) atomicAdd(&A.ctl[CTL_ABORT], 1u); wave_join(); return true; }      // a record never arrived: fail loudly
             const ull ph3 = STATS ? c2a_now() : 0;
-            // ---- the node
-            const u32 depth = ch == C2A_NONE ? 0u : ch_depth + 1;
-            const u32 my_label = ch == C2A_NONE ? 0u : ch_el;
+            // ---- the node: its string is the champion's string with the label appended — the register built above
+            u32 depth = 0, my_label = 0, cprev = C2A_NONE, my_pos = 0;
+            u64 str = 0;
+            if (ch != C2A_NONE) {
+                depth = ch_depth + 1; my_label = ch_el;
+                u32 wi = ch_pos >> 8, bp = ch_pos & 255u;
+                if (wi >= kStrWords) {           // the parent filled its chunk: a fresh one, the parent is its anchor
+                    cprev = ch; wi = 0; bp = 0;
+                    str = lane == kHdrWords ? (u64)my_label : 0ull;
+                } else {
+                    cprev = rdlane((u32)ch_w, 1);
+                    str = ch_x;
+                }
+                ++bp;
+                if (bp == kWordBits) { bp = 0; ++wi; }
+                my_pos = (wi << 8) | bp;
+            }
             max_level = level > max_level ? level : max_level;
             if (lane == 0) {
                 A.meta[g] = make_uint4(ch, depth, ch_root, my_label | (level << 1));
                 if (ch != C2A_NONE) A.child[2 * (u64)ch + my_label] = g;
             }
-            u64 my_w;
-            {
-                const bool fresh = ch == C2A_NONE || ch_depth == 0 || chunk_of(depth) != chunk_of(ch_depth);
-                const u32 bit = depth ? (depth - 1) - chunk_of(depth) * kChunkBits : 0u;
-                const u32 cprev = chunk_of(depth) == 0 ? C2A_NONE : (fresh ? ch : (u32)rdlane64(ch_w, 1));
-                const u32 wi = bit / kWordBits;
-                // the parent's words of this chunk (bits past its end are zero by construction, lanes past them garbage)
-                u64 w = (!fresh && lane - kHdrWords < str_words(bit)) ? (ch_w & kPayload) : 0ull;
-                if (lane == 0) w = hdr0_word(ch_root, depth);
-                else if (lane == 1) w = hdr1_word(level, cprev);
-                else if (depth && lane - kHdrWords == wi) w |= (u64)my_label << (bit % kWordBits);
-                my_w = w | tag;
-                const u32 nw = kHdrWords + (depth ? wi + 1 : 0u);
-                if (lane < nw) st_nw(&A.node[(u64)g * kNodeWords + lane], my_w);         // words past the end are never read
-            }
+            wave_join();
+            u64 my_w = str;
+            if (lane == 0) my_w = hdr0_word(ch_root, depth);
+            else if (lane == 1) my_w = hdr1_word(level, cprev);
+            else if (lane == 2) my_w = my_pos;
+            my_w |= tag;
+            st_nw(&A.node[(u64)g * kNodeWords + lane], my_w);
             ++processed;
             if ((processed & 63u) == 0 && lane == 0) atomicAdd(&A.ctl[CTL_HEARTBEAT], 1u);
             if (STATS) {
                 const ull ph4 = c2a_now();
                 ++ph_steps;
-                if (ph1 == 0) { ++ph_noload; ph1 = ph0; }
+                if (cur.take == 0) ++ph_noload;
                 ph_a += ph1 - ph0; ph_b += ph2 - ph1; ph_c += ph3 - ph2; ph_d += ph4 - ph3;
             }
-            if (rmask == 0) break;                                  // the chain ends here
-            // continue with the first claimed producer; a second one goes to whoever is idle
-            const u32 j0 = ctz64(rmask);
-            const u32 nxt = rdlane(dl, j0);
-            if (rmask & (rmask - 1)) {
-                const u32 other = rdlane(dl, 1);
-                ++st_push;
-                if (!peel_push(A, push_rr, lane, other, rdlane(gd.z, 1))) {
-                    if (lane == 0) st_a32(&A.link[other], head);
-                    head = other;
-                }
-            }
-            // what the next step reuses: this gate as a candidate of nxt, and nxt's static data
-            own_valid = true; own_node = g; own_label = j0; own_depth = depth; own_root = ch_root; own_level = level; own_w = my_w;
-            g = nxt;
-            gi = make_uint4(rdlane(gd.x, j0), rdlane(gd.y, j0), rdlane(gd.z, j0), rdlane(gd.w, j0));
-            gi2 = make_uint4(rdlane(gd2.x, j0), rdlane(gd2.y, j0), rdlane(gd2.z, j0), rdlane(gd2.w, j0));
-            if (gi.w <= 32u) cl = __shfl(clp, (int)((lane + 32u * j0) & 63u), 64);
-            else cl = A.clist[gi.z + lane];
+            if (nxt == C2A_NONE) return true;                       // the chain ends here
+            // what the next step reuses: this gate as a candidate of nxt
+            own_valid = true; own_node = g; own_label = nxt_label; own_depth = depth; own_root = ch_root; own_level = level; own_pos = my_pos; own_w = my_w;
+            own_x = str;
+            if (lane == kHdrWords + (my_pos >> 8)) own_x |= (u64)nxt_label << (my_pos & 255u);
+            g = nxt; gi = ngi; gi2 = ngi2;
+            return false;
+        };
+        for (;;) {
+            if (step(S0, S1)) break;
+            if (step(S1, S0)) break;
         }
+        if (push_pending) write_entry(push_q, rdlane(push_t, 0), push_gate, push_off);
         if ((++iters & 63u) == 0) {                                 // somebody gave up (watchdog): leave, the host reports it
             u32 ab = 0;
-            if (lane == 0) ab = ld_a32(&A.ctl[CTL_ABORT]);
+            if (lane == 0) ab = ld_a32(&A.ctl[CTL_ABORT]); wave_join();
             if (rdlane(ab, 0)) break;
         }
     }
@@ -590,14 +671,17 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A) {
         if (processed) atomicAdd(&A.ctl[CTL_PROCESSED], processed);
         if (max_level) atomicMax(&A.ctl[CTL_MAXLEVEL], max_level);
         if (st_rpolls) atomicAdd(&A.ctl[CTL_REREADS], st_rpolls);
-        if (STATS && A.stats) {
-            if (STATS) { const ull t = c2a_now(); st_busy += t - st_t0; }
-            atomicAdd(&A.stats[0], (ull)st_pops); atomicAdd(&A.stats[1], (ull)st_polls); atomicAdd(&A.stats[2], (ull)st_push);
-            atomicAdd(&A.stats[3], st_busy); atomicAdd(&A.stats[4], st_idle); atomicAdd(&A.stats[5], (ull)st_seeds); atomicAdd(&A.stats[6], (ull)processed);
-            atomicMax(&A.stats[7], st_busy);
-            atomicAdd(&A.stats[8], (ull)st_rpolls);
-            atomicAdd(&A.stats[9], ph_a); atomicAdd(&A.stats[10], ph_b); atomicAdd(&A.stats[11], ph_c); atomicAdd(&A.stats[12], ph_d);
-            atomicAdd(&A.stats[13], ph_steps); atomicAdd(&A.stats[14], ph_noload); atomicAdd(&A.stats[15], ph_start);
+        if (STATS) {
+            ull* stats = A.cold->stats;
+            if (stats) {
+                const ull t = c2a_now(); st_busy += t - st_t0;
+                atomicAdd(&stats[0], (ull)st_pops); atomicAdd(&stats[1], (ull)st_polls); atomicAdd(&stats[2], (ull)st_push);
+                atomicAdd(&stats[3], st_busy); atomicAdd(&stats[4], st_idle); atomicAdd(&stats[5], (ull)st_seeds); atomicAdd(&stats[6], (ull)processed);
+                atomicAdd(&stats[7], ph_w1 | (ph_w2 << 32)); atomicAdd(&stats[16], ph_w3);
+                atomicAdd(&stats[8], (ull)st_rpolls);
+                atomicAdd(&stats[9], ph_a); atomicAdd(&stats[10], ph_b); atomicAdd(&stats[11], ph_c); atomicAdd(&stats[12], ph_d);
+                atomicAdd(&stats[13], ph_steps); atomicAdd(&stats[14], ph_noload); atomicAdd(&stats[15], ph_start);
+            }
         }
     }
 }
