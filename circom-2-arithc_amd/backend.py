@@ -85,7 +85,7 @@ class BoolInfo:
         return np.where(W < M, W * w + bit, M * w + self.aux_total + (W - M) * w + bit)
 
 
-_EXPORTS = ["c2a_create", "c2a_destroy", "c2a_last_error", "c2a_version", "c2a_load_gates", "c2a_topo_sort",
+_EXPORTS = ["c2a_create", "c2a_device_count", "c2a_destroy", "c2a_last_error", "c2a_version", "c2a_load_gates", "c2a_topo_sort",
             "c2a_topo_sort_serial", "c2a_assign_wires", "c2a_emit_gates", "c2a_build_circuit", "c2a_boolify",
             "c2a_bool_read", "c2a_template_size", "c2a_checksum", "c2a_get_timings", "c2a_get_stats", "c2a_verify_boolify",
             "c2a_debug_patch_bool_op", "c2a_boolify_plan", "c2a_boolify_chunk"]
@@ -110,7 +110,9 @@ def load_library(lib_path: Optional[str] = None):
     vp, u32p, u8p, u64p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint8), \
         ctypes.POINTER(ctypes.c_uint64)
     L.c2a_create.restype = ctypes.c_int
-    L.c2a_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    L.c2a_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(vp)]
+    L.c2a_device_count.restype = ctypes.c_int
+    L.c2a_device_count.argtypes = [vp]
     L.c2a_destroy.restype = None
     L.c2a_destroy.argtypes = [vp]
     L.c2a_last_error.restype = ctypes.c_char_p
@@ -168,13 +170,17 @@ CHECKSUM_STREAMS = {"sorted": 0, "in0": 1, "in1": 2, "out": 3, "op": 4, "bool_in
 
 
 class Backend:
-    """One c2a context (one GPU, one HIP stream).  Call order mirrors build_circuit + boolify:
+    """One c2a context.  `device` is one HIP device id or a list of them: the first is the primary (sort, numbering,
+    emission), boolify is cut by sorted-position range over all of them.  Call order mirrors build_circuit + boolify:
     load_gates -> topo_sort -> assign_wires -> emit_gates -> boolify (or build_circuit for the first three)."""
 
-    def __init__(self, device: int = 0, lib_path: Optional[str] = None):
+    def __init__(self, device=0, lib_path: Optional[str] = None):
         self._lib = load_library(lib_path)
         self._ctx = ctypes.c_void_p()
-        rc = self._lib.c2a_create(int(device), ctypes.byref(self._ctx))
+        ids = [int(device)] if np.isscalar(device) else [int(d) for d in device]
+        self.devices = ids
+        arr = (ctypes.c_int * len(ids))(*ids)
+        rc = self._lib.c2a_create(len(ids), arr, ctypes.byref(self._ctx))
         if rc != C2A_OK:
             raise BackendError(f"c2a_create(device={device}) failed with status {rc}: no usable HIP device "
                                "(this back end has no CPU fallback)")

@@ -107,7 +107,10 @@ class Compiler:
         na, nb = self._sig_node.get(a, 0), self._sig_node.get(b, 0)
         if na == nb:
             return
-        node_a, node_b = self.nodes[na], self.nodes[nb]
+        # an unknown signal id leaves the reference's scan on its placeholder `(0, &Node::new())` (:215-228): the merge then
+        # goes through with an empty node 0 (node ids start at 1, so 0 is never a real node)
+        node_a = self.nodes[na] if na else _Node(False, False, [])
+        node_b = self.nodes[nb] if nb else _Node(False, False, [])
         if node_a.is_out and node_b.is_out:
             raise CannotMergeOutputNodes()
         if node_a.is_const and node_b.is_const:
@@ -116,10 +119,17 @@ class Compiler:
                        node_a.signals + node_b.signals)
         mid = self._get_node_id()
         # the reference rewrites every gate here (:260-270); we forward lazily and resolve in _flat()
-        self._fwd[na] = mid
-        self._fwd[nb] = mid
-        del self.nodes[na]
-        del self.nodes[nb]
+        for old in (na, nb):
+            if old:
+                self._fwd[old] = mid
+                del self.nodes[old]
+            else:
+                # gates that reference the placeholder id 0 are rewritten NOW, like the reference does (:260-270): a gate
+                # added later with an unknown signal must keep its 0
+                for arr in (self._g_lh, self._g_rh, self._g_out):
+                    for k, v in enumerate(arr):
+                        if v == 0:
+                            arr[k] = mid
         self.nodes[mid] = merged
         for sid in merged.signals:
             self._sig_node[sid] = mid

@@ -31,8 +31,22 @@ enum Ev { EV_PREP0, EV_PREP1, EV_PEEL1, EV_ORDER1, EV_WIRES0, EV_WIRES1, EV_EMIT
 
 }  // namespace
 
-struct c2a_ctx {
+// One extra device of a multi-device context: it bit-blasts its own sorted-position range of the emitted circuit.
+struct PeerDev {
     int device = 0;
+    hipStream_t stream{};
+    u32 p_lo = 0, p_hi = 0;        // sorted positions [p_lo, p_hi)
+    u64 q_lo = 0, q_hi = 0;        // boolean gates [q_lo, q_hi) of the whole circuit
+    u64 q_bias = 0;                // boolean gate q is stored at index q - q_bias
+    DevBuf e_in0, e_in1, e_out, e_op, goff, aoff, tmpl, tables, b_in0, b_in1, b_out, b_op, acc;
+    u32 tmpl_width = 0;
+};
+
+struct c2a_ctx {
+    int device = 0;                // primary device: the sort, the wire numbering, the emission, shard 0 of boolify
+    std::vector<PeerDev> peers;    // devices 1..N-1 of c2a_create (boolify shards 1..N-1)
+    u32 shard0_hi = 0;             // multi-device: the primary's own range is [0, shard0_hi)
+    u64 shard0_qhi = 0;
     hipStream_t stream{};
     hipEvent_t ev[EV_COUNT]{};
     bool ev_valid[EV_COUNT]{};
@@ -43,6 +57,8 @@ struct c2a_ctx {
     u32 peel_sinks_blocks = 4096;  // grid cap of the sinks pass (latency-bound per thread: two dependent round trips per sink)
     u32 peel_waves = 8;            // dataflow launch: single-wave workgroups per CU (clamped by the occupancy query)
     u32 peel_epoch = 0;            // tag of the node words written by the last run (alternates; restarts after a clear)
+    bool io_clash = false;         // a node is both an input and an output (compiler.rs:363-383), found at load time
+    bool peel_meta_valid = false;  // meta[] / stats.levels describe the circuit now loaded (c2a_verify_boolify schedules by them)
     bool node_clear = true;        // node records must be zeroed before the next run (new graph, or a run that failed)
 
     // problem
@@ -339,6 +355,7 @@ int do_topo_sort(c2a_ctx* c, u64* cycle_at) {
     if (c->stage < ST_LOADED) return fail(c, C2A_ERR_STATE, "c2a_topo_sort: no gates loaded");
     c->stage = ST_LOADED;
     c->bool_planned = false;
+    c->peel_meta_valid = false;
     const u32 n = c->n;
     std::memset(c->ev_valid, 0, sizeof(c->ev_valid));
     c->stats = c2a_stats{};
@@ -373,6 +390,7 @@ int do_topo_sort(c2a_ctx* c, u64* cycle_at) {
     if (r) return r;
     rec(c, EV_ORDER1);
     c->stage = ST_SORTED;
+    c->peel_meta_valid = true;
     return C2A_OK;
 }
 
@@ -460,12 +478,14 @@ const char* c2a_version(void) {
 #endif
 }
 
-int c2a_create(int device_id, c2a_ctx** out) {
-    if (!out || device_id < 0) return C2A_ERR_ARG;
+int c2a_create(int n_devices, const int* device_ids, c2a_ctx** out) {
+    if (!out || n_devices < 1 || n_devices > 64 || !device_ids) return C2A_ERR_ARG;
     *out = nullptr;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return C2A_ERR_HIP;
-    if (device_id >= count) return C2A_ERR_ARG;
+    for (int i = 0; i < n_devices; ++i)
+        if (device_ids[i] < 0 || device_ids[i] >= count) return C2A_ERR_ARG;
+    const int device_id = device_ids[0];
     if (hipSetDevice(device_id) != hipSuccess) return C2A_ERR_HIP;
     c2a_ctx* c = new (std::nothrow) c2a_ctx();
     if (!c) return C2A_ERR_NOMEM;
@@ -478,20 +498,37 @@ int c2a_create(int device_id, c2a_ctx** out) {
     if (const char* e = std::getenv("C2A_PEEL_WAVES")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 32) c->peel_waves = v; }
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return C2A_ERR_HIP; }
     for (int i = 0; i < EV_COUNT; ++i)
-        if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return C2A_ERR_HIP; }
+        if (hipEventCreate(&c->ev[i]) != hipSuccess) { c2a_destroy(c); return C2A_ERR_HIP; }
+    // devices 1..N-1: one stream each (the same device may be listed twice: it then simply gets two shards)
+    c->peers.resize((size_t)n_devices - 1);
+    for (int i = 1; i < n_devices; ++i) {
+        PeerDev& P = c->peers[(size_t)i - 1];
+        P.device = device_ids[i];
+        if (hipSetDevice(P.device) != hipSuccess || hipStreamCreate(&P.stream) != hipSuccess) { (void)hipSetDevice(device_id); c2a_destroy(c); return C2A_ERR_HIP; }
+    }
+    (void)hipSetDevice(device_id);
     *out = c;
     return C2A_OK;
 }
 
 void c2a_destroy(c2a_ctx* c) {
     if (!c) return;
+    for (PeerDev& P : c->peers) {
+        (void)hipSetDevice(P.device);
+        if (P.stream) { (void)hipStreamSynchronize(P.stream); }
+        for (DevBuf* b : {&P.e_in0, &P.e_in1, &P.e_out, &P.e_op, &P.goff, &P.aoff, &P.tmpl, &P.tables, &P.b_in0, &P.b_in1, &P.b_out, &P.b_op, &P.acc})
+            if (b->p) (void)hipFree(b->p);
+        if (P.stream) (void)hipStreamDestroy(P.stream);
+    }
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : c->all) if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < EV_COUNT; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-    (void)hipStreamDestroy(c->stream);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
+
+int c2a_device_count(const c2a_ctx* c) { return c ? 1 + (int)c->peers.size() : 0; }
 
 const char* c2a_last_error(const c2a_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
@@ -517,6 +554,16 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
         if (output_nodes[i] >= n_nodes) return fail(c, C2A_ERR_ARG, "c2a_load_gates: output node id >= n_nodes");
     HIP_TRY(hipSetDevice(c->device));
     c->n = n; c->n_nodes = n_nodes; c->n_in = n_in; c->n_out = n_out;
+    c->bool_planned = false; c->peel_meta_valid = false; c->stats = c2a_stats{}; c->binfo = c2a_bool_info{};
+    {   // the reference checks this BEFORE it sorts (compiler.rs:363-383 precede :408), so build_circuit must report it first
+        std::vector<u32> a(input_nodes, input_nodes + n_in), b(output_nodes, output_nodes + n_out);
+        std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
+        c->io_clash = false;
+        for (size_t i = 0, j = 0; i < a.size() && j < b.size();) {
+            if (a[i] == b[j]) { c->io_clash = true; break; }
+            if (a[i] < b[j]) ++i; else ++j;
+        }
+    }
     const size_t n4 = (size_t)n * 4, nn4 = (size_t)n_nodes * 4;
     ENSURE(c->lh, n4); ENSURE(c->rh, n4); ENSURE(c->out, n4); ENSURE(c->op, n); ENSURE(c->gate4, (size_t)n * 16);
     ENSURE(c->in_nodes, (size_t)n_in * 4); ENSURE(c->out_nodes, (size_t)n_out * 4);
@@ -565,6 +612,8 @@ int c2a_topo_sort_serial(c2a_ctx* c, uint32_t* sorted, uint64_t* cycle_at) {
     if (c->stage < ST_LOADED) return fail(c, C2A_ERR_STATE, "c2a_topo_sort_serial: no gates loaded");
     HIP_TRY(hipSetDevice(c->device));
     c->stage = ST_LOADED;
+    c->bool_planned = false; c->peel_meta_valid = false;
+    c->stats = c2a_stats{}; c->stats.n_gates = c->n;
     if (cycle_at) *cycle_at = 0;
     if (c->n == 0) { c->stage = ST_SORTED; return C2A_OK; }
     // the deps closure only (no peel)
@@ -623,6 +672,7 @@ int c2a_build_circuit(c2a_ctx* c, uint64_t* cycle_at, uint32_t* wire_count) {
     if (!c) return C2A_ERR_ARG;
     HIP_TRY(hipSetDevice(c->device));
     if (c->stage < ST_LOADED) return fail(c, C2A_ERR_STATE, "c2a_build_circuit: no gates loaded");
+    if (c->io_clash) return fail(c, C2A_ERR_INCONSISTENCY, "Inconsistency: a node is used for both input and output");
     hipEvent_t b0 = c->ev[EV_BUILD0];
     HIP_TRY(hipEventRecord(b0, c->stream));
     int r = do_topo_sort(c, cycle_at);
@@ -698,21 +748,97 @@ int bool_plan(c2a_ctx* c, uint32_t width) {
 }
 
 // the map kernel over sorted positions [p_first, p_end) into buffers where boolean gate q sits at q - q_bias
-int bool_map(c2a_ctx* c, u32 p_first, u32 p_end, u64 q_bias, u32* o_in0, u32* o_in1, u32* o_out, u8* o_op) {
+// where the map kernel reads the emitted circuit from: the arrays are indexed by sorted position p - p_base
+struct BoolSrc {
+    const u32* e_in0; const u32* e_in1; const u32* e_out; const u8* e_op;
+    const u64* goff; const u64* aoff; const uint4* tmpl; const BoolTables* tables;
+    u32 p_base;
+    hipStream_t stream;
+};
+
+BoolSrc primary_src(c2a_ctx* c) {
+    return BoolSrc{c->e_in0.as<u32>(), c->e_in1.as<u32>(), c->e_out.as<u32>(), c->e_op.as<u8>(), c->goff.as<u64>(), c->aoff.as<u64>(),
+                   c->tmpl.as<uint4>(), c->tables.as<BoolTables>(), 0u, c->stream};
+}
+
+// the map kernel over sorted positions [p_first, p_end) into buffers where boolean gate q sits at q - q_bias
+int bool_map(c2a_ctx* c, const BoolSrc& S, u32 p_first, u32 p_end, u64 q_bias, u32* o_in0, u32* o_in1, u32* o_out, u8* o_op) {
     if (p_end <= p_first) return C2A_OK;
     const u32 width = c->binfo.width, M = c->binfo.m_wires;
     BoolArgs A;
     A.n = c->n; A.width = width; A.M = M; A.aux_base = (u64)M * width; A.out_base = (u64)M * width + c->binfo.aux_total;
-    A.e_in0 = c->e_in0.as<u32>(); A.e_in1 = c->e_in1.as<u32>(); A.e_out = c->e_out.as<u32>(); A.e_op = c->e_op.as<u8>();
-    A.goff = c->goff.as<u64>(); A.aoff = c->aoff.as<u64>(); A.tmpl = c->tmpl.as<uint4>();
+    // (a shard holds its own slice of the emitted circuit: the kernel indexes by global sorted position)
+    A.e_in0 = S.e_in0 - S.p_base; A.e_in1 = S.e_in1 - S.p_base; A.e_out = S.e_out - S.p_base; A.e_op = S.e_op - S.p_base;
+    A.goff = S.goff - S.p_base; A.aoff = S.aoff - S.p_base; A.tmpl = S.tmpl;
     A.b_in0 = o_in0; A.b_in1 = o_in1; A.b_out = o_out; A.b_op = o_op;
     A.p_first = p_first; A.p_end = p_end; A.q_bias = q_bias;
-    const BoolTables* Tb = c->tables.as<BoolTables>();
     const u32 ch = c->bool_chunk;
     const u32 blocks = (p_end - p_first + ch - 1) / ch;
-    if (ch == 128) C2A_LAUNCH((k_boolify<128>), blocks, kThreads, c->stream, A, Tb);
-    else if (ch == 512) C2A_LAUNCH((k_boolify<512>), blocks, kThreads, c->stream, A, Tb);
-    else C2A_LAUNCH((k_boolify<256>), blocks, kThreads, c->stream, A, Tb);
+    if (ch == 128) C2A_LAUNCH((k_boolify<128>), blocks, kThreads, S.stream, A, S.tables);
+    else if (ch == 512) C2A_LAUNCH((k_boolify<512>), blocks, kThreads, S.stream, A, S.tables);
+    else C2A_LAUNCH((k_boolify<256>), blocks, kThreads, S.stream, A, S.tables);
+    return C2A_OK;
+}
+
+// Multi-device boolify: the emitted circuit is cut by sorted-position range, one range per device of c2a_create; every
+// extra device receives its slice (peer copies of e_*, goff, aoff + the templates), runs the same map kernel on its own
+// stream and keeps its part of the boolean circuit.  No collective: the map is independent per arithmetic gate, the one
+// thing a shard needs from the others — the index of its first boolean gate and aux wire — is in the scans of the plan.
+int bool_map_sharded(c2a_ctx* c) {
+    const u32 n = c->n, N = 1 + (u32)c->peers.size();
+    hipStream_t s = c->stream;
+    std::vector<u32> cut(N + 1);
+    for (u32 k = 0; k <= N; ++k) cut[k] = (u32)((u64)n * k / N);
+    std::vector<u64> qcut(N + 1);
+    for (u32 k = 0; k <= N; ++k) HIP_TRY(hipMemcpyAsync(&qcut[k], c->goff.as<u64>() + cut[k], 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    c->shard0_hi = cut[1]; c->shard0_qhi = qcut[1];
+    const u64 G0 = qcut[1];
+    ENSURE(c->b_in0, G0 * 4 + 16); ENSURE(c->b_in1, G0 * 4 + 16); ENSURE(c->b_out, G0 * 4 + 16); ENSURE(c->b_op, G0 + 16);
+    rec(c, EV_BPREP1);
+    // peers first (their copies and kernels overlap the primary's own shard)
+    std::vector<TemplateEntry> tmpl_host;
+    for (u32 k = 1; k < N; ++k) {
+        PeerDev& P = c->peers[k - 1];
+        P.p_lo = cut[k]; P.p_hi = cut[k + 1]; P.q_lo = qcut[k]; P.q_hi = qcut[k + 1]; P.q_bias = qcut[k] & ~3ull;
+        const size_t np = P.p_hi - P.p_lo;
+        const u64 cntq = P.q_hi - P.q_bias;
+        HIP_TRY(hipSetDevice(P.device));
+        auto ens = [&](DevBuf& b, size_t bytes) -> int {
+            if (bytes == 0) bytes = 16;
+            if (b.cap >= bytes) return C2A_OK;
+            if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+            if (hipMalloc(&b.p, bytes) != hipSuccess) { b.p = nullptr; return fail(c, C2A_ERR_NOMEM, "hipMalloc on device " + std::to_string(P.device)); }
+            b.cap = bytes;
+            return C2A_OK;
+        };
+        int r;
+        if ((r = ens(P.e_in0, np * 4)) || (r = ens(P.e_in1, np * 4)) || (r = ens(P.e_out, np * 4)) || (r = ens(P.e_op, np)) ||
+            (r = ens(P.goff, (np + 1) * 8)) || (r = ens(P.aoff, (np + 1) * 8)) || (r = ens(P.tmpl, c->tmpl.cap)) || (r = ens(P.tables, sizeof(BoolTables))) ||
+            (r = ens(P.b_in0, (cntq + 8) * 4)) || (r = ens(P.b_in1, (cntq + 8) * 4)) || (r = ens(P.b_out, (cntq + 8) * 4)) || (r = ens(P.b_op, cntq + 8)) ||
+            (r = ens(P.acc, 16))) { (void)hipSetDevice(c->device); return r; }
+        HIP_TRY(hipMemcpyPeerAsync(P.e_in0.p, P.device, c->e_in0.as<u32>() + P.p_lo, c->device, np * 4, P.stream));
+        HIP_TRY(hipMemcpyPeerAsync(P.e_in1.p, P.device, c->e_in1.as<u32>() + P.p_lo, c->device, np * 4, P.stream));
+        HIP_TRY(hipMemcpyPeerAsync(P.e_out.p, P.device, c->e_out.as<u32>() + P.p_lo, c->device, np * 4, P.stream));
+        HIP_TRY(hipMemcpyPeerAsync(P.e_op.p, P.device, c->e_op.as<u8>() + P.p_lo, c->device, np, P.stream));
+        HIP_TRY(hipMemcpyPeerAsync(P.goff.p, P.device, c->goff.as<u64>() + P.p_lo, c->device, (np + 1) * 8, P.stream));
+        HIP_TRY(hipMemcpyPeerAsync(P.aoff.p, P.device, c->aoff.as<u64>() + P.p_lo, c->device, (np + 1) * 8, P.stream));
+        if (P.tmpl_width != c->bool_width) {
+            HIP_TRY(hipMemcpyPeerAsync(P.tmpl.p, P.device, c->tmpl.p, c->device, c->tmpl.cap, P.stream));
+            HIP_TRY(hipMemcpyPeerAsync(P.tables.p, P.device, c->tables.p, c->device, sizeof(BoolTables), P.stream));
+            P.tmpl_width = c->bool_width;
+        }
+        const BoolSrc S{P.e_in0.as<u32>(), P.e_in1.as<u32>(), P.e_out.as<u32>(), P.e_op.as<u8>(), P.goff.as<u64>(), P.aoff.as<u64>(),
+                        P.tmpl.as<uint4>(), P.tables.as<BoolTables>(), P.p_lo, P.stream};
+        r = bool_map(c, S, P.p_lo, P.p_hi, P.q_bias, P.b_in0.as<u32>(), P.b_in1.as<u32>(), P.b_out.as<u32>(), P.b_op.as<u8>());
+        if (r) { (void)hipSetDevice(c->device); return r; }
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    int r = bool_map(c, primary_src(c), 0, cut[1], 0, c->b_in0.as<u32>(), c->b_in1.as<u32>(), c->b_out.as<u32>(), c->b_op.as<u8>());
+    if (r) return r;
+    for (PeerDev& P : c->peers) { HIP_TRY(hipSetDevice(P.device)); HIP_TRY(hipStreamSynchronize(P.stream)); }
+    HIP_TRY(hipSetDevice(c->device));
+    rec(c, EV_BMAP1);
     return C2A_OK;
 }
 
@@ -725,12 +851,17 @@ int c2a_boolify(c2a_ctx* c, uint32_t width, c2a_bool_info* info) {
     HIP_TRY(hipSetDevice(c->device));
     int r = bool_plan(c, width);
     if (r) return r;
-    const u64 G = c->binfo.n_gates;
-    ENSURE(c->b_in0, G * 4); ENSURE(c->b_in1, G * 4); ENSURE(c->b_out, G * 4); ENSURE(c->b_op, G);
-    rec(c, EV_BPREP1);
-    r = bool_map(c, 0, c->n, 0, c->b_in0.as<u32>(), c->b_in1.as<u32>(), c->b_out.as<u32>(), c->b_op.as<u8>());
-    if (r) return r;
-    rec(c, EV_BMAP1);
+    if (!c->peers.empty()) {
+        r = bool_map_sharded(c);
+        if (r) return r;
+    } else {
+        const u64 G = c->binfo.n_gates;
+        ENSURE(c->b_in0, G * 4); ENSURE(c->b_in1, G * 4); ENSURE(c->b_out, G * 4); ENSURE(c->b_op, G);
+        rec(c, EV_BPREP1);
+        r = bool_map(c, primary_src(c), 0, c->n, 0, c->b_in0.as<u32>(), c->b_in1.as<u32>(), c->b_out.as<u32>(), c->b_op.as<u8>());
+        if (r) return r;
+        rec(c, EV_BMAP1);
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (info) *info = c->binfo;
     c->stage = ST_BOOLIFIED;
@@ -760,7 +891,7 @@ int c2a_boolify_chunk(c2a_ctx* c, uint64_t first_gate, uint64_t n_gates, uint32_
     HIP_TRY(hipStreamSynchronize(s));
     const u64 cntq = q[1] - q[0], bias = q[0] & ~3ull, lead = q[0] - bias;
     ENSURE(c->cb_in0, (cntq + 8) * 4); ENSURE(c->cb_in1, (cntq + 8) * 4); ENSURE(c->cb_out, (cntq + 8) * 4); ENSURE(c->cb_op, cntq + 8);
-    int r = bool_map(c, (u32)first_gate, (u32)(first_gate + n_gates), bias, c->cb_in0.as<u32>(), c->cb_in1.as<u32>(),
+    int r = bool_map(c, primary_src(c), (u32)first_gate, (u32)(first_gate + n_gates), bias, c->cb_in0.as<u32>(), c->cb_in1.as<u32>(),
                      c->cb_out.as<u32>(), c->cb_op.as<u8>());
     if (r) return r;
     if ((r = copy_out(c, in0, c->cb_in0.as<u32>() + lead, cntq * 4)) || (r = copy_out(c, in1, c->cb_in1.as<u32>() + lead, cntq * 4)) ||
@@ -776,12 +907,30 @@ int c2a_bool_read(c2a_ctx* c, uint64_t first, uint64_t count, uint32_t* in0, uin
     if (!c) return C2A_ERR_ARG;
     if (c->stage < ST_BOOLIFIED) return fail(c, C2A_ERR_STATE, "c2a_bool_read: call c2a_boolify first");
     if (first + count > c->binfo.n_gates) return fail(c, C2A_ERR_ARG, "c2a_bool_read: range out of bounds");
-    HIP_TRY(hipSetDevice(c->device));
+    // the boolean circuit may be spread over the devices of the context: copy each owner's part of [first, first + count)
+    const u64 last = first + count;
+    const u64 own_hi = c->peers.empty() ? c->binfo.n_gates : c->shard0_qhi;
     int r;
-    if ((r = copy_out(c, in0, c->b_in0.as<u32>() + first, count * 4)) || (r = copy_out(c, in1, c->b_in1.as<u32>() + first, count * 4)) ||
-        (r = copy_out(c, out, c->b_out.as<u32>() + first, count * 4)) || (r = copy_out(c, op, c->b_op.as<u8>() + first, count)))
-        return r;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipSetDevice(c->device));
+    if (first < own_hi && count) {
+        const u64 hi = std::min(last, own_hi), cntq = hi - first;
+        if ((r = copy_out(c, in0, c->b_in0.as<u32>() + first, cntq * 4)) || (r = copy_out(c, in1, c->b_in1.as<u32>() + first, cntq * 4)) ||
+            (r = copy_out(c, out, c->b_out.as<u32>() + first, cntq * 4)) || (r = copy_out(c, op, c->b_op.as<u8>() + first, cntq)))
+            return r;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    for (PeerDev& P : c->peers) {
+        const u64 lo = std::max(first, P.q_lo), hi = std::min(last, P.q_hi);
+        if (lo >= hi) continue;
+        const u64 cntq = hi - lo, src = lo - P.q_bias, dst = lo - first;
+        HIP_TRY(hipSetDevice(P.device));
+        if (in0) HIP_TRY(hipMemcpyAsync(in0 + dst, P.b_in0.as<u32>() + src, cntq * 4, hipMemcpyDeviceToHost, P.stream));
+        if (in1) HIP_TRY(hipMemcpyAsync(in1 + dst, P.b_in1.as<u32>() + src, cntq * 4, hipMemcpyDeviceToHost, P.stream));
+        if (out) HIP_TRY(hipMemcpyAsync(out + dst, P.b_out.as<u32>() + src, cntq * 4, hipMemcpyDeviceToHost, P.stream));
+        if (op) HIP_TRY(hipMemcpyAsync(op + dst, P.b_op.as<u8>() + src, cntq, hipMemcpyDeviceToHost, P.stream));
+        HIP_TRY(hipStreamSynchronize(P.stream));
+    }
+    HIP_TRY(hipSetDevice(c->device));
     return C2A_OK;
 }
 
@@ -792,16 +941,17 @@ int c2a_checksum(c2a_ctx* c, int which, uint64_t* value) {
     u64 cnt = 0;
     bool bytes = false;
     Stage need = ST_SORTED;
+    const u64 own_bool = c->peers.empty() ? c->binfo.n_gates : c->shard0_qhi;     // boolean gates held by the primary device
     switch (which) {
     case 0: p = c->sorted.p; cnt = c->n; need = ST_SORTED; break;
     case 1: p = c->e_in0.p; cnt = c->n; need = ST_EMITTED; break;
     case 2: p = c->e_in1.p; cnt = c->n; need = ST_EMITTED; break;
     case 3: p = c->e_out.p; cnt = c->n; need = ST_EMITTED; break;
     case 4: p = c->e_op.p; cnt = c->n; need = ST_EMITTED; bytes = true; break;
-    case 5: p = c->b_in0.p; cnt = c->binfo.n_gates; need = ST_BOOLIFIED; break;
-    case 6: p = c->b_in1.p; cnt = c->binfo.n_gates; need = ST_BOOLIFIED; break;
-    case 7: p = c->b_out.p; cnt = c->binfo.n_gates; need = ST_BOOLIFIED; break;
-    case 8: p = c->b_op.p; cnt = c->binfo.n_gates; need = ST_BOOLIFIED; bytes = true; break;
+    case 5: p = c->b_in0.p; cnt = own_bool; need = ST_BOOLIFIED; break;
+    case 6: p = c->b_in1.p; cnt = own_bool; need = ST_BOOLIFIED; break;
+    case 7: p = c->b_out.p; cnt = own_bool; need = ST_BOOLIFIED; break;
+    case 8: p = c->b_op.p; cnt = own_bool; need = ST_BOOLIFIED; bytes = true; break;
     case 9: p = c->node_wire1.p; cnt = c->n_nodes; need = ST_WIRED; break;
     default: return fail(c, C2A_ERR_ARG, "c2a_checksum: unknown stream id");
     }
@@ -809,12 +959,30 @@ int c2a_checksum(c2a_ctx* c, int which, uint64_t* value) {
     ull* acc = reinterpret_cast<ull*>(c->scalars.as<u32>() + SC_TOTAL64);
     HIP_TRY(hipMemsetAsync(acc, 0, 8, c->stream));
     if (cnt) {
-        if (bytes) C2A_LAUNCH_NOSYNC(k_checksum_u8, grid_for(cnt, 2048), kThreads, c->stream, cnt, (const u8*)p, acc);
-        else C2A_LAUNCH_NOSYNC(k_checksum_u32, grid_for(cnt, 2048), kThreads, c->stream, cnt, (const u32*)p, acc);
+        if (bytes) C2A_LAUNCH_NOSYNC(k_checksum_u8, grid_for(cnt, 2048), kThreads, c->stream, cnt, (u64)0, (const u8*)p, acc);
+        else C2A_LAUNCH_NOSYNC(k_checksum_u32, grid_for(cnt, 2048), kThreads, c->stream, cnt, (u64)0, (const u32*)p, acc);
     }
     u64 v = 0;
     HIP_TRY(hipMemcpyAsync(&v, acc, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    // a sharded boolean circuit: the checksum is a sum of position-salted terms, so the shards' parts simply add up
+    if (which >= 5 && which <= 8) {
+        for (PeerDev& P : c->peers) {
+            const u64 cntq = P.q_hi - P.q_lo, skip = P.q_lo - P.q_bias;
+            if (!cntq) continue;
+            HIP_TRY(hipSetDevice(P.device));
+            ull* pacc = P.acc.as<ull>();
+            HIP_TRY(hipMemsetAsync(pacc, 0, 8, P.stream));
+            const DevBuf& B = which == 5 ? P.b_in0 : which == 6 ? P.b_in1 : which == 7 ? P.b_out : P.b_op;
+            if (bytes) C2A_LAUNCH_NOSYNC(k_checksum_u8, grid_for(cntq, 2048), kThreads, P.stream, cntq, P.q_lo, (const u8*)(B.as<u8>() + skip), pacc);
+            else C2A_LAUNCH_NOSYNC(k_checksum_u32, grid_for(cntq, 2048), kThreads, P.stream, cntq, P.q_lo, (const u32*)(B.as<u32>() + skip), pacc);
+            u64 pv = 0;
+            HIP_TRY(hipMemcpyAsync(&pv, pacc, 8, hipMemcpyDeviceToHost, P.stream));
+            HIP_TRY(hipStreamSynchronize(P.stream));
+            v += pv;
+        }
+        HIP_TRY(hipSetDevice(c->device));
+    }
     *value = v;
     return C2A_OK;
 }
@@ -822,6 +990,8 @@ int c2a_checksum(c2a_ctx* c, int which, uint64_t* value) {
 int c2a_verify_boolify(c2a_ctx* c, uint64_t seed, uint64_t* n_checked, uint64_t* n_mismatch) {
     if (!c) return C2A_ERR_ARG;
     if (c->stage < ST_BOOLIFIED) return fail(c, C2A_ERR_STATE, "c2a_verify_boolify: call c2a_boolify first");
+    if (!c->peers.empty()) return fail(c, C2A_ERR_STATE, "c2a_verify_boolify: needs the whole boolean circuit on one device (single-device context)");
+    if (!c->peel_meta_valid) return fail(c, C2A_ERR_STATE, "c2a_verify_boolify: needs the level data of c2a_topo_sort (not of c2a_topo_sort_serial)");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const u32 n = c->n, wc = c->wire_count, width = c->binfo.width, M = c->binfo.m_wires;
@@ -879,7 +1049,7 @@ int c2a_verify_boolify(c2a_ctx* c, uint64_t seed, uint64_t* n_checked, uint64_t*
 
 int c2a_debug_patch_bool_op(c2a_ctx* c, uint64_t index, uint8_t new_op) {
     if (!c) return C2A_ERR_ARG;
-    if (c->stage < ST_BOOLIFIED || index >= c->binfo.n_gates || new_op > C2A_INV) return fail(c, C2A_ERR_ARG, "c2a_debug_patch_bool_op: bad index / op");
+    if (c->stage < ST_BOOLIFIED || index >= c->binfo.n_gates || new_op > C2A_INV || !c->peers.empty()) return fail(c, C2A_ERR_ARG, "c2a_debug_patch_bool_op: bad index / op");
     HIP_TRY(hipMemcpyAsync(c->b_op.as<u8>() + index, &new_op, 1, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return C2A_OK;

@@ -630,14 +630,15 @@ __global__ void k_eval_compare(u32 wire_count, u32 width, u32 M, u64 out_base, c
     if (bad) atomicAdd(mismatches, (ull)bad);
 }
 
-__global__ void k_checksum_u32(u64 n, const u32* __restrict__ v, ull* acc) {
+// (v[k] is element base + k of the whole stream: a stream held in parts is summed part by part)
+__global__ void k_checksum_u32(u64 n, u64 base, const u32* __restrict__ v, ull* acc) {
     u64 local = 0;
-    for (u64 i = gtid(); i < n; i += gstride()) local += mix64((i << 32) ^ (i >> 32) ^ ((u64)v[i] * 0x9E3779B97F4A7C15ULL));
+    for (u64 k = gtid(); k < n; k += gstride()) { const u64 i = base + k; local += mix64((i << 32) ^ (i >> 32) ^ ((u64)v[k] * 0x9E3779B97F4A7C15ULL)); }
     if (local) atomicAdd(acc, (ull)local);
 }
-__global__ void k_checksum_u8(u64 n, const u8* __restrict__ v, ull* acc) {
+__global__ void k_checksum_u8(u64 n, u64 base, const u8* __restrict__ v, ull* acc) {
     u64 local = 0;
-    for (u64 i = gtid(); i < n; i += gstride()) local += mix64((i << 32) ^ (i >> 32) ^ ((u64)v[i] * 0x9E3779B97F4A7C15ULL));
+    for (u64 k = gtid(); k < n; k += gstride()) { const u64 i = base + k; local += mix64((i << 32) ^ (i >> 32) ^ ((u64)v[k] * 0x9E3779B97F4A7C15ULL)); }
     if (local) atomicAdd(acc, (ull)local);
 }
 

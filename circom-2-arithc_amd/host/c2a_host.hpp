@@ -159,7 +159,7 @@ struct ArithmeticGate { AGateType op; uint32_t lh_in, rh_in, out; };
 class Backend {          // RAII owner of one c2a context
 public:
     explicit Backend(int device = 0) {
-        const int rc = c2a_create(device, &ctx_);
+        const int rc = c2a_create(1, &device, &ctx_);
         if (rc != C2A_OK) throw CircuitError(CircuitError::Backend, "c2a_create failed with status " + std::to_string(rc) +
                                                                       ": no usable HIP device (no CPU fallback)");
     }
@@ -205,8 +205,11 @@ public:
     void add_connection(uint32_t a, uint32_t b) {                                                                       // :213-278
         const uint32_t na = node_of(a), nb = node_of(b);
         if (na == nb) return;
-        const Node& A = nodes_.at(na);
-        const Node& B = nodes_.at(nb);
+        // an unknown signal id leaves the reference's scan on its placeholder `(0, &Node::new())` (:215-228): the merge
+        // then goes through with an empty node 0 (node ids start at 1, so 0 is never a real node)
+        static const Node kEmpty{};
+        const Node& A = na ? nodes_.at(na) : kEmpty;
+        const Node& B = nb ? nodes_.at(nb) : kEmpty;
         if (A.is_out && B.is_out) throw CircuitError(CircuitError::CannotMergeOutputNodes, "Cannot merge output nodes");
         if (A.is_const && B.is_const) throw CircuitError(CircuitError::CannotMergeConstantNodes, "Cannot merge constant nodes");
         Node merged;
@@ -215,9 +218,12 @@ public:
         merged.signals = A.signals;
         merged.signals.insert(merged.signals.end(), B.signals.begin(), B.signals.end());
         const uint32_t mid = get_node_id();
-        fwd_[na] = mid; fwd_[nb] = mid;                     // the reference rewrites every gate here (:260-270); resolved lazily
+        for (uint32_t old : {na, nb}) {
+            if (old) { fwd_[old] = mid; nodes_.erase(old); }   // the reference rewrites every gate here (:260-270); resolved lazily
+            else                                               // ... except for the placeholder id 0: rewritten now, a later gate keeps its 0
+                for (auto& g : gates_) { if (g.lh_in == 0) g.lh_in = mid; if (g.rh_in == 0) g.rh_in = mid; if (g.out == 0) g.out = mid; }
+        }
         for (uint32_t s : merged.signals) sig_node_[s] = mid;
-        nodes_.erase(na); nodes_.erase(nb);
         nodes_[mid] = std::move(merged);
     }
     std::vector<ArithmeticGate> gates() const {            // Vec<ArithmeticGate> with merges applied (:113)

@@ -83,8 +83,15 @@ typedef struct c2a_stats {
     uint32_t peel_rereads;       /* times a wave read a candidate record again because a word of it had not arrived yet */
 } c2a_stats;
 
-/* Create a context on HIP device `device_id` (>= 0).  Fails with C2A_ERR_HIP when no device / runtime. */
-int c2a_create(int device_id, c2a_ctx** ctx);
+/*
+ * Create a context on the HIP devices device_ids[0..n_devices).  device_ids[0] is the primary device: the
+ * sort, the wire numbering and the emission run there (the sort is a chain of ~5 000 dependent steps and does not shard,
+ * DESIGN.md §7); c2a_boolify cuts the emitted circuit by sorted-position range and bit-blasts one range per device
+ * (peer copies of the slices, one stream per device, no collective).  n_devices == 1 is the single-GPU context.
+ * Fails with C2A_ERR_HIP when there is no device / runtime, C2A_ERR_ARG for an id out of range.
+ */
+int c2a_create(int n_devices, const int* device_ids, c2a_ctx** ctx);
+int c2a_device_count(const c2a_ctx* ctx);
 void c2a_destroy(c2a_ctx* ctx);
 const char* c2a_last_error(const c2a_ctx* ctx);
 const char* c2a_version(void);
@@ -125,7 +132,8 @@ int c2a_build_circuit(c2a_ctx* ctx, uint64_t* cycle_at, uint32_t* wire_count);
 /*
  * == boolify(&circuit, width) (src/main.rs:30-32), under the frozen bit-blast spec of DESIGN.md §5
  * (the crate's source is absent: parity with it is unpinned).  Result stays in HBM as SoA
- * in0[]/in1[]/out[]/op[]; read ranges back with c2a_bool_read.  1 <= width <= 64.
+ * in0[]/in1[]/out[]/op[] — on a multi-device context each device keeps the boolean gates of its own range; read ranges
+ * back with c2a_bool_read (it gathers from the owners).  1 <= width <= 64.
  */
 int c2a_boolify(c2a_ctx* ctx, uint32_t width, c2a_bool_info* info);
 int c2a_bool_read(c2a_ctx* ctx, uint64_t first, uint64_t count, uint32_t* in0, uint32_t* in1, uint32_t* out,

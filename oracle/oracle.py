@@ -182,7 +182,9 @@ class CompilerModel:
         na, nb = self._node_of(a), self._node_of(b)
         if na == nb:
             return
-        node_a, node_b = self.nodes[na], self.nodes[nb]
+        # (:215-228: a signal found in no node leaves the scan on its placeholder `(0, &Node::new())`)
+        node_a = self.nodes[na] if na in self.nodes else Node(is_const=False, is_out=False, signals=[])
+        node_b = self.nodes[nb] if nb in self.nodes else Node(is_const=False, is_out=False, signals=[])
         if node_a.is_out and node_b.is_out:
             raise CircuitError("Cannot merge output nodes")
         if node_a.is_const and node_b.is_const:
@@ -197,8 +199,8 @@ class CompilerModel:
                 g.rh_in = mid
             if g.out in (na, nb):
                 g.out = mid
-        del self.nodes[na]
-        del self.nodes[nb]
+        self.nodes.pop(na, None)                                                # HashMap::remove (:273-274)
+        self.nodes.pop(nb, None)
         self.nodes[mid] = merged
 
     # -- name maps (compiler.rs:323-383), canonical order of DESIGN.md §3 -------------------------

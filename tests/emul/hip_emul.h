@@ -270,7 +270,7 @@ inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "h
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
-inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 2; return hipSuccess; }      // two "devices" so that the multi-device path can run
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     p->multiProcessorCount = 4; std::strcpy(p->name, "hip_emul"); std::strcpy(p->gcnArchName, "emul"); p->totalGlobalMem = 1ull << 34; return hipSuccess;
 }
@@ -279,6 +279,7 @@ template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMall
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) std::memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { if (n) std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t) { if (n) std::memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) std::memset(d, v, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { if (n) std::memset(d, v, n); return hipSuccess; }
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = 0; return hipSuccess; }

@@ -166,3 +166,63 @@ def test_chunked_boolify_equals_the_full_result(backend, orc, c2a, width):
     backend.build_circuit()
     with pytest.raises(c2a.BackendError):
         backend.boolify_chunk(0, 1)
+
+
+MULTI = [pytest.param(("emul", [0, 1]), id="emul-2dev"), pytest.param(("emul", [0, 1, 1]), id="emul-3shards"),
+         pytest.param(("hip", [0, 0]), id="hip-2shards", marks=pytest.mark.gpu),
+         pytest.param(("hip", [0, 0, 0, 0, 0]), id="hip-5shards", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(params=MULTI)
+def multi_backend(request, c2a):
+    """A multi-device context (c2a_create(n_devices, device_ids)).  A box with one GPU lists it several
+    times: every listed id gets its own stream, buffers and shard, so the peer-copy / shard / gather code runs for real."""
+    kind, ids = request.param
+    be = c2a.Backend(ids, lib_path=request.getfixturevalue("emul_lib")) if kind == "emul" else c2a.Backend(ids)
+    yield be
+    be.close()
+
+
+@pytest.mark.parametrize("width", [3, 32])
+def test_multi_device_boolify_equals_the_single_device_result(multi_backend, orc, c2a, width):
+    """boolify cut by sorted-position range over the devices of the context: the gathered SoA, ranged reads across shard
+    boundaries and the (additive) checksums are those of the whole circuit."""
+    be = multi_backend
+    mix = tuple(m for m in c2a.synth.MIX_ALL if m[0] != "APow")
+    fg = c2a.synth.layered_dag(14, 23, n_in=16, n_const=4, window=4, mix=mix, seed=7 + width)
+    for rerun in range(2):                                  # same buffers twice
+        _load(be, fg)
+        info = be.boolify(width)
+        exp = orc.boolify(_oracle(orc, fg), width)
+        assert info.n_gates == len(exp.in0) and info.wire_count == exp.wire_count
+        got = be.bool_read()
+        for g, e in zip(got, (exp.in0, exp.in1, exp.out, exp.op)):
+            np.testing.assert_array_equal(g, e)
+        n = info.n_gates
+        for first, count in ((0, 1), (n // 3 - 2, 9), (n // 2 - 5, n // 3), (n - 4, 4)):
+            part = be.bool_read(first, count)
+            np.testing.assert_array_equal(part[0], exp.in0[first:first + count])
+            np.testing.assert_array_equal(part[3], exp.op[first:first + count])
+        backend_mod = __import__("importlib").import_module("circom-2-arithc_amd.backend")
+        for name, arr in (("bool_in0", exp.in0), ("bool_in1", exp.in1), ("bool_out", exp.out), ("bool_op", exp.op)):
+            assert be.checksum(name) == backend_mod.checksum_host(arr), name
+    with pytest.raises(c2a.BackendError):                   # the verifier wants the whole circuit on one device
+        be.verify_boolify(1)
+
+
+def test_verifier_refuses_stale_level_data(backend, c2a):
+    """c2a_topo_sort_serial leaves no reverse Kahn levels behind: the verifier must say so instead of scheduling by the
+    level data of an earlier circuit."""
+    fg = c2a.synth.layered_dag(6, 10, n_in=6, n_const=2, window=2, seed=3)
+    _load(backend, fg)
+    backend.boolify(8)
+    assert backend.verify_boolify(5)[1] == 0
+    backend.load_gates(fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes)
+    backend.topo_sort(serial=True)
+    backend.assign_wires(); backend.emit_gates(); backend.boolify(8)
+    with pytest.raises(c2a.BackendError):
+        backend.verify_boolify(5)
+    with pytest.raises(c2a.BackendError):                   # and a chunk needs a plan made for THIS circuit
+        backend.load_gates(fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes)
+        backend.build_circuit()
+        backend.boolify_chunk(0, 4)
