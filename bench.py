@@ -6,16 +6,25 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N ...
 
-A "step" = one pass of the hot path over one gate graph already resident in HBM: c2a_build_circuit (sort,
-numbering, emission) + c2a_boolify(width).  N > 1: the sort is a chain of ~5 000 dependent level steps and does
-not shard, so every rank processes its OWN 10 M-gate graph (independent circuits, different
-seeds) with no data-path collective: weak scaling; value = all gates processed / max-over-ranks time.
+A "step" = one pass of the hot path over ONE gate graph already resident in HBM: c2a_build_circuit (sort,
+numbering, emission) + c2a_boolify(width).
 
-One JSON line on stdout (rank 0).  `roofline` is for the dominant kernel (k_boolify): algorithmic bytes per
-launch = 13 B read per arithmetic gate + 13 B written per boolean gate, divided by the kernel's
-launch duration measured with HIP events on the library's stream.  `cpu_baseline` = the CPU oracle ("port":
-the reference is Rust and cannot be built here) timed on a bounded sample of the same generator, 1 core (the
-reference path is single-threaded).
+N > 1 (default `--mode shard`): still ONE 10 M-gate graph — BASELINE's metric.  The sort is a chain of ~5 000
+dependent steps and does not shard, so every rank sorts the same graph and bit-blasts only its own
+sorted-position range (no data-path collective: each rank holds the whole sorted circuit).  `"scaling": "strong"`,
+value = n / max-over-ranks time; the line says what bounds it (`config.strong_scaling_bound`).  `--mode replicas` is
+the explicitly named throughput mode: N independent graphs, one per GPU, `"scaling": "weak"`.
+
+One JSON line on stdout (rank 0):
+  * `roofline` describes the WHOLE timed step: achieved = (30 n + sum_g (13 + 13 T(op_g, w))) bytes
+    / ms_per_step, against the 8 TB/s HBM spec; `roofline.kernels` has one entry per dominant kernel (the dataflow
+    peel, the boolify map) with its own algorithmic bytes, its launch time from HIP events on the library's stream,
+    and its HBM traffic from the rocprofv3 PMC passes committed under profiles/;
+  * `cpu_baseline`: the CPU oracle ("port": the reference is Rust and cannot be built here), 1 core, on the SAME
+    10 M-gate input: flat-array build_circuit on the whole graph + the bit-blast timed on a bounded slice of the
+    sorted circuit and scaled (the full 9.6 GB boolean output takes about a minute of host time); the
+    structure-faithful variant (hash maps, per-visit Vec) is timed on a 2 M-gate sample in `faithful_sample`;
+  * `width64`: the same step at --boolify-width 64 (SURVEY §8(d) "widths 32 and 64").
 """
 import argparse
 import importlib
@@ -30,7 +39,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (~6.3 TB/s achievable)
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_hbm_bytes.json")
 
 
 def timed_region(warm_step, step, steps, warmup, dist=None, torch=None, device=None):
@@ -58,9 +68,71 @@ def timed_region(warm_step, step, steps, warmup, dist=None, torch=None, device=N
     return elapsed
 
 
-def whole_job_rate(world, units_per_rank, steps, elapsed_max):
-    """value = units processed by ALL ranks / max-over-ranks time (weak scaling: one graph per rank)."""
-    return world * units_per_rank * steps / elapsed_max
+def whole_job_rate(graphs, gates_per_graph, steps, elapsed_max):
+    """value = gates of all graphs processed by the job / max-over-ranks time."""
+    return graphs * gates_per_graph * steps / elapsed_max
+
+
+def shard_range(rank, world, n):
+    """sorted positions [lo, hi) that `rank` bit-blasts in shard mode"""
+    return (rank * n) // world, ((rank + 1) * n) // world
+
+
+def shard_step(be, width, lo, hi, fetch=False):
+    """One step of shard mode on one rank: the whole build_circuit (replicated), then only this rank's range of the
+    boolify map.  Returns (plan info, chunk or None)."""
+    be.build_circuit()
+    info = be.boolify_plan(width)
+    chunk = be.boolify_chunk(lo, hi - lo, fetch=fetch)
+    return info, chunk
+
+
+def load_pmc(n, width):
+    try:
+        with open(PMC_PROFILE) as f:
+            pmc = json.load(f)
+        if pmc["workload"] == {"n_gates": n, "width": width}:
+            return pmc["kernels"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return {}
+
+
+def cpu_baseline(synth, fg, width, bool_slice_gates, faithful_layers, layer_width):
+    """CPU oracle on the host cores of this box, 1 thread."""
+    from oracle import oracle as orc
+    orc.lib()
+    t0 = time.perf_counter()
+    circ, handle = orc.build_circuit(fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes, mode=1,
+                                     keep_handle=True)
+    t_build = time.perf_counter() - t0
+    cnt = min(bool_slice_gates, fg.n)
+    t0 = time.perf_counter()
+    bslice, _ = orc.boolify_range(circ, width, 0, cnt)
+    t_slice = time.perf_counter() - t0
+    ng_slice = len(bslice.in0)
+    del bslice
+    orc.free_circuit(handle)
+    t_bool_scaled = t_slice * fg.n / max(1, cnt)
+    out = {"value": fg.n / (t_build + t_bool_scaled), "unit": "gates/s", "cores": 1, "kind": "port",
+           "sample": f"the SAME {fg.n}-gate input as the GPU run: flat-array build_circuit on the whole graph {t_build:.2f}s; "
+                     f"bit-blast timed on the first {cnt} sorted gates ({ng_slice} boolean gates, {t_slice:.2f}s) and scaled "
+                     f"x{fg.n / max(1, cnt):.1f} = {t_bool_scaled:.2f}s",
+           "host_cores_available": os.cpu_count()}
+    if faithful_layers > 0:
+        sfg = synth.layered_dag(faithful_layers, layer_width, seed=synth.SEED)
+        t0 = time.perf_counter()
+        c2, h2 = orc.build_circuit(sfg.lh, sfg.rh, sfg.out, sfg.op, sfg.n_nodes, sfg.input_nodes, sfg.output_nodes,
+                                   mode=0, keep_handle=True)
+        t1 = time.perf_counter()
+        b2, bh = orc.boolify_handle(h2, width, copy=False)
+        t2 = time.perf_counter()
+        orc.lib().orc_free_bool(bh)
+        orc.free_circuit(h2)
+        out["faithful_sample"] = {"value": sfg.n / (t2 - t0), "unit": "gates/s",
+                                  "sample": f"structure-faithful build_circuit (hash maps, per-visit Vec) {t1 - t0:.2f}s + bit-blast "
+                                            f"{t2 - t1:.2f}s on the first {faithful_layers} layers = {sfg.n} gates of the same generator"}
+    return out
 
 
 def main():
@@ -71,11 +143,14 @@ def main():
     ap.add_argument("--width", type=int, default=32, help="--boolify-width")
     ap.add_argument("--layers", type=int, default=5000)
     ap.add_argument("--layer-width", type=int, default=2000)
-    ap.add_argument("--cpu-sample-layers", type=int, default=1000, help="layers of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--check", action="store_true", help="verify the GPU result against the oracle (sample-sized run)")
-    ap.add_argument("--mode", choices=["replicas", "shard"], default="replicas",
-                    help="N>1: 'replicas' = one independent graph per rank (weak scaling, default); 'shard' = ONE graph, "
-                         "sort replicated on every rank, boolify sharded by sorted-position range (strong scaling, DESIGN.md §7)")
+    ap.add_argument("--cpu-sample-layers", type=int, default=1000,
+                    help="layers of the structure-faithful CPU sample; 0 = skip the whole CPU baseline")
+    ap.add_argument("--cpu-bool-slice", type=int, default=2_000_000, help="sorted gates the CPU bit-blast is timed on")
+    ap.add_argument("--no-width64", action="store_true", help="skip the extra --boolify-width 64 step")
+    ap.add_argument("--check", action="store_true", help="verify the GPU result against the oracle at full size")
+    ap.add_argument("--mode", choices=["shard", "replicas"], default="shard",
+                    help="N>1: 'shard' (default) = ONE graph, sort replicated on every rank, boolify sharded by sorted-position "
+                         "range (strong scaling, BASELINE's metric); 'replicas' = N independent graphs, one per GPU (throughput, weak)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -99,24 +174,23 @@ def main():
     c2a = importlib.import_module("circom-2-arithc_amd")
     synth = c2a.synth
 
-    t0 = time.time()
     shard = args.mode == "shard" and world > 1
-    fg = synth.layered_dag(args.layers, args.layer_width, seed=synth.SEED + (0 if shard else rank))
+    replicas = args.mode == "replicas" and world > 1
+    t0 = time.time()
+    fg = synth.layered_dag(args.layers, args.layer_width, seed=synth.SEED + (rank if replicas else 0))
     gen_s = time.time() - t0
     be = c2a.Backend(local_rank)
     t0 = time.time()
     be.load_gates(fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes)
     h2d_s = time.time() - t0
 
-    n_all = fg.n
-    my_lo, my_hi = (rank * n_all) // world, ((rank + 1) * n_all) // world
+    n = fg.n
+    my_lo, my_hi = shard_range(rank, world, n)
 
     def step():
-        be.build_circuit()
         if shard:      # every rank holds the whole sorted circuit, so it can place its own range without any exchange
-            info = be.boolify_plan(args.width)
-            be.boolify_chunk(my_lo, my_hi - my_lo, fetch=False)
-            return info
+            return shard_step(be, args.width, my_lo, my_hi)[0]
+        be.build_circuit()
         return be.boolify(args.width)
 
     stage_acc = {}
@@ -136,48 +210,40 @@ def main():
             dist.destroy_process_group()
         return
 
-    n = fg.n
     steps = max(1, args.steps)
     stages = {k: v / steps for k, v in stage_acc.items()}
     ms_per_step = elapsed * 1e3 / steps
-    value = whole_job_rate(1 if shard else world, n, steps, elapsed)
-    algo_bytes = 13.0 * n + 13.0 * info.n_gates                  # per k_boolify launch
-    bool_ms = stages.get("bool_map", 0.0)
-    achieved = algo_bytes / (bool_ms * 1e-3) / 1e9 if bool_ms > 0 else 0.0
+    value = whole_job_rate(world if replicas else 1, n, steps, elapsed)
     stats = be.stats()
-    # HBM bytes of the dominant kernel from the PMC passes committed under profiles/ (bench.py cannot run
-    # rocprofv3 on itself): only quoted when the workload is the one those passes measured
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_bytes.json")) as f:
-            pmc = json.load(f)
-        if pmc["workload"] == {"n_gates": n, "width": args.width}:
-            traffic = pmc["kernels"]["c2a::k_boolify"]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+    # ---- roofline of the whole step: 30 B per gate for sort + numbering + emission, 13 B read per
+    # arithmetic gate + 13 B written per boolean gate for the map
+    sort_bytes = 30.0 * n
+    bool_bytes = 13.0 * n + 13.0 * info.n_gates
+    step_bytes = sort_bytes + bool_bytes
+    achieved = step_bytes / (ms_per_step * 1e-3) / 1e9
+    pmc = load_pmc(n, args.width)
+
+    def kernel_entry(name, pmc_key, algo_bytes, ms):
+        e = {"kernel": name, "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": ms,
+             "achieved": (algo_bytes / (ms * 1e-3) / 1e9) if ms > 0 else 0.0, "unit": "GB/s"}
+        e["frac"] = e["achieved"] / HBM_PEAK_GBS
+        k = pmc.get(pmc_key)
+        e["traffic"] = k["hbm_bytes_per_launch"] if k else None
+        if k:
+            for extra in ("fetch_bytes", "write_bytes", "ea_read_requests", "ea_write_requests", "atomics", "sq_wait_frac"):
+                if extra in k:
+                    e[extra] = k[extra]
+        return e
+
+    kernels = [kernel_entry("k_peel (dataflow launch: DFS-tree parents of all gates)", "c2a::k_peel", sort_bytes, stages.get("peel", 0.0)),
+               kernel_entry("k_boolify (bit-blast map)", "c2a::k_boolify", bool_bytes, stages.get("bool_map", 0.0))]
+    total_traffic = None
+    if pmc:
+        total_traffic = sum(k["hbm_bytes_per_launch"] * k.get("launches_per_step", 1) for k in pmc.values())
 
     cpu = None
-    if args.cpu_sample_layers > 0:
-        from oracle import oracle as orc
-        sfg = synth.layered_dag(min(args.cpu_sample_layers, args.layers), args.layer_width, seed=synth.SEED)
-        orc.lib()
-        t0 = time.perf_counter()
-        circ, handle = orc.build_circuit(sfg.lh, sfg.rh, sfg.out, sfg.op, sfg.n_nodes, sfg.input_nodes,
-                                         sfg.output_nodes, mode=0, keep_handle=True)
-        t1 = time.perf_counter()
-        bc, bh = orc.boolify_handle(handle, args.width, copy=False)
-        t2 = time.perf_counter()
-        ng = len(bc.in0)
-        orc.lib().orc_free_bool(bh)
-        tf0 = time.perf_counter()
-        orc.build_circuit(sfg.lh, sfg.rh, sfg.out, sfg.op, sfg.n_nodes, sfg.input_nodes, sfg.output_nodes, mode=1)
-        tf1 = time.perf_counter()
-        orc.free_circuit(handle)
-        cpu = {"value": sfg.n / (t2 - t0), "unit": "gates/s", "cores": 1, "kind": "port",
-               "sample": f"same generator, first {sfg.layers} layers x {sfg.layer_width} = {sfg.n} gates, width {args.width}: "
-                         f"structure-faithful build_circuit (hash maps, per-visit Vec) {t1 - t0:.2f}s + bit-blast of {ng} "
-                         f"boolean gates {t2 - t1:.2f}s; flat-array build_circuit variant {tf1 - tf0:.2f}s",
-               "host_cores_available": os.cpu_count()}
+    if args.cpu_sample_layers > 0 and not replicas:
+        cpu = cpu_baseline(synth, fg, args.width, args.cpu_bool_slice, min(args.cpu_sample_layers, args.layers), args.layer_width)
 
     checked = None
     if args.check:
@@ -189,24 +255,45 @@ def main():
             assert be.checksum(name) == backend_mod.checksum_host(arr), f"{name} differs from the oracle"
         checked = "sorted/in0/in1/out/op checksums == oracle at full size"
 
+    width64 = None
+    if not args.no_width64 and args.width != 64 and world == 1:
+        be.build_circuit(); be.boolify(64)                     # warm-up (templates, buffers)
+        t0 = time.perf_counter()
+        reps = 2
+        for _ in range(reps):
+            be.build_circuit()
+            i64 = be.boolify(64)
+        dt = (time.perf_counter() - t0) / reps
+        t64 = be.timings()
+        width64 = {"ms_per_step": dt * 1e3, "value": n / dt, "unit": "gates/s", "boolean_gates": i64.n_gates,
+                   "bool_map_ms": t64.get("bool_map"), "roofline_frac": (30.0 * n + 13.0 * n + 13.0 * i64.n_gates) / dt / 1e9 / HBM_PEAK_GBS}
+
+    sort_ms = stages.get("build_total", 0.0)
+    bool_ms = stages.get("boolify_total", 0.0) if not shard else ms_per_step - sort_ms
     line = {
         "metric": "gates/sec (topo-sort + boolify), 10M-gate DAG",
         "value": value, "unit": "gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if replicas else "strong", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
-        "config": {"workload": f"synthetic layered DAG, {args.layers} layers x {args.layer_width} = {n} gates/GPU, fan-in 2, "
-                               f"gate ids permuted, sparse node ids, seed {synth.SEED}(+rank), --boolify-width {args.width}",
-                   "n_gates_per_gpu": n, "boolean_gates_per_gpu": info.n_gates, "boolify_width": args.width,
+        "config": {"workload": (f"{world} INDEPENDENT synthetic layered DAGs, one per GPU (throughput mode, NOT BASELINE's one-graph metric), each "
+                                if replicas else "ONE synthetic layered DAG, ") +
+                               f"{args.layers} layers x {args.layer_width} = {n} gates, fan-in 2, gate ids permuted, sparse node ids, "
+                               f"seed {synth.SEED}{'(+rank)' if replicas else ''}, --boolify-width {args.width}",
+                   "n_gates": n, "boolean_gates": info.n_gates, "boolify_width": args.width,
                    "levels": stats["levels"], "dfs_tree_depth": stats["max_depth"],
-                   "parallelism": ("1 graph, sort replicated, boolify sharded by sorted-position range" if shard else
-                                   "1 graph per GPU (replicated pipeline, no collective)") if world > 1 else "single GPU"},
-        "roofline": {"bound": "hbm", "kernel": "k_boolify", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": "profiles/r01_pmc_hbm_bytes.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None,
-                     "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": bool_ms},
+                   "parallelism": ("1 graph: sort + numbering + emission replicated on every rank, boolify sharded by sorted-position range, no collective"
+                                   if shard else "1 graph per GPU (replicated pipeline, no collective)" if replicas else "single GPU"),
+                   "strong_scaling_bound": (f"the sort does not shard (a chain of {stats['levels']} dependent levels, DESIGN.md §7): "
+                                            f"speed-up over 1 GPU <= (sort {sort_ms:.1f} ms + boolify B) / (sort + B / N)") if shard else None},
+        "roofline": {"bound": "hbm", "scope": "whole timed step (sort + numbering + emission + boolify)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "algorithmic_bytes_per_step": step_bytes, "traffic": total_traffic,
+                     "traffic_source": "profiles/r02_pmc_hbm_bytes.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 per the gfx950 note)" if pmc else None,
+                     "kernels": kernels,
+                     "note": "the step is bound by the dependent-step latency of the exact DFS order (k_peel), not by bytes: its algorithmic traffic is 0.3 GB"},
         "cpu_baseline": cpu,
+        "width64": width64,
         "stages_ms": stages,
-        "whole_job_algorithmic_GBps": (30.0 * n + algo_bytes) / (ms_per_step * 1e-3) / 1e9,
         "setup_s": {"generate": gen_s, "h2d_and_alloc": h2d_s},
         "stats": stats,
         "checked": checked,

@@ -1,19 +1,30 @@
-"""The N > 1 path of bench.py on CPU: world_size-2 gloo.  bench.py's multi-GPU mode is "one independent gate graph
-per rank, no data-path collective" (DESIGN.md §7), so what has to be right is (a) the timed region: barrier on
-both sides and MAX over ranks, (b) the whole-job rate, (c) per-rank seeds giving different graphs."""
+"""The N > 1 path of bench.py on CPU: world_size-2 gloo, the REAL shard step on the emulated library.
+
+bench.py's default multi-GPU mode is "ONE gate graph: sort + numbering + emission replicated on every rank, boolify
+sharded by sorted-position range, no data-path collective" (DESIGN.md §7).  What has to be right:
+  (a) every rank, on its own, produces exactly its range of the boolean circuit — the ranks' chunks, concatenated in rank
+      order, are bit-for-bit the oracle's boolify of the whole circuit;
+  (b) the timed region: W untimed + exactly K timed steps, barrier on both sides, MAX over ranks;
+  (c) the whole-job rate counts ONE graph in shard mode (strong scaling) and N graphs in the replicas mode.
+"""
 import importlib
 import os
 import sys
-import time
 
 import numpy as np
-import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+WIDTH = 16
 
-def _worker(rank, world, port, q):
+
+def _graph(c2a, seed_offset=0):
+    mix = tuple(m for m in c2a.synth.MIX_ALL if m[0] != "APow")
+    return c2a.synth.layered_dag(9, 14, n_in=6, n_const=2, window=3, mix=mix, seed=c2a.synth.SEED + seed_offset)
+
+
+def _worker(rank, world, port, emul_lib, q):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -21,38 +32,52 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import bench
     c2a = importlib.import_module("circom-2-arithc_amd")
-    fg = c2a.synth.layered_dag(6, 10, n_in=4, n_const=2, window=2, seed=c2a.synth.SEED + rank)
+    fg = _graph(c2a)                                         # shard mode: the SAME graph on every rank
+    be = c2a.Backend(0, lib_path=emul_lib)
+    be.load_gates(fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes)
+    lo, hi = bench.shard_range(rank, world, fg.n)
     calls = {"warm": 0, "timed": 0}
+    got = {}
 
     def warm():
         calls["warm"] += 1
+        bench.shard_step(be, WIDTH, lo, hi)
 
     def step():
         calls["timed"] += 1
-        time.sleep(0.05 * (rank + 1))            # rank 1 is the slow one
+        got["info"], got["chunk"] = bench.shard_step(be, WIDTH, lo, hi, fetch=True)
 
-    elapsed = bench.timed_region(warm, step, steps=3, warmup=2, dist=dist, torch=torch, device=None)
-    q.put((rank, elapsed, calls["warm"], calls["timed"], int(fg.lh.sum()), fg.n))
+    elapsed = bench.timed_region(warm, step, steps=2, warmup=1, dist=dist, torch=torch, device=None)
+    q0, (in0, in1, out, op) = got["chunk"]
+    q.put((rank, elapsed, calls["warm"], calls["timed"], lo, hi, int(q0), in0, in1, out, op, int(got["info"].n_gates),
+           int(_graph(c2a, rank).lh.sum())))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_gloo():
+def test_two_ranks_shard_step_equals_the_whole_circuit(emul_lib, orc, c2a):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, emul_lib, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=180) for _ in range(2))
+    res = sorted((q.get(timeout=240) for _ in range(2)), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, e0, w0, t0, s0, n0), (r1, e1, w1, t1, s1, n1) = res
-    assert (w0, t0, w1, t1) == (2, 3, 2, 3)                 # W untimed + exactly K timed steps on every rank
-    assert abs(e0 - e1) < 1e-9                              # both ranks hold the MAX
-    assert e0 >= 3 * 0.1 * 0.95                             # ... which is the slow rank's time
-    assert s0 != s1 and n0 == n1                            # different graphs, same size (weak scaling)
+    fg = _graph(c2a)
+    exp_c = orc.build_circuit(fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes, mode=1)
+    exp = orc.boolify(exp_c, WIDTH)
+    (_, e0, w0, t0, lo0, hi0, q00, *a0, g0, s0), (_, e1, w1, t1, lo1, hi1, q01, *a1, g1, s1) = res
+    assert (w0, t0, w1, t1) == (1, 2, 1, 2)                  # W untimed + exactly K timed steps on every rank
+    assert abs(e0 - e1) < 1e-9                               # both ranks hold the MAX
+    assert (lo0, hi0, lo1, hi1) == (0, fg.n // 2, fg.n // 2, fg.n) and g0 == g1 == len(exp.in0)
+    assert q00 == 0 and q01 == len(a0[0])                    # rank 1 starts where rank 0 ends: no exchange needed to know it
+    for k, e in enumerate((exp.in0, exp.in1, exp.out, exp.op)):
+        np.testing.assert_array_equal(np.concatenate([a0[k], a1[k]]), e)
+    assert s0 != s1                                          # (the replicas mode would have given the ranks different graphs)
     import bench
-    assert bench.whole_job_rate(2, 1000, 3, 2.0) == 3000.0
+    assert bench.whole_job_rate(1, 1000, 3, 2.0) == 1500.0   # shard mode: one graph whatever N is
+    assert bench.whole_job_rate(2, 1000, 3, 2.0) == 3000.0   # replicas mode: N graphs
