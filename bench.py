@@ -147,6 +147,7 @@ def main():
                     help="layers of the structure-faithful CPU sample; 0 = skip the whole CPU baseline")
     ap.add_argument("--cpu-bool-slice", type=int, default=2_000_000, help="sorted gates the CPU bit-blast is timed on")
     ap.add_argument("--no-width64", action="store_true", help="skip the extra --boolify-width 64 step")
+    ap.add_argument("--no-artefacts", action="store_true", help="skip the circuit.txt formatting measurement")
     ap.add_argument("--check", action="store_true", help="verify the GPU result against the oracle at full size")
     ap.add_argument("--mode", choices=["shard", "replicas"], default="shard",
                     help="N>1: 'shard' (default) = ONE graph, sort replicated on every rank, boolify sharded by sorted-position "
@@ -268,6 +269,27 @@ def main():
         width64 = {"ms_per_step": dt * 1e3, "value": n / dt, "unit": "gates/s", "boolean_gates": i64.n_gates,
                    "bool_map_ms": t64.get("bool_map"), "roofline_frac": (30.0 * n + 13.0 * n + 13.0 * i64.n_gates) / dt / 1e9 / HBM_PEAK_GBS}
 
+    # ---- artefact emission (outside the timed region): the gate lines of circuit.txt printed on the GPU and copied to
+    # the host — all of the arithmetic circuit, a bounded slice of the boolean one (the whole text is ~27 GB)
+    artefacts = None
+    if world == 1 and not args.no_artefacts:
+        be.build_circuit()
+        bi = be.boolify(args.width)
+        t0 = time.perf_counter()
+        nbytes = 0
+        for first in range(0, n, 1 << 23):
+            nbytes += len(be.format_bristol(0, first, min(1 << 23, n - first)))
+        t_arith = time.perf_counter() - t0
+        cnt = min(1 << 24, bi.n_gates)
+        t0 = time.perf_counter()
+        bbytes = len(be.format_bristol(1, 0, cnt))
+        t_bool = time.perf_counter() - t0
+        artefacts = {"circuit_txt_arithmetic": {"gates": n, "bytes": nbytes, "seconds": t_arith},
+                     "circuit_txt_boolean_slice": {"gates": cnt, "bytes": bbytes, "seconds": t_bool,
+                                                   "whole_circuit_estimate": {"bytes": bbytes * bi.n_gates / max(1, cnt),
+                                                                              "seconds": t_bool * bi.n_gates / max(1, cnt)}},
+                     "note": "c2a_format_bristol: lengths + scan + print on the GPU, one D2H copy per chunk (PCIe-bound); file writing not included"}
+
     sort_ms = stages.get("build_total", 0.0)
     bool_ms = stages.get("boolify_total", 0.0) if not shard else ms_per_step - sort_ms
     line = {
@@ -293,6 +315,7 @@ def main():
                      "note": "the step is bound by the dependent-step latency of the exact DFS order (k_peel), not by bytes: its algorithmic traffic is 0.3 GB"},
         "cpu_baseline": cpu,
         "width64": width64,
+        "artefacts": artefacts,
         "stages_ms": stages,
         "setup_s": {"generate": gen_s, "h2d_and_alloc": h2d_s},
         "stats": stats,

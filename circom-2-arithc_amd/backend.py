@@ -85,7 +85,7 @@ class BoolInfo:
         return np.where(W < M, W * w + bit, M * w + self.aux_total + (W - M) * w + bit)
 
 
-_EXPORTS = ["c2a_create", "c2a_device_count", "c2a_destroy", "c2a_last_error", "c2a_version", "c2a_load_gates", "c2a_topo_sort",
+_EXPORTS = ["c2a_create", "c2a_device_count", "c2a_format_bristol", "c2a_destroy", "c2a_last_error", "c2a_version", "c2a_load_gates", "c2a_topo_sort",
             "c2a_topo_sort_serial", "c2a_assign_wires", "c2a_emit_gates", "c2a_build_circuit", "c2a_boolify",
             "c2a_bool_read", "c2a_template_size", "c2a_checksum", "c2a_get_timings", "c2a_get_stats", "c2a_verify_boolify",
             "c2a_debug_patch_bool_op", "c2a_boolify_plan", "c2a_boolify_chunk"]
@@ -111,6 +111,8 @@ def load_library(lib_path: Optional[str] = None):
         ctypes.POINTER(ctypes.c_uint64)
     L.c2a_create.restype = ctypes.c_int
     L.c2a_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(vp)]
+    L.c2a_format_bristol.restype = ctypes.c_int
+    L.c2a_format_bristol.argtypes = [vp, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_uint64, u64p]
     L.c2a_device_count.restype = ctypes.c_int
     L.c2a_device_count.argtypes = [vp]
     L.c2a_destroy.restype = None
@@ -314,6 +316,16 @@ class Backend:
                                      _p(in1, ctypes.c_uint32), _p(out, ctypes.c_uint32), _p(op, ctypes.c_uint8))
         self._check(rc)
         return in0, in1, out, op
+
+    def format_bristol(self, which: int, first: int, count: int) -> bytes:
+        """The gate lines of circuit.txt for gates [first, first + count), printed by the GPU (c2a_format_bristol):
+        which = 0 arithmetic circuit, 1 boolean circuit, 2 the last boolify chunk."""
+        need = ctypes.c_uint64(0)
+        self._check(self._lib.c2a_format_bristol(self._ctx, int(which), int(first), int(count), None, 0, ctypes.byref(need)))
+        buf = ctypes.create_string_buffer(max(1, need.value))
+        got = ctypes.c_uint64(0)
+        self._check(self._lib.c2a_format_bristol(self._ctx, int(which), int(first), int(count), buf, need.value, ctypes.byref(got)))
+        return buf.raw[:got.value]
 
     def template_size(self, op: int, width: int) -> Tuple[int, int]:
         g, a = ctypes.c_uint64(0), ctypes.c_uint64(0)

@@ -54,10 +54,15 @@ class BristolCircuit:               # compiler.rs:478-493
     io_widths: Optional[Tuple[List[int], List[int]]] = None     # None for arithmetic circuits (:492)
     unary_ops: Sequence[int] = ()    # ops printed with one input (INV)
     sorted_gate_ids: Optional[np.ndarray] = None
+    gates_on_device: Optional[int] = None   # set when the SoA was left in HBM (fetch=False): the gate count
 
     @property
     def n_gates(self) -> int:
         return int(self.op.shape[0])
+
+    @property
+    def n_gates_total(self) -> int:
+        return int(self.gates_on_device) if self.gates_on_device is not None else self.n_gates
 
     def gates(self) -> Iterator[Tuple[List[int], List[int], str]]:
         """Gate{inputs, outputs, op} triples (compiler.rs:456-463)."""
@@ -91,6 +96,29 @@ class BristolCircuit:               # compiler.rs:478-493
                 u = un[s:e].tolist()
                 lines = [(f"1 1 {x} {z} {k}" if uu else f"2 1 {x} {y} {z} {k}") for x, y, z, k, uu in zip(a, b, o, nm, u)]
             emit("\n".join(lines) + "\n")
+
+    def header(self) -> str:
+        """the three header lines + the blank line of circuit.txt"""
+        n_in = len(self.info.input_name_to_wire_index)
+        n_out = len(self.info.output_name_to_wire_index)
+        iw, ow = self.io_widths if self.io_widths is not None else ([1] * n_in, [1] * n_out)
+        return (f"{self.n_gates_total} {self.wire_count}\n" + " ".join([str(len(iw))] + [str(x) for x in iw]) + "\n" +
+                " ".join([str(len(ow))] + [str(x) for x in ow]) + "\n\n")
+
+    def write_bristol_gpu(self, w, backend, chunk_gates: int = 1 << 24) -> int:
+        """circuit.txt with the gate lines printed on the GPU and streamed chunk by chunk (the boolean circuit of the
+        10 M-gate config is ~27 GB of text: Python string formatting would take hours).  `backend` must still hold the
+        circuit this object describes.  Returns the bytes written."""
+        which = 1 if self.io_widths is not None else 0
+        total = self.n_gates_total
+        head = self.header().encode()
+        w.write(head)
+        nbytes = len(head)
+        for first in range(0, total, chunk_gates):
+            part = backend.format_bristol(which, first, min(chunk_gates, total - first))
+            w.write(part)
+            nbytes += len(part)
+        return nbytes
 
     def info_json(self) -> str:
         """circuit_info.json (src/main.rs:43-44), serde_json::to_string_pretty layout with sorted keys."""

@@ -234,4 +234,35 @@ class Compiler:
             output_name_to_wire_index={k: int(bi.wire(v)) for k, v in ci.output_name_to_wire_index.items()})
         return BristolCircuit(wire_count=bi.wire_count, info=info, in0=in0, in1=in1, out=out, op=op,
                               op_names=BOOL_OP_NAMES, io_widths=([width] * bi.n_in, [width] * bi.n_out),
-                              unary_ops=(2,))
+                              unary_ops=(2,), gates_on_device=None if fetch else int(bi.n_gates))
+
+    # -- report.json (src/main.rs:22, :46-47) ------------------------------------------------------
+    def generate_circuit_report(self, value_type: str = "sint") -> dict:
+        """compiler.rs:287-319 + :502-531: nodes split into inputs (not the output of any gate) and outputs (gate outputs
+        that no gate reads), each sorted by node id; per node the names of its signals (those containing "random_" are
+        dropped, :519) and the value of its last valued signal.  The reference scans all gates per output node
+        (:300-304); a set of the nodes some gate reads does the same in one pass."""
+        read = set()
+        for a, b in zip(self._g_lh, self._g_rh):
+            read.add(self._resolve(a)); read.add(self._resolve(b))
+        input_nodes = sorted(nid for nid, nd in self.nodes.items() if not nd.is_out)
+        output_nodes = sorted(nid for nid, nd in self.nodes.items() if nd.is_out and nid not in read)
+
+        def reports(ids):
+            out = []
+            for nid in ids:
+                names, value = [], None
+                for sid in self.nodes[nid].signals:
+                    nm, v = self.signals[sid]
+                    if "random_" not in nm:
+                        names.append(nm)
+                    if v is not None:
+                        value = v
+                out.append({"id": nid, "names": names, "value": value})
+            return out
+        return {"inputs": reports(input_nodes), "outputs": reports(output_nodes), "value_type": value_type}
+
+    def report_json(self, value_type: str = "sint") -> str:
+        """serde_json::to_string_pretty(&report) (src/main.rs:46-47)"""
+        import json
+        return json.dumps(self.generate_circuit_report(value_type), indent=2)

@@ -76,6 +76,8 @@ struct c2a_ctx {
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op;
     DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof;
     DevBuf tsz, asz, goff, aoff, tmpl, tables, b_in0, b_in1, b_out, b_op;
+    DevBuf fmt_len, fmt_off, fmt_text, fmt_table;
+    u64 fmt_chunk_first = 0, fmt_chunk_cnt = 0;      // boolean gates held by the chunk buffers (c2a_boolify_chunk)
     DevBuf ev_produced, ev_spos, ev_aval, ev_bval, ev_lcount, ev_lbase, ev_lorder, cb_in0, cb_in1, cb_out, cb_op;
     bool bool_planned = false;
     std::vector<DevBuf*> all;
@@ -85,7 +87,7 @@ struct c2a_ctx {
                &gstat, &clist, &pctl, &pcold, &meta, &node, &child, &rflag, &ridx, &rlist, &next,
                &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
                &node_wire, &e_in0, &e_in1, &e_out, &e_op, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &tsz, &asz, &goff,
-               &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &ev_lcount, &ev_lbase, &ev_lorder, &cb_in0, &cb_in1, &cb_out, &cb_op};
+               &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &fmt_len, &fmt_off, &fmt_text, &fmt_table, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &ev_lcount, &ev_lbase, &ev_lorder, &cb_in0, &cb_in1, &cb_out, &cb_op};
     }
 };
 
@@ -898,6 +900,7 @@ int c2a_boolify_chunk(c2a_ctx* c, uint64_t first_gate, uint64_t n_gates, uint32_
         (r = copy_out(c, out, c->cb_out.as<u32>() + lead, cntq * 4)) || (r = copy_out(c, op, c->cb_op.as<u8>() + lead, cntq)))
         return r;
     HIP_TRY(hipStreamSynchronize(s));
+    c->fmt_chunk_first = q[0]; c->fmt_chunk_cnt = cntq;
     if (first_bool_gate) *first_bool_gate = q[0];
     if (n_bool_gates) *n_bool_gates = cntq;
     return C2A_OK;
@@ -1044,6 +1047,67 @@ int c2a_verify_boolify(c2a_ctx* c, uint64_t seed, uint64_t* n_checked, uint64_t*
     HIP_TRY(hipStreamSynchronize(s));
     if (n_checked) *n_checked = (u64)wc * 64;
     if (n_mismatch) *n_mismatch = bad;
+    return C2A_OK;
+}
+
+int c2a_format_bristol(c2a_ctx* c, int which, uint64_t first, uint64_t count, char* text, uint64_t capacity, uint64_t* written) {
+    if (!c || !written) return C2A_ERR_ARG;
+    *written = 0;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const u32 *in0 = nullptr, *in1 = nullptr, *out = nullptr;
+    const u8* op = nullptr;
+    u64 total = 0;
+    bool boolean = which != 0;
+    switch (which) {
+    case 0:
+        if (c->stage < ST_EMITTED) return fail(c, C2A_ERR_STATE, "c2a_format_bristol: call c2a_emit_gates / c2a_build_circuit first");
+        in0 = c->e_in0.as<u32>(); in1 = c->e_in1.as<u32>(); out = c->e_out.as<u32>(); op = c->e_op.as<u8>(); total = c->n; break;
+    case 1:
+        if (c->stage < ST_BOOLIFIED) return fail(c, C2A_ERR_STATE, "c2a_format_bristol: call c2a_boolify first");
+        if (!c->peers.empty()) return fail(c, C2A_ERR_STATE, "c2a_format_bristol: the boolean circuit is spread over several devices; format it chunk by chunk (which = 2)");
+        in0 = c->b_in0.as<u32>(); in1 = c->b_in1.as<u32>(); out = c->b_out.as<u32>(); op = c->b_op.as<u8>(); total = c->binfo.n_gates; break;
+    case 2: {
+        if (!c->bool_planned || !c->fmt_chunk_cnt) return fail(c, C2A_ERR_STATE, "c2a_format_bristol: call c2a_boolify_chunk first");
+        const u64 lead = c->fmt_chunk_first - (c->fmt_chunk_first & ~3ull);
+        in0 = c->cb_in0.as<u32>() + lead; in1 = c->cb_in1.as<u32>() + lead; out = c->cb_out.as<u32>() + lead; op = c->cb_op.as<u8>() + lead;
+        total = c->fmt_chunk_cnt; break;
+    }
+    default: return fail(c, C2A_ERR_ARG, "c2a_format_bristol: which must be 0 (arithmetic), 1 (boolean) or 2 (last boolean chunk)");
+    }
+    if (first > total || count > total - first) return fail(c, C2A_ERR_ARG, "c2a_format_bristol: range out of bounds");
+    if (count == 0) return C2A_OK;
+    if (count >= (1ull << 32)) return fail(c, C2A_ERR_ARG, "c2a_format_bristol: at most 2^32 - 1 gates per call");
+    // op names: AGateType Display strings (a_gate_type.rs:6-28, compiler.rs:462) / XOR AND INV
+    FmtTable T;
+    std::memset(&T, 0, sizeof(T));
+    if (boolean) {
+        const char* nm[3] = {"XOR", "AND", "INV"};
+        for (int i = 0; i < 3; ++i) { T.len[i] = 3; std::memcpy(T.name[i], nm[i], 3); }
+        T.unary[C2A_INV] = 1;
+    } else {
+        const char* nm[20] = {"AAdd", "ADiv", "AEq", "AGEq", "AGt", "ALEq", "ALt", "AMul", "ANeq", "ASub", "AXor", "APow", "AIntDiv", "AMod",
+                              "AShiftL", "AShiftR", "ABoolOr", "ABoolAnd", "ABitOr", "ABitAnd"};
+        for (int i = 0; i < 20; ++i) { T.len[i] = (u8)std::strlen(nm[i]); std::memcpy(T.name[i], nm[i], T.len[i]); }
+    }
+    ENSURE(c->fmt_table, sizeof(FmtTable)); ENSURE(c->fmt_len, count * 4); ENSURE(c->fmt_off, (count + 1) * 8);
+    HIP_TRY(hipMemcpyAsync(c->fmt_table.p, &T, sizeof(T), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const FmtTable* dT = c->fmt_table.as<FmtTable>();
+    C2A_LAUNCH_NOSYNC(k_fmt_len, grid_for(count, 4096), kThreads, s, count, in0 + first, in1 + first, out + first, op + first, dT, c->fmt_len.as<u32>());
+    int r = scan_exclusive<u64>(c, c->fmt_len.as<u32>(), c->fmt_off.as<u64>(), count);
+    if (r) return r;
+    u64 bytes = 0;
+    HIP_TRY(hipMemcpyAsync(&bytes, c->fmt_off.as<u64>() + count, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *written = bytes;
+    if (!text) return C2A_OK;                        // size query
+    if (bytes > capacity) return fail(c, C2A_ERR_ARG, "c2a_format_bristol: buffer too small (" + std::to_string(bytes) + " bytes needed)");
+    ENSURE(c->fmt_text, bytes);
+    C2A_LAUNCH_NOSYNC(k_fmt_write, grid_for(count, 4096), kThreads, s, count, in0 + first, in1 + first, out + first, op + first, dT,
+                      (const u64*)c->fmt_off.as<u64>(), c->fmt_text.as<char>());
+    HIP_TRY(hipMemcpyAsync(text, c->fmt_text.p, bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return C2A_OK;
 }
 

@@ -507,6 +507,49 @@ __global__ void __launch_bounds__(kThreads) k_boolify(BoolArgs A, const BoolTabl
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// circuit.txt on the GPU (BristolCircuit::write_bristol, src/main.rs:34-35; crate absent, format = SURVEY C.2):
+// one line per gate, "2 1 <in0> <in1> <out> <OP>\n" or "1 1 <in0> <out> <OP>\n" for a one-input op.  Two passes:
+// line lengths -> exclusive scan (byte offsets) -> every lane prints its own line.  The text of 742 M boolean gates
+// is ~27 GB: it is produced chunk by chunk and streamed to the host (c2a_format_bristol).
+// ------------------------------------------------------------------------------------------------
+struct FmtTable {
+    u8 len[32];          // op name length
+    u8 unary[32];        // 1 = printed with one input
+    char name[32][8];    // op names, not terminated
+};
+__device__ __forceinline__ u32 dec_digits(u32 v) {
+    return v < 10u ? 1u : v < 100u ? 2u : v < 1000u ? 3u : v < 10000u ? 4u : v < 100000u ? 5u : v < 1000000u ? 6u : v < 10000000u ? 7u
+         : v < 100000000u ? 8u : v < 1000000000u ? 9u : 10u;
+}
+__device__ __forceinline__ u32 fmt_line_len(u32 a, u32 b, u32 o, u32 op, const FmtTable* T) {
+    const u32 un = T->unary[op];
+    return 4u + dec_digits(a) + 1u + (un ? 0u : dec_digits(b) + 1u) + dec_digits(o) + 1u + T->len[op] + 1u;
+}
+__global__ void k_fmt_len(u64 n, const u32* __restrict__ in0, const u32* __restrict__ in1, const u32* __restrict__ out,
+                          const u8* __restrict__ op, const FmtTable* __restrict__ T, u32* len) {
+    for (u64 k = gtid(); k < n; k += gstride()) len[k] = fmt_line_len(in0[k], in1[k], out[k], op[k], T);
+}
+__device__ __forceinline__ char* put_dec(char* p, u32 v) {
+    const u32 d = dec_digits(v);
+    for (u32 i = d; i-- > 0;) { p[i] = (char)('0' + v % 10u); v /= 10u; }
+    return p + d;
+}
+__global__ void k_fmt_write(u64 n, const u32* __restrict__ in0, const u32* __restrict__ in1, const u32* __restrict__ out,
+                            const u8* __restrict__ op, const FmtTable* __restrict__ T, const u64* __restrict__ off, char* text) {
+    for (u64 k = gtid(); k < n; k += gstride()) {
+        const u32 o = op[k], un = T->unary[o];
+        char* p = text + off[k];
+        *p++ = un ? '1' : '2'; *p++ = ' '; *p++ = '1'; *p++ = ' ';
+        p = put_dec(p, in0[k]); *p++ = ' ';
+        if (!un) { p = put_dec(p, in1[k]); *p++ = ' '; }
+        p = put_dec(p, out[k]); *p++ = ' ';
+        const u32 L = T->len[o];
+        for (u32 i = 0; i < L; ++i) *p++ = T->name[o][i];
+        *p = '\n';
+    }
+}
+
 // order-sensitive 64-bit checksum of a u32 stream: sum over i of mix(i, v[i]) (commutative combine of
 // position-salted hashes => parallel, deterministic).  Used by the full-size parity tests.
 __device__ __forceinline__ u64 mix64(u64 x) {

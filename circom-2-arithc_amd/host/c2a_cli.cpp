@@ -9,8 +9,9 @@
 //     gate <AGateType> <lhs id> <rhs id> <out id>        ac.add_gate(type, lhs, rhs, out)
 //     connect <a id> <b id>                              ac.add_connection(a, b)
 //     inputs <prefix>      / outputs <prefix>            compiler.add_inputs/outputs(compiler.get_signals("0.<prefix>"))
-// Outputs, as in the reference (src/main.rs:34-44): <out>/circuit.txt and <out>/circuit_info.json.
-// (report.json, src/main.rs:46-47, belongs to the out-of-scope front-end report.)
+// Outputs, as in the reference (src/main.rs:34-47): <out>/circuit.txt, <out>/circuit_info.json and <out>/report.json.
+// The gate lines of circuit.txt are printed on the GPU (c2a_format_bristol) and streamed to the file chunk by chunk;
+// `--host-writer` uses the host writer instead (the two are byte-identical: tests/test_cpp_host.py).
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -25,6 +26,8 @@ int main(int argc, char** argv) {
     std::string input = "./input/calls.txt", output = "./output/";        // cli.rs:23-33 defaults (input kind differs)
     std::optional<uint32_t> boolify_width;
     int device = 0;
+    bool host_writer = false;
+    std::string value_type = "sint";                                                                          // cli.rs:35-45
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto need = [&](const char* what) -> std::string {
@@ -35,6 +38,8 @@ int main(int argc, char** argv) {
         else if (a == "-o" || a == "--output") output = need("--output");
         else if (a == "--boolify-width") boolify_width = (uint32_t)std::stoul(need("--boolify-width"));
         else if (a == "--device") device = std::stoi(need("--device"));
+        else if (a == "--host-writer") host_writer = true;
+        else if (a == "-v" || a == "--value-type") value_type = need("--value-type");
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     try {
@@ -66,17 +71,22 @@ int main(int argc, char** argv) {
                 if (kind == "inputs") compiler.add_inputs(sigs); else compiler.add_outputs(sigs);
             } else { std::fprintf(stderr, "unknown line kind: %s\n", kind.c_str()); return 1; }
         }
+        const std::string report = compiler.report_json(value_type);                                          // main.rs:22
         BristolCircuit circuit = compiler.build_circuit();                                                    // main.rs:28
-        if (boolify_width) circuit = boolify(compiler, circuit, *boolify_width);                              // main.rs:30-32
+        if (boolify_width) circuit = boolify(compiler, circuit, *boolify_width, /*fetch=*/host_writer);       // main.rs:30-32
         if (!output.empty() && output.back() != '/') output += '/';
         std::system(("mkdir -p '" + output + "'").c_str());                                                   // main.rs:25-26
         {
-            std::ofstream f(output + "circuit.txt");                                                          // main.rs:34-35
-            circuit.write_bristol(f);
+            std::ofstream f(output + "circuit.txt", std::ios::binary);                                        // main.rs:34-35
+            if (host_writer) circuit.write_bristol(f); else circuit.write_bristol_gpu(f, backend.get());
         }
         {
             std::ofstream f(output + "circuit_info.json");                                                    // main.rs:43-44
             f << circuit.info_json();
+        }
+        {
+            std::ofstream f(output + "report.json");                                                          // main.rs:46-47
+            f << report;
         }
         return 0;
     } catch (const CircuitError& e) {

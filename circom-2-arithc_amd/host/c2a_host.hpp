@@ -97,7 +97,8 @@ struct BristolCircuit {
     std::optional<std::pair<std::vector<size_t>, std::vector<size_t>>> io_widths;   // None for arithmetic (:492)
     std::vector<uint32_t> sorted_gate_ids;
 
-    size_t n_gates() const { return op.size(); }
+    size_t gates_on_device = 0;     // > 0: the SoA was left in HBM (fetch = false); this is the gate count
+    size_t n_gates() const { return gates_on_device ? gates_on_device : op.size(); }
     std::string op_name(size_t k) const {
         static const char* const b[] = {"XOR", "AND", "INV"};
         return boolean ? b[op[k]] : to_string(static_cast<AGateType>(op[k]));
@@ -124,6 +125,34 @@ struct BristolCircuit {
             if (boolean && op[k] == C2A_INV) w << "1 1 " << in0[k] << ' ' << out[k] << ' ' << op_name(k) << '\n';
             else w << "2 1 " << in0[k] << ' ' << in1[k] << ' ' << out[k] << ' ' << op_name(k) << '\n';
         }
+    }
+    // the same file with the gate lines printed on the GPU (c2a_format_bristol) and streamed chunk by chunk: the boolean
+    // circuit of the 10 M-gate config is ~27 GB of text.  `ctx` must still hold the circuit this object describes.
+    size_t write_bristol_gpu(std::ostream& w, c2a_ctx* ctx, size_t chunk_gates = size_t(1) << 24) const {
+        const size_t n_in = info.input_name_to_wire_index.size(), n_out = info.output_name_to_wire_index.size();
+        std::vector<size_t> iw(n_in, 1), ow(n_out, 1);
+        if (io_widths) { iw = io_widths->first; ow = io_widths->second; }
+        std::ostringstream h;
+        h << n_gates() << ' ' << wire_count << '\n' << iw.size();
+        for (size_t x : iw) h << ' ' << x;
+        h << '\n' << ow.size();
+        for (size_t x : ow) h << ' ' << x;
+        h << "\n\n";
+        w << h.str();
+        size_t total = h.str().size();
+        std::vector<char> buf;
+        for (size_t first = 0; first < n_gates(); first += chunk_gates) {
+            const size_t cnt = std::min(chunk_gates, n_gates() - first);
+            uint64_t need = 0, got = 0;
+            int rc = c2a_format_bristol(ctx, boolean ? 1 : 0, first, cnt, nullptr, 0, &need);
+            if (rc != C2A_OK) throw std::runtime_error(std::string("c2a_format_bristol: ") + c2a_last_error(ctx));
+            buf.resize(need);
+            rc = c2a_format_bristol(ctx, boolean ? 1 : 0, first, cnt, buf.data(), need, &got);
+            if (rc != C2A_OK) throw std::runtime_error(std::string("c2a_format_bristol: ") + c2a_last_error(ctx));
+            w.write(buf.data(), (std::streamsize)got);
+            total += got;
+        }
+        return total;
     }
     // circuit_info.json (main.rs:43-44), serde_json::to_string_pretty layout
     std::string info_json() const {
@@ -233,6 +262,55 @@ public:
     }
     uint32_t node_count() const { return node_count_; }
 
+    // report.json (main.rs:22, :46-47): compiler.rs:287-319 + :502-531 — nodes split into inputs (not the output of any gate)
+    // and outputs (gate outputs that no gate reads), each sorted by node id; per node the names of its signals (those
+    // containing "random_" are dropped, :519) and the value of its last valued signal.  serde_json::to_string_pretty layout.
+    std::string report_json(const std::string& value_type = "sint") const {
+        std::vector<uint32_t> in_nodes, out_nodes;
+        std::unordered_map<uint32_t, bool> read;
+        for (const auto& g : gates_) { read[resolve(g.lh_in)] = true; read[resolve(g.rh_in)] = true; }    // (:300-304 scans per node)
+        for (const auto& kv : nodes_) {
+            if (!kv.second.is_out) in_nodes.push_back(kv.first);
+            else if (!read.count(kv.first)) out_nodes.push_back(kv.first);
+        }
+        std::sort(in_nodes.begin(), in_nodes.end());
+        std::sort(out_nodes.begin(), out_nodes.end());
+        auto esc = [](const std::string& s) {
+            std::string o = "\"";
+            for (char ch : s) { if (ch == '"' || ch == '\\') o += '\\'; o += ch; }
+            return o + "\"";
+        };
+        auto reports = [&](const std::vector<uint32_t>& ids) {
+            std::ostringstream j;
+            if (ids.empty()) return std::string("[]");
+            j << "[";
+            bool first = true;
+            for (uint32_t id : ids) {
+                std::vector<std::string> names;
+                std::optional<uint32_t> value;
+                for (uint32_t sid : nodes_.at(id).signals) {
+                    const Signal& sg = signals_.at(sid);
+                    if (sg.name.find("random_") == std::string::npos) names.push_back(sg.name);
+                    if (sg.value) value = sg.value;
+                }
+                j << (first ? "\n" : ",\n") << "    {\n      \"id\": " << id << ",\n      \"names\": ";
+                if (names.empty()) j << "[]";
+                else {
+                    j << "[";
+                    for (size_t k = 0; k < names.size(); ++k) j << (k ? ",\n" : "\n") << "        " << esc(names[k]);
+                    j << "\n      ]";
+                }
+                j << ",\n      \"value\": ";
+                if (value) j << *value; else j << "null";
+                j << "\n    }";
+                first = false;
+            }
+            j << "\n  ]";
+            return j.str();
+        };
+        return "{\n  \"inputs\": " + reports(in_nodes) + ",\n  \"outputs\": " + reports(out_nodes) + ",\n  \"value_type\": \"" + value_type + "\"\n}";
+    }
+
     // compiler.rs:321-494
     BristolCircuit build_circuit() const {
         // -- name maps + the two name-level checks (:323-383), canonical order = ascending signal id
@@ -336,7 +414,7 @@ inline BristolCircuit boolify(const Compiler& compiler, const BristolCircuit& ci
     if (fetch) {
         b.in0.resize(bi.n_gates); b.in1.resize(bi.n_gates); b.out.resize(bi.n_gates); b.op.resize(bi.n_gates);
         be.check(c2a_bool_read(be.get(), 0, bi.n_gates, b.in0.data(), b.in1.data(), b.out.data(), b.op.data()));
-    }
+    } else b.gates_on_device = bi.n_gates;
     return b;
 }
 

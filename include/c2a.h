@@ -150,6 +150,15 @@ int c2a_boolify_plan(c2a_ctx* ctx, uint32_t width, c2a_bool_info* info);
 int c2a_boolify_chunk(c2a_ctx* ctx, uint64_t first_gate, uint64_t n_gates, uint32_t* in0, uint32_t* in1, uint32_t* out,
                       uint8_t* op, uint64_t* first_bool_gate, uint64_t* n_bool_gates);
 
+/*
+ * == the gate lines of BristolCircuit::write_bristol (src/main.rs:34-35; crate absent: Bristol-fashion text per SURVEY C.2),
+ * printed on the GPU: "2 1 <in0> <in1> <out> <OP>\n", "1 1 <in0> <out> INV\n" for the one-input op.  Gates
+ * [first, first + count) of  which = 0: the arithmetic circuit (c2a_emit_gates);  1: the boolean circuit (c2a_boolify,
+ * single-device context);  2: the chunk of the last c2a_boolify_chunk.  text == NULL only queries *written (bytes).
+ * The header lines (gate / wire counts, io widths) are the host's: it knows the name tables.
+ */
+int c2a_format_bristol(c2a_ctx* ctx, int which, uint64_t first, uint64_t count, char* text, uint64_t capacity, uint64_t* written);
+
 /* T(op,width) and AUX(op,width) of the frozen spec (host-side query; no GPU work). */
 int c2a_template_size(uint32_t op, uint32_t width, uint64_t* n_gates, uint64_t* n_aux);
 

@@ -203,6 +203,28 @@ class CompilerModel:
         self.nodes.pop(nb, None)
         self.nodes[mid] = merged
 
+    def generate_circuit_report(self, value_type: str = "sint") -> dict:          # compiler.rs:287-319, :502-531
+        input_nodes, output_nodes = [], []
+        for nid, node in self.nodes.items():                                      # :291-297
+            (output_nodes if node.is_out else input_nodes).append(nid)
+        output_nodes = [nid for nid in output_nodes                               # :300-304
+                        if all(g.lh_in != nid and g.rh_in != nid for g in self.gates)]
+        input_nodes.sort(); output_nodes.sort()                                   # :307-308
+
+        def reports(ids):                                                         # :503-531
+            out = []
+            for nid in ids:
+                names, value = [], None
+                for sid in self.nodes[nid].signals:
+                    sg = self.signals[sid]
+                    if "random_" not in sg.name:                                  # :519
+                        names.append(sg.name)
+                    if sg.value is not None:                                      # :522-524
+                        value = sg.value
+                out.append({"id": nid, "names": names, "value": value})
+            return out
+        return {"inputs": reports(input_nodes), "outputs": reports(output_nodes), "value_type": value_type}
+
     # -- name maps (compiler.rs:323-383), canonical order of DESIGN.md §3 -------------------------
     def io_maps(self):
         """Returns (inputs [(name,node)], outputs [(name,node)], constants {key:(node,value)}).

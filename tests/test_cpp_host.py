@@ -75,3 +75,40 @@ def test_cli_writes_the_reference_artefacts(kind, tmp_path, request):
     assert head[1] == "6 " + " ".join(["8"] * 6) and head[2].startswith("29 8 8")
     ops = {ln.split()[-1] for ln in (outdir / "circuit.txt").read_text().split("\n")[4:] if ln}
     assert ops <= {"XOR", "AND", "INV"}
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_cli_gpu_writer_equals_host_writer_and_report_json(kind, tmp_path, request, orc):
+    """circuit.txt printed on the GPU (c2a_format_bristol, the CLI's default) is byte-identical to the host writer
+    (--host-writer), arithmetic and boolean; report.json (src/main.rs:46-47) equals the literal restatement of
+    compiler.rs:287-319 + :502-531 driven by the same calls."""
+    exes = _build(tmp_path, kind, request.getfixturevalue("emul_lib") if kind == "emul" else None)
+    fx = FX["infixOps"]
+    calls = tmp_path / "calls.txt"
+    lit = orc.CompilerModel()
+    with open(calls, "w") as f:
+        for st in fx["script"]:
+            if st[0] == "signal":
+                f.write(f"signal {st[1]} {st[2]}" + (f" {st[3]}" if st[3] is not None else "") + "\n")
+                lit.add_signal(st[1], st[2], st[3])
+            elif st[0] == "gate":
+                f.write(f"gate {st[1]} {st[2]} {st[3]} {st[4]}\n")
+                lit.add_gate(orc.OP[st[1]], st[2], st[3], st[4])
+            else:
+                f.write(f"connect {st[1]} {st[2]}\n")
+                lit.add_connection(st[1], st[2])
+        for p in fx["input_prefixes"]:
+            f.write(f"inputs {p}\n")
+        for p in fx["output_prefixes"]:
+            f.write(f"outputs {p}\n")
+    for extra in ([], ["--boolify-width", "5"]):
+        a, b = tmp_path / "gpu", tmp_path / "host"
+        subprocess.check_call([exes["cli"], "-i", str(calls), "-o", str(a)] + extra, timeout=600)
+        subprocess.check_call([exes["cli"], "-i", str(calls), "-o", str(b), "--host-writer"] + extra, timeout=600)
+        assert (a / "circuit.txt").read_bytes() == (b / "circuit.txt").read_bytes()
+        assert (a / "circuit_info.json").read_bytes() == (b / "circuit_info.json").read_bytes()
+    rep = json.loads((a / "report.json").read_text())
+    assert rep == lit.generate_circuit_report("sint")
+    assert (a / "report.json").read_text() == json.dumps(lit.generate_circuit_report("sint"), indent=2)   # serde pretty layout
+    assert all("random_" not in nm for r in rep["inputs"] + rep["outputs"] for nm in r["names"])
+    assert len(rep["outputs"]) == 29 and len(rep["inputs"]) >= 6
