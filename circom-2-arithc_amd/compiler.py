@@ -236,6 +236,27 @@ class Compiler:
                               op_names=BOOL_OP_NAMES, io_widths=([width] * bi.n_in, [width] * bi.n_out),
                               unary_ops=(2,), gates_on_device=None if fetch else int(bi.n_gates))
 
+    @classmethod
+    def from_circom(cls, text: str, backend: Optional[Backend] = None, device: int = 0) -> "Compiler":
+        """program.rs::compile for the supported Circom subset: unroll the templates (circom_frontend.py restates
+        src/process.rs call for call) into add_signal / add_gate / add_connection, then IO discovery by name prefix
+        (program.rs:57-66).  Raises circom_frontend.ProgramError with the reference's Display strings."""
+        from .circom_frontend import unroll
+        d = unroll(text)
+        c = cls(backend=backend, device=device)
+        for st in d["script"]:
+            if st[0] == "signal":
+                c.add_signal(st[1], st[2], st[3])
+            elif st[0] == "gate":
+                c.add_gate(st[1], st[2], st[3], st[4])
+            else:
+                c.add_connection(st[1], st[2])
+        for p in d["input_prefixes"]:
+            c.add_inputs(c.get_signals(f"0.{p}"))
+        for p in d["output_prefixes"]:
+            c.add_outputs(c.get_signals(f"0.{p}"))
+        return c
+
     # -- report.json (src/main.rs:22, :46-47) ------------------------------------------------------
     def generate_circuit_report(self, value_type: str = "sint") -> dict:
         """compiler.rs:287-319 + :502-531: nodes split into inputs (not the output of any gate) and outputs (gate outputs
