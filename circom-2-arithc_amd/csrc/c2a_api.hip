@@ -73,7 +73,8 @@ struct c2a_ctx {
     DevBuf lh, rh, out, op, gate4, in_nodes, out_nodes;
     DevBuf prod1, dep0, dep1, cons_cnt, cons_off, eslot, link, aq_ht, aq_items, aq_idle, aq_seeds, aq_seed_cnt, fill, meta, node, child, gstat, clist, pctl, pcold;
     DevBuf rflag, ridx, rlist, next, owner, local, slist, snext, ssum, jnxt, jval, sorted;
-    DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op;
+    DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op, gs, wcnt, wfo;
+    bool has_dup = false;          // two gates write one node (compiler.rs:403-406 keeps the last): the general numbering path
     DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof;
     DevBuf tsz, asz, goff, aoff, tmpl, tables, b_in0, b_in1, b_out, b_op;
     DevBuf fmt_len, fmt_off, fmt_text, fmt_table;
@@ -86,7 +87,7 @@ struct c2a_ctx {
         all = {&lh, &rh, &out, &op, &gate4, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &link, &aq_ht, &aq_items, &aq_idle, &aq_seeds, &aq_seed_cnt, &fill,
                &gstat, &clist, &pctl, &pcold, &meta, &node, &child, &rflag, &ridx, &rlist, &next,
                &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
-               &node_wire, &e_in0, &e_in1, &e_out, &e_op, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &tsz, &asz, &goff,
+               &node_wire, &e_in0, &e_in1, &e_out, &e_op, &gs, &wcnt, &wfo, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &tsz, &asz, &goff,
                &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &fmt_len, &fmt_off, &fmt_text, &fmt_table, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &ev_lcount, &ev_lbase, &ev_lorder, &cb_in0, &cb_in1, &cb_out, &cb_op};
     }
 };
@@ -373,10 +374,12 @@ int do_topo_sort(c2a_ctx* c, u64* cycle_at) {
     if (r) return r;
     rec(c, EV_PEEL1);
     {
-        u32 edges = 0;
+        u32 edges = 0, dup = 0;
         HIP_TRY(hipMemcpyAsync(&edges, c->cons_off.as<u32>() + n, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(&dup, c->scalars.as<u32>() + SC_DUP, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->stats.n_edges = edges;
+        c->has_dup = dup != 0;
     }
     if (peeled != n) {
         // leftover gates sit on or above a dependency cycle: replay the reference's DFS for its message
@@ -412,27 +415,48 @@ int do_assign_wires(c2a_ctx* c) {
     if (c->n_out)
         C2A_LAUNCH_NOSYNC(k_mark_outputs, grid_for(c->n_out, 1024), kThreads, s, c->n_out, c->out_nodes.as<u32>(),
                           c->nflag.as<u8>(), c->scalars.as<u32>() + SC_ERR);
-    if (n) {
-        const u32 G = grid_for(n, 4096);
-        C2A_LAUNCH_NOSYNC(k_first_seen, G, kThreads, s, n, c->sorted.as<u32>(), (const uint4*)c->gate4.as<uint4>(),
-                          (const u32*)c->prod1.as<u32>(), (const u32*)(c->scalars.as<u32>() + SC_DUP), c->first.as<u32>());
-        C2A_LAUNCH_NOSYNC(k_new_wire_flags, G, kThreads, s, n, c->sorted.as<u32>(), (const uint4*)c->gate4.as<uint4>(),
-                          c->first.as<u32>(), c->nflag.as<u8>(), (const u32*)c->prod1.as<u32>(),
-                          (const u32*)(c->scalars.as<u32>() + SC_DUP), c->wflag.as<u32>());
-    }
-    int r = scan_exclusive<u32>(c, c->wflag.as<u32>(), c->widx.as<u32>(), m);
-    if (r) return r;
-    if (n) {
-        C2A_LAUNCH_NOSYNC(k_assign_wires, grid_for(n, 4096), kThreads, s, n, c->sorted.as<u32>(),
-                          (const uint4*)c->gate4.as<uint4>(), c->wflag.as<u32>(), c->widx.as<u32>(), c->n_in,
-                          c->node_wire1.as<u32>());
+    const bool fast = !c->has_dup;
+    const u64 n_scan = fast ? (u64)n : m;          // entries of the scanned flag array; widx[n_scan] = wires handed out
+    const u32 G = grid_for(n, 4096), GN = grid_for(c->n_nodes, 4096);
+    int r;
+    if (fast) {
+        if (n) {
+            C2A_LAUNCH_NOSYNC(k_walk, G, kThreads, s, n, c->sorted.as<u32>(), (const uint4*)c->gate4.as<uint4>(), (const u32*)c->prod1.as<u32>(),
+                              (const u8*)c->nflag.as<u8>(), c->gs.as<uint4>(), c->wcnt.as<u32>(), c->wfo.as<u8>(), c->first.as<u32>());
+            C2A_LAUNCH_NOSYNC(k_walk_nodes, GN, kThreads, s, c->n_nodes, (const u32*)c->prod1.as<u32>(), (const u8*)c->nflag.as<u8>(),
+                              (const u32*)c->first.as<u32>(), c->wcnt.as<u32>());
+        }
+        r = scan_exclusive<u32>(c, c->wcnt.as<u32>(), c->widx.as<u32>(), n_scan);
+        if (r) return r;
+        if (n) {
+            C2A_LAUNCH_NOSYNC(k_assign_fast, G, kThreads, s, n, (const uint4*)c->gs.as<uint4>(), (const u32*)c->wcnt.as<u32>(),
+                              (const u8*)c->wfo.as<u8>(), (const u32*)c->widx.as<u32>(), c->n_in, c->node_wire1.as<u32>());
+            C2A_LAUNCH_NOSYNC(k_assign_nodes, GN, kThreads, s, c->n_nodes, (const u32*)c->prod1.as<u32>(), (const u8*)c->nflag.as<u8>(),
+                              (const u32*)c->first.as<u32>(), (const uint4*)c->gs.as<uint4>(), (const u32*)c->widx.as<u32>(), c->n_in,
+                              c->node_wire1.as<u32>());
+        }
+    } else {
+        if (n) {
+            C2A_LAUNCH_NOSYNC(k_first_seen, G, kThreads, s, n, c->sorted.as<u32>(), (const uint4*)c->gate4.as<uint4>(),
+                              (const u32*)c->prod1.as<u32>(), (const u32*)(c->scalars.as<u32>() + SC_DUP), c->first.as<u32>());
+            C2A_LAUNCH_NOSYNC(k_new_wire_flags, G, kThreads, s, n, c->sorted.as<u32>(), (const uint4*)c->gate4.as<uint4>(),
+                              c->first.as<u32>(), c->nflag.as<u8>(), (const u32*)c->prod1.as<u32>(),
+                              (const u32*)(c->scalars.as<u32>() + SC_DUP), c->wflag.as<u32>());
+        }
+        r = scan_exclusive<u32>(c, c->wflag.as<u32>(), c->widx.as<u32>(), m);
+        if (r) return r;
+        if (n) {
+            C2A_LAUNCH_NOSYNC(k_assign_wires, G, kThreads, s, n, c->sorted.as<u32>(),
+                              (const uint4*)c->gate4.as<uint4>(), c->wflag.as<u32>(), c->widx.as<u32>(), c->n_in,
+                              c->node_wire1.as<u32>());
+        }
     }
     if (c->n_out)
         C2A_LAUNCH_NOSYNC(k_assign_outputs, grid_for(c->n_out, 1024), kThreads, s, c->n_out, c->out_nodes.as<u32>(), c->n_in,
-                          (const u32*)(c->widx.as<u32>() + m), c->node_wire1.as<u32>());
+                          (const u32*)(c->widx.as<u32>() + n_scan), c->node_wire1.as<u32>());
     rec(c, EV_WIRES1);
     u32 n_mid = 0, err = 0;
-    HIP_TRY(hipMemcpyAsync(&n_mid, c->widx.as<u32>() + m, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&n_mid, c->widx.as<u32>() + n_scan, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&err, c->scalars.as<u32>() + SC_ERR, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (err) return fail(c, C2A_ERR_INCONSISTENCY, "Inconsistency: a node is used for both input and output");
@@ -445,7 +469,11 @@ int do_assign_wires(c2a_ctx* c) {
 int do_emit(c2a_ctx* c) {
     if (c->stage < ST_WIRED) return fail(c, C2A_ERR_STATE, "c2a_emit_gates: call c2a_assign_wires first");
     rec(c, EV_EMIT0);
-    if (c->n)
+    if (c->n && !c->has_dup)
+        C2A_LAUNCH_NOSYNC(k_emit_fast, grid_for(c->n, 4096), kThreads, c->stream, c->n, (const uint4*)c->gs.as<uint4>(),
+                          (const u32*)c->wcnt.as<u32>(), (const u8*)c->wfo.as<u8>(), (const u32*)c->widx.as<u32>(), c->n_in,
+                          (const u32*)c->node_wire1.as<u32>(), c->e_in0.as<u32>(), c->e_in1.as<u32>(), c->e_out.as<u32>(), c->e_op.as<u8>());
+    else if (c->n)
         C2A_LAUNCH_NOSYNC(k_emit, grid_for(c->n, 4096), kThreads, c->stream, c->n, c->sorted.as<u32>(),
                           (const uint4*)c->gate4.as<uint4>(), c->node_wire1.as<u32>(), c->e_in0.as<u32>(), c->e_in1.as<u32>(),
                           c->e_out.as<u32>(), c->e_op.as<u8>());
@@ -580,6 +608,7 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     ENSURE(c->sorted, n4);
     ENSURE(c->first, nn4); ENSURE(c->nflag, n_nodes); ENSURE(c->wflag, 3 * n4); ENSURE(c->widx, 3 * n4 + 4);
     ENSURE(c->node_wire1, nn4); ENSURE(c->node_wire, nn4);
+    ENSURE(c->gs, (size_t)n * 16); ENSURE(c->wcnt, n4 + 4); ENSURE(c->wfo, n);
     ENSURE(c->e_in0, n4); ENSURE(c->e_in1, n4); ENSURE(c->e_out, n4); ENSURE(c->e_op, n);
     ENSURE(c->scalars, SC_WORDS * 4);
     hipStream_t s = c->stream;
@@ -630,6 +659,12 @@ int c2a_topo_sort_serial(c2a_ctx* c, uint32_t* sorted, uint64_t* cycle_at) {
     u64 at = 0;
     int r = run_serial_dfs(c, &status, &at);
     if (r) return r;
+    {
+        u32 dup = 0;
+        HIP_TRY(hipMemcpyAsync(&dup, c->scalars.as<u32>() + SC_DUP, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->has_dup = dup != 0;
+    }
     if (status == 1) {
         if (cycle_at) *cycle_at = at;
         return fail(c, C2A_ERR_CYCLIC, "Cyclic dependency: detected at i=" + std::to_string(at));

@@ -386,6 +386,68 @@ __global__ void k_emit(u32 n, const u32* __restrict__ sorted, const uint4* __res
     }
 }
 
+// ---- fast path: every node has one writer (*dup == 0, the normal case).  The sorted order is topological, so a produced
+// node is first seen as its producer's `out`: whether it gets a new wire is local (it does unless it is an IO node),
+// and only nodes NO gate produces (constants, dangling nodes) need the first-appearance race.  One gather of the gate
+// record per sorted position for the whole numbering + emission (the record is re-stored in sorted order), instead of
+// four; the first-appearance flags are scattered per NODE, not re-derived per reference.
+//   k_walk          gs[pos] = gate4[sorted[pos]]; cnt[pos] = fo[pos] = (out is no IO node); first[] race for un-produced lh / rh
+//   k_walk_nodes    every un-produced, non-IO node that appears: cnt[first / 3] += 1
+//   (scan cnt -> widx)
+//   k_assign_fast   node_wire1[out] = n_in + widx[pos] + (cnt[pos] - 1) for fo[pos]
+//   k_assign_nodes  the un-produced nodes' wires (lh before rh inside one gate, compiler.rs:430)
+//   k_emit_fast     in0 / in1 by gather, out by formula, op from the record
+__global__ void k_walk(u32 n, const u32* __restrict__ sorted, const uint4* __restrict__ gate4, const u32* __restrict__ prod1,
+                       const u8* __restrict__ nflag, uint4* gs, u32* cnt, u8* fo, u32* first) {
+    for (u64 pos = gtid(); pos < n; pos += gstride()) {
+        const uint4 g = gate4[sorted[pos]];
+        gs[pos] = g;
+        const u32 i = 3u * (u32)pos;
+        if (prod1[g.x] == 0) atomicMin(&first[g.x], i);
+        if (prod1[g.y] == 0) atomicMin(&first[g.y], i + 1);
+        const u32 f = nflag[g.z] == 0 ? 1u : 0u;                                 // :431-438 for the out node
+        cnt[pos] = f;
+        fo[pos] = (u8)f;
+    }
+}
+__global__ void k_walk_nodes(u32 n_nodes, const u32* __restrict__ prod1, const u8* __restrict__ nflag, const u32* __restrict__ first,
+                             u32* cnt) {
+    for (u64 v = gtid(); v < n_nodes; v += gstride()) {
+        const u32 f = first[v];
+        if (f != 0xFFFFFFFFu && prod1[v] == 0 && nflag[v] == 0) atomicAdd(&cnt[f / 3u], 1u);
+    }
+}
+__global__ void k_assign_fast(u32 n, const uint4* __restrict__ gs, const u32* __restrict__ cnt, const u8* __restrict__ fo,
+                              const u32* __restrict__ widx, u32 n_in, u32* node_wire1) {
+    for (u64 pos = gtid(); pos < n; pos += gstride())
+        if (fo[pos]) node_wire1[gs[pos].z] = n_in + widx[pos] + (cnt[pos] - 1u) + 1u;        // out comes last in [lh, rh, out]
+}
+__global__ void k_assign_nodes(u32 n_nodes, const u32* __restrict__ prod1, const u8* __restrict__ nflag, const u32* __restrict__ first,
+                               const uint4* __restrict__ gs, const u32* __restrict__ widx, u32 n_in, u32* node_wire1) {
+    for (u64 v = gtid(); v < n_nodes; v += gstride()) {
+        const u32 f = first[v];
+        if (f == 0xFFFFFFFFu || prod1[v] != 0 || nflag[v] != 0) continue;
+        const u32 pos = f / 3u, k = f - 3u * pos;
+        u32 before = 0;
+        if (k == 1u) {                                                           // rh: one more if lh got its wire at this very gate
+            const u32 x = gs[pos].x;
+            before = (prod1[x] == 0 && nflag[x] == 0 && first[x] == 3u * pos) ? 1u : 0u;
+        }
+        node_wire1[v] = n_in + widx[pos] + before + 1u;
+    }
+}
+__global__ void k_emit_fast(u32 n, const uint4* __restrict__ gs, const u32* __restrict__ cnt, const u8* __restrict__ fo,
+                            const u32* __restrict__ widx, u32 n_in, const u32* __restrict__ node_wire1, u32* e_in0, u32* e_in1,
+                            u32* e_out, u8* e_op) {
+    for (u64 pos = gtid(); pos < n; pos += gstride()) {
+        const uint4 g = gs[pos];
+        e_in0[pos] = node_wire1[g.x] - 1;
+        e_in1[pos] = node_wire1[g.y] - 1;
+        e_out[pos] = fo[pos] ? n_in + widx[pos] + (cnt[pos] - 1u) : node_wire1[g.z] - 1;
+        e_op[pos] = (u8)g.w;
+    }
+}
+
 __global__ void k_unbias(u64 n, const u32* __restrict__ in1, u32* out) {
     for (u64 i = gtid(); i < n; i += gstride()) out[i] = in1[i] - 1;   // 0 -> 0xFFFFFFFF (no wire)
 }
