@@ -139,6 +139,30 @@ __device__ __forceinline__ void wave_join() {
     __builtin_amdgcn_wave_barrier();
 #endif
 }
+// A kernel argument in scalar registers OF ITS OWN.  The argument block arrives as one 16-register load; under register
+// pressure the allocator spills and reloads that block as a unit — sixteen v_readlane for every pointer the chain step
+// touches (measured: 315 -> 180 vector instructions per gate).  A copy through an opaque s_mov makes each pointer its own
+// two-register value.  (The copy is made on a GLOBAL-address-space pointer and cast back: a generic pointer of unknown
+// origin would turn every access through it into a flat_ instruction.)
+template <class T> __device__ __forceinline__ T* own_sgprs(T* p) {
+#ifdef C2A_EMULATE
+    return p;
+#else
+    typedef __attribute__((address_space(1))) T* G;
+    G q;
+    asm volatile("s_mov_b64 %0, %1" : "=s"(q) : "s"((G)p));
+    return (T*)q;
+#endif
+}
+__device__ __forceinline__ u32 own_sgpr(u32 v) {
+#ifdef C2A_EMULATE
+    return v;
+#else
+    u32 q;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(q) : "s"(v));
+    return q;
+#endif
+}
 // the compiler must treat v as used (and redefined) here: pins the wait for a pending load to this point
 #ifdef C2A_EMULATE
 #define C2A_PIN(v) ((void)0)
@@ -310,7 +334,12 @@ struct StepIO {
 
 // the dataflow launch: 64-thread workgroups (one wave each)
 template <bool STATS>
-__global__ void __launch_bounds__(64) k_peel(PeelArgs A) {
+__global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
+    PeelArgs A = A_in;
+    A.gstat = own_sgprs(A_in.gstat); A.clist = own_sgprs(A_in.clist); A.node = own_sgprs(A_in.node); A.fill = own_sgprs(A_in.fill);
+    A.meta = own_sgprs(A_in.meta); A.child = own_sgprs(A_in.child); A.q_ht = own_sgprs(A_in.q_ht); A.q_items = own_sgprs(A_in.q_items);
+    A.idle = own_sgprs(A_in.idle); A.ctl = own_sgprs(A_in.ctl); A.link = own_sgprs(A_in.link); A.cold = own_sgprs(A_in.cold);
+    A.epoch = own_sgpr(A_in.epoch); A.n_queues = own_sgpr(A_in.n_queues); A.q_cap = own_sgpr(A_in.q_cap);
     const u32 lane = threadIdx.x;
     const u32 me = blockIdx.x;
     const u32 epoch = A.epoch;
@@ -348,7 +377,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A) {
                     if (r >= uniform(C->n_regions)) { seeds_left = false; break; }
                     region = r; idx = 0; region_cnt = uniform(C->seed_cnt[r]);
                 }
-                if (seeds_left) { g = uniform(C->seeds[(u64)region * uniform(C->region_cap) + idx]); ++idx; ++st_seeds; }
+                if (seeds_left) { g = uniform(C->seeds[(u64)region * uniform(C->region_cap) + idx]); ++idx; if (STATS) ++st_seeds; }
             }
             if (g == C2A_NONE) {
                 if (STATS) { const ull t = c2a_now(); st_busy += t - st_t0; st_t0 = t; }
@@ -383,7 +412,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A) {
                             if (v) {
                                 g = (u32)v - 1u;
                                 coff = (u32)(v >> 32);
-                                ++st_pops;
+                                if (STATS) ++st_pops;
                             } else { if (lane == 0) atomicAdd(&A.ctl[CTL_ABORT], 1u); wave_join(); }
                             break;
                         }
@@ -421,7 +450,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A) {
                     // back off: the longer nothing turns up, the less often this wave asks (64 clocks per unit, <= ~3 us)
                     peel_sleep(polls < 16 ? 4 : 16);
                 }
-                st_polls += polls;
+                if (STATS) st_polls += polls;
                 if (STATS) { const ull t = c2a_now(); st_idle += t - st_t0; st_t0 = t; }
                 if (g == C2A_NONE) break;
             }
@@ -518,7 +547,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A) {
                     push_pending = true;
                     push_gate = g_dep1; push_off = rdlane(cur.ga.z, 1);
                     push_q = (push_rr++) % A.n_queues;
-                    ++st_push;
+                    if (STATS) ++st_push;
                     push_t = 0;
                     if (lane == 0) push_t = atomicAdd(&head_w[2 * (u64)push_q * kQStride + 1], 1u); wave_join();
                 }
