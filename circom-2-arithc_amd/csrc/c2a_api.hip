@@ -251,11 +251,11 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
     HIP_TRY(hipMemsetAsync(c->aq_idle.p, 0, (size_t)kIdleCounters * 64, s));
     HIP_TRY(hipMemsetAsync(c->pctl.p, 0, (size_t)CTL_WORDS * 4, s));
     A.q_ht = c->aq_ht.as<u64>(); A.q_items = c->aq_items.as<u64>(); A.idle = c->aq_idle.as<u32>(); A.ctl = c->pctl.as<u32>();
-    cold.stats = nullptr;
+    cold.stats = nullptr; cold.q_time = nullptr;
     if (want_stats) {
-        ENSURE(c->peel_prof, 256);
-        HIP_TRY(hipMemsetAsync(c->peel_prof.p, 0, 256, s));
-        cold.stats = c->peel_prof.as<ull>();
+        ENSURE(c->peel_prof, 256 + (size_t)A.n_queues * A.q_cap * 8);
+        HIP_TRY(hipMemsetAsync(c->peel_prof.p, 0, 256 + (size_t)A.n_queues * A.q_cap * 8, s));
+        cold.stats = c->peel_prof.as<ull>(); cold.q_time = c->peel_prof.as<ull>() + 32;
     }
     // seed regions: one per workgroup of the sinks pass; a workgroup sees at most gates_per_block gates, each claims <= 2 producers
     const u32 sink_blocks = grid_for(n, c->peel_sinks_blocks);
@@ -281,6 +281,8 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
         HIP_TRY(hipMemcpy(st, c->peel_prof.p, 256, hipMemcpyDeviceToHost));
         std::fprintf(stderr, "[c2a peel stats] waves %u queues %u | seeds %llu, popped %llu, pushed %llu, processed %llu, idle polls %llu, record re-reads %llu | busy %.1f ms-waves, idle %.1f ms-waves\n",
                      waves, A.n_queues, st[5], st[0], st[2], st[6], st[1], st[8], st[3] / 1e5, st[4] / 1e5);
+        if (st[18]) std::fprintf(stderr, "[c2a peel stats] hand-off (push decided -> popped gate ready to issue): mean %.0f ns over %llu; < 2 us %llu, 2-4 %llu, 4-8 %llu, 8-16 %llu, >= 16 %llu\n",
+                                 st[17] * 10.0 / st[18], st[18], st[19], st[20], st[21], st[22], st[23]);
         if (st[13]) std::fprintf(stderr, "[c2a peel stats] wait at the top of a step (ns): ticket %.0f, then static data %.0f, then records %.0f\n",
                      (double)(st[7] & 0xFFFFFFFFull) * 10.0 / st[13], (double)(st[7] >> 32) * 10.0 / st[13], st[16] * 10.0 / st[13]);
         if (st[13]) std::fprintf(stderr, "[c2a peel stats] per chain step (ns): wait for tickets/static data/records %.0f, issue of the next step %.0f, tournament %.0f, record + stores %.0f | steps without a load %.1f %% | chain start (static loads) %.0f ns per chain\n",

@@ -67,7 +67,8 @@ struct PeelCold {
     const u32* seeds;          // [n_regions][region_cap] producers claimed by the sinks pass
     const u32* seed_cnt;       // [n_regions]
     u32 n_regions, region_cap;
-    ull* stats;                // optional diagnostics (16 words), nullptr normally
+    ull* stats;                // optional diagnostics (32 words), nullptr normally
+    ull* q_time;               // with stats: when the push of every queue entry was decided
 };
 
 struct PeelArgs {
@@ -170,6 +171,7 @@ __device__ __forceinline__ u32 own_sgpr(u32 v) {
 #define C2A_PIN(v) asm volatile("" : "+v"(v) :: "memory")
 #endif
 
+__device__ __forceinline__ ull ld_word_time(const ull* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u64 hdr0_word(u32 root, u32 depth) { return ((u64)(root & kIdMask) << 32) | depth; }
 __device__ __forceinline__ u64 hdr1_word(u32 level, u32 cprev) { return ((u64)(level & kIdMask) << 32) | cprev; }
 __device__ __forceinline__ u32 hdr_hi(u64 w) { return (u32)(w >> 32) & kIdMask; }
@@ -355,13 +357,14 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
     u32 processed = 0, max_level = 0, iters = 0;
     u32 st_pops = 0, st_polls = 0, st_push = 0, st_seeds = 0, st_rpolls = 0;
     ull st_busy = 0, st_idle = 0, st_t0 = STATS ? c2a_now() : 0;
-    ull ph_w1 = 0, ph_w2 = 0, ph_w3 = 0;
+    ull ph_w1 = 0, ph_w2 = 0, ph_w3 = 0, ho_sum = 0, ho_cnt = 0, ho_hist[5] = {0, 0, 0, 0, 0};
     ull ph_a = 0, ph_b = 0, ph_c = 0, ph_d = 0, ph_steps = 0, ph_noload = 0, ph_start = 0;      // STATS: phase times of the chain step
     if (lane == 0) atomicAdd(&A.ctl[CTL_STARTED], 1u); wave_join();
     for (;;) {
         // ---- next piece of work: own stack, the seed pool, then the hand-off queues
         u32 g = C2A_NONE;
         u32 coff = C2A_NONE;                 // cons_off of g when the entry carried it
+        ull pop_when = 0;                    // STATS: push time of the popped entry
         if (head != C2A_NONE) {
             g = head;
             head = uniform(ld_a32(&A.link[g]));
@@ -412,6 +415,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                             if (v) {
                                 g = (u32)v - 1u;
                                 coff = (u32)(v >> 32);
+                                if (STATS) pop_when = ld_word_time(A.cold->q_time + (u64)q * A.q_cap + qh);
                                 if (STATS) ++st_pops;
                             } else { if (lane == 0) atomicAdd(&A.ctl[CTL_ABORT], 1u); wave_join(); }
                             break;
@@ -466,7 +470,11 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
         if (coff == C2A_NONE) coff = gi.z;
         u32 cl0 = A.clist[coff + lane];                                  // clist is padded by 64 entries
         C2A_PIN(cl0);
-        if (STATS) ph_start += c2a_now() - ph_s0;
+        if (STATS) {
+            const ull tn = c2a_now();
+            ph_start += tn - ph_s0;
+            if (pop_when) { const ull dt = tn - pop_when; ho_sum += dt; ++ho_cnt; ho_hist[dt < 200 ? 0 : dt < 400 ? 1 : dt < 800 ? 2 : dt < 1600 ? 3 : 4] += 1; }
+        }
 
         // issue everything the step of a gate needs from memory
         auto issue = [&](StepIO& S, u32 dep0, u32 dep1, u32 n_cons, u32 off0, u32 cnt0, u32 off1, u32 cnt1, u32 scl, u32 cbase, u32 ccap,
@@ -508,7 +516,9 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
         // (the ticket is back by then: nothing in between may wait for memory)
         bool push_pending = false;
         u32 push_q = 0, push_t = 0, push_gate = 0, push_off = 0;
+        ull push_when = 0;                   // STATS: when the pending push was decided
         auto write_entry = [&](u32 q, u32 t, u32 gate, u32 off) {
+            if (STATS && t < A.q_cap && lane == 0) A.cold->q_time[(u64)q * A.q_cap + t] = push_when;
             if (t < A.q_cap) { if (lane == 0) st_nw(&A.q_items[(u64)q * A.q_cap + t], (u64)(gate + 1u) | ((u64)off << 32)); wave_join(); }
             else { if (lane == 0) st_a32(&A.link[gate], head); wave_join(); head = gate; }      // queue full: cannot happen with the host's q_cap
         };
@@ -545,6 +555,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                 ngi2 = make_uint4(rdlane(cur.gb.x, j0), rdlane(cur.gb.y, j0), rdlane(cur.gb.z, j0), rdlane(cur.gb.w, j0));
                 if (rmask == 3u) {
                     push_pending = true;
+                    if (STATS) push_when = ph0;
                     push_gate = g_dep1; push_off = rdlane(cur.ga.z, 1);
                     push_q = (push_rr++) % A.n_queues;
                     if (STATS) ++st_push;
@@ -709,6 +720,8 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                 atomicAdd(&stats[7], ph_w1 | (ph_w2 << 32)); atomicAdd(&stats[16], ph_w3);
                 atomicAdd(&stats[8], (ull)st_rpolls);
                 atomicAdd(&stats[9], ph_a); atomicAdd(&stats[10], ph_b); atomicAdd(&stats[11], ph_c); atomicAdd(&stats[12], ph_d);
+                atomicAdd(&stats[17], ho_sum); atomicAdd(&stats[18], ho_cnt);
+                for (int k = 0; k < 5; ++k) atomicAdd(&stats[19 + k], ho_hist[k]);
                 atomicAdd(&stats[13], ph_steps); atomicAdd(&stats[14], ph_noload); atomicAdd(&stats[15], ph_start);
             }
         }
