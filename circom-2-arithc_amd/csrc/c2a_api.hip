@@ -56,6 +56,7 @@ struct c2a_ctx {
     u32 bool_chunk = 256;          // arithmetic gates per k_boolify workgroup: 128, 256 (measured best) or 512
     u32 peel_sinks_blocks = 4096;  // grid cap of the sinks pass (latency-bound per thread: two dependent round trips per sink)
     u32 peel_waves = 8;            // dataflow launch: single-wave workgroups per CU (clamped by the occupancy query)
+    u32 peel_run = 0;              // number of the last dataflow run on this context (tag of its hand-off entries)
     u32 peel_epoch = 0;            // tag of the node words written by the last run (alternates; restarts after a clear)
     bool io_clash = false;         // a node is both an input and an output (compiler.rs:363-383), found at load time
     bool peel_meta_valid = false;  // meta[] / stats.levels describe the circuit now loaded (c2a_verify_boolify schedules by them)
@@ -71,7 +72,7 @@ struct c2a_ctx {
 
     // device buffers
     DevBuf lh, rh, out, op, gate4, in_nodes, out_nodes;
-    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, eslot, link, aq_ht, aq_items, aq_idle, aq_seeds, aq_seed_cnt, fill, meta, node, child, gstat, clist, pctl, pcold;
+    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, eslot, aq_items, aq_pc, aq_seeds, aq_seed_cnt, fill, meta, node, child, gstat, clist, pctl, pcold;
     DevBuf rflag, ridx, rlist, next, owner, local, slist, snext, ssum, jnxt, jval, sorted;
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op, gs, wcnt, wfo;
     bool has_dup = false;          // two gates write one node (compiler.rs:403-406 keeps the last): the general numbering path
@@ -84,7 +85,7 @@ struct c2a_ctx {
     std::vector<DevBuf*> all;
 
     c2a_ctx() {
-        all = {&lh, &rh, &out, &op, &gate4, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &link, &aq_ht, &aq_items, &aq_idle, &aq_seeds, &aq_seed_cnt, &fill,
+        all = {&lh, &rh, &out, &op, &gate4, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &aq_items, &aq_pc, &aq_seeds, &aq_seed_cnt, &fill,
                &gstat, &clist, &pctl, &pcold, &meta, &node, &child, &rflag, &ridx, &rlist, &next,
                &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
                &node_wire, &e_in0, &e_in1, &e_out, &e_op, &gs, &wcnt, &wfo, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &tsz, &asz, &goff,
@@ -204,10 +205,10 @@ int do_prep(c2a_ctx* c) {
 }
 
 // how many single-wave workgroups of the dataflow launch fit the device at once (the launch is CORRECT with any
-// grid — termination counts the waves that have started — but waves beyond residency only queue up behind it)
+// grid — termination counts units of work, not waves — but waves beyond residency only queue up behind it)
 u32 peel_grid(c2a_ctx* c, bool stats) {
 #ifdef C2A_EMULATE
-    (void)stats;
+    (void)stats; (void)c;
     return 16;                                      // the emulation runs them one after the other
 #else
     int per_cu = 0;
@@ -228,7 +229,6 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
     A.n = n; A.gstat = c->gstat.as<uint4>(); A.clist = c->clist.as<u32>();
     A.node = c->node.as<u64>(); A.fill = c->fill.as<u32>(); A.meta = c->meta.as<uint4>(); A.child = c->child.as<u32>();
     PeelCold cold;
-    A.link = c->link.as<u32>();
     // node words carry the tag of the run that wrote them: zeroed memory first sees tag 1, then the tag alternates (a word
     // left over from two runs ago holds the same value: the peel of one loaded graph is deterministic)
     if (c->node_clear) {
@@ -239,23 +239,29 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
     c->node_clear = true;                            // until this run has finished cleanly
     A.epoch = c->peel_epoch;
     const u32 waves = peel_grid(c, want_stats);
-    // hand-off queues: every entry is used once per run (no wrap-around); a wave spreads its pushes round robin, so a
-    // queue receives at most pushes / n_queues + waves entries
-    A.n_queues = std::max<u32>(1u, waves / 4);
-    if (const char* e = std::getenv("C2A_PEEL_QUEUES")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= waves) A.n_queues = v; }
-    A.q_cap = n / A.n_queues + waves + 64;
-    ENSURE(c->aq_ht, (size_t)A.n_queues * kQStride * 8); ENSURE(c->aq_items, (size_t)A.n_queues * A.q_cap * 8); ENSURE(c->aq_idle, (size_t)kIdleCounters * 64);
+    // hand-off arrays: every slot is used once per run (no wrap-around).  A wave spreads its pushes round robin, so an
+    // array receives at most pushes / n_fifos + waves entries, and a wave holds at most one unserved consumer ticket
+    A.n_fifos = 64;
+    if (const char* e = std::getenv("C2A_PEEL_FIFOS")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) A.n_fifos = v; }
+    A.q_cap = n / A.n_fifos + 2 * waves + 64;
+    const size_t slots = (size_t)A.n_fifos * A.q_cap;
+    // (slots are never cleared between runs: every word of an entry carries the number of the run that wrote it)
+    if (c->aq_items.cap < slots * kSlotWords * 8 || c->peel_run == 0xFFFFFFFFu) {
+        ENSURE(c->aq_items, slots * kSlotWords * 8);
+        HIP_TRY(hipMemsetAsync(c->aq_items.p, 0, c->aq_items.cap, s));
+        c->peel_run = 0;
+    }
+    A.run = ++c->peel_run;
+    ENSURE(c->aq_pc, (size_t)A.n_fifos * kPcStride * 8);
     ENSURE(c->pctl, (size_t)CTL_WORDS * 4);
-    HIP_TRY(hipMemsetAsync(c->aq_ht.p, 0, (size_t)A.n_queues * kQStride * 8, s));
-    HIP_TRY(hipMemsetAsync(c->aq_items.p, 0, (size_t)A.n_queues * A.q_cap * 8, s));
-    HIP_TRY(hipMemsetAsync(c->aq_idle.p, 0, (size_t)kIdleCounters * 64, s));
+    HIP_TRY(hipMemsetAsync(c->aq_pc.p, 0, (size_t)A.n_fifos * kPcStride * 8, s));
     HIP_TRY(hipMemsetAsync(c->pctl.p, 0, (size_t)CTL_WORDS * 4, s));
-    A.q_ht = c->aq_ht.as<u64>(); A.q_items = c->aq_items.as<u64>(); A.idle = c->aq_idle.as<u32>(); A.ctl = c->pctl.as<u32>();
-    cold.stats = nullptr; cold.q_time = nullptr;
+    A.fifo = c->aq_items.as<u64>(); A.q_pc = c->aq_pc.as<u64>(); A.ctl = c->pctl.as<u32>();
+    cold.stats = nullptr; cold.q_time = nullptr; cold.p_time = nullptr;
     if (want_stats) {
-        ENSURE(c->peel_prof, 256 + (size_t)A.n_queues * A.q_cap * 8);
-        HIP_TRY(hipMemsetAsync(c->peel_prof.p, 0, 256 + (size_t)A.n_queues * A.q_cap * 8, s));
-        cold.stats = c->peel_prof.as<ull>(); cold.q_time = c->peel_prof.as<ull>() + 32;
+        ENSURE(c->peel_prof, 256 + 2 * slots * 8);
+        HIP_TRY(hipMemsetAsync(c->peel_prof.p, 0, 256 + 2 * slots * 8, s));
+        cold.stats = c->peel_prof.as<ull>(); cold.q_time = c->peel_prof.as<ull>() + 32; cold.p_time = cold.q_time + slots;
     }
     // seed regions: one per workgroup of the sinks pass; a workgroup sees at most gates_per_block gates, each claims <= 2 producers
     const u32 sink_blocks = grid_for(n, c->peel_sinks_blocks);
@@ -279,10 +285,30 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
     if (want_stats) {
         ull st[32];
         HIP_TRY(hipMemcpy(st, c->peel_prof.p, 256, hipMemcpyDeviceToHost));
-        std::fprintf(stderr, "[c2a peel stats] waves %u queues %u | seeds %llu, popped %llu, pushed %llu, processed %llu, idle polls %llu, record re-reads %llu | busy %.1f ms-waves, idle %.1f ms-waves\n",
-                     waves, A.n_queues, st[5], st[0], st[2], st[6], st[1], st[8], st[3] / 1e5, st[4] / 1e5);
-        if (st[18]) std::fprintf(stderr, "[c2a peel stats] hand-off (push decided -> popped gate ready to issue): mean %.0f ns over %llu; < 2 us %llu, 2-4 %llu, 4-8 %llu, 8-16 %llu, >= 16 %llu\n",
-                                 st[17] * 10.0 / st[18], st[18], st[19], st[20], st[21], st[22], st[23]);
+        std::fprintf(stderr, "[c2a peel stats] waves %u, hand-off arrays %u | seeds %llu, received %llu, pushed %llu, processed %llu, idle polls %llu, record re-reads %llu | busy %.1f ms-waves, idle %.1f ms-waves\n",
+                     waves, A.n_fifos, st[5], st[0], st[2], st[6], st[1], (ull)t4[CTL_REREADS], st[3] / 1e5, st[4] / 1e5);
+        {
+            // hand-off latency: the pusher noted when it decided to push (the top of its step), the receiver when it had the
+            // gate ready to issue (100 MHz clock)
+            std::vector<ull> tq(slots), tp(slots);
+            HIP_TRY(hipMemcpy(tq.data(), cold.q_time, slots * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(tp.data(), cold.p_time, slots * 8, hipMemcpyDeviceToHost));
+            const double edges_us[] = {0.5, 1, 1.5, 2, 3, 4, 6, 8, 16, 1e30};
+            ull hist[10] = {0}, cnt = 0, late = 0;
+            double sum = 0;
+            for (size_t i = 0; i < slots; ++i) {
+                if (!tq[i] || !tp[i]) continue;
+                if (tp[i] < tq[i]) { ++late; continue; }
+                const double us = (double)(tp[i] - tq[i]) / 100.0;
+                int k = 0;
+                while (us >= edges_us[k]) ++k;
+                ++hist[k]; ++cnt; sum += us;
+            }
+            std::fprintf(stderr, "[c2a peel stats] hand-off (push decided -> received gate ready to issue): mean %.2f us over %llu;", cnt ? sum / cnt : 0.0, cnt);
+            const char* names[] = {"<0.5", "<1", "<1.5", "<2", "<3", "<4", "<6", "<8", "<16", ">=16"};
+            for (int k = 0; k < 10; ++k) std::fprintf(stderr, " %s us: %llu", names[k], hist[k]);
+            std::fprintf(stderr, " (receiver waiting before the push was decided: %llu)\n", late);
+        }
         if (st[13]) std::fprintf(stderr, "[c2a peel stats] wait at the top of a step (ns): ticket %.0f, then static data %.0f, then records %.0f\n",
                      (double)(st[7] & 0xFFFFFFFFull) * 10.0 / st[13], (double)(st[7] >> 32) * 10.0 / st[13], st[16] * 10.0 / st[13]);
         if (st[13]) std::fprintf(stderr, "[c2a peel stats] per chain step (ns): wait for tickets/static data/records %.0f, issue of the next step %.0f, tournament %.0f, record + stores %.0f | steps without a load %.1f %% | chain start (static loads) %.0f ns per chain\n",
@@ -600,7 +626,7 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     ENSURE(c->lh, n4); ENSURE(c->rh, n4); ENSURE(c->out, n4); ENSURE(c->op, n); ENSURE(c->gate4, (size_t)n * 16);
     ENSURE(c->in_nodes, (size_t)n_in * 4); ENSURE(c->out_nodes, (size_t)n_out * 4);
     ENSURE(c->prod1, nn4); ENSURE(c->dep0, n4); ENSURE(c->dep1, n4); ENSURE(c->cons_cnt, n4);
-    ENSURE(c->cons_off, n4 + 4); ENSURE(c->eslot, 2 * n4); ENSURE(c->link, n4); ENSURE(c->fill, n4);
+    ENSURE(c->cons_off, n4 + 4); ENSURE(c->eslot, 2 * n4); ENSURE(c->fill, n4);
     ENSURE(c->meta, (size_t)n * 16); ENSURE(c->gstat, (size_t)n * 32); ENSURE(c->clist, 2 * n4 + 64 * 4);
     ENSURE(c->node, (size_t)n * kNodeWords * 8); ENSURE(c->child, 2 * n4);
     c->node_clear = true;

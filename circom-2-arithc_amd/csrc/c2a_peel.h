@@ -26,17 +26,35 @@
 // tickets are taken when a consumer is claimed, NOT when it is finished, so the ticket round trip overlaps the
 // consumer's own tournament and the claiming wave goes on with g right after finishing the consumer: its own record is
 // still in registers, the other consumers' records are loaded in one round trip (and read again if a word is not there
-// yet).  A single-consumer producer needs no ticket at all.  A second producer completed by the same gate is handed to a
-// ticket queue; idle waves pop.  The chain loop is SOFTWARE-PIPELINED: the loads and tickets of the next step are issued
-// as soon as this step's tickets say where the chain goes on, before this step's own tournament and stores.
-// No deadlock: a ticket is only ever taken by a wave for a step that it then runs to the end, so when a gate is claimed
-// every one of its candidates is in a step that is running (or done) on some resident wave; a wave only ever waits for
-// such a record, the graph is acyclic, so every wait ends.
-// Termination: a wave counts as idle from its first empty-handed poll until the moment BEFORE it tries to claim an
-// entry; when the idle count reaches the number of waves that have STARTED, nobody can push any more and the peel is
-// over once every queue is seen empty — co-residency of the whole grid is not required (a wave that starts late finds
-// the seed pool empty and leaves).  Watchdog: lack of GLOBAL progress (a heartbeat the working waves bump) — a long
-// critical path followed by one wave is not an error.
+// yet).  A single-consumer producer needs no ticket at all.  The chain loop is SOFTWARE-PIPELINED: the loads and tickets
+// of the next step are issued as soon as this step's tickets say where the chain goes on, before this step's own
+// tournament and stores.
+// A step is ONE cross-die round trip long: the tickets of the next gate can only be taken when this gate's tickets are
+// back (~1.3 us through the memory-side cache that keeps the eight XCDs coherent — a 20 000-level graph 16 gates wide
+// peels at 1.45 us per level); the ~440 instructions of a step run in the shadow of that round trip.
+// HAND-OFF.  A second producer completed by the same gate goes to one of F first-in-first-out arrays with tickets on
+// BOTH sides: a wave without work takes a consumer ticket c on one of them and watches slot c alone; the pusher takes a
+// producer ticket p (the round trip overlaps its tournament) and stores the entry into slot p — there is no claim step
+// and no search on the receiving side.  F arrays, not one: a fifth of all gates is handed off, and one counter takes
+// agent-scope atomics from eight XCDs at some ten nanoseconds apiece.  An entry is one 128-byte line of sixteen
+// self-validating words (payload | number of the run << 32, so the slots are never cleared): the pushed gate's two gstat
+// records, its first seven consumers and its id — all of it in the pusher's registers anyway (prefetched as static data
+// of the producers of ITS gate) — so the receiver issues the gate's tickets and record loads straight from the entry.
+// A wave is committed to the slot its ticket names; an entry pushed to an array where nobody waits any more would sit
+// there for good, so a waiting wave that sees such a backlog takes a ticket that is ALREADY served (compare-and-swap on
+// the array's pair of counts) and works on that entry; its own ticket stays good until it is served.
+// No deadlock: a ticket on fill[] is only ever taken by a wave for a step that it then runs to the end, so when a gate is
+// claimed every one of its candidates is in a step that is running (or done) on some resident wave; a wave only ever
+// waits for such a record, the graph is acyclic, so every wait ends.
+// Termination: two counters that only grow (kept in 64 parts).  BEGIN counts units of work when they come into being: a
+// wave that starts (one unit until it first runs out of work), and every pushed entry — counted by the pusher, with a
+// returning atomic, BEFORE the entry is visible.  END counts a unit when the wave that worked on it runs out of work.
+// END never passes BEGIN, so "END (read first) == BEGIN (read afterwards)" means they were equal at every moment in
+// between: nothing active, nothing in flight, nobody can push any more.  How entries travel (which array, whose ticket)
+// plays no part in it, and co-residency of the grid is not required: a wave that starts late adds its unit, finds the
+// seed pool empty, ends it, and sees the counters equal.
+// Watchdog: lack of GLOBAL progress (a heartbeat the working waves bump) — a long critical path followed by one wave is
+// not an error.
 #pragma once
 #include "c2a_platform.h"
 
@@ -51,16 +69,20 @@ constexpr u32 kChunkBits = kStrWords * kWordBits;                     // 3843
 constexpr u64 kTagBit = 1ull << 63;
 constexpr u64 kPayload = kTagBit - 1ull;
 
-constexpr u32 kIdleCounters = 64;
-constexpr u32 kQStride = 16;                // u64 words between two queues' head/tail words (one queue per 128-byte line)
 #ifdef C2A_EMULATE
 constexpr u32 kPollLimit = 1;               // steps are atomic there: a missing record is a bug, fail at once
 #else
 constexpr u32 kPollLimit = 1u << 21;        // ~1 s of polling for a record: give up (reported as an error) instead of hanging
 #endif
 constexpr u32 kWatchdogChecks = 1u << 15;   // idle-side checks (one per 32 polls, ~100 us apart) without global progress
-// control block (u32 words; every hot word on its own 64-byte line)
-enum PeelCtl { CTL_PROCESSED = 0, CTL_MAXLEVEL = 1, CTL_ABORT = 2, CTL_REREADS = 3, CTL_HEARTBEAT = 16, CTL_STARTED = 32, CTL_SEEDNEXT = 48, CTL_WORDS = 64 };
+// control block (u32 words; every hot word on its own 128-byte line)
+enum PeelCtl { CTL_PROCESSED = 0, CTL_MAXLEVEL = 1, CTL_ABORT = 2, CTL_REREADS = 3, CTL_HEARTBEAT = 32, CTL_SEEDNEXT = 64,
+               CTL_BEGIN = 128, CTL_END = CTL_BEGIN + 64 * 32, CTL_WORDS = CTL_END + 64 * 32 };
+constexpr u32 kPcStride = 16;               // u64 words between two hand-off arrays' ticket words (128 bytes)
+constexpr u32 kSlotWords = 16;              // a hand-off entry: words 0..7 gstat[2g], gstat[2g + 1]; 8..14 first consumers; 15 gate id
+constexpr u32 kSlotCons = 7;
+constexpr u32 kAcctShards = 64;             // BEGIN / END are kept in this many parts, kAcctStride words (128 bytes) apart
+constexpr u32 kAcctStride = 32;
 
 // what only the edges of the launch touch (kept out of the kernel's scalar registers)
 struct PeelCold {
@@ -68,12 +90,12 @@ struct PeelCold {
     const u32* seed_cnt;       // [n_regions]
     u32 n_regions, region_cap;
     ull* stats;                // optional diagnostics (32 words), nullptr normally
-    ull* q_time;               // with stats: when the push of every queue entry was decided
+    ull* q_time;               // with stats: when the push of every hand-off entry was decided ...
+    ull* p_time;               // ... and when the receiver had it ready to issue
 };
 
 struct PeelArgs {
     u32 epoch;                 // tag (0/1) of this run's node words
-    u32 n_queues, q_cap;
     u32 n;
     const uint4* gstat;        // [2n] {dep0, dep1, cons_off, cons_cnt} {cons_off[dep0], cons_cnt[dep0], cons_off[dep1], cons_cnt[dep1]}
     const u32* clist;          // [edges + 64] consumer | edge label << 31, grouped by producer
@@ -81,11 +103,12 @@ struct PeelArgs {
     u32* fill;                 // [n] claim tickets taken so far (zeroed per run)
     uint4* meta;               // [n] {parent | NONE, depth, root, label | level << 1}: read by later launches only
     u32* child;                // [2n] tree children by label (0xFF-filled per run)
-    u64* q_ht;                 // [n_queues * kQStride] head (low word) | tail (high word)
-    u64* q_items;              // [n_queues][q_cap] (gate + 1) | cons_off << 32; 0 = not written yet
-    u32* idle;                 // [kIdleCounters * 16]
+    u32 n_fifos, q_cap;        // hand-off arrays (a power of two) and slots of each
+    u64* q_pc;                 // [n_fifos * kPcStride] tickets taken: producer side (low word) | consumer side (high word)
+    u64* fifo;                 // [n_fifos][q_cap][kSlotWords] slots (used once per run, no wrap-around: a wave spreads its pushes
+                               // round robin and holds at most one unserved consumer ticket; never cleared: the tag says which run)
+    u32 run;                   // tag of this run's hand-off entries (never zero)
     u32* ctl;                  // [CTL_WORDS]
-    u32* link;                 // [n] wave-private overflow stacks (queue full — never in practice)
     const PeelCold* cold;
     // the sinks pass only
     u32* seeds_w; u32* seed_cnt_w; u32 region_cap;
@@ -93,7 +116,7 @@ struct PeelArgs {
 
 __device__ __forceinline__ u32 chunk_of(u32 depth) { return depth ? (depth - 1) / kChunkBits : 0u; }
 __device__ __forceinline__ u32 chunk_len(u32 depth) { return depth - chunk_of(depth) * kChunkBits; }
-__device__ __forceinline__ u32 ctz64(u64 x) { return (u32)__ffsll((long long)x) - 1u; }
+__device__ __forceinline__ u32 ctz64(u64 x) { return (u32)__builtin_ctzll(x); }      // (callers never pass 0)
 
 __device__ __forceinline__ u64 ld_nw(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_nw(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -127,9 +150,10 @@ __device__ __forceinline__ ull c2a_now() {
 }
 __device__ __forceinline__ void peel_sleep(int units) {
 #ifndef C2A_EMULATE
-    if (units <= 4) __builtin_amdgcn_s_sleep(4); else if (units <= 16) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(64);
+    if (units <= 1) __builtin_amdgcn_s_sleep(1); else if (units <= 4) __builtin_amdgcn_s_sleep(4); else if (units <= 16) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(64);
 #else
     (void)units;
+    hipemu_wave_yield();        // (the emulation interleaves the waves of a workgroup at these points only)
 #endif
 }
 // Where one lane does something and the wave then LEAVES a loop (break / return), the lanes must be seen to meet again
@@ -218,6 +242,21 @@ __device__ __forceinline__ bool str_less_len(u64 wa, u32 lena, u32 la, u64 wb, u
     if (lena == lenb) return la < lb;
     if (lena < lenb) return la < str_bit(wb, lena);
     return str_bit(wa, lenb) < lb;
+}
+// A candidate's record was not (all) there when its load arrived: read it again until it is (a sink's record has header
+// words only).  Gives up after kPollLimit polls: the caller sees the stale tag.
+__device__ __attribute__((noinline)) u64 peel_reread(const u64* node_base, u32 epoch, u32* ctl, u32 c, u64 w, u32 lane) {
+    const u64* p = node_base + (u64)c * kNodeWords + lane;
+    u32 polls = 0;
+    for (;;) {
+        u64 badm = __ballot((u32)(w >> 63) != epoch);
+        if ((u32)rdlane64(w, 0) == 0u) badm &= 7ull;
+        if (badm == 0 || ++polls > kPollLimit) break;
+        peel_sleep(polls < 8 ? 4 : 16);
+        w = ld_nw(p);
+    }
+    if (polls && lane == 0) atomicAdd(&ctl[CTL_REREADS], polls);
+    return w;
 }
 // Trees deeper than one chunk: bring the two nodes to the first chunk in which their paths can differ (cprev hops),
 // then compare that chunk.  wa_in / wb_in: the two nodes' own records (already in registers).
@@ -325,12 +364,10 @@ __global__ void __launch_bounds__(256) k_peel_sinks(PeelArgs A) {
 // copy of a value still in flight is a use, and its wait would drain the step that was just issued)
 struct StepIO {
     u32 kfill;                 // lane l < 2: ticket taken on producer l
-    uint4 ga, gb;              // lane l < 2: the two gstat records of producer l
+    u32 gw;                    // lane 8 l + j (l < 2, j < 8): word j of the two gstat records of producer l
     u32 clp;                   // lanes 0..31: producer 0's consumers, 32..63: producer 1's
-    u32 cl;                    // this gate's consumers (its first block), one per lane from lane cbase on
-    u32 cbase, ccap;           // first lane / lanes of that block
-    u64 rest;                  // lanes of cl whose records are not loaded yet
     u32 e0, e1, take;          // consumer | label << 31 of the (up to two) records in flight
+    u32 more;                  // the consumer list holds candidates beyond those (the step reads the list itself: cold)
     u64 w0, w1;                // this lane's word of those records
 };
 
@@ -339,189 +376,177 @@ template <bool STATS>
 __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
     PeelArgs A = A_in;
     A.gstat = own_sgprs(A_in.gstat); A.clist = own_sgprs(A_in.clist); A.node = own_sgprs(A_in.node); A.fill = own_sgprs(A_in.fill);
-    A.meta = own_sgprs(A_in.meta); A.child = own_sgprs(A_in.child); A.q_ht = own_sgprs(A_in.q_ht); A.q_items = own_sgprs(A_in.q_items);
-    A.idle = own_sgprs(A_in.idle); A.ctl = own_sgprs(A_in.ctl); A.link = own_sgprs(A_in.link); A.cold = own_sgprs(A_in.cold);
-    A.epoch = own_sgpr(A_in.epoch); A.n_queues = own_sgpr(A_in.n_queues); A.q_cap = own_sgpr(A_in.q_cap);
+    A.meta = own_sgprs(A_in.meta); A.child = own_sgprs(A_in.child); A.fifo = own_sgprs(A_in.fifo); A.q_pc = own_sgprs(A_in.q_pc);
+    A.ctl = own_sgprs(A_in.ctl); A.cold = own_sgprs(A_in.cold);
+    A.epoch = own_sgpr(A_in.epoch); A.n_fifos = own_sgpr(A_in.n_fifos); A.q_cap = own_sgpr(A_in.q_cap); A.run = own_sgpr(A_in.run);
     const u32 lane = threadIdx.x;
     const u32 me = blockIdx.x;
+    // this wave is one unit of work from now until it first runs out of work; BEGIN counts it before it moves
+    {
+        u32 r = 0;
+        if (lane == 0) r = atomicAdd(&A.ctl[CTL_BEGIN + (me & (kAcctShards - 1u)) * kAcctStride], 1u);
+        C2A_PIN(r);
+    }
     const u32 epoch = A.epoch;
     const u64 tag = epoch ? kTagBit : 0ull;
-    u32* head_w = reinterpret_cast<u32*>(A.q_ht);            // head of queue q = word 2 q kQStride, tail = the next word
-    const u32 home_q = me % A.n_queues;
-    u32 push_rr = me;                        // round-robin cursor of this wave's pushes
-    u32 roam = me * 0x9E3779B1u;             // pseudo-random walk over the other queues
-    bool registered = false;                 // counted in idle[]
     bool seeds_left = true;
     u32 region = 0, idx = 0, region_cnt = 0;
-    u32 head = C2A_NONE;                     // wave-private stack (overflow of the hand-off queues)
+    u32 push_rr = me, pop_rr = me * 7u;      // round-robin cursors over the hand-off arrays
+    u32 held = 0;                            // this wave holds a consumer ticket that has not been served yet ...
+    u64 held_slot = 0;                       // ... for this slot
     u32 processed = 0, max_level = 0, iters = 0;
-    u32 st_pops = 0, st_polls = 0, st_push = 0, st_seeds = 0, st_rpolls = 0;
+    u32 st_pops = 0, st_polls = 0, st_push = 0, st_seeds = 0;
     ull st_busy = 0, st_idle = 0, st_t0 = STATS ? c2a_now() : 0;
-    ull ph_w1 = 0, ph_w2 = 0, ph_w3 = 0, ho_sum = 0, ho_cnt = 0, ho_hist[5] = {0, 0, 0, 0, 0};
+    ull ph_w1 = 0, ph_w2 = 0, ph_w3 = 0;
     ull ph_a = 0, ph_b = 0, ph_c = 0, ph_d = 0, ph_steps = 0, ph_noload = 0, ph_start = 0;      // STATS: phase times of the chain step
-    if (lane == 0) atomicAdd(&A.ctl[CTL_STARTED], 1u); wave_join();
     for (;;) {
-        // ---- next piece of work: own stack, the seed pool, then the hand-off queues
+        // ---- next piece of work: the seed pool, then the hand-off slots
         u32 g = C2A_NONE;
-        u32 coff = C2A_NONE;                 // cons_off of g when the entry carried it
-        ull pop_when = 0;                    // STATS: push time of the popped entry
-        if (head != C2A_NONE) {
-            g = head;
-            head = uniform(ld_a32(&A.link[g]));
+        uint4 gi, gi2;
+        u32 cl0 = 0, cl0_base = 0, cl0_cap = 64;       // g's consumers: one per lane from lane cl0_base on, cl0_cap lanes
+        ull pop_slot = ~0ull;                // STATS: slot of the popped entry
+        if (seeds_left) {
+            // (pointers read from memory are generic pointers, and a load through one counts as divergent: every value
+            // read through A.cold is declared wave-uniform by hand)
+            const PeelCold* C = A.cold;
+            while (idx >= region_cnt) {
+                u32 r = 0;
+                if (lane == 0) r = atomicAdd(&A.ctl[CTL_SEEDNEXT], 1u); wave_join();
+                r = rdlane(r, 0);
+                if (r >= uniform(C->n_regions)) { seeds_left = false; break; }
+                region = r; idx = 0; region_cnt = uniform(C->seed_cnt[r]);
+            }
+            if (seeds_left) { g = uniform(C->seeds[(u64)region * uniform(C->region_cap) + idx]); ++idx; if (STATS) ++st_seeds; }
+        }
+        const ull ph_s0 = STATS ? c2a_now() : 0;
+        if (g != C2A_NONE) {
+            // static data of a seed (a chain step gets all of this prefetched by the step before; a popped gate brings it
+            // along); consumed HERE, in scalar registers where wave-uniform: a load still pending at the loop header would
+            // cost every chain step a wait
+            gi = uniform4(A.gstat[2 * (u64)g]);
+            gi2 = uniform4(A.gstat[2 * (u64)g + 1]);
+            cl0 = A.clist[gi.z + lane];                                      // clist is padded by 64 entries
+            C2A_PIN(cl0);
         } else {
-            if (seeds_left) {
-                // (pointers read from memory are generic pointers, and a load through one counts as divergent: every value
-                // read through A.cold is declared wave-uniform by hand)
-                const PeelCold* C = A.cold;
-                while (idx >= region_cnt) {
-                    u32 r = 0;
-                    if (lane == 0) r = atomicAdd(&A.ctl[CTL_SEEDNEXT], 1u); wave_join();
-                    r = rdlane(r, 0);
-                    if (r >= uniform(C->n_regions)) { seeds_left = false; break; }
-                    region = r; idx = 0; region_cnt = uniform(C->seed_cnt[r]);
-                }
-                if (seeds_left) { g = uniform(C->seeds[(u64)region * uniform(C->region_cap) + idx]); ++idx; if (STATS) ++st_seeds; }
+            if (STATS) { const ull t = c2a_now(); st_busy += t - st_t0; st_t0 = t; }
+            // ---- this unit of work is over: END counts it (every entry this wave pushed meanwhile is in BEGIN already:
+            // those were returning atomics, waited for)
+            if (lane == 0) atomicAdd(&A.ctl[CTL_END + (me & (kAcctShards - 1u)) * kAcctStride], 1u); wave_join();
+            // ---- a consumer ticket — kept until it is served, whatever else this wave does meanwhile — and the slot it names
+            if (!held) {
+                const u32 f = (pop_rr++) & (A.n_fifos - 1u);
+                u64 pc = 0;
+                if (lane == 0) pc = atomicAdd(reinterpret_cast<ull*>(&A.q_pc[(u64)f * kPcStride]), 1ull << 32); wave_join();
+                held_slot = (u64)f * A.q_cap + rdlane((u32)(pc >> 32), 0);
+                held = 1;
             }
-            if (g == C2A_NONE) {
-                if (STATS) { const ull t = c2a_now(); st_busy += t - st_t0; st_t0 = t; }
-                // poll: home queue, then a roaming one
-                u32 polls = 0, hint = C2A_NONE, hb_seen = 0, hb_checks = 0;
-                for (;;) {
-                    u32 q = (polls & 1u) ? (roam = roam * 1664525u + 1013904223u, (roam >> 8) % A.n_queues) : home_q;
-#ifdef C2A_EMULATE
-                    q = (home_q + polls) % A.n_queues;           // deterministic sweep
-#endif
-                    if (hint != C2A_NONE) { q = hint; hint = C2A_NONE; }
-                    u64 ht = 0;
-                    if (lane == 0) ht = ld_nw(&A.q_ht[(u64)q * kQStride]); wave_join();
-                    ht = rdlane64(ht, 0);
-                    const u32 qh = (u32)ht, qt_raw = (u32)(ht >> 32);
-                    const u32 qt = qt_raw < A.q_cap ? qt_raw : A.q_cap;
-                    if (qh < qt) {
-                        if (registered) { if (lane == 0) atomicAdd(&A.idle[(me % kIdleCounters) * 16], 0xFFFFFFFFu); wave_join(); registered = false; }
-                        // claim the head entry and read it in the same round trip (lane 1 reads what lane 0 claims)
-                        u32 old = 0;
-                        u64 v = 0;
-                        if (lane == 0) old = atomicCAS(&head_w[2 * (u64)q * kQStride], qh, qh + 1); wave_join();
-                        if (lane == 1) v = ld_nw(&A.q_items[(u64)q * A.q_cap + qh]); wave_join();
-                        old = rdlane(old, 0);
-                        v = rdlane64(v, 1);
-                        if (old == qh) {
-                            u32 spins = 0;
-                            while (v == 0 && ++spins < (1u << 22)) {
-                                if (lane == 0) v = ld_nw(&A.q_items[(u64)q * A.q_cap + qh]); wave_join();
-                                v = rdlane64(v, 0);
-                            }
-                            if (v) {
-                                g = (u32)v - 1u;
-                                coff = (u32)(v >> 32);
-                                if (STATS) pop_when = ld_word_time(A.cold->q_time + (u64)q * A.q_cap + qh);
-                                if (STATS) ++st_pops;
-                            } else { if (lane == 0) atomicAdd(&A.ctl[CTL_ABORT], 1u); wave_join(); }
-                            break;
-                        }
-                        hint = q;                                    // lost the race: look at the same queue again at once
-                        continue;
-                    }
-                    if (!registered) { if (lane == 0) atomicAdd(&A.idle[(me % kIdleCounters) * 16], 1u); wave_join(); registered = true; }
-                    ++polls;
-                    if ((polls & 31u) == 0) {
-                        u32 cnt = lane < kIdleCounters ? ld_a32(&A.idle[lane * 16]) : 0u;
+            u64 slot_i = held_slot;          // the slot this wave watches: its own, or (see below) one that is served already
+            u32 polls = 0, hb_seen = 0, hb_checks = 0;
+            u64 v = 0;
+            bool got = false;
+            for (;;) {
+                v = ld_nw(A.fifo + slot_i * kSlotWords + (lane & (kSlotWords - 1u)));
+                if (((u32)__ballot((u32)(v >> 32) == A.run) & 0xFFFFu) == 0xFFFFu) { got = true; break; }
+                ++polls;
+                if ((polls & 31u) == 0) {
+                    // every END, then every BEGIN (and the abort flag and the heartbeat): each read waits for the one before
+                    u32 n_end = lane < kAcctShards ? ld_a32(&A.ctl[CTL_END + lane * kAcctStride]) : 0u;
 #pragma unroll
-                        for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-                        cnt = uniform(cnt);          // (a shuffle result counts as divergent: the branches below must not)
-                        // the number of started waves is read AFTER the idle counters (a wave registers as started first)
-                        u32 c3 = 0;
-                        if (cnt != 0xFFFFFFFFu && lane < 3) c3 = ld_a32(&A.ctl[lane == 0 ? CTL_STARTED : (lane == 1 ? CTL_ABORT : CTL_HEARTBEAT)]);
-                        const u32 started = rdlane(c3, 0), aborted = rdlane(c3, 1), hb = rdlane(c3, 2);
-                        if (aborted) break;
-                        if (cnt >= started) {
-                            // every started wave is idle or gone, so nobody pushes any more: finished unless an entry is still queued
-                            u32 found = C2A_NONE;
-                            for (u32 qq = lane; qq < A.n_queues; qq += 64) {
-                                const u64 x = ld_nw(&A.q_ht[(u64)qq * kQStride]);
-                                const u32 xt = (u32)(x >> 32) < A.q_cap ? (u32)(x >> 32) : A.q_cap;
-                                if ((u32)x < xt) found = qq;
-                            }
-                            const u64 fm = __ballot(found != C2A_NONE);
-                            if (fm == 0) break;
-                            hint = rdlane(found, ctz64(fm));
-                            continue;
+                    for (int off = 32; off >= 1; off >>= 1) n_end += __shfl_xor(n_end, off, 64);
+                    n_end = uniform(n_end);          // (a shuffle result counts as divergent: the branches below must not)
+                    u32 n_begin = lane < kAcctShards ? ld_a32(&A.ctl[CTL_BEGIN + lane * kAcctStride]) : 0u;
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) n_begin += __shfl_xor(n_begin, off, 64);
+                    n_begin = uniform(n_begin);
+                    u32 c3 = 0;
+                    if (lane < 2) c3 = ld_a32(&A.ctl[lane == 0 ? CTL_ABORT : CTL_HEARTBEAT]); wave_join();
+                    const u32 aborted = rdlane(c3, 0), hb = rdlane(c3, 1);
+                    if (aborted || n_end == n_begin) break;          // nothing active, nothing in flight: the peel is over
+                    if (hb != hb_seen) { hb_seen = hb; hb_checks = 0; }
+                    else if (++hb_checks > kWatchdogChecks) { if (lane == 0) atomicAdd(&A.ctl[CTL_ABORT], 1u); wave_join(); break; }
+                    // An entry in an array where nobody waits (every wave is committed to a slot elsewhere) would sit there
+                    // for good: a wave that sees such a backlog takes a ticket that is served ALREADY (compare-and-swap on
+                    // the pair of counts) and works on that entry; its own ticket stays good for later
+                    if (slot_i == held_slot) {
+                        const u64 pcw = lane < A.n_fifos ? ld_nw(&A.q_pc[(u64)lane * kPcStride]) : 0ull;
+                        const u64 bm = __ballot((u32)pcw > (u32)(pcw >> 32));
+                        if (bm) {
+                            const u32 r = me & 63u;
+                            const u64 from_r = bm & (~0ull << r);
+                            const u32 j = ctz64(from_r ? from_r : bm);
+                            const u64 expect = rdlane64(pcw, j);
+                            u64 seen = 0;
+                            if (lane == 0) seen = atomicCAS(reinterpret_cast<ull*>(&A.q_pc[(u64)j * kPcStride]), (ull)expect, (ull)(expect + (1ull << 32))); wave_join();
+                            if (rdlane64(seen, 0) == expect) slot_i = (u64)j * A.q_cap + (u32)(expect >> 32);
                         }
-                        if (hb != hb_seen) { hb_seen = hb; hb_checks = 0; }
-                        else if (++hb_checks > kWatchdogChecks) { if (lane == 0) atomicAdd(&A.ctl[CTL_ABORT], 1u); wave_join(); break; }
                     }
-                    // back off: the longer nothing turns up, the less often this wave asks (64 clocks per unit, <= ~3 us)
-                    peel_sleep(polls < 16 ? 4 : 16);
                 }
-                if (STATS) st_polls += polls;
-                if (STATS) { const ull t = c2a_now(); st_idle += t - st_t0; st_t0 = t; }
-                if (g == C2A_NONE) break;
+                // back off: the longer nothing turns up, the less often this wave asks (64 clocks per unit)
+                peel_sleep(polls < 64 ? 4 : 16);
             }
+            if (STATS) st_polls += polls;
+            if (STATS) { const ull tt = c2a_now(); st_idle += tt - st_t0; st_t0 = tt; }
+            if (!got) break;
+            if (slot_i == held_slot) held = 0;
+            if (STATS) { pop_slot = slot_i; ++st_pops; }
+            const u32 pv = (u32)v;
+            gi = make_uint4(rdlane(pv, 0), rdlane(pv, 1), rdlane(pv, 2), rdlane(pv, 3));
+            gi2 = make_uint4(rdlane(pv, 4), rdlane(pv, 5), rdlane(pv, 6), rdlane(pv, 7));
+            g = rdlane(pv, 15);
+            // its consumers came along (lanes 8..14) unless it has more than seven: then none is taken from the entry and
+            // the cold loop of the step reads the list itself
+            cl0 = pv; cl0_base = 8; cl0_cap = kSlotCons;
         }
         // (wave-uniform by construction — say so: one value the compiler takes for divergent here, and every value of the
         // chain loop that depends on the gate id moves to vector registers and is handled as divergent code)
-        g = uniform(g); coff = uniform(coff);
-        const ull ph_s0 = STATS ? c2a_now() : 0;
-        // ---- static data of g (a chain step gets all of this prefetched by the step before); consumed HERE, in scalar
-        // registers where wave-uniform: a load still pending at the loop header would cost every chain step a wait
-        uint4 gi = uniform4(A.gstat[2 * (u64)g]);
-        uint4 gi2 = uniform4(A.gstat[2 * (u64)g + 1]);
-        if (coff == C2A_NONE) coff = gi.z;
-        u32 cl0 = A.clist[coff + lane];                                  // clist is padded by 64 entries
-        C2A_PIN(cl0);
+        g = uniform(g);
         if (STATS) {
             const ull tn = c2a_now();
             ph_start += tn - ph_s0;
-            if (pop_when) { const ull dt = tn - pop_when; ho_sum += dt; ++ho_cnt; ho_hist[dt < 200 ? 0 : dt < 400 ? 1 : dt < 800 ? 2 : dt < 1600 ? 3 : 4] += 1; }
+            if (pop_slot != ~0ull && lane == 0) A.cold->p_time[pop_slot] = tn;
         }
 
-        // issue everything the step of a gate needs from memory
+        // issue everything the step of a gate needs from memory.  scl: the gate's consumer list, one entry per lane from
+        // lane cbase on, when it fits ccap lanes (else nothing is loaded ahead and the step reads the list itself)
         auto issue = [&](StepIO& S, u32 dep0, u32 dep1, u32 n_cons, u32 off0, u32 cnt0, u32 off1, u32 cnt1, u32 scl, u32 cbase, u32 ccap,
                          bool have_own, u32 own_id) {
             const u32 dl = lane == 0 ? dep0 : (lane == 1 ? dep1 : C2A_NONE);
             const u32 dcnt = lane == 0 ? cnt0 : (lane == 1 ? cnt1 : 0u);
             S.kfill = 0;
             if (dl != C2A_NONE && dcnt > 1u) S.kfill = atomicAdd(&A.fill[dl], 1u);
-            // static data of both producers, BRANCH-FREE (clamped index, result discarded by lanes with nothing to load)
-            const u32 dl_c = dl != C2A_NONE ? dl : 0u;
-            S.ga = A.gstat[2 * (u64)dl_c];
-            S.gb = A.gstat[2 * (u64)dl_c + 1];
+            // static data of both producers, one word per lane, BRANCH-FREE (clamped index, result discarded where there
+            // is nothing to load)
+            {
+                const u32 dw = (lane & 8u) ? dep1 : dep0;
+                S.gw = reinterpret_cast<const u32*>(A.gstat)[8 * (u64)(dw != C2A_NONE ? dw : 0u) + (lane & 7u)];
+            }
             {
                 const u32 half = lane >> 5, i = lane & 31u;
                 const u32 poff = half ? off1 : off0, pcnt = half ? cnt1 : cnt0;
                 S.clp = A.clist[poff + (i < pcnt ? i : 0u)];
             }
-            const u32 n_here = n_cons < ccap ? n_cons : ccap;
-            S.cl = scl; S.cbase = cbase; S.ccap = ccap;
-            u64 smask = __ballot(lane - cbase < n_here && !(have_own && (scl & kIdMask) == own_id));
+            // the records of the first two consumers that are not the gate in hand (slots that are not loaded stay
+            // UNDEFINED on purpose: merging a loaded value with a constant is a register copy, a copy is a use, and its wait
+            // would land right behind the load)
+            const bool in_lanes = n_cons <= ccap;
+            u64 smask = __ballot(in_lanes && lane - cbase < n_cons && !(have_own && (scl & kIdMask) == own_id));
             S.take = 0; S.e0 = 0; S.e1 = 0;
             if (smask) {
                 S.e0 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 1;
-                if (smask) { S.e1 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 2; }
+                S.w0 = ld_nw(&A.node[(u64)(S.e0 & kIdMask) * kNodeWords + lane]);
+                if (smask) {
+                    S.e1 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 2;
+                    S.w1 = ld_nw(&A.node[(u64)(S.e1 & kIdMask) * kNodeWords + lane]);
+                }
             }
-            S.rest = smask;
-            // the records (slots that are not loaded stay UNDEFINED on purpose: merging a loaded value with a constant is
-            // a register copy, a copy is a use, and its wait would land right behind the load)
-            if (S.take >= 1) S.w0 = ld_nw(&A.node[(u64)(S.e0 & kIdMask) * kNodeWords + lane]);
-            if (S.take >= 2) S.w1 = ld_nw(&A.node[(u64)(S.e1 & kIdMask) * kNodeWords + lane]);
+            S.more = (!in_lanes || smask != 0) ? 1u : 0u;
         };
         StepIO S0, S1;
-        issue(S0, gi.x, gi.y, gi.w, gi2.x, gi2.y, gi2.z, gi2.w, cl0, 0u, 64u, false, 0u);
+        issue(S0, gi.x, gi.y, gi.w, gi2.x, gi2.y, gi2.z, gi2.w, cl0, cl0_base, cl0_cap, false, 0u);
         // the gate just finished stays in registers as a candidate of the next one
-        bool own_valid = false;
+        u32 own_valid = 0;
         u32 own_node = 0, own_label = 0, own_depth = 0, own_root = 0, own_level = 0, own_pos = 0;
         u64 own_w = 0, own_x = 0;            // its record, and its string with own_label appended
-        // a second claimed producer's queue ticket is taken at the top of a step and its entry written one step later
-        // (the ticket is back by then: nothing in between may wait for memory)
-        bool push_pending = false;
-        u32 push_q = 0, push_t = 0, push_gate = 0, push_off = 0;
-        ull push_when = 0;                   // STATS: when the pending push was decided
-        auto write_entry = [&](u32 q, u32 t, u32 gate, u32 off) {
-            if (STATS && t < A.q_cap && lane == 0) A.cold->q_time[(u64)q * A.q_cap + t] = push_when;
-            if (t < A.q_cap) { if (lane == 0) st_nw(&A.q_items[(u64)q * A.q_cap + t], (u64)(gate + 1u) | ((u64)off << 32)); wave_join(); }
-            else { if (lane == 0) st_a32(&A.link[gate], head); wave_join(); head = gate; }      // queue full: cannot happen with the host's q_cap
-        };
 
         // one step: `cur` is in hand (issued one step ago), `nx` receives the next one.  true = the chain ends (or abort)
         auto step = [&](StepIO& cur, StepIO& nx) -> bool {
@@ -530,43 +555,40 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             // the compiler still counts as in flight further down would put its wait behind the issue of the next step
             C2A_PIN(cur.kfill);
             const ull ph0a = STATS ? c2a_now() : 0;
-            C2A_PIN(cur.ga.x); C2A_PIN(cur.ga.y); C2A_PIN(cur.ga.z); C2A_PIN(cur.ga.w);
-            C2A_PIN(cur.gb.x); C2A_PIN(cur.gb.y); C2A_PIN(cur.gb.z); C2A_PIN(cur.gb.w);
+            C2A_PIN(cur.gw);
             C2A_PIN(cur.clp);
             const ull ph0b = STATS ? c2a_now() : 0;
             C2A_PIN(cur.w0); C2A_PIN(cur.w1);
             if (STATS) { const ull ph0c = c2a_now(); ph_w1 += ph0a - ph0; ph_w2 += ph0b - ph0a; ph_w3 += ph0c - ph0b; }
-            const bool old_pending = push_pending;
-            const u32 old_q = push_q, old_t = old_pending ? rdlane(push_t, 0) : 0u, old_gate = push_gate, old_off = push_off;
-            push_pending = false;
             const u32 g_dep0 = gi.x, g_dep1 = gi.y, g_off = gi.z, g_cnt = gi.w, g_dcnt0 = gi2.y, g_dcnt1 = gi2.w;
             const u32 dl = lane == 0 ? g_dep0 : (lane == 1 ? g_dep1 : C2A_NONE);
             const u32 dcnt = lane == 0 ? g_dcnt0 : (lane == 1 ? g_dcnt1 : 0u);
             const bool last = dl != C2A_NONE && (dcnt == 1u || cur.kfill + 1u == dcnt);
             const u32 rmask = (u32)__ballot(last) & 3u;
             const ull ph1 = STATS ? c2a_now() : 0;
-            // ---- go on with the first claimed producer: issue its step now; a second one goes to whoever is idle
+            // ---- go on with the first claimed producer: issue its step now; a second one goes to whoever has no work: its
+            // producer ticket is taken here and its entry stored after the tournament (the ticket is back by then)
             u32 nxt = C2A_NONE, nxt_label = 0;
             uint4 ngi = make_uint4(0, 0, 0, 0), ngi2 = make_uint4(0, 0, 0, 0);
+            u32 push_t = 0, push_f = 0;
             if (rmask) {
                 const u32 j0 = (rmask & 1u) ? 0u : 1u;
                 nxt = j0 ? g_dep1 : g_dep0; nxt_label = j0;
-                ngi = make_uint4(rdlane(cur.ga.x, j0), rdlane(cur.ga.y, j0), rdlane(cur.ga.z, j0), rdlane(cur.ga.w, j0));
-                ngi2 = make_uint4(rdlane(cur.gb.x, j0), rdlane(cur.gb.y, j0), rdlane(cur.gb.z, j0), rdlane(cur.gb.w, j0));
+                const u32 jb = 8u * j0;
+                ngi = make_uint4(rdlane(cur.gw, jb), rdlane(cur.gw, jb + 1), rdlane(cur.gw, jb + 2), rdlane(cur.gw, jb + 3));
+                ngi2 = make_uint4(rdlane(cur.gw, jb + 4), rdlane(cur.gw, jb + 5), rdlane(cur.gw, jb + 6), rdlane(cur.gw, jb + 7));
                 if (rmask == 3u) {
-                    push_pending = true;
-                    if (STATS) push_when = ph0;
-                    push_gate = g_dep1; push_off = rdlane(cur.ga.z, 1);
-                    push_q = (push_rr++) % A.n_queues;
                     if (STATS) ++st_push;
-                    push_t = 0;
-                    if (lane == 0) push_t = atomicAdd(&head_w[2 * (u64)push_q * kQStride + 1], 1u); wave_join();
+                    // one of the hand-off arrays: the ticket now, the entry after the tournament; BEGIN counts the entry
+                    // before anybody can see it
+                    push_f = (push_rr++) & (A.n_fifos - 1u);
+                    if (lane == 0) push_t = (u32)atomicAdd(reinterpret_cast<ull*>(&A.q_pc[(u64)push_f * kPcStride]), 1ull);
+                    if (lane == 1) push_t = atomicAdd(&A.ctl[CTL_BEGIN + (me & (kAcctShards - 1u)) * kAcctStride], 1u);
+                    wave_join();
                 }
                 // the consumers of nxt are already here (lanes 32 j0 ... of the prefetched lists) unless it has more than 32
-                // of them: then none is loaded ahead and the cold loop below reads the list itself
-                issue(nx, ngi.x, ngi.y, ngi.w, ngi2.x, ngi2.y, ngi2.z, ngi2.w, cur.clp, 32u * j0, ngi.w <= 32u ? 32u : 0u, true, g);
+                issue(nx, ngi.x, ngi.y, ngi.w, ngi2.x, ngi2.y, ngi2.z, ngi2.w, cur.clp, 32u * j0, 32u, true, g);
             }
-            if (old_pending) write_entry(old_q, old_t, old_gate, old_off);
             const ull ph2 = STATS ? c2a_now() : 0;
             // ---- tournament of THIS gate.  Champion so far (wave-uniform); NONE = the virtual-root candidate [g]
             u32 ch = C2A_NONE, ch_el = 0, ch_root = g, ch_depth = 0, ch_pos = 0, level = 0;
@@ -575,23 +597,18 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                 level = own_level + 1;
                 if (own_root < g) { ch = own_node; ch_el = own_label; ch_root = own_root; ch_depth = own_depth; ch_pos = own_pos; ch_w = own_w; ch_x = own_x; }
             }
-            bool gave_up = false;
-            // one candidate: its record must be all there (else read it again: cold), then it meets the champion
+            u32 gave_up = 0;
+            // one candidate: its record must be all there (else read it again: out of line), then it meets the champion
             auto candidate = [&](u64 w, u32 e) {
                 const u32 c = e & kIdMask, el = e >> 31;
+                // (a sink's record has header words only: its string is empty whatever its string words hold)
                 u64 badm = __ballot((u32)(w >> 63) != epoch);
+                if ((u32)rdlane64(w, 0) == 0u) badm &= 7ull;
                 if (badm) {
-                    // a sink's record has header words only; anything else is still being written
-                    u32 polls = 0;
-                    for (;;) {
-                        if ((badm & 7ull) == 0 && (u32)rdlane64(w, 0) == 0u) { if (lane >= kHdrWords) w = tag; break; }
-                        if (++polls > kPollLimit) { gave_up = true; return; }
-                        peel_sleep(polls < 8 ? 4 : 16);
-                        w = ld_nw(&A.node[(u64)c * kNodeWords + lane]);
-                        badm = __ballot((u32)(w >> 63) != epoch);
-                        if (!badm) break;
-                    }
-                    st_rpolls += polls;
+                    w = peel_reread(A.node, epoch, A.ctl, c, w, lane);
+                    badm = __ballot((u32)(w >> 63) != epoch);
+                    if ((u32)rdlane64(w, 0) == 0u) badm &= 7ull;
+                    if (badm) { gave_up = 1; return; }
                 }
                 const u64 h0 = rdlane64(w, 0);
                 const u32 croot = hdr_hi(h0), cdepth = (u32)h0;
@@ -599,56 +616,60 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                 const u32 cpos = rdlane((u32)w, 2);
                 level = clevel > level ? clevel : level;
                 // the candidate's string with its edge label appended (meaningful while the chunk has room: cpos < kStrWords << 8)
-                u64 x = w & kPayload;
+                u64 x = cdepth ? (w & kPayload) : 0ull;
                 if (lane == kHdrWords + (cpos >> 8)) x |= (u64)el << (cpos & 255u);
-                bool less;
-                if (croot != ch_root) less = croot < ch_root;              // a larger DFS root loses at once (also to [g] itself)
-                else if (ch == C2A_NONE) less = false;                     // (root == g: impossible in a DAG)
-                else if (c == ch) less = el < ch_el;
-                else if (cdepth < kChunkBits && ch_depth < kChunkBits) {
-                    // neither path is a prefix of the other (that would be a cycle): the first differing bit decides
+                u32 less;                     // (0 / 1 in a scalar register: a bool merged over branches becomes a lane mask)
+                if (croot != ch_root) {
+                    less = croot < ch_root ? 1u : 0u;                                // a larger DFS root loses at once (also to [g] itself)
+                } else if ((cdepth > ch_depth ? cdepth : ch_depth) < kChunkBits) {
+                    // neither path is a prefix of the other (that would be a cycle), and the same node with the other label
+                    // differs in the appended bit: the first differing bit decides
                     const u64 d = x ^ ch_x;
                     const u64 bal = __ballot(d != 0) & ~7ull;
                     const u32 L = ctz64(bal);
-                    less = ((rdlane64(x, L) >> ctz64(rdlane64(d, L))) & 1ull) == 0;
+                    less = (u32)(~(rdlane64(x, L) >> ctz64(rdlane64(d, L)))) & 1u;
+                } else if (c == ch) {
+                    less = el < ch_el ? 1u : 0u;
                 } else {
                     // (the result of an out-of-line call counts as divergent; left like that, every value that depends on the
                     // champion would move to vector registers and the whole tournament would be compiled as divergent code)
-                    less = uniform(deep_less(A.node, epoch, A.ctl, c, el, cdepth, w, ch, ch_el, ch_depth, ch_w, lane) ? 1u : 0u) != 0u;
+                    less = uniform(deep_less(A.node, epoch, A.ctl, c, el, cdepth, w, ch, ch_el, ch_depth, ch_w, lane) ? 1u : 0u);
                 }
                 if (less) { ch = c; ch_el = el; ch_root = croot; ch_depth = cdepth; ch_pos = cpos; ch_w = w; ch_x = x; }
             };
-            // the (up to two) records loaded ahead, then — cold — whatever else the consumer list holds, one at a time:
-            // more than two other consumers (cur.rest), or a list that was not prefetched (cur.ccap < 64: blocks from eb on)
-            {
-                u32 k = 0, blk = cur.cl, eb = cur.ccap == 64u ? 64u : 0u;
-                u64 smask = cur.rest;
-                const bool more_blocks = g_cnt > cur.ccap;
-                for (;;) {
-                    u64 w;
-                    u32 e;
-                    if (k < cur.take) {
-                        w = k ? cur.w1 : cur.w0; e = k ? cur.e1 : cur.e0;
-                    } else {
-                        if (smask == 0) {
-                            if (!more_blocks || eb >= g_cnt) break;
-                            blk = A.clist[g_off + eb + lane];
-                            C2A_PIN(blk);                        // (consumed here, like w below)
-                            smask = __ballot(eb + lane < g_cnt && !(own_valid && (blk & kIdMask) == own_node));
-                            eb += 64;
-                            if (smask == 0) continue;
-                        }
-                        e = rdlane(blk, ctz64(smask));
+            // the (up to two) records loaded ahead ...
+            if (cur.take >= 1) {
+                candidate(cur.w0, cur.e0);
+                if (cur.take >= 2) candidate(cur.w1, cur.e1);
+            }
+            // ... then — cold — the consumer list itself, one record at a time, when it holds more than that
+            if (cur.more && !gave_up) {
+                for (u32 eb = 0; eb < g_cnt && !gave_up; eb += 64) {
+                    u32 blk = A.clist[g_off + eb + lane];
+                    C2A_PIN(blk);                                // (consumed here, like w below)
+                    u64 smask = __ballot(eb + lane < g_cnt && !(own_valid && (blk & kIdMask) == own_node) &&
+                                         !(cur.take >= 1 && blk == cur.e0) && !(cur.take >= 2 && blk == cur.e1));
+                    while (smask && !gave_up) {
+                        const u32 e = rdlane(blk, ctz64(smask));
                         smask &= smask - 1;
-                        w = ld_nw(&A.node[(u64)(e & kIdMask) * kNodeWords + lane]);
+                        u64 w = ld_nw(&A.node[(u64)(e & kIdMask) * kNodeWords + lane]);
                         C2A_PIN(w);                              // (consumed here: pending at the join it would cost the hot path a wait)
+                        candidate(w, e);
                     }
-                    candidate(w, e);
-                    if (gave_up) break;
-                    ++k;
                 }
             }
             if (gave_up) { if (lane == 0) atomicAdd(&A.ctl[CTL_ABORT], 1u); wave_join(); return true; }      // a record never arrived: fail loudly
+            if (rmask == 3u) {
+                // the entry: lanes 8..15 hold the pushed gate's static records, lanes 32..38 its first consumers
+                C2A_PIN(push_t);                                    // (both atomics are back)
+                const u64 t = (u64)push_f * A.q_cap + rdlane(push_t, 0);
+                u64* slot = A.fifo + t * kSlotWords;
+                const u64 rt = (u64)A.run << 32;
+                if (STATS && lane == 0) A.cold->q_time[t] = ph0;
+                if (lane >= 8 && lane < 16) st_nw(slot + (lane - 8), rt | cur.gw);
+                if (lane >= 32 && lane < 40) st_nw(slot + (lane - 24), rt | (lane == 39 ? g_dep1 : cur.clp));
+                wave_join();
+            }
             const ull ph3 = STATS ? c2a_now() : 0;
             // ---- the node: its string is the champion's string with the label appended — the register built above
             u32 depth = 0, my_label = 0, cprev = C2A_NONE, my_pos = 0;
@@ -689,7 +710,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             }
             if (nxt == C2A_NONE) return true;                       // the chain ends here
             // what the next step reuses: this gate as a candidate of nxt
-            own_valid = true; own_node = g; own_label = nxt_label; own_depth = depth; own_root = ch_root; own_level = level; own_pos = my_pos; own_w = my_w;
+            own_valid = 1; own_node = g; own_label = nxt_label; own_depth = depth; own_root = ch_root; own_level = level; own_pos = my_pos; own_w = my_w;
             own_x = str;
             if (lane == kHdrWords + (my_pos >> 8)) own_x |= (u64)nxt_label << (my_pos & 255u);
             g = nxt; gi = ngi; gi2 = ngi2;
@@ -699,7 +720,6 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             if (step(S0, S1)) break;
             if (step(S1, S0)) break;
         }
-        if (push_pending) write_entry(push_q, rdlane(push_t, 0), push_gate, push_off);
         if ((++iters & 63u) == 0) {                                 // somebody gave up (watchdog): leave, the host reports it
             u32 ab = 0;
             if (lane == 0) ab = ld_a32(&A.ctl[CTL_ABORT]); wave_join();
@@ -707,10 +727,8 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
         }
     }
     if (lane == 0) {
-        if (!registered) atomicAdd(&A.idle[(me % kIdleCounters) * 16], 1u);      // a wave that has left counts as idle for good
         if (processed) atomicAdd(&A.ctl[CTL_PROCESSED], processed);
         if (max_level) atomicMax(&A.ctl[CTL_MAXLEVEL], max_level);
-        if (st_rpolls) atomicAdd(&A.ctl[CTL_REREADS], st_rpolls);
         if (STATS) {
             ull* stats = A.cold->stats;
             if (stats) {
@@ -718,10 +736,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                 atomicAdd(&stats[0], (ull)st_pops); atomicAdd(&stats[1], (ull)st_polls); atomicAdd(&stats[2], (ull)st_push);
                 atomicAdd(&stats[3], st_busy); atomicAdd(&stats[4], st_idle); atomicAdd(&stats[5], (ull)st_seeds); atomicAdd(&stats[6], (ull)processed);
                 atomicAdd(&stats[7], ph_w1 | (ph_w2 << 32)); atomicAdd(&stats[16], ph_w3);
-                atomicAdd(&stats[8], (ull)st_rpolls);
                 atomicAdd(&stats[9], ph_a); atomicAdd(&stats[10], ph_b); atomicAdd(&stats[11], ph_c); atomicAdd(&stats[12], ph_d);
-                atomicAdd(&stats[17], ho_sum); atomicAdd(&stats[18], ho_cnt);
-                for (int k = 0; k < 5; ++k) atomicAdd(&stats[19 + k], ho_hist[k]);
                 atomicAdd(&stats[13], ph_steps); atomicAdd(&stats[14], ph_noload); atomicAdd(&stats[15], ph_start);
             }
         }

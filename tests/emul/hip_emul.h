@@ -71,7 +71,7 @@ struct Fiber {
     char* stack = nullptr;
     dim3 tid;
     bool done = false;
-    int wait_kind = 0;  // 0 none, 1 block barrier, 2 wave rendezvous
+    int wait_kind = 0;  // 0 none, 1 block barrier, 2 wave rendezvous, 3 the wave lets the other waves of the block run
 };
 struct State {
     dim3 tid, bid, bdim, gdim;
@@ -122,7 +122,9 @@ void run_block_fibers(unsigned nthreads, dim3 bdim, F&& per_thread) {
     }
     s.body = per_thread;
     // Waves are scheduled as units so that wave rendezvous complete: run each wave's fibers round-robin
-    // until every fiber of the wave is done or parked at a block barrier; then next wave; repeat.
+    // until every fiber of the wave is done, parked at a block barrier, or has stepped aside for the other waves
+    // (hipemu_wave_yield: a polling loop's back-off — the only points where the waves of a block interleave); then the
+    // next wave; repeat.  A barrier opens when nothing else in the block can run.
     unsigned nwaves = (nthreads + 63) / 64;
     for (;;) {
         bool any_alive = false;
@@ -132,20 +134,22 @@ void run_block_fibers(unsigned nthreads, dim3 bdim, F&& per_thread) {
                 bool progressed = false;
                 for (unsigned t = lo; t < hi; ++t) {
                     Fiber& f = fibers[t];
-                    if (f.done || f.wait_kind == 1) continue;
+                    if (f.done || f.wait_kind == 1 || f.wait_kind == 3) continue;
                     f.wait_kind = 0;
                     s.cur = &f; s.tid = f.tid;
                     hipemu_switch(&s.sched_sp, f.sp);
                     progressed = true;
                 }
                 bool all_parked = true;
-                for (unsigned t = lo; t < hi; ++t) if (!fibers[t].done && fibers[t].wait_kind != 1) all_parked = false;
+                for (unsigned t = lo; t < hi; ++t) if (!fibers[t].done && fibers[t].wait_kind != 1 && fibers[t].wait_kind != 3) all_parked = false;
                 if (all_parked) break;
                 if (!progressed) { std::fprintf(stderr, "hip_emul: wave deadlock\n"); std::abort(); }
             }
         }
-        for (unsigned t = 0; t < nthreads; ++t) if (!fibers[t].done) { any_alive = true; fibers[t].wait_kind = 0; }
+        bool any_aside = false;
+        for (unsigned t = 0; t < nthreads; ++t) if (!fibers[t].done) { any_alive = true; if (fibers[t].wait_kind == 3) { any_aside = true; fibers[t].wait_kind = 0; } }
         if (!any_alive) break;
+        if (!any_aside) for (unsigned t = 0; t < nthreads; ++t) if (!fibers[t].done) fibers[t].wait_kind = 0;      // the barrier opens
     }
     s.cur = nullptr;
 }
@@ -158,6 +162,8 @@ void run_block_fibers(unsigned nthreads, dim3 bdim, F&& per_thread) {
 #define warpSize 64
 
 inline void __syncthreads() { hipemu::yield(1); }
+// every thread of a wave, in uniform control flow: the other waves of the block run until they step aside or finish
+inline void hipemu_wave_yield() { if (hipemu::st().cur) hipemu::yield(3); }
 inline void __threadfence() {}
 inline void __threadfence_block() {}
 
@@ -251,6 +257,7 @@ template <class T> inline T atomicCAS(T* p, T c, T v) { T o = *p; if (o == c) *p
 // ---- scoped atomic load/store builtins (sc1 accesses on the GPU; plain here) + misc ----
 #ifndef __HIP_MEMORY_SCOPE_AGENT
 #define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
 #endif
 #define __hip_atomic_load(p, order, scope) (*(p))
 #define __hip_atomic_store(p, v, order, scope) ((void)(*(p) = (v)))
