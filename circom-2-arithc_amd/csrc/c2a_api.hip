@@ -56,6 +56,7 @@ struct c2a_ctx {
     u32 bool_chunk = 256;          // arithmetic gates per k_boolify workgroup: 128, 256 (measured best) or 512
     u32 peel_sinks_blocks = 4096;  // grid cap of the sinks pass (latency-bound per thread: two dependent round trips per sink)
     u32 peel_waves = 8;            // dataflow launch: single-wave workgroups per CU (clamped by the occupancy query)
+    u32 peel_fifos = 64;           // dataflow launch: hand-off arrays (a power of two <= 64)
     u32 peel_run = 0;              // number of the last dataflow run on this context (tag of its hand-off entries)
     u32 peel_epoch = 0;            // tag of the node words written by the last run (alternates; restarts after a clear)
     bool io_clash = false;         // a node is both an input and an output (compiler.rs:363-383), found at load time
@@ -200,7 +201,7 @@ int do_prep(c2a_ctx* c) {
     int r = scan_exclusive<u32>(c, c->cons_cnt.as<u32>(), c->cons_off.as<u32>(), n);
     if (r) return r;
     C2A_LAUNCH_NOSYNC(k_gstat, G, kThreads, s, n, c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_off.as<u32>(),
-                      c->cons_cnt.as<u32>(), c->eslot.as<u32>(), c->gstat.as<uint4>(), c->clist.as<u32>());
+                      c->eslot.as<u32>(), c->gstat.as<uint4>(), c->clist.as<u32>());
     return C2A_OK;
 }
 
@@ -241,8 +242,7 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
     const u32 waves = peel_grid(c, want_stats);
     // hand-off arrays: every slot is used once per run (no wrap-around).  A wave spreads its pushes round robin, so an
     // array receives at most pushes / n_fifos + waves entries, and a wave holds at most one unserved consumer ticket
-    A.n_fifos = 64;
-    if (const char* e = std::getenv("C2A_PEEL_FIFOS")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) A.n_fifos = v; }
+    A.n_fifos = c->peel_fifos;
     A.q_cap = n / A.n_fifos + 2 * waves + 64;
     const size_t slots = (size_t)A.n_fifos * A.q_cap;
     // (slots are never cleared between runs: every word of an entry carries the number of the run that wrote it)
@@ -554,6 +554,7 @@ int c2a_create(int n_devices, const int* device_ids, c2a_ctx** out) {
     if (const char* e = std::getenv("C2A_BOOL_CHUNK")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 128 || v == 256 || v == 512) c->bool_chunk = v; }
     if (const char* e = std::getenv("C2A_PEEL_SINKS_BLOCKS")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 16) c->peel_sinks_blocks = v; }
     if (const char* e = std::getenv("C2A_PEEL_WAVES")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 32) c->peel_waves = v; }
+    if (const char* e = std::getenv("C2A_PEEL_FIFOS")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->peel_fifos = v; }
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return C2A_ERR_HIP; }
     for (int i = 0; i < EV_COUNT; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) { c2a_destroy(c); return C2A_ERR_HIP; }

@@ -294,13 +294,17 @@ __device__ __attribute__((noinline)) bool deep_less(const u64* node_base, u32 ep
 // gstat and the consumer lists (eslot[2g + l] = index of edge (g, l) in its producer's list, from k_deps)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_gstat(u32 n, const u32* __restrict__ dep0, const u32* __restrict__ dep1, const u32* __restrict__ cons_off,
-                        const u32* __restrict__ cons_cnt, const u32* __restrict__ eslot, uint4* gstat, u32* clist) {
+                        const u32* __restrict__ eslot, uint4* gstat, u32* clist) {
+    // (the consumer count of a gate is the difference of two neighbouring offsets — cons_off has n + 1 entries —: ONE
+    // random 8-byte access per producer instead of two 4-byte ones in two arrays; gate ids are in no particular order,
+    // so every such access is an HBM sector of its own)
     for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (u64)gridDim.x * blockDim.x) {
         const u32 d0 = dep0[g], d1 = dep1[g];
-        gstat[2 * g] = make_uint4(d0, d1, cons_off[g], cons_cnt[g]);
+        const u32 o = cons_off[g];
+        gstat[2 * g] = make_uint4(d0, d1, o, cons_off[g + 1] - o);
         uint4 g2 = make_uint4(0, 0, 0, 0);
-        if (d0 != C2A_NONE) { g2.x = cons_off[d0]; g2.y = cons_cnt[d0]; clist[g2.x + eslot[2 * g]] = (u32)g; }
-        if (d1 != C2A_NONE) { g2.z = cons_off[d1]; g2.w = cons_cnt[d1]; clist[g2.z + eslot[2 * g + 1]] = (u32)g | 0x80000000u; }
+        if (d0 != C2A_NONE) { g2.x = cons_off[d0]; g2.y = cons_off[(u64)d0 + 1] - g2.x; clist[g2.x + eslot[2 * g]] = (u32)g; }
+        if (d1 != C2A_NONE) { g2.z = cons_off[d1]; g2.w = cons_off[(u64)d1 + 1] - g2.z; clist[g2.z + eslot[2 * g + 1]] = (u32)g | 0x80000000u; }
         gstat[2 * g + 1] = g2;
     }
 }

@@ -141,6 +141,16 @@ def test_deep_chain_exercises_path_string_chunks(backend, orc):
     assert backend.stats()["max_depth"] >= 4096
 
 
+def test_handoff_arrays_any_number(backend_fifo, orc, c2a):
+    """Hand-off of a second claimed producer (c2a_peel.h): entries travel through F ticketed arrays; a waiting wave is
+    committed to one slot, so an entry pushed where nobody waits has to be picked up by a wave that sees the backlog.
+    Forks are everywhere in a layered DAG; the result must not depend on F."""
+    for seed in (1, 2, 3):
+        fg = c2a.synth.layered_dag(12, 24, n_in=6, n_const=2, window=3, seed=c2a.synth.SEED + seed)
+        p = dict(lh=fg.lh, rh=fg.rh, out=fg.out, op=fg.op, n_nodes=fg.n_nodes, input_nodes=fg.input_nodes, output_nodes=fg.output_nodes)
+        assert _compare(backend_fifo, orc, p, check_serial=False) == "ok"
+
+
 def test_wave_per_gate_kernel_small_graphs(backend_wave, orc):
     """Every peel variant (dataflow launch, wave-per-gate and lane-per-gate launch-per-level) on adversarial small graphs."""
     rng = np.random.default_rng(4242)
