@@ -79,7 +79,7 @@ typedef struct c2a_stats {
     uint32_t n_splitters;        /* list-ranking sublists */
     uint32_t level_launches;     /* peel kernel launches: 2 (the sinks pass + the one dataflow launch) */
     uint32_t peel_waves;         /* single-wave workgroups of the dataflow launch (CUs x min(knob, occupancy query)) */
-    uint32_t path_chunks;        /* 3906-bit path-string chunks the deepest DFS path spans (1 = every tournament is one round trip) */
+    uint32_t path_chunks;        /* 3843-bit path-string chunks the deepest DFS path spans (1 = every tournament is one round trip) */
     uint32_t peel_rereads;       /* times a wave read a candidate record again because a word of it had not arrived yet */
 } c2a_stats;
 
