@@ -52,7 +52,8 @@
 // END never passes BEGIN, so "END (read first) == BEGIN (read afterwards)" means they were equal at every moment in
 // between: nothing active, nothing in flight, nobody can push any more.  How entries travel (which array, whose ticket)
 // plays no part in it, and co-residency of the grid is not required: a wave that starts late adds its unit, finds the
-// seed pool empty, ends it, and sees the counters equal.
+// seed pool empty, ends it, and sees the counters equal.  (One waiting wave in 64 looks at the counters every 32 polls
+// and raises a DONE flag for the others; every wave looks for itself once in 1024 polls.)
 // Watchdog: lack of GLOBAL progress (a heartbeat the working waves bump) — a long critical path followed by one wave is
 // not an error.
 #pragma once
@@ -76,7 +77,7 @@ constexpr u32 kPollLimit = 1u << 21;        // ~1 s of polling for a record: giv
 #endif
 constexpr u32 kWatchdogChecks = 1u << 15;   // idle-side checks (one per 32 polls, ~100 us apart) without global progress
 // control block (u32 words; every hot word on its own 128-byte line)
-enum PeelCtl { CTL_PROCESSED = 0, CTL_MAXLEVEL = 1, CTL_ABORT = 2, CTL_REREADS = 3, CTL_HEARTBEAT = 32, CTL_SEEDNEXT = 64,
+enum PeelCtl { CTL_PROCESSED = 0, CTL_MAXLEVEL = 1, CTL_ABORT = 2, CTL_REREADS = 3, CTL_DONE = 4, CTL_HEARTBEAT = 32, CTL_SEEDNEXT = 64,
                CTL_BEGIN = 128, CTL_END = CTL_BEGIN + 64 * 32, CTL_WORDS = CTL_END + 64 * 32 };
 constexpr u32 kPcStride = 16;               // u64 words between two hand-off arrays' ticket words (128 bytes)
 constexpr u32 kSlotWords = 16;              // a hand-off entry: words 0..7 gstat[2g], gstat[2g + 1]; 8..14 first consumers; 15 gate id
@@ -150,7 +151,7 @@ __device__ __forceinline__ ull c2a_now() {
 }
 __device__ __forceinline__ void peel_sleep(int units) {
 #ifndef C2A_EMULATE
-    if (units <= 1) __builtin_amdgcn_s_sleep(1); else if (units <= 4) __builtin_amdgcn_s_sleep(4); else if (units <= 16) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(64);
+    if (units <= 1) __builtin_amdgcn_s_sleep(1); else if (units <= 4) __builtin_amdgcn_s_sleep(4); else if (units <= 16) __builtin_amdgcn_s_sleep(16); else if (units <= 64) __builtin_amdgcn_s_sleep(64); else __builtin_amdgcn_s_sleep(127);
 #else
     (void)units;
     hipemu_wave_yield();        // (the emulation interleaves the waves of a workgroup at these points only)
@@ -453,40 +454,51 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                 if (((u32)__ballot((u32)(v >> 32) == A.run) & 0xFFFFu) == 0xFFFFu) { got = true; break; }
                 ++polls;
                 if ((polls & 31u) == 0) {
-                    // every END, then every BEGIN (and the abort flag and the heartbeat): each read waits for the one before
-                    u32 n_end = lane < kAcctShards ? ld_a32(&A.ctl[CTL_END + lane * kAcctStride]) : 0u;
-#pragma unroll
-                    for (int off = 32; off >= 1; off >>= 1) n_end += __shfl_xor(n_end, off, 64);
-                    n_end = uniform(n_end);          // (a shuffle result counts as divergent: the branches below must not)
-                    u32 n_begin = lane < kAcctShards ? ld_a32(&A.ctl[CTL_BEGIN + lane * kAcctStride]) : 0u;
-#pragma unroll
-                    for (int off = 32; off >= 1; off >>= 1) n_begin += __shfl_xor(n_begin, off, 64);
-                    n_begin = uniform(n_begin);
+                    // cheap and frequent: has somebody seen the end (or given up)?  is the launch still making progress?
                     u32 c3 = 0;
-                    if (lane < 2) c3 = ld_a32(&A.ctl[lane == 0 ? CTL_ABORT : CTL_HEARTBEAT]); wave_join();
-                    const u32 aborted = rdlane(c3, 0), hb = rdlane(c3, 1);
-                    if (aborted || n_end == n_begin) break;          // nothing active, nothing in flight: the peel is over
+                    if (lane < 3) c3 = ld_a32(&A.ctl[lane == 0 ? CTL_ABORT : (lane == 1 ? CTL_DONE : CTL_HEARTBEAT)]); wave_join();
+                    const u32 aborted = rdlane(c3, 0), done = rdlane(c3, 1), hb = rdlane(c3, 2);
+                    if (aborted || done) break;
                     if (hb != hb_seen) { hb_seen = hb; hb_checks = 0; }
                     else if (++hb_checks > kWatchdogChecks) { if (lane == 0) atomicAdd(&A.ctl[CTL_ABORT], 1u); wave_join(); break; }
-                    // An entry in an array where nobody waits (every wave is committed to a slot elsewhere) would sit there
-                    // for good: a wave that sees such a backlog takes a ticket that is served ALREADY (compare-and-swap on
-                    // the pair of counts) and works on that entry; its own ticket stays good for later
-                    if (slot_i == held_slot) {
-                        const u64 pcw = lane < A.n_fifos ? ld_nw(&A.q_pc[(u64)lane * kPcStride]) : 0ull;
-                        const u64 bm = __ballot((u32)pcw > (u32)(pcw >> 32));
-                        if (bm) {
-                            const u32 r = me & 63u;
-                            const u64 from_r = bm & (~0ull << r);
-                            const u32 j = ctz64(from_r ? from_r : bm);
-                            const u64 expect = rdlane64(pcw, j);
-                            u64 seen = 0;
-                            if (lane == 0) seen = atomicCAS(reinterpret_cast<ull*>(&A.q_pc[(u64)j * kPcStride]), (ull)expect, (ull)(expect + (1ull << 32))); wave_join();
-                            if (rdlane64(seen, 0) == expect) slot_i = (u64)j * A.q_cap + (u32)(expect >> 32);
+                    // The full look at the counters (192 lines that every pusher writes) is for one wave in 64 at this rate —
+                    // with every waiting wave doing it, those reads alone were 0.4-1.5 TB/s on the lines the tickets live
+                    // on — and for every wave once in 1024 polls, so that ending (and picking up a stranded entry) never
+                    // depends on a particular wave being resident
+                    if ((me & 63u) == 0 || (polls & 1023u) == 0) {
+                        // every END, then every BEGIN: each read waits for the one before
+                        u32 n_end = lane < kAcctShards ? ld_a32(&A.ctl[CTL_END + lane * kAcctStride]) : 0u;
+#pragma unroll
+                        for (int off = 32; off >= 1; off >>= 1) n_end += __shfl_xor(n_end, off, 64);
+                        n_end = uniform(n_end);      // (a shuffle result counts as divergent: the branches below must not)
+                        u32 n_begin = lane < kAcctShards ? ld_a32(&A.ctl[CTL_BEGIN + lane * kAcctStride]) : 0u;
+#pragma unroll
+                        for (int off = 32; off >= 1; off >>= 1) n_begin += __shfl_xor(n_begin, off, 64);
+                        n_begin = uniform(n_begin);
+                        if (n_end == n_begin) {      // nothing active, nothing in flight: the peel is over — tell everybody
+                            if (lane == 0) st_a32(&A.ctl[CTL_DONE], 1u); wave_join();
+                            break;
+                        }
+                        // An entry in an array where nobody waits (every wave is committed to a slot elsewhere) would sit
+                        // there for good: a wave that sees such a backlog takes a ticket that is served ALREADY (compare-and-
+                        // swap on the pair of counts) and works on that entry; its own ticket stays good for later
+                        if (slot_i == held_slot) {
+                            const u64 pcw = lane < A.n_fifos ? ld_nw(&A.q_pc[(u64)lane * kPcStride]) : 0ull;
+                            const u64 bm = __ballot((u32)pcw > (u32)(pcw >> 32));
+                            if (bm) {
+                                const u32 r = me & 63u;
+                                const u64 from_r = bm & (~0ull << r);
+                                const u32 j = ctz64(from_r ? from_r : bm);
+                                const u64 expect = rdlane64(pcw, j);
+                                u64 seen = 0;
+                                if (lane == 0) seen = atomicCAS(reinterpret_cast<ull*>(&A.q_pc[(u64)j * kPcStride]), (ull)expect, (ull)(expect + (1ull << 32))); wave_join();
+                                if (rdlane64(seen, 0) == expect) slot_i = (u64)j * A.q_cap + (u32)(expect >> 32);
+                            }
                         }
                     }
                 }
                 // back off: the longer nothing turns up, the less often this wave asks (64 clocks per unit)
-                peel_sleep(polls < 64 ? 4 : 16);
+                peel_sleep(polls < 16 ? 4 : (polls < 64 ? 16 : 64));
             }
             if (STATS) st_polls += polls;
             if (STATS) { const ull tt = c2a_now(); st_idle += tt - st_t0; st_t0 = tt; }
