@@ -78,7 +78,7 @@ constexpr u32 kPollLimit = 1u << 21;        // ~1 s of polling for a record: giv
 constexpr u32 kWatchdogChecks = 1u << 15;   // idle-side checks (one per 32 polls, ~100 us apart) without global progress
 // control block (u32 words; every hot word on its own 128-byte line)
 enum PeelCtl { CTL_PROCESSED = 0, CTL_MAXLEVEL = 1, CTL_ABORT = 2, CTL_REREADS = 3, CTL_DONE = 4, CTL_HEARTBEAT = 32, CTL_SEEDNEXT = 64,
-               CTL_BEGIN = 128, CTL_END = CTL_BEGIN + 64 * 32, CTL_WORDS = CTL_END + 64 * 32 };
+               CTL_BEGIN = 128, CTL_END = CTL_BEGIN + 64 * 32, CTL_DEMAND = CTL_END + 64 * 32, CTL_WORDS = CTL_DEMAND + 64 * 32 };
 constexpr u32 kPcStride = 16;               // u64 words between two hand-off arrays' ticket words (128 bytes)
 constexpr u32 kSlotWords = 16;              // a hand-off entry: words 0..7 gstat[2g], gstat[2g + 1]; 8..14 first consumers; 15 gate id
 constexpr u32 kSlotCons = 7;
@@ -109,6 +109,8 @@ struct PeelArgs {
     u64* fifo;                 // [n_fifos][q_cap][kSlotWords] slots (used once per run, no wrap-around: a wave spreads its pushes
                                // round robin and holds at most one unserved consumer ticket; never cleared: the tag says which run)
     u32 run;                   // tag of this run's hand-off entries (never zero)
+    u32 n_primary;             // waves beyond this many are a RESERVE: they join the hand-off lines only on demand
+    u32 reserve_min;           // ... of this many pushes (per 64th of the pushers) that found nobody in line
     u32* ctl;                  // [CTL_WORDS]
     const PeelCold* cold;
     // the sinks pass only
@@ -383,7 +385,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
     A.gstat = own_sgprs(A_in.gstat); A.clist = own_sgprs(A_in.clist); A.node = own_sgprs(A_in.node); A.fill = own_sgprs(A_in.fill);
     A.meta = own_sgprs(A_in.meta); A.child = own_sgprs(A_in.child); A.fifo = own_sgprs(A_in.fifo); A.q_pc = own_sgprs(A_in.q_pc);
     A.ctl = own_sgprs(A_in.ctl); A.cold = own_sgprs(A_in.cold);
-    A.epoch = own_sgpr(A_in.epoch); A.n_fifos = own_sgpr(A_in.n_fifos); A.q_cap = own_sgpr(A_in.q_cap); A.run = own_sgpr(A_in.run);
+    A.epoch = own_sgpr(A_in.epoch); A.n_fifos = own_sgpr(A_in.n_fifos); A.q_cap = own_sgpr(A_in.q_cap); A.run = own_sgpr(A_in.run); A.n_primary = own_sgpr(A_in.n_primary); A.reserve_min = own_sgpr(A_in.reserve_min);
     const u32 lane = threadIdx.x;
     const u32 me = blockIdx.x;
     // this wave is one unit of work from now until it first runs out of work; BEGIN counts it before it moves
@@ -397,6 +399,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
     bool seeds_left = true;
     u32 region = 0, idx = 0, region_cnt = 0;
     u32 push_rr = me, pop_rr = me * 7u;      // round-robin cursors over the hand-off arrays
+    u32 demand_seen = 0;                     // (reserve waves) the demand count this wave has answered
     u32 held = 0;                            // this wave holds a consumer ticket that has not been served yet ...
     u64 held_slot = 0;                       // ... for this slot
     u32 processed = 0, max_level = 0, iters = 0;
@@ -438,6 +441,26 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             // those were returning atomics, waited for)
             if (lane == 0) atomicAdd(&A.ctl[CTL_END + (me & (kAcctShards - 1u)) * kAcctStride], 1u); wave_join();
             // ---- a consumer ticket — kept until it is served, whatever else this wave does meanwhile — and the slot it names
+            if (!held && me >= A.n_primary) {
+                // A RESERVE wave (C2A_PEEL_RESERVE per CU, off by default) stays out of the lines — every wave in line makes
+                // the others' polls and the ticket lines slower, and 8 waves per CU are enough for a graph 2 000 gates wide —
+                // until enough pushers have found a line EMPTY: then the launch is short of waves, not of work
+                bool leave = false;
+                for (u32 sb = 1; sb < 128; ++sb) {
+                    u32 dm = 0;
+                    if (lane == 0) dm = ld_a32(&A.ctl[CTL_DEMAND + (me & (kAcctShards - 1u)) * kAcctStride]); wave_join();
+                    dm = rdlane(dm, 0);
+                    if (dm - demand_seen >= A.reserve_min) { demand_seen = dm; break; }
+                    if ((sb & 7u) == 0) {
+                        u32 c2 = 0;
+                        if (lane < 2) c2 = ld_a32(&A.ctl[lane == 0 ? CTL_ABORT : CTL_DONE]); wave_join();
+                        if (rdlane(c2, 0) | rdlane(c2, 1)) { leave = true; break; }
+                    }
+                    peel_sleep(127);
+                }
+                if (leave) break;
+                // (after 128 looks it joins a line anyway: ending, and picking up a stranded entry, never depends on others)
+            }
             if (!held) {
                 const u32 f = (pop_rr++) & (A.n_fifos - 1u);
                 u64 pc = 0;
@@ -586,7 +609,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             // producer ticket is taken here and its entry stored after the tournament (the ticket is back by then)
             u32 nxt = C2A_NONE, nxt_label = 0;
             uint4 ngi = make_uint4(0, 0, 0, 0), ngi2 = make_uint4(0, 0, 0, 0);
-            u32 push_t = 0, push_f = 0;
+            u32 push_t = 0, push_c = 0, push_f = 0;
             if (rmask) {
                 const u32 j0 = (rmask & 1u) ? 0u : 1u;
                 nxt = j0 ? g_dep1 : g_dep0; nxt_label = j0;
@@ -598,7 +621,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                     // one of the hand-off arrays: the ticket now, the entry after the tournament; BEGIN counts the entry
                     // before anybody can see it
                     push_f = (push_rr++) & (A.n_fifos - 1u);
-                    if (lane == 0) push_t = (u32)atomicAdd(reinterpret_cast<ull*>(&A.q_pc[(u64)push_f * kPcStride]), 1ull);
+                    if (lane == 0) { const ull pc = atomicAdd(reinterpret_cast<ull*>(&A.q_pc[(u64)push_f * kPcStride]), 1ull); push_t = (u32)pc; push_c = (u32)(pc >> 32); }
                     if (lane == 1) push_t = atomicAdd(&A.ctl[CTL_BEGIN + (me & (kAcctShards - 1u)) * kAcctStride], 1u);
                     wave_join();
                 }
@@ -679,6 +702,8 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                 // the entry: lanes 8..15 hold the pushed gate's static records, lanes 32..38 its first consumers
                 C2A_PIN(push_t);                                    // (both atomics are back)
                 const u64 t = (u64)push_f * A.q_cap + rdlane(push_t, 0);
+                // nobody was in line for this entry: tell the reserve
+                if (rdlane(push_c, 0) <= rdlane(push_t, 0)) { if (lane == 0) atomicAdd(&A.ctl[CTL_DEMAND + (me & (kAcctShards - 1u)) * kAcctStride], 1u); wave_join(); }
                 u64* slot = A.fifo + t * kSlotWords;
                 const u64 rt = (u64)A.run << 32;
                 if (STATS && lane == 0) A.cold->q_time[t] = ph0;

@@ -96,14 +96,15 @@ def _variant(kind, mode):
 WAVE_BACKENDS = [_variant("emul", "w8"), _variant("hip", "w8"), _variant("hip", "w1"), _variant("hip", "w32")]
 
 
-FIFO_BACKENDS = [_variant("emul", "f1"), _variant("emul", "f2"), _variant("emul", "f64"), _variant("hip", "f1"), _variant("hip", "f4")]
+FIFO_BACKENDS = [_variant("emul", "f1"), _variant("emul", "f2"), _variant("emul", "f64"), _variant("hip", "f1"), _variant("hip", "f4"),
+                 _variant("hip", "r8")]       # (r8: 8 reserve waves per CU that join the hand-off lines on demand)
 
 
 @pytest.fixture(params=FIFO_BACKENDS)
 def backend_fifo(request, c2a):
     """The dataflow peel with 1 .. 64 hand-off arrays: every pushed entry must be picked up wherever the waves wait."""
     kind, mode = request.param
-    with _Env(C2A_PEEL_FIFOS=int(mode[1:])):
+    with _Env(**({"C2A_PEEL_RESERVE": int(mode[1:])} if mode[0] == "r" else {"C2A_PEEL_FIFOS": int(mode[1:])})):
         be = c2a.Backend(0, lib_path=request.getfixturevalue("emul_lib")) if kind == "emul" else c2a.Backend(0)
     yield be
     be.close()
