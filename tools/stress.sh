@@ -1,0 +1,13 @@
+#!/bin/bash
+# usage (on the GPU box): tools/stress.sh <rounds> — the full-size parity check over and over, across shapes, wave counts,
+# hand-off array counts and the reserve: the hand-off / termination protocol of the dataflow launch has no second chance
+R=${GRAFT_REPO_ROOT:-/root/repo}; rounds=${1:-3}; fail=0
+for r in $(seq $rounds); do
+  for cfg in "5000x2000 8 64 0" "5000x2000 16 64 0" "5000x2000 8 4 0" "5000x2000 8 64 8" "5000x2000 3 1 0" "20000x64 8 64 0" "200x50000 8 64 8" "1000x10000 12 16 4" "50000x8 8 64 0"; do
+    set -- $cfg
+    out=$(C2A_PEEL_FIFOS=$3 C2A_PEEL_RESERVE=$4 $R/tools/shape_check.sh $1@$2 2>&1 | tail -1)
+    case "$out" in *"== oracle"*) ;; *) fail=$((fail+1)); echo "FAIL [$cfg]: $out";; esac
+    echo "$r [$cfg] $out" | cut -c1-150
+  done
+done
+echo "failures: $fail"
