@@ -29,9 +29,9 @@
 // yet).  A single-consumer producer needs no ticket at all.  The chain loop is SOFTWARE-PIPELINED: the loads and tickets
 // of the next step are issued as soon as this step's tickets say where the chain goes on, before this step's own
 // tournament and stores.
-// A step is ONE cross-die round trip long: the tickets of the next gate can only be taken when this gate's tickets are
-// back (~1.3 us through the memory-side cache that keeps the eight XCDs coherent — a 20 000-level graph 16 gates wide
-// peels at 1.45 us per level); the ~440 instructions of a step run in the shadow of that round trip.
+// A step is ~440 instructions of one wave, most of them scalar and dependent on the one before; the memory round trip of
+// the tickets and loads issued at its top (0.4 us unloaded) hides behind them: a graph one gate wide peels at 1.0 us per
+// level, 16 wide at 1.45 us.
 // HAND-OFF.  A second producer completed by the same gate goes to one of F first-in-first-out arrays with tickets on
 // BOTH sides: a wave without work takes a consumer ticket c on one of them and watches slot c alone; the pusher takes a
 // producer ticket p (the round trip overlaps its tournament) and stores the entry into slot p — there is no claim step
