@@ -134,6 +134,25 @@ __device__ __forceinline__ u32 rdlane(u32 v, u32 j) {
     return (u32)__builtin_amdgcn_readlane((int)v, (int)j);
 #endif
 }
+// v with lane j replaced by the wave-uniform x (v_writelane: one instruction; a compare + select costs three)
+template <int J> __device__ __forceinline__ u32 wrlane_c(u32 x, u32 v) {
+#ifdef C2A_EMULATE
+    return (threadIdx.x & 63u) == (u32)J ? x : v;
+#else
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane((int)x)), "n"(J));
+    return v;
+#endif
+}
+// lane i takes the value of lane i + 8 of its row of 16 lanes (one DPP move; lanes 8..15 of a row keep their own)
+__device__ __forceinline__ u32 row_shl8(u32 v) {
+#ifdef C2A_EMULATE
+    const u32 l = threadIdx.x & 63u;
+    const u32 up = (u32)__shfl(v, (int)((l & 15u) < 8u ? l + 8u : l), 64);
+    return up;
+#else
+    return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x108, 0xF, 0xF, false);
+#endif
+}
 __device__ __forceinline__ u32 uniform(u32 v) {
 #ifdef C2A_EMULATE
     return v;
@@ -371,6 +390,7 @@ __global__ void __launch_bounds__(256) k_peel_sinks(PeelArgs A) {
 // copy of a value still in flight is a use, and its wait would drain the step that was just issued)
 struct StepIO {
     u32 kfill;                 // lane l < 2: ticket taken on producer l
+    u32 dcnt;                  // lane l < 2: consumers of producer l (0: no such producer)
     u32 gw;                    // lane 8 l + j (l < 2, j < 8): word j of the two gstat records of producer l
     u32 clp;                   // lanes 0..31: producer 0's consumers, 32..63: producer 1's
     u32 e0, e1, take;          // consumer | label << 31 of the (up to two) records in flight
@@ -549,9 +569,9 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
         // lane cbase on, when it fits ccap lanes (else nothing is loaded ahead and the step reads the list itself)
         auto issue = [&](StepIO& S, u32 dep0, u32 dep1, u32 n_cons, u32 off0, u32 cnt0, u32 off1, u32 cnt1, u32 scl, u32 cbase, u32 ccap,
                          bool have_own, u32 own_id) {
-            const u32 dl = lane == 0 ? dep0 : (lane == 1 ? dep1 : C2A_NONE);
-            const u32 dcnt = lane == 0 ? cnt0 : (lane == 1 ? cnt1 : 0u);
-            S.kfill = 0;
+            const u32 dl = wrlane_c<1>(dep1, wrlane_c<0>(dep0, C2A_NONE));
+            const u32 dcnt = wrlane_c<1>(cnt1, wrlane_c<0>(cnt0, 0u));       // (0 where there is no producer: gstat holds 0 then)
+            S.kfill = 0; S.dcnt = dcnt;
             if (dl != C2A_NONE && dcnt > 1u) S.kfill = atomicAdd(&A.fill[dl], 1u);
             // static data of both producers, one word per lane, BRANCH-FREE (clamped index, result discarded where there
             // is nothing to load)
@@ -599,11 +619,10 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             const ull ph0b = STATS ? c2a_now() : 0;
             C2A_PIN(cur.w0); C2A_PIN(cur.w1);
             if (STATS) { const ull ph0c = c2a_now(); ph_w1 += ph0a - ph0; ph_w2 += ph0b - ph0a; ph_w3 += ph0c - ph0b; }
-            const u32 g_dep0 = gi.x, g_dep1 = gi.y, g_off = gi.z, g_cnt = gi.w, g_dcnt0 = gi2.y, g_dcnt1 = gi2.w;
-            const u32 dl = lane == 0 ? g_dep0 : (lane == 1 ? g_dep1 : C2A_NONE);
-            const u32 dcnt = lane == 0 ? g_dcnt0 : (lane == 1 ? g_dcnt1 : 0u);
-            const bool last = dl != C2A_NONE && (dcnt == 1u || cur.kfill + 1u == dcnt);
-            const u32 rmask = (u32)__ballot(last) & 3u;
+            const u32 g_dep0 = gi.x, g_dep1 = gi.y, g_off = gi.z, g_cnt = gi.w;
+            // lane l < 2 claimed producer l when its ticket was the last of dcnt (no ticket was taken for a single-consumer
+            // producer: kfill 0, dcnt 1; no producer: dcnt 0 — the one comparison covers all three)
+            const u32 rmask = (u32)__ballot(cur.kfill + 1u == cur.dcnt) & 3u;
             const ull ph1 = STATS ? c2a_now() : 0;
             // ---- go on with the first claimed producer: issue its step now; a second one goes to whoever has no work: its
             // producer ticket is taken here and its entry stored after the tournament (the ticket is back by then)
@@ -613,9 +632,9 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             if (rmask) {
                 const u32 j0 = (rmask & 1u) ? 0u : 1u;
                 nxt = j0 ? g_dep1 : g_dep0; nxt_label = j0;
-                const u32 jb = 8u * j0;
-                ngi = make_uint4(rdlane(cur.gw, jb), rdlane(cur.gw, jb + 1), rdlane(cur.gw, jb + 2), rdlane(cur.gw, jb + 3));
-                ngi2 = make_uint4(rdlane(cur.gw, jb + 4), rdlane(cur.gw, jb + 5), rdlane(cur.gw, jb + 6), rdlane(cur.gw, jb + 7));
+                const u32 gsel = j0 ? row_shl8(cur.gw) : cur.gw;         // lanes 0..7: the static records of nxt
+                ngi = make_uint4(rdlane(gsel, 0), rdlane(gsel, 1), rdlane(gsel, 2), rdlane(gsel, 3));
+                ngi2 = make_uint4(rdlane(gsel, 4), rdlane(gsel, 5), rdlane(gsel, 6), rdlane(gsel, 7));
                 if (rmask == 3u) {
                     if (STATS) ++st_push;
                     // one of the hand-off arrays: the ticket now, the entry after the tournament; BEGIN counts the entry
