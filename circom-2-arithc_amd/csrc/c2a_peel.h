@@ -415,7 +415,6 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
         C2A_PIN(r);
     }
     const u32 epoch = A.epoch;
-    const u64 tag = epoch ? kTagBit : 0ull;
     bool seeds_left = true;
     u32 region = 0, idx = 0, region_cnt = 0;
     u32 push_rr = me, pop_rr = me * 7u;      // round-robin cursors over the hand-off arrays
@@ -581,8 +580,9 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             }
             {
                 const u32 half = lane >> 5, i = lane & 31u;
-                const u32 poff = half ? off1 : off0, pcnt = half ? cnt1 : cnt0;
-                S.clp = A.clist[poff + (i < pcnt ? i : 0u)];
+                const u32 poff = half ? off1 : off0;
+                S.clp = A.clist[poff + i];                               // (clist is padded by 64 entries: lanes beyond the list read
+                                                                         // somebody else's entries, which nobody looks at)
             }
             // the records of the first two consumers that are not the gate in hand (slots that are not loaded stay
             // UNDEFINED on purpose: merging a loaded value with a constant is a register copy, a copy is a use, and its wait
@@ -754,11 +754,13 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                 if (ch != C2A_NONE) A.child[2 * (u64)ch + my_label] = g;
             }
             wave_join();
-            u64 my_w = str;
-            if (lane == 0) my_w = hdr0_word(ch_root, depth);
-            else if (lane == 1) my_w = hdr1_word(level, cprev);
-            else if (lane == 2) my_w = my_pos;
-            my_w |= tag;
+            // (the three header words go into lanes 0..2 with v_writelane: a lane == k ladder is masked code)
+            const u32 tag_hi = epoch << 31;
+            u32 w_lo = (u32)str, w_hi = (u32)(str >> 32) | tag_hi;
+            w_lo = wrlane_c<0>(depth, w_lo);  w_hi = wrlane_c<0>((ch_root & kIdMask) | tag_hi, w_hi);
+            w_lo = wrlane_c<1>(cprev, w_lo);  w_hi = wrlane_c<1>((level & kIdMask) | tag_hi, w_hi);
+            w_lo = wrlane_c<2>(my_pos, w_lo); w_hi = wrlane_c<2>(tag_hi, w_hi);
+            const u64 my_w = (u64)w_lo | ((u64)w_hi << 32);
             st_nw(&A.node[(u64)g * kNodeWords + lane], my_w);
             ++processed;
             if ((processed & 63u) == 0 && lane == 0) atomicAdd(&A.ctl[CTL_HEARTBEAT], 1u);
