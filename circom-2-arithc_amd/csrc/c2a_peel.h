@@ -602,10 +602,12 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
         };
         StepIO S0, S1;
         issue(S0, gi.x, gi.y, gi.w, gi2.x, gi2.y, gi2.z, gi2.w, cl0, cl0_base, cl0_cap, false, 0u);
-        // the gate just finished stays in registers as a candidate of the next one
-        u32 own_valid = 0;
-        u32 own_node = 0, own_label = 0, own_depth = 0, own_root = 0, own_level = 0, own_pos = 0;
-        u64 own_w = 0, own_x = 0;            // its record, and its string with own_label appended
+        // The champion of a gate's tournament so far (wave-uniform); ch == NONE: the virtual-root candidate [g].  The gate
+        // just finished stays in these registers as the first candidate of the next one: it is the champion to beat unless
+        // its DFS root is not smaller than the next gate's own id (then the step starts from [g])
+        u32 ch = C2A_NONE, ch_el = 0, ch_root = 0, ch_depth = 0, ch_pos = 0;
+        u64 ch_w = 0, ch_x = 0;              // the champion's record / its string with the edge label appended
+        u32 own_valid = 0, own_node = 0, own_level = 0;      // the gate just finished (a consumer of the gate in hand)
 
         // one step: `cur` is in hand (issued one step ago), `nx` receives the next one.  true = the chain ends (or abort)
         auto step = [&](StepIO& cur, StepIO& nx) -> bool {
@@ -648,25 +650,23 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                 issue(nx, ngi.x, ngi.y, ngi.w, ngi2.x, ngi2.y, ngi2.z, ngi2.w, cur.clp, 32u * j0, 32u, true, g);
             }
             const ull ph2 = STATS ? c2a_now() : 0;
-            // ---- tournament of THIS gate.  Champion so far (wave-uniform); NONE = the virtual-root candidate [g]
-            u32 ch = C2A_NONE, ch_el = 0, ch_root = g, ch_depth = 0, ch_pos = 0, level = 0;
-            u64 ch_w = 0, ch_x = 0;              // the champion's record / its string with the edge label appended
-            if (own_valid) {
-                level = own_level + 1;
-                if (own_root < g) { ch = own_node; ch_el = own_label; ch_root = own_root; ch_depth = own_depth; ch_pos = own_pos; ch_w = own_w; ch_x = own_x; }
-            }
+            // ---- tournament of THIS gate
+            u32 level = own_valid ? own_level + 1u : 0u;
+            if (!(own_valid && ch_root < g)) { ch = C2A_NONE; ch_el = 0; ch_root = g; ch_depth = 0; ch_pos = 0; ch_w = 0; ch_x = 0; }
             u32 gave_up = 0;
             // one candidate: its record must be all there (else read it again: out of line), then it meets the champion
             auto candidate = [&](u64 w, u32 e) {
                 const u32 c = e & kIdMask, el = e >> 31;
-                // (a sink's record has header words only: its string is empty whatever its string words hold)
                 u64 badm = __ballot((u32)(w >> 63) != epoch);
-                if ((u32)rdlane64(w, 0) == 0u) badm &= 7ull;
                 if (badm) {
-                    w = peel_reread(A.node, epoch, A.ctl, c, w, lane);
-                    badm = __ballot((u32)(w >> 63) != epoch);
-                    if ((u32)rdlane64(w, 0) == 0u) badm &= 7ull;
-                    if (badm) { gave_up = 1; return; }
+                    // not all there: a sink (header words only: its string is empty whatever its string words hold) or a
+                    // record that is still on its way
+                    if ((badm & 7ull) != 0 || (u32)rdlane64(w, 0) != 0u) {
+                        w = peel_reread(A.node, epoch, A.ctl, c, w, lane);
+                        badm = __ballot((u32)(w >> 63) != epoch);
+                        if ((badm & 7ull) != 0 || (badm != 0 && (u32)rdlane64(w, 0) != 0u)) { gave_up = 1; return; }
+                    }
+                    if ((u32)(w >> 63) != epoch) w = (u64)epoch << 63;       // (string words of a depth-0 record)
                 }
                 const u64 h0 = rdlane64(w, 0);
                 const u32 croot = hdr_hi(h0), cdepth = (u32)h0;
@@ -674,7 +674,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                 const u32 cpos = rdlane((u32)w, 2);
                 level = clevel > level ? clevel : level;
                 // the candidate's string with its edge label appended (meaningful while the chunk has room: cpos < kStrWords << 8)
-                u64 x = cdepth ? (w & kPayload) : 0ull;
+                u64 x = w & kPayload;
                 if (lane == kHdrWords + (cpos >> 8)) x |= (u64)el << (cpos & 255u);
                 u32 less;                     // (0 / 1 in a scalar register: a bool merged over branches becomes a lane mask)
                 if (croot != ch_root) {
@@ -771,10 +771,11 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                 ph_a += ph1 - ph0; ph_b += ph2 - ph1; ph_c += ph3 - ph2; ph_d += ph4 - ph3;
             }
             if (nxt == C2A_NONE) return true;                       // the chain ends here
-            // what the next step reuses: this gate as a candidate of nxt
-            own_valid = 1; own_node = g; own_label = nxt_label; own_depth = depth; own_root = ch_root; own_level = level; own_pos = my_pos; own_w = my_w;
-            own_x = str;
-            if (lane == kHdrWords + (my_pos >> 8)) own_x |= (u64)nxt_label << (my_pos & 255u);
+            // what the next step reuses: this gate as the first candidate of nxt (same DFS root: ch_root stays)
+            own_valid = 1; own_node = g; own_level = level;
+            ch_x = str;
+            if (lane == kHdrWords + (my_pos >> 8)) ch_x |= (u64)nxt_label << (my_pos & 255u);
+            ch = g; ch_el = nxt_label; ch_depth = depth; ch_pos = my_pos; ch_w = my_w;
             g = nxt; gi = ngi; gi2 = ngi2;
             return false;
         };
