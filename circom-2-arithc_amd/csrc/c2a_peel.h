@@ -571,7 +571,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             const u32 dl = wrlane_c<1>(dep1, wrlane_c<0>(dep0, C2A_NONE));
             const u32 dcnt = wrlane_c<1>(cnt1, wrlane_c<0>(cnt0, 0u));       // (0 where there is no producer: gstat holds 0 then)
             S.kfill = 0; S.dcnt = dcnt;
-            if (dl != C2A_NONE && dcnt > 1u) S.kfill = atomicAdd(&A.fill[dl], 1u);
+            if (dcnt > 1u) S.kfill = atomicAdd(&A.fill[dl], 1u);         // (a ticket is needed where there is a producer with other consumers)
             // static data of both producers, one word per lane, BRANCH-FREE (clamped index, result discarded where there
             // is nothing to load)
             {
@@ -589,7 +589,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             // would land right behind the load)
             const bool in_lanes = n_cons <= ccap;
             u64 smask = __ballot(in_lanes && lane - cbase < n_cons && !(have_own && (scl & kIdMask) == own_id));
-            S.take = 0; S.e0 = 0; S.e1 = 0;
+            S.take = 0;                  // (e0 / e1 stay undefined like w0 / w1: they are only looked at under take)
             if (smask) {
                 S.e0 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 1;
                 S.w0 = ld_nw(&A.node[(u64)(S.e0 & kIdMask) * kNodeWords + lane]);
