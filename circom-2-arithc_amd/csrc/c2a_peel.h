@@ -621,7 +621,8 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             const ull ph0b = STATS ? c2a_now() : 0;
             C2A_PIN(cur.w0); C2A_PIN(cur.w1);
             if (STATS) { const ull ph0c = c2a_now(); ph_w1 += ph0a - ph0; ph_w2 += ph0b - ph0a; ph_w3 += ph0c - ph0b; }
-            const u32 g_dep0 = gi.x, g_dep1 = gi.y, g_off = gi.z, g_cnt = gi.w;
+            // (the next gate's static records are written over gi / gi2 below: what the rest of this step needs of its own)
+            const u32 gc = g, g_dep0 = gi.x, g_dep1 = gi.y, g_off = gi.z, g_cnt = gi.w;
             // lane l < 2 claimed producer l when its ticket was the last of dcnt (no ticket was taken for a single-consumer
             // producer: kfill 0, dcnt 1; no producer: dcnt 0 — the one comparison covers all three)
             const u32 rmask = (u32)__ballot(cur.kfill + 1u == cur.dcnt) & 3u;
@@ -629,14 +630,13 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             // ---- go on with the first claimed producer: issue its step now; a second one goes to whoever has no work: its
             // producer ticket is taken here and its entry stored after the tournament (the ticket is back by then)
             u32 nxt = C2A_NONE, nxt_label = 0;
-            uint4 ngi = make_uint4(0, 0, 0, 0), ngi2 = make_uint4(0, 0, 0, 0);
             u32 push_t = 0, push_c = 0, push_f = 0;
             if (rmask) {
                 const u32 j0 = (rmask & 1u) ? 0u : 1u;
                 nxt = j0 ? g_dep1 : g_dep0; nxt_label = j0;
                 const u32 gsel = j0 ? row_shl8(cur.gw) : cur.gw;         // lanes 0..7: the static records of nxt
-                ngi = make_uint4(rdlane(gsel, 0), rdlane(gsel, 1), rdlane(gsel, 2), rdlane(gsel, 3));
-                ngi2 = make_uint4(rdlane(gsel, 4), rdlane(gsel, 5), rdlane(gsel, 6), rdlane(gsel, 7));
+                gi = make_uint4(rdlane(gsel, 0), rdlane(gsel, 1), rdlane(gsel, 2), rdlane(gsel, 3));
+                gi2 = make_uint4(rdlane(gsel, 4), rdlane(gsel, 5), rdlane(gsel, 6), rdlane(gsel, 7));
                 if (rmask == 3u) {
                     if (STATS) ++st_push;
                     // one of the hand-off arrays: the ticket now, the entry after the tournament; BEGIN counts the entry
@@ -647,12 +647,12 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                     wave_join();
                 }
                 // the consumers of nxt are already here (lanes 32 j0 ... of the prefetched lists) unless it has more than 32
-                issue(nx, ngi.x, ngi.y, ngi.w, ngi2.x, ngi2.y, ngi2.z, ngi2.w, cur.clp, 32u * j0, 32u, true, g);
+                issue(nx, gi.x, gi.y, gi.w, gi2.x, gi2.y, gi2.z, gi2.w, cur.clp, 32u * j0, 32u, true, gc);
             }
             const ull ph2 = STATS ? c2a_now() : 0;
             // ---- tournament of THIS gate
             u32 level = own_valid ? own_level + 1u : 0u;
-            if (!(own_valid && ch_root < g)) { ch = C2A_NONE; ch_el = 0; ch_root = g; ch_depth = 0; ch_pos = 0; ch_w = 0; ch_x = 0; }
+            if (!(own_valid && ch_root < gc)) { ch = C2A_NONE; ch_el = 0; ch_root = gc; ch_depth = 0; ch_pos = 0; ch_w = 0; ch_x = 0; }
             u32 gave_up = 0;
             // one candidate: its record must be all there (else read it again: out of line), then it meets the champion
             auto candidate = [&](u64 w, u32 e) {
@@ -750,8 +750,8 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             }
             max_level = level > max_level ? level : max_level;
             if (lane == 0) {
-                A.meta[g] = make_uint4(ch, depth, ch_root, my_label | (level << 1));
-                if (ch != C2A_NONE) A.child[2 * (u64)ch + my_label] = g;
+                A.meta[gc] = make_uint4(ch, depth, ch_root, my_label | (level << 1));
+                if (ch != C2A_NONE) A.child[2 * (u64)ch + my_label] = gc;
             }
             wave_join();
             // (the three header words go into lanes 0..2 with v_writelane: a lane == k ladder is masked code)
@@ -761,7 +761,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             w_lo = wrlane_c<1>(cprev, w_lo);  w_hi = wrlane_c<1>((level & kIdMask) | tag_hi, w_hi);
             w_lo = wrlane_c<2>(my_pos, w_lo); w_hi = wrlane_c<2>(tag_hi, w_hi);
             const u64 my_w = (u64)w_lo | ((u64)w_hi << 32);
-            st_nw(&A.node[(u64)g * kNodeWords + lane], my_w);
+            st_nw(&A.node[(u64)gc * kNodeWords + lane], my_w);
             ++processed;
             if ((processed & 63u) == 0 && lane == 0) atomicAdd(&A.ctl[CTL_HEARTBEAT], 1u);
             if (STATS) {
@@ -772,11 +772,11 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             }
             if (nxt == C2A_NONE) return true;                       // the chain ends here
             // what the next step reuses: this gate as the first candidate of nxt (same DFS root: ch_root stays)
-            own_valid = 1; own_node = g; own_level = level;
+            own_valid = 1; own_node = gc; own_level = level;
             ch_x = str;
             if (lane == kHdrWords + (my_pos >> 8)) ch_x |= (u64)nxt_label << (my_pos & 255u);
-            ch = g; ch_el = nxt_label; ch_depth = depth; ch_pos = my_pos; ch_w = my_w;
-            g = nxt; gi = ngi; gi2 = ngi2;
+            ch = gc; ch_el = nxt_label; ch_depth = depth; ch_pos = my_pos; ch_w = my_w;
+            g = nxt;
             return false;
         };
         for (;;) {
