@@ -655,7 +655,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             if (!(own_valid && ch_root < gc)) { ch = C2A_NONE; ch_el = 0; ch_root = gc; ch_depth = 0; ch_pos = 0; ch_w = 0; ch_x = 0; }
             u32 gave_up = 0;
             // one candidate: its record must be all there (else read it again: out of line), then it meets the champion
-            auto candidate = [&](u64 w, u32 e) {
+            auto candidate = [&](u64& w, u32 e) {             // (w by reference: the cold path mends it in place, no copy)
                 const u32 c = e & kIdMask, el = e >> 31;
                 u64 badm = __ballot((u32)(w >> 63) != epoch);
                 if (badm) {
