@@ -29,7 +29,7 @@
 // yet).  A single-consumer producer needs no ticket at all.  The chain loop is SOFTWARE-PIPELINED: the loads and tickets
 // of the next step are issued as soon as this step's tickets say where the chain goes on, before this step's own
 // tournament and stores.
-// A step is ~420 instructions of one wave, most of them scalar and dependent on the one before; the memory round trip of
+// A step is ~380 instructions of one wave, most of them scalar and dependent on the one before; the memory round trip of
 // the tickets and loads issued at its top (0.4 us unloaded) hides behind them: a graph one gate wide peels at 1.0 us per
 // level, 16 wide at 1.45 us.
 // HAND-OFF.  A second producer completed by the same gate goes to one of F first-in-first-out arrays with tickets on
