@@ -16,8 +16,8 @@ Layers:
 There is NO CPU fallback: if ``libc2a_hip.so`` is missing or no GPU is visible, the calls raise.
 """
 from .backend import (Backend, BackendError, BoolInfo, CircuitError, CyclicDependency, Inconsistency,  # noqa: F401
-                      OP, OP_NAMES, BOOL_OP_NAMES, library_path, load_library)
+                      OP, OP_NAMES, BOOL_OP_NAMES, library_path, load_library, visible_devices)
 from . import synth  # noqa: F401
 
 __all__ = ["Backend", "BackendError", "BoolInfo", "CircuitError", "CyclicDependency", "Inconsistency", "OP",
-           "OP_NAMES", "BOOL_OP_NAMES", "library_path", "load_library", "synth"]
+           "OP_NAMES", "BOOL_OP_NAMES", "library_path", "load_library", "visible_devices", "synth"]

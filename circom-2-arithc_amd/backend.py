@@ -85,7 +85,9 @@ class BoolInfo:
         return np.where(W < M, W * w + bit, M * w + self.aux_total + (W - M) * w + bit)
 
 
-_EXPORTS = ["c2a_create", "c2a_device_count", "c2a_format_bristol", "c2a_destroy", "c2a_last_error", "c2a_version", "c2a_load_gates", "c2a_topo_sort",
+ABI_VERSION = 3          # == C2A_ABI_VERSION of include/c2a.h this binding was written against
+
+_EXPORTS = ["c2a_abi_version", "c2a_visible_devices", "c2a_create", "c2a_device_count", "c2a_format_bristol", "c2a_destroy", "c2a_last_error", "c2a_version", "c2a_load_gates", "c2a_topo_sort",
             "c2a_topo_sort_serial", "c2a_assign_wires", "c2a_emit_gates", "c2a_build_circuit", "c2a_boolify",
             "c2a_bool_read", "c2a_template_size", "c2a_checksum", "c2a_get_timings", "c2a_get_stats", "c2a_verify_boolify",
             "c2a_debug_patch_bool_op", "c2a_boolify_plan", "c2a_boolify_chunk"]
@@ -107,6 +109,11 @@ def load_library(lib_path: Optional[str] = None):
             f"{path} not found: build it with `make -C circom-2-arithc_amd/csrc` (hipcc --offload-arch=gfx950). "
             "There is no CPU fallback.")
     L = ctypes.CDLL(path)
+    if not hasattr(L, "c2a_abi_version") or L.c2a_abi_version() != ABI_VERSION:
+        got = L.c2a_abi_version() if hasattr(L, "c2a_abi_version") else "none (pre-versioning build)"
+        raise BackendError(f"{path}: C ABI version {got}, this binding needs {ABI_VERSION} — rebuild the library "
+                           "(make -C circom-2-arithc_amd/csrc)")
+    L.c2a_visible_devices.restype = ctypes.c_int
     vp, u32p, u8p, u64p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint8), \
         ctypes.POINTER(ctypes.c_uint64)
     L.c2a_create.restype = ctypes.c_int
@@ -155,6 +162,11 @@ def load_library(lib_path: Optional[str] = None):
     L.c2a_get_stats.argtypes = [vp, ctypes.POINTER(_Stats)]
     _libs[path] = L
     return L
+
+
+def visible_devices(lib_path: Optional[str] = None) -> int:
+    """HIP devices c2a_create can be given (0 without a GPU)."""
+    return int(load_library(lib_path).c2a_visible_devices())
 
 
 def _c(a, dt):

@@ -79,10 +79,11 @@ struct c2a_ctx {
     DevBuf rflag, ridx, rlist, next, owner, local, slist, snext, ssum, jnxt, jval, sorted;
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op, gs, wcnt, wfo;
     bool has_dup = false;          // two gates write one node (compiler.rs:403-406 keeps the last): the general numbering path
-    DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof;
+    DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof, oq;
     DevBuf tsz, asz, goff, aoff, tmpl, tables, b_in0, b_in1, b_out, b_op;
-    DevBuf fmt_len, fmt_off, fmt_text, fmt_table;
+    DevBuf fmt_len, fmt_off, fmt_text, fmt_table, shard_cut, shard_qcut;
     u64 fmt_chunk_first = 0, fmt_chunk_cnt = 0;      // boolean gates held by the chunk buffers (c2a_boolify_chunk)
+    bool fmt_chunk_valid = false;                    // ... of the circuit and plan now current (reset wherever the plan is)
     DevBuf ev_produced, ev_spos, ev_aval, ev_bval, ev_lcount, ev_lbase, ev_lorder, cb_in0, cb_in1, cb_out, cb_op;
     bool bool_planned = false;
     std::vector<DevBuf*> all;
@@ -91,8 +92,8 @@ struct c2a_ctx {
         all = {&lh, &rh, &out, &op, &gate4, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &aq_items, &aq_pc, &aq_seeds, &aq_seed_cnt, &fill,
                &gstat, &clist, &pctl, &pcold, &meta, &node, &child, &rflag, &ridx, &rlist, &next,
                &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
-               &node_wire, &e_in0, &e_in1, &e_out, &e_op, &gs, &wcnt, &wfo, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &tsz, &asz, &goff,
-               &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &fmt_len, &fmt_off, &fmt_text, &fmt_table, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &ev_lcount, &ev_lbase, &ev_lorder, &cb_in0, &cb_in1, &cb_out, &cb_op};
+               &node_wire, &e_in0, &e_in1, &e_out, &e_op, &gs, &wcnt, &wfo, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &oq, &tsz, &asz, &goff,
+               &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &fmt_len, &fmt_off, &fmt_text, &fmt_table, &shard_cut, &shard_qcut, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &ev_lcount, &ev_lbase, &ev_lorder, &cb_in0, &cb_in1, &cb_out, &cb_op};
     }
 };
 
@@ -326,6 +327,52 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
                      st[9] * 10.0 / st[13], st[10] * 10.0 / st[13], st[11] * 10.0 / st[13], st[12] * 10.0 / st[13], 100.0 * st[14] / st[13], st[15] * 10.0 / (st[5] + st[0] + 1));
     }
     if (t4[CTL_ABORT]) return fail(c, C2A_ERR_HIP, "dataflow peel: watchdog tripped (" + std::to_string(t4[CTL_ABORT]) + " waves gave up waiting)");
+    if (const char* ex = std::getenv("C2A_TOURNEY_EXP")) {
+        // EXPERIMENT: the tournament engine alone over a precomputed order (gates sorted by the reverse Kahn level the
+        // launch above has just found), into fresh records — how fast can the tree be built when claims cost nothing?
+        const u32 L = t4[CTL_MAXLEVEL] + 1;
+        ENSURE(c->ev_lcount, ((size_t)L + 1) * 4); ENSURE(c->ev_lbase, ((size_t)L + 2) * 4); ENSURE(c->ev_lorder, (size_t)n * 4);
+        HIP_TRY(hipMemsetAsync(c->ev_lcount.p, 0, ((size_t)L + 1) * 4, s));
+        C2A_LAUNCH_NOSYNC(k_level_hist, grid_for(n, 4096), kThreads, s, n, (const uint4*)c->meta.as<uint4>(), c->ev_lcount.as<u32>());
+        int r = scan_exclusive<u32>(c, c->ev_lcount.as<u32>(), c->ev_lbase.as<u32>(), L);
+        if (r) return r;
+        HIP_TRY(hipMemsetAsync(c->ev_lcount.p, 0, ((size_t)L + 1) * 4, s));
+        C2A_LAUNCH_NOSYNC(k_level_scatter, grid_for(n, 4096), kThreads, s, n, (const uint4*)c->meta.as<uint4>(),
+                          (const u32*)c->ev_lbase.as<u32>(), c->ev_lcount.as<u32>(), c->ev_lorder.as<u32>());
+        u32 first = 0;
+        HIP_TRY(hipMemcpyAsync(&first, c->ev_lbase.as<u32>() + 1, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        const u32 cnt = n - first;                   // gates of level >= 1 (the sinks pass does level 0)
+        ENSURE(c->oq, (size_t)(cnt + 64) * 8);
+        TourArgs T;
+        T.epoch = (c->peel_epoch ^= 1u); T.n = n; T.gstat = c->gstat.as<uint4>(); T.clist = c->clist.as<u32>(); T.node = c->node.as<u64>();
+        T.meta = c->meta.as<uint4>(); T.child = c->child.as<u32>(); T.oq = c->oq.as<u64>(); T.n_queues = 1; T.q_cap = cnt; T.run = A.run;
+        T.oq_final = c->pctl.as<u32>() + 96; T.ctl = c->pctl.as<u32>();
+        C2A_LAUNCH_NOSYNC(k_make_entries, grid_for(cnt, 4096), kThreads, s, cnt, (const u32*)(c->ev_lorder.as<u32>() + first), A.run, c->oq.as<u64>());
+        HIP_TRY(hipMemsetAsync(c->fill.p, 0, (size_t)n * 4, s));
+        HIP_TRY(hipMemsetAsync(c->child.p, 0xFF, (size_t)n * 8, s));
+        HIP_TRY(hipMemsetAsync(c->meta.p, 0xEE, (size_t)n * 16, s));
+        HIP_TRY(hipMemsetAsync(c->aq_seed_cnt.p, 0, (size_t)cold.n_regions * 4, s));
+        HIP_TRY(hipMemsetAsync(c->pctl.p, 0, (size_t)CTL_WORDS * 4, s));
+        A.epoch = T.epoch;
+        C2A_LAUNCH(k_peel_sinks, sink_blocks, kThreads, s, A);
+        const u32 per_cu = (u32)std::max(1, std::atoi(ex));
+        const u32 tw = (u32)c->n_cu * per_cu;
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, s));
+        C2A_LAUNCH(k_tourney, tw, 64, s, T);
+        HIP_TRY(hipEventRecord(e1, s));
+        u32 tc[TCTL_WORDS];
+        HIP_TRY(hipMemcpyAsync(tc, c->pctl.p, sizeof(tc), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        std::fprintf(stderr, "[c2a tourney exp] %u waves (%u per CU): k_tourney %.3f ms for %u gates in %u levels; processed %u, aborts %u, re-reads %u\n",
+                     tw, per_cu, ms, cnt, L, tc[TCTL_PROCESSED], tc[TCTL_ABORT], tc[TCTL_REREADS]);
+        if (tc[TCTL_ABORT] || tc[TCTL_PROCESSED] != cnt) return fail(c, C2A_ERR_HIP, "tourney experiment failed");
+    }
     c->node_clear = false;
     *peeled_out = t4[CTL_PROCESSED];
     c->stats.levels = t4[CTL_PROCESSED] ? t4[CTL_MAXLEVEL] + 1 : 0;
@@ -396,7 +443,7 @@ int run_serial_dfs(c2a_ctx* c, u32* status, u64* cycle_at) {
 int do_topo_sort(c2a_ctx* c, u64* cycle_at) {
     if (c->stage < ST_LOADED) return fail(c, C2A_ERR_STATE, "c2a_topo_sort: no gates loaded");
     c->stage = ST_LOADED;
-    c->bool_planned = false;
+    c->bool_planned = false; c->fmt_chunk_valid = false;
     c->peel_meta_valid = false;
     const u32 n = c->n;
     std::memset(c->ev_valid, 0, sizeof(c->ev_valid));
@@ -541,10 +588,18 @@ extern "C" {
 
 const char* c2a_version(void) {
 #ifdef C2A_EMULATE
-    return "c2a 0.1 (host emulation build — tests only)";
+    return "c2a 0.3 (host emulation build — tests only)";
 #else
-    return "c2a 0.1 (hip gfx950)";
+    return "c2a 0.3 (hip gfx950)";
 #endif
+}
+
+int c2a_abi_version(void) { return C2A_ABI_VERSION; }
+
+int c2a_visible_devices(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 0) return 0;
+    return count;
 }
 
 int c2a_create(int n_devices, const int* device_ids, c2a_ctx** out) {
@@ -625,7 +680,7 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
         if (output_nodes[i] >= n_nodes) return fail(c, C2A_ERR_ARG, "c2a_load_gates: output node id >= n_nodes");
     HIP_TRY(hipSetDevice(c->device));
     c->n = n; c->n_nodes = n_nodes; c->n_in = n_in; c->n_out = n_out;
-    c->bool_planned = false; c->peel_meta_valid = false; c->stats = c2a_stats{}; c->binfo = c2a_bool_info{};
+    c->bool_planned = false; c->fmt_chunk_valid = false; c->peel_meta_valid = false; c->stats = c2a_stats{}; c->binfo = c2a_bool_info{};
     {   // the reference checks this BEFORE it sorts (compiler.rs:363-383 precede :408), so build_circuit must report it first
         std::vector<u32> a(input_nodes, input_nodes + n_in), b(output_nodes, output_nodes + n_out);
         std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
@@ -684,7 +739,7 @@ int c2a_topo_sort_serial(c2a_ctx* c, uint32_t* sorted, uint64_t* cycle_at) {
     if (c->stage < ST_LOADED) return fail(c, C2A_ERR_STATE, "c2a_topo_sort_serial: no gates loaded");
     HIP_TRY(hipSetDevice(c->device));
     c->stage = ST_LOADED;
-    c->bool_planned = false; c->peel_meta_valid = false;
+    c->bool_planned = false; c->fmt_chunk_valid = false; c->peel_meta_valid = false;
     c->stats = c2a_stats{}; c->stats.n_gates = c->n;
     if (cycle_at) *cycle_at = 0;
     if (c->n == 0) { c->stage = ST_SORTED; return C2A_OK; }
@@ -781,6 +836,7 @@ namespace {
 int bool_plan(c2a_ctx* c, uint32_t width) {
     if (c->stage < ST_EMITTED) return fail(c, C2A_ERR_STATE, "c2a_boolify: call c2a_emit_gates / c2a_build_circuit first");
     if (width == 0 || width > 64) return fail(c, C2A_ERR_ARG, "c2a_boolify: width must be in 1..64");
+    c->bool_planned = false; c->fmt_chunk_valid = false;      // (until this plan is complete; the chunk buffers belong to the plan before)
     hipStream_t s = c->stream;
     const u32 n = c->n;
     // templates for this width (host-generated once per width, cached in HBM)
@@ -862,14 +918,32 @@ int bool_map(c2a_ctx* c, const BoolSrc& S, u32 p_first, u32 p_end, u64 q_bias, u
 // extra device receives its slice (peer copies of e_*, goff, aoff + the templates), runs the same map kernel on its own
 // stream and keeps its part of the boolean circuit.  No collective: the map is independent per arithmetic gate, the one
 // thing a shard needs from the others — the index of its first boolean gate and aux wire — is in the scans of the plan.
+// sorted-position cuts of the emitted circuit into N ranges of (nearly) equal BOOLEAN gate counts — the bytes a shard
+// writes — by binary search in the scanned template sizes (a multiplier is 2 824 boolean gates, an XOR 32: equal
+// arithmetic counts would not balance a circuit with clustered multipliers)
+int shard_cuts(c2a_ctx* c, u32 N, std::vector<u32>& cut, std::vector<u64>& qcut) {
+    cut.assign(N + 1, 0); qcut.assign(N + 1, 0);
+    ENSURE(c->shard_cut, ((size_t)N + 1) * 4); ENSURE(c->shard_qcut, ((size_t)N + 1) * 8);
+    C2A_LAUNCH_NOSYNC(k_shard_cuts, 1, 64, c->stream, c->n, N, (const u64*)c->goff.as<u64>(), c->shard_cut.as<u32>(), c->shard_qcut.as<u64>());
+    HIP_TRY(hipMemcpyAsync(cut.data(), c->shard_cut.p, ((size_t)N + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(qcut.data(), c->shard_qcut.p, ((size_t)N + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return C2A_OK;
+}
+
+struct DeviceGuard {         // whatever path leaves the scope, the context's primary device is current again
+    int device;
+    explicit DeviceGuard(int d) : device(d) {}
+    ~DeviceGuard() { (void)hipSetDevice(device); }
+};
+
 int bool_map_sharded(c2a_ctx* c) {
-    const u32 n = c->n, N = 1 + (u32)c->peers.size();
+    const u32 N = 1 + (u32)c->peers.size();
     hipStream_t s = c->stream;
-    std::vector<u32> cut(N + 1);
-    for (u32 k = 0; k <= N; ++k) cut[k] = (u32)((u64)n * k / N);
-    std::vector<u64> qcut(N + 1);
-    for (u32 k = 0; k <= N; ++k) HIP_TRY(hipMemcpyAsync(&qcut[k], c->goff.as<u64>() + cut[k], 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    DeviceGuard guard(c->device);
+    std::vector<u32> cut;
+    std::vector<u64> qcut;
+    { int r0 = shard_cuts(c, N, cut, qcut); if (r0) return r0; }
     c->shard0_hi = cut[1]; c->shard0_qhi = qcut[1];
     const u64 G0 = qcut[1];
     ENSURE(c->b_in0, G0 * 4 + 16); ENSURE(c->b_in1, G0 * 4 + 16); ENSURE(c->b_out, G0 * 4 + 16); ENSURE(c->b_op, G0 + 16);
@@ -927,6 +1001,7 @@ extern "C" {
 int c2a_boolify(c2a_ctx* c, uint32_t width, c2a_bool_info* info) {
     if (!c) return C2A_ERR_ARG;
     HIP_TRY(hipSetDevice(c->device));
+    if (c->stage > ST_EMITTED) c->stage = ST_EMITTED;        // the boolean circuit of an earlier call is gone from here on, whatever happens below
     int r = bool_plan(c, width);
     if (r) return r;
     if (!c->peers.empty()) {
@@ -976,7 +1051,7 @@ int c2a_boolify_chunk(c2a_ctx* c, uint64_t first_gate, uint64_t n_gates, uint32_
         (r = copy_out(c, out, c->cb_out.as<u32>() + lead, cntq * 4)) || (r = copy_out(c, op, c->cb_op.as<u8>() + lead, cntq)))
         return r;
     HIP_TRY(hipStreamSynchronize(s));
-    c->fmt_chunk_first = q[0]; c->fmt_chunk_cnt = cntq;
+    c->fmt_chunk_first = q[0]; c->fmt_chunk_cnt = cntq; c->fmt_chunk_valid = true;
     if (first_bool_gate) *first_bool_gate = q[0];
     if (n_bool_gates) *n_bool_gates = cntq;
     return C2A_OK;
@@ -1144,7 +1219,7 @@ int c2a_format_bristol(c2a_ctx* c, int which, uint64_t first, uint64_t count, ch
         if (!c->peers.empty()) return fail(c, C2A_ERR_STATE, "c2a_format_bristol: the boolean circuit is spread over several devices; format it chunk by chunk (which = 2)");
         in0 = c->b_in0.as<u32>(); in1 = c->b_in1.as<u32>(); out = c->b_out.as<u32>(); op = c->b_op.as<u8>(); total = c->binfo.n_gates; break;
     case 2: {
-        if (!c->bool_planned || !c->fmt_chunk_cnt) return fail(c, C2A_ERR_STATE, "c2a_format_bristol: call c2a_boolify_chunk first");
+        if (!c->bool_planned || !c->fmt_chunk_valid) return fail(c, C2A_ERR_STATE, "c2a_format_bristol: call c2a_boolify_chunk first");
         const u64 lead = c->fmt_chunk_first - (c->fmt_chunk_first & ~3ull);
         in0 = c->cb_in0.as<u32>() + lead; in1 = c->cb_in1.as<u32>() + lead; out = c->cb_out.as<u32>() + lead; op = c->cb_op.as<u8>() + lead;
         total = c->fmt_chunk_cnt; break;

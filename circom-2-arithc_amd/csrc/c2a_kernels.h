@@ -105,6 +105,7 @@ __global__ void k_deps(u32 n, const u32* __restrict__ lh, const u32* __restrict_
 }  // namespace c2a
 
 #include "c2a_peel.h"
+#include "c2a_tourney.h"
 
 namespace c2a {
 
@@ -467,6 +468,23 @@ __global__ void k_bool_sizes(u32 n, const u8* __restrict__ e_op, const BoolTable
         const u32 o = e_op[p];
         tsz[p] = T->tsize[o];
         asz[p] = T->taux[o];
+    }
+}
+
+// cut[k] = first sorted position p with goff[p] >= G k / N (k = 0..N; cut[N] = n), qcut[k] = goff[cut[k]]: N ranges of
+// sorted positions holding (nearly) equal numbers of boolean gates
+__global__ void k_shard_cuts(u32 n, u32 N, const u64* __restrict__ goff, u32* cut, u64* qcut) {
+    for (u32 k = threadIdx.x; k <= N; k += blockDim.x) {
+        const u64 G = goff[n];
+        const u64 target = G / N * k + G % N * k / N;            // floor(G k / N) without overflow
+        u32 lo = 0, hi = n;
+        while (lo < hi) {
+            const u32 mid = lo + (hi - lo) / 2;
+            if (goff[mid] < target) lo = mid + 1; else hi = mid;
+        }
+        if (k == N) lo = n;
+        cut[k] = lo;
+        qcut[k] = goff[lo];
     }
 }
 

@@ -91,10 +91,16 @@ typedef struct c2a_stats {
  * Fails with C2A_ERR_HIP when there is no device / runtime, C2A_ERR_ARG for an id out of range.
  */
 int c2a_create(int n_devices, const int* device_ids, c2a_ctx** ctx);
+/* HIP devices this process can list in c2a_create (0 when there is no runtime / no GPU; never fails). */
+int c2a_visible_devices(void);
 int c2a_device_count(const c2a_ctx* ctx);
 void c2a_destroy(c2a_ctx* ctx);
 const char* c2a_last_error(const c2a_ctx* ctx);
 const char* c2a_version(void);
+/* Bumped whenever a signature or a struct layout of this header changes (round 2 changed c2a_create and c2a_stats without
+ * a signal): a binding built against another header must refuse to go on.  c2a_abi_version() == C2A_ABI_VERSION. */
+#define C2A_ABI_VERSION 3
+int c2a_abi_version(void);
 
 /*
  * Marshal `Compiler.gates` (src/compiler.rs:113, :85-90) as SoA plus the IO node lists that
