@@ -105,7 +105,7 @@ __global__ void k_deps(u32 n, const u32* __restrict__ lh, const u32* __restrict_
 }  // namespace c2a
 
 #include "c2a_peel.h"
-#include "c2a_tourney.h"
+#include "c2a_peel2.h"
 
 namespace c2a {
 

@@ -71,7 +71,7 @@ constexpr u64 kTagBit = 1ull << 63;
 constexpr u64 kPayload = kTagBit - 1ull;
 
 #ifdef C2A_EMULATE
-constexpr u32 kPollLimit = 1;               // steps are atomic there: a missing record is a bug, fail at once
+constexpr u32 kPollLimit = 1u << 16;        // (the emulation runs every wave of the launch side by side and switches at the back-offs: a poll is one turn of all the others)
 #else
 constexpr u32 kPollLimit = 1u << 21;        // ~1 s of polling for a record: give up (reported as an error) instead of hanging
 #endif

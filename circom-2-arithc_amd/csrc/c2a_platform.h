@@ -8,8 +8,13 @@
 // kernels without __syncthreads()/wave intrinsics run as plain loops under emulation
 #define C2A_LAUNCH_NOSYNC(kernel, grid, block, stream, ...) \
     hipemuLaunchNoSync(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
+// kernels whose workgroups exchange data while they run: every block alive at once under emulation
+#define C2A_LAUNCH_CONCURRENT(kernel, grid, block, stream, ...) \
+    hipemuLaunchConcurrent(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
 #else
 #include <hip/hip_runtime.h>
+#define C2A_LAUNCH_CONCURRENT(kernel, grid, block, stream, ...) \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
 #define C2A_LAUNCH_NOSYNC(kernel, grid, block, stream, ...) \
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
 #endif

@@ -47,7 +47,7 @@ def orc():
 @pytest.fixture(scope="session")
 def emul_lib():
     srcs = [os.path.join(ROOT, "circom-2-arithc_amd", "csrc", f) for f in
-            ("c2a_api.hip", "c2a_kernels.h", "c2a_peel.h", "c2a_templates.h", "c2a_platform.h")] + [
+            ("c2a_api.hip", "c2a_kernels.h", "c2a_peel.h", "c2a_peel2.h", "c2a_templates.h", "c2a_platform.h")] + [
         os.path.join(EMUL_DIR, "hip_emul.h"), os.path.join(ROOT, "include", "c2a.h")]
     if (not os.path.exists(EMUL_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(EMUL_LIB) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", EMUL_DIR])

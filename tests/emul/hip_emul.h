@@ -316,6 +316,98 @@ inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t, hipStrea
                 hipemu::run_block_fibers(nthreads, block, [&]() { kernel(args...); });
             }
 }
+// kernels whose workgroups talk to each other while they run (c2a_peel2.h: claim waves feed tournament waves through
+// mailboxes in memory): EVERY block of the grid is alive at once; the waves of all blocks take turns, a wave runs until
+// its fibers are done, at a block barrier or have stepped aside (hipemu_wave_yield: the back-off of a polling loop).
+// C2A_EMUL_SEED=<n> shuffles the order of the waves in every pass and lets a wave sit a pass out now and then: a different
+// interleaving of the protocol per seed (a randomized-schedule stress of what only a real GPU runs truly in parallel).
+template <class K, class... A>
+inline void hipemuLaunchConcurrent(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, A... args) {
+    using namespace hipemu;
+    State& s = st();
+    s.gdim = grid; s.bdim = block;
+    const unsigned nthreads = block.x * block.y * block.z, nblocks = grid.x;
+    const unsigned wpb = (nthreads + 63) / 64, nwaves = nblocks * wpb;
+    std::vector<Fiber> fibers((size_t)nblocks * nthreads);
+    std::vector<dim3> bids(fibers.size());
+    for (unsigned b = 0; b < nblocks; ++b)
+        for (unsigned t = 0; t < nthreads; ++t) {
+            Fiber& f = fibers[(size_t)b * nthreads + t];
+            f.stack = stack_pool(b * nthreads + t);
+            f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+            bids[(size_t)b * nthreads + t] = dim3(b, 0, 0);
+            void** top = reinterpret_cast<void**>((reinterpret_cast<uintptr_t>(f.stack) + kStack) & ~uintptr_t(15));
+            top[-1] = nullptr;
+            top[-2] = reinterpret_cast<void*>(&trampoline);
+            for (int r = 3; r <= 8; ++r) top[-r] = nullptr;
+            f.sp = top - 8;
+        }
+    s.body = [&]() { kernel(args...); };
+    unsigned long long rng = 0;
+    if (const char* e = std::getenv("C2A_EMUL_SEED")) rng = std::strtoull(e, nullptr, 10) * 0x9E3779B97F4A7C15ull + 1;
+    auto next_rand = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+    std::vector<unsigned> order(nwaves);
+    unsigned long long passes = 0, pass_limit = 50000000ull;
+    if (const char* e = std::getenv("C2A_EMUL_PASS_LIMIT")) pass_limit = std::strtoull(e, nullptr, 10);
+    for (unsigned i = 0; i < nwaves; ++i) order[i] = i;
+    for (;;) {
+        if (rng) for (unsigned i = nwaves; i > 1; --i) std::swap(order[i - 1], order[next_rand() % i]);
+        bool ran_any = false;
+        for (unsigned oi = 0; oi < nwaves; ++oi) {
+            const unsigned wv = order[oi];
+            if (rng && (next_rand() & 3u) == 0 && ran_any) continue;          // (this wave sits the pass out)
+            const unsigned b = wv / wpb, lo = b * nthreads + (wv % wpb) * 64, hi = std::min(b * nthreads + nthreads, lo + 64);
+            unsigned long long spins = 0;
+            for (;;) {
+                if (++spins == 300000ull) {
+                    std::fprintf(stderr, "hip_emul: block %u never steps aside (a polling loop without a back-off?) kinds:", b);
+                    for (unsigned t = lo; t < hi; ++t) std::fprintf(stderr, " %d", fibers[t].done ? 9 : fibers[t].wait_kind);
+                    std::fprintf(stderr, "\n");
+                    std::abort();
+                }
+                bool progressed = false;
+                for (unsigned t = lo; t < hi; ++t) {
+                    Fiber& f = fibers[t];
+                    if (f.done || f.wait_kind == 1 || f.wait_kind == 3) continue;
+                    f.wait_kind = 0;
+                    s.cur = &f; s.tid = f.tid; s.bid = bids[t];
+                    hipemu_switch(&s.sched_sp, f.sp);
+                    progressed = true; ran_any = true;
+                }
+                bool all_parked = true;
+                for (unsigned t = lo; t < hi; ++t) if (!fibers[t].done && fibers[t].wait_kind != 1 && fibers[t].wait_kind != 3) all_parked = false;
+                if (all_parked) break;
+                if (!progressed) { std::fprintf(stderr, "hip_emul: wave deadlock\n"); std::abort(); }
+            }
+        }
+        // end of a pass: waves that stepped aside may go on; a block barrier opens when every live fiber of the block is at it
+        bool any_alive = false;
+        for (unsigned b = 0; b < nblocks; ++b) {
+            bool at_barrier = true, alive = false;
+            for (unsigned t = b * nthreads; t < (b + 1) * nthreads; ++t) {
+                Fiber& f = fibers[t];
+                if (f.done) continue;
+                alive = true;
+                if (f.wait_kind == 3) f.wait_kind = 0;
+                if (f.wait_kind != 1) at_barrier = false;
+            }
+            if (alive && at_barrier) for (unsigned t = b * nthreads; t < (b + 1) * nthreads; ++t) if (!fibers[t].done) fibers[t].wait_kind = 0;
+            any_alive = any_alive || alive;
+        }
+        if (!any_alive) break;
+        if (++passes == pass_limit) {
+            std::fprintf(stderr, "hip_emul: concurrent launch still alive after %llu passes:", passes);
+            for (unsigned b = 0; b < nblocks; ++b) {
+                unsigned alive = 0;
+                for (unsigned t = b * nthreads; t < (b + 1) * nthreads; ++t) alive += !fibers[t].done;
+                std::fprintf(stderr, " b%u:%u", b, alive);
+            }
+            std::fprintf(stderr, "\n");
+            std::abort();
+        }
+    }
+    s.cur = nullptr;
+}
 // kernels with no intra-block synchronisation: plain loops (fast path)
 template <class K, class... A>
 inline void hipemuLaunchNoSync(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, A... args) {
