@@ -393,9 +393,9 @@ struct StepIO {
     u32 dcnt;                  // lane l < 2: consumers of producer l (0: no such producer)
     u32 gw;                    // lane 8 l + j (l < 2, j < 8): word j of the two gstat records of producer l
     u32 clp;                   // lanes 0..31: producer 0's consumers, 32..63: producer 1's
-    u32 e0, e1, take;          // consumer | label << 31 of the (up to two) records in flight
+    u32 e0, e1, e2, e3, take;  // consumer | label << 31 of the (up to four) records in flight
     u32 more;                  // the consumer list holds candidates beyond those (the step reads the list itself: cold)
-    u64 w0, w1;                // this lane's word of those records
+    u64 w0, w1, w2, w3;        // this lane's word of those records
 };
 
 // the dataflow launch: 64-thread workgroups (one wave each)
@@ -596,6 +596,16 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                 if (smask) {
                     S.e1 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 2;
                     S.w1 = ld_nw(&A.node[(u64)(S.e1 & kIdMask) * kNodeWords + lane]);
+                    // (a third and a fourth: one gate in six has more than two other consumers, and the cold loop below costs it
+                    // two dependent round trips per candidate)
+                    if (smask) {
+                        S.e2 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 3;
+                        S.w2 = ld_nw(&A.node[(u64)(S.e2 & kIdMask) * kNodeWords + lane]);
+                        if (smask) {
+                            S.e3 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 4;
+                            S.w3 = ld_nw(&A.node[(u64)(S.e3 & kIdMask) * kNodeWords + lane]);
+                        }
+                    }
                 }
             }
             S.more = (!in_lanes || smask != 0) ? 1u : 0u;
@@ -619,7 +629,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             C2A_PIN(cur.gw);
             C2A_PIN(cur.clp);
             const ull ph0b = STATS ? c2a_now() : 0;
-            C2A_PIN(cur.w0); C2A_PIN(cur.w1);
+            C2A_PIN(cur.w0); C2A_PIN(cur.w1); C2A_PIN(cur.w2); C2A_PIN(cur.w3);
             if (STATS) { const ull ph0c = c2a_now(); ph_w1 += ph0a - ph0; ph_w2 += ph0b - ph0a; ph_w3 += ph0c - ph0b; }
             // (the next gate's static records are written over gi / gi2 below: what the rest of this step needs of its own)
             const u32 gc = g, g_dep0 = gi.x, g_dep1 = gi.y, g_off = gi.z, g_cnt = gi.w;
@@ -698,7 +708,13 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             // the (up to two) records loaded ahead ...
             if (cur.take >= 1) {
                 candidate(cur.w0, cur.e0);
-                if (cur.take >= 2) candidate(cur.w1, cur.e1);
+                if (cur.take >= 2) {
+                    candidate(cur.w1, cur.e1);
+                    if (cur.take >= 3) {
+                        candidate(cur.w2, cur.e2);
+                        if (cur.take >= 4) candidate(cur.w3, cur.e3);
+                    }
+                }
             }
             // ... then — cold — the consumer list itself, one record at a time, when it holds more than that
             if (cur.more && !gave_up) {
@@ -706,7 +722,8 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                     u32 blk = A.clist[g_off + eb + lane];
                     C2A_PIN(blk);                                // (consumed here, like w below)
                     u64 smask = __ballot(eb + lane < g_cnt && !(own_valid && (blk & kIdMask) == own_node) &&
-                                         !(cur.take >= 1 && blk == cur.e0) && !(cur.take >= 2 && blk == cur.e1));
+                                         !(cur.take >= 1 && blk == cur.e0) && !(cur.take >= 2 && blk == cur.e1) &&
+                                         !(cur.take >= 3 && blk == cur.e2) && !(cur.take >= 4 && blk == cur.e3));
                     while (smask && !gave_up) {
                         const u32 e = rdlane(blk, ctz64(smask));
                         smask &= smask - 1;
