@@ -90,7 +90,7 @@ ABI_VERSION = 3          # == C2A_ABI_VERSION of include/c2a.h this binding was 
 _EXPORTS = ["c2a_abi_version", "c2a_visible_devices", "c2a_create", "c2a_device_count", "c2a_format_bristol", "c2a_destroy", "c2a_last_error", "c2a_version", "c2a_load_gates", "c2a_topo_sort",
             "c2a_topo_sort_serial", "c2a_assign_wires", "c2a_emit_gates", "c2a_build_circuit", "c2a_boolify",
             "c2a_bool_read", "c2a_template_size", "c2a_checksum", "c2a_get_timings", "c2a_get_stats", "c2a_verify_boolify",
-            "c2a_debug_patch_bool_op", "c2a_boolify_plan", "c2a_boolify_chunk"]
+            "c2a_debug_patch_bool_op", "c2a_boolify_plan", "c2a_boolify_chunk", "c2a_boolify_shard_range"]
 
 
 def library_path() -> str:
@@ -146,6 +146,8 @@ def load_library(lib_path: Optional[str] = None):
     L.c2a_boolify_plan.argtypes = [vp, ctypes.c_uint32, ctypes.POINTER(_BoolInfo)]
     L.c2a_boolify_chunk.restype = ctypes.c_int
     L.c2a_boolify_chunk.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64, u32p, u32p, u32p, u8p, u64p, u64p]
+    L.c2a_boolify_shard_range.restype = ctypes.c_int
+    L.c2a_boolify_shard_range.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, u64p, u64p]
     L.c2a_bool_read.restype = ctypes.c_int
     L.c2a_bool_read.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64, u32p, u32p, u32p, u8p]
     L.c2a_template_size.restype = ctypes.c_int
@@ -318,6 +320,12 @@ class Backend:
                                                 _p(in1, ctypes.c_uint32), _p(out, ctypes.c_uint32), _p(op, ctypes.c_uint8),
                                                 ctypes.byref(q0), ctypes.byref(cnt)))
         return q0.value, (in0, in1, out, op)
+
+    def boolify_shard_range(self, k: int, n_shards: int) -> Tuple[int, int]:
+        """Sorted positions (first_gate, n_gates) of shard k of n_shards ranges with equal boolean-gate counts (after a plan)."""
+        first, cnt = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._check(self._lib.c2a_boolify_shard_range(self._ctx, int(k), int(n_shards), ctypes.byref(first), ctypes.byref(cnt)))
+        return first.value, cnt.value
 
     def bool_read(self, first: int = 0, count: Optional[int] = None):
         if count is None:

@@ -157,6 +157,14 @@ int c2a_boolify_chunk(c2a_ctx* ctx, uint64_t first_gate, uint64_t n_gates, uint3
                       uint8_t* op, uint64_t* first_bool_gate, uint64_t* n_bool_gates);
 
 /*
+ * Where to cut: sorted positions [*first_gate, *first_gate + *n_gates) of shard `k` of `n_shards` ranges holding (nearly) equal
+ * numbers of BOOLEAN gates — the bytes a shard writes; equal arithmetic counts would not balance a circuit with clustered
+ * multipliers (T(AMul, 32) = 2 824 boolean gates, T(AXor, 32) = 32).  Needs c2a_boolify_plan / c2a_boolify; this is the cut a
+ * multi-device context makes itself, exported for callers that shard over processes (bench.py --gpus N: one rank per GPU).
+ */
+int c2a_boolify_shard_range(c2a_ctx* ctx, uint32_t k, uint32_t n_shards, uint64_t* first_gate, uint64_t* n_gates);
+
+/*
  * == the gate lines of BristolCircuit::write_bristol (src/main.rs:34-35; crate absent: Bristol-fashion text per SURVEY C.2),
  * printed on the GPU: "2 1 <in0> <in1> <out> <OP>\n", "1 1 <in0> <out> INV\n" for the one-input op.  Gates
  * [first, first + count) of  which = 0: the arithmetic circuit (c2a_emit_gates);  1: the boolean circuit (c2a_boolify,

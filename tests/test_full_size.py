@@ -73,6 +73,29 @@ def test_synthetic_10m_full_size(hip_backend, orc, c2a):
     assert be.checksum("bool_out") == c1
 
 
+def test_synthetic_10m_width_64(hip_backend, orc, c2a):
+    """SURVEY §8(d) "widths 32 and 64": the 10 M-gate graph bit-blasted at --boolify-width 64 (1.5 G boolean gates, 19.5 GB):
+    totals against the template table, three slices bit-exact against the oracle, and every wire of the boolean circuit
+    simulated against the arithmetic one on the GPU."""
+    be = hip_backend
+    fg = c2a.synth.config("synthetic_10m")
+    be.load_gates(fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes)
+    wire_count = be.build_circuit()
+    exp = orc.build_circuit(fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes, mode=1)
+    assert wire_count == exp.wire_count
+    info = be.boolify(64)
+    T = np.array([orc.template_size(o, 64)[0] for o in range(20)], dtype=np.int64)
+    assert info.n_gates == int(T[exp.op].sum())
+    for first in (0, fg.n // 3 + 11, fg.n - 10_000):
+        sl, g0 = orc.boolify_range(exp, 64, first, 10_000)
+        assert sl.wire_count == info.wire_count
+        got = be.bool_read(g0, len(sl.in0))
+        for a, b in zip(got, (sl.in0, sl.in1, sl.out, sl.op)):
+            np.testing.assert_array_equal(a, b)
+    checked, bad = be.verify_boolify(seed=64)
+    assert checked == wire_count * 64 and bad == 0
+
+
 @pytest.mark.parametrize("name,width", [("sha256_standin", 32), ("keccak_standin", 64), ("poseidon2_standin", 32)])
 def test_config_standins_bit_exact(hip_backend, orc, c2a, name, width):
     be = hip_backend

@@ -35,20 +35,20 @@ def _worker(rank, world, port, emul_lib, q):
     fg = _graph(c2a)                                         # shard mode: the SAME graph on every rank
     be = c2a.Backend(0, lib_path=emul_lib)
     be.load_gates(fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes)
-    lo, hi = bench.shard_range(rank, world, fg.n)
     calls = {"warm": 0, "timed": 0}
     got = {}
 
     def warm():
         calls["warm"] += 1
-        bench.shard_step(be, WIDTH, lo, hi)
+        bench.shard_step(be, WIDTH, rank, world)
 
     def step():
         calls["timed"] += 1
-        got["info"], got["chunk"] = bench.shard_step(be, WIDTH, lo, hi, fetch=True)
+        got["info"], got["chunk"], got["range"] = bench.shard_step(be, WIDTH, rank, world, fetch=True)
 
     elapsed = bench.timed_region(warm, step, steps=2, warmup=1, dist=dist, torch=torch, device=None)
     q0, (in0, in1, out, op) = got["chunk"]
+    lo, hi = got["range"][0], got["range"][0] + got["range"][1]
     q.put((rank, elapsed, calls["warm"], calls["timed"], lo, hi, int(q0), in0, in1, out, op, int(got["info"].n_gates),
            int(_graph(c2a, rank).lh.sum())))
     dist.barrier()
@@ -73,7 +73,13 @@ def test_two_ranks_shard_step_equals_the_whole_circuit(emul_lib, orc, c2a):
     (_, e0, w0, t0, lo0, hi0, q00, *a0, g0, s0), (_, e1, w1, t1, lo1, hi1, q01, *a1, g1, s1) = res
     assert (w0, t0, w1, t1) == (1, 2, 1, 2)                  # W untimed + exactly K timed steps on every rank
     assert abs(e0 - e1) < 1e-9                               # both ranks hold the MAX
-    assert (lo0, hi0, lo1, hi1) == (0, fg.n // 2, fg.n // 2, fg.n) and g0 == g1 == len(exp.in0)
+    # the cut: two ranges of sorted positions with (nearly) equal numbers of BOOLEAN gates — the first position whose
+    # boolean offset reaches half of the total (c2a_boolify_shard_range)
+    T = np.array([orc.template_size(o, WIDTH)[0] for o in range(20)], dtype=np.int64)
+    goff = np.concatenate([[0], np.cumsum(T[exp_c.op])])
+    mid = int(np.searchsorted(goff, goff[-1] // 2, side="left"))
+    assert (lo0, hi0, lo1, hi1) == (0, mid, mid, fg.n) and g0 == g1 == len(exp.in0)
+    assert abs(len(a0[0]) - len(a1[0])) <= int(T[exp_c.op].max())
     assert q00 == 0 and q01 == len(a0[0])                    # rank 1 starts where rank 0 ends: no exchange needed to know it
     for k, e in enumerate((exp.in0, exp.in1, exp.out, exp.op)):
         np.testing.assert_array_equal(np.concatenate([a0[k], a1[k]]), e)

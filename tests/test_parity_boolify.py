@@ -170,7 +170,13 @@ def test_chunked_boolify_equals_the_full_result(backend, orc, c2a, width):
 
 MULTI = [pytest.param(("emul", [0, 1]), id="emul-2dev"), pytest.param(("emul", [0, 1, 1]), id="emul-3shards"),
          pytest.param(("hip", [0, 0]), id="hip-2shards", marks=pytest.mark.gpu),
-         pytest.param(("hip", [0, 0, 0, 0, 0]), id="hip-5shards", marks=pytest.mark.gpu)]
+         pytest.param(("hip", [0, 0, 0, 0, 0]), id="hip-5shards", marks=pytest.mark.gpu),
+         # real peers (hipSetDevice switching, cross-device hipMemcpyPeerAsync, per-device allocation): run wherever the box
+         # has that many GPUs, skipped on the 1-GPU test boxes
+         pytest.param(("hip", [0, 1]), id="hip-2gpus", marks=pytest.mark.gpu),
+         pytest.param(("hip", [1, 0, 1]), id="hip-2gpus-3shards", marks=pytest.mark.gpu),
+         pytest.param(("hip", [0, 1, 2, 3]), id="hip-4gpus", marks=pytest.mark.gpu),
+         pytest.param(("hip", list(range(8))), id="hip-8gpus", marks=pytest.mark.gpu)]
 
 
 @pytest.fixture(params=MULTI)
@@ -178,6 +184,8 @@ def multi_backend(request, c2a):
     """A multi-device context (c2a_create(n_devices, device_ids)).  A box with one GPU lists it several
     times: every listed id gets its own stream, buffers and shard, so the peer-copy / shard / gather code runs for real."""
     kind, ids = request.param
+    if kind == "hip" and max(ids) >= c2a.visible_devices():
+        pytest.skip(f"needs {max(ids) + 1} GPUs, this box has {c2a.visible_devices()}")
     be = c2a.Backend(ids, lib_path=request.getfixturevalue("emul_lib")) if kind == "emul" else c2a.Backend(ids)
     yield be
     be.close()
