@@ -594,3 +594,50 @@ def eval_bool(bc: BoolCircuit, wires: np.ndarray) -> np.ndarray:
 def fnv1a(a: np.ndarray, seed: int = 0) -> int:
     a = np.ascontiguousarray(a)
     return int(lib().orc_fnv1a(a.ctypes.data, a.nbytes, seed))
+
+
+# ---------------------------------------------------------------------------------------------
+# artefact writers (src/main.rs:34-35 circuit.txt, :43-44 circuit_info.json) — the checker's own, written per gate, one
+# `Gate{inputs, outputs, op}` at a time (compiler.rs:456-463), so that the product's GPU formatter (c2a_format_bristol) and
+# its host writers are compared with something that is not product code.
+# PARITY UNPINNED: the `bristol-circuit` crate (Cargo.toml:20) is not in the reference tree and no reference test reads
+# the text; the layout is Bristol fashion as SURVEY.md Appendix C.2 recollects it — "{ngates} {nwires}", "{n_in} {widths}",
+# "{n_out} {widths}", a blank line, then "{n_inputs} {n_outputs} {inputs...} {outputs...} {op}" per gate; width 1 per named
+# input / output when io_widths is None (compiler.rs:492).
+# ---------------------------------------------------------------------------------------------
+def bristol_text(gates, wire_count: int, n_in: int, n_out: int, io_widths=None) -> str:
+    """`gates`: iterable of (inputs list, outputs list, op name)."""
+    gates = list(gates)
+    iw, ow = io_widths if io_widths is not None else ([1] * n_in, [1] * n_out)
+    out = [f"{len(gates)} {wire_count}", " ".join(str(v) for v in [len(iw)] + list(iw)),
+           " ".join(str(v) for v in [len(ow)] + list(ow)), ""]
+    for ins, outs, op in gates:
+        out.append(" ".join([str(len(ins)), str(len(outs))] + [str(v) for v in ins] + [str(v) for v in outs] + [op]))
+    return "\n".join(out) + "\n"
+
+
+def bristol_text_of(circ, io_widths=None) -> str:
+    """circuit.txt of a literal BristolCircuit (CompilerModel.build_circuit), an ArithCircuit or a BoolCircuit."""
+    if isinstance(circ, BristolCircuit):
+        gates = (([a, b], [o], op) for a, b, o, op in circ.gates)
+        return bristol_text(gates, circ.wire_count, len(circ.input_name_to_wire_index), len(circ.output_name_to_wire_index),
+                            circ.io_widths)
+    if isinstance(circ, BoolCircuit):
+        def gen():
+            for a, b, o, p in zip(circ.in0.tolist(), circ.in1.tolist(), circ.out.tolist(), circ.op.tolist()):
+                yield ([a] if p == 2 else [a, b]), [o], BOOL_OP_NAMES[p]          # INV has one input
+        return bristol_text(gen(), circ.wire_count, circ.n_in, circ.n_out, ([circ.width] * circ.n_in, [circ.width] * circ.n_out))
+    gates = (([a, b], [o], OP_NAMES[p]) for a, b, o, p in zip(circ.in0.tolist(), circ.in1.tolist(), circ.out.tolist(), circ.op.tolist()))
+    return bristol_text(gates, circ.wire_count, circ.n_in, circ.n_out, io_widths)
+
+
+def circuit_info_json(circ: BristolCircuit, bool_width: Optional[int] = None, bool_wire_of=None) -> str:
+    """circuit_info.json (serde_json::to_string_pretty of CircuitInfo, src/main.rs:43-44; keys sorted: the reference's map
+    order is undefined).  For the boolified circuit pass the wire map of DESIGN.md §5.1 (first bit of each wire)."""
+    import json
+    m = (lambda w: int(bool_wire_of(w))) if bool_wire_of is not None else (lambda w: int(w))
+    return json.dumps({
+        "input_name_to_wire_index": {k: m(v) for k, v in sorted(circ.input_name_to_wire_index.items())},
+        "constants": {k: {"value": c.value, "wire_index": m(c.wire_index)} for k, c in sorted(circ.constants.items())},
+        "output_name_to_wire_index": {k: m(v) for k, v in sorted(circ.output_name_to_wire_index.items())},
+    }, indent=2)

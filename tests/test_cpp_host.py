@@ -101,12 +101,27 @@ def test_cli_gpu_writer_equals_host_writer_and_report_json(kind, tmp_path, reque
             f.write(f"inputs {p}\n")
         for p in fx["output_prefixes"]:
             f.write(f"outputs {p}\n")
+    for p in fx["input_prefixes"]:
+        lit.add_inputs(lit.get_signals("0." + p))
+    for p in fx["output_prefixes"]:
+        lit.add_outputs(lit.get_signals("0." + p))
+    lit_circ = lit.build_circuit()
+    pay = lit.flat_payload()
+    o_arith = orc.build_circuit(pay["lh"], pay["rh"], pay["out"], pay["op"], pay["n_nodes"], pay["input_nodes"], pay["output_nodes"], mode=0)
+    o_bool = orc.boolify(o_arith, 5)
+    # what both writers of the CLI must produce: the checker's own per-gate writer over the literal build_circuit / the oracle's bit-blast
+    want = {0: (orc.bristol_text_of(lit_circ).encode(), orc.circuit_info_json(lit_circ).encode()),
+            5: (orc.bristol_text_of(o_bool).encode(),
+                orc.circuit_info_json(lit_circ, 5, lambda w: orc.bool_wire(o_arith, o_bool.wire_count - o_arith.wire_count * 5, 5, w)).encode())}
     for extra in ([], ["--boolify-width", "5"]):
         a, b = tmp_path / "gpu", tmp_path / "host"
         subprocess.check_call([exes["cli"], "-i", str(calls), "-o", str(a)] + extra, timeout=600)
         subprocess.check_call([exes["cli"], "-i", str(calls), "-o", str(b), "--host-writer"] + extra, timeout=600)
         assert (a / "circuit.txt").read_bytes() == (b / "circuit.txt").read_bytes()
         assert (a / "circuit_info.json").read_bytes() == (b / "circuit_info.json").read_bytes()
+        text, info = want[5 if extra else 0]
+        assert (a / "circuit.txt").read_bytes() == text
+        assert (a / "circuit_info.json").read_bytes().rstrip(b"\n") == info
     rep = json.loads((a / "report.json").read_text())
     assert rep == lit.generate_circuit_report("sint")
     assert (a / "report.json").read_text() == json.dumps(lit.generate_circuit_report("sint"), indent=2)   # serde pretty layout

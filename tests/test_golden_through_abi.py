@@ -153,18 +153,29 @@ def test_gpu_bristol_writer_and_report(backend, orc, name):
         else:
             C.add_connection(st[1], st[2]); lit.add_connection(st[1], st[2])
     for p in fx["input_prefixes"]:
-        C.add_inputs(C.get_signals("0." + p))
+        C.add_inputs(C.get_signals("0." + p)); lit.add_inputs(lit.get_signals("0." + p))
     for p in fx["output_prefixes"]:
-        C.add_outputs(C.get_signals("0." + p))
+        C.add_outputs(C.get_signals("0." + p)); lit.add_outputs(lit.get_signals("0." + p))
     assert C.generate_circuit_report() == lit.generate_circuit_report()
     circ = C.build_circuit()
     host = io.BytesIO(); circ.write_bristol(host)
+    # the checker's own writer over the LITERAL build_circuit (dict-based restatement of compiler.rs:321-494, one Gate at a
+    # time): the GPU formatter and the host writer must both reproduce it byte for byte — and circuit_info.json likewise
+    lit_circ = lit.build_circuit()
+    assert host.getvalue() == orc.bristol_text_of(lit_circ).encode()
+    assert circ.info_json() == orc.circuit_info_json(lit_circ)
     for chunk in (1 << 24, 3, 1):
         gpu = io.BytesIO()
         nbytes = circ.write_bristol_gpu(gpu, backend, chunk_gates=chunk)
-        assert gpu.getvalue() == host.getvalue() and nbytes == len(host.getvalue())
+        assert gpu.getvalue() == orc.bristol_text_of(lit_circ).encode() and nbytes == len(host.getvalue())
     full = C.boolify(circ, 7)
     host = io.BytesIO(); full.write_bristol(host)
+    # boolean circuit: the oracle's bit-blast of the oracle's arithmetic circuit, printed by the oracle's writer
+    pay = lit.flat_payload()
+    o_arith = orc.build_circuit(pay["lh"], pay["rh"], pay["out"], pay["op"], pay["n_nodes"], pay["input_nodes"], pay["output_nodes"], mode=0)
+    o_bool = orc.boolify(o_arith, 7)
+    assert host.getvalue() == orc.bristol_text_of(o_bool).encode()
+    assert full.info_json() == orc.circuit_info_json(lit_circ, 7, lambda w: orc.bool_wire(o_arith, o_bool.wire_count - o_arith.wire_count * 7, 7, w))
     circ = C.build_circuit()
     lazy = C.boolify(circ, 7, fetch=False)                 # SoA stays in HBM: only the GPU writer can print it
     gpu = io.BytesIO(); lazy.write_bristol_gpu(gpu, backend, chunk_gates=1000)
