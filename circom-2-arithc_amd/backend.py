@@ -90,7 +90,7 @@ ABI_VERSION = 3          # == C2A_ABI_VERSION of include/c2a.h this binding was 
 _EXPORTS = ["c2a_abi_version", "c2a_visible_devices", "c2a_create", "c2a_device_count", "c2a_format_bristol", "c2a_destroy", "c2a_last_error", "c2a_version", "c2a_load_gates", "c2a_topo_sort",
             "c2a_topo_sort_serial", "c2a_assign_wires", "c2a_emit_gates", "c2a_build_circuit", "c2a_boolify",
             "c2a_bool_read", "c2a_template_size", "c2a_checksum", "c2a_get_timings", "c2a_get_stats", "c2a_verify_boolify",
-            "c2a_debug_patch_bool_op", "c2a_boolify_plan", "c2a_boolify_chunk", "c2a_boolify_shard_range"]
+            "c2a_debug_patch_bool_op", "c2a_boolify_plan", "c2a_boolify_chunk", "c2a_boolify_shard_range", "c2a_eval"]
 
 
 def library_path() -> str:
@@ -156,6 +156,8 @@ def load_library(lib_path: Optional[str] = None):
     L.c2a_checksum.argtypes = [vp, ctypes.c_int, u64p]
     L.c2a_verify_boolify.restype = ctypes.c_int
     L.c2a_verify_boolify.argtypes = [vp, ctypes.c_uint64, u64p, u64p]
+    L.c2a_eval.restype = ctypes.c_int
+    L.c2a_eval.argtypes = [vp, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, u64p, ctypes.c_uint32, u32p, u64p, u64p]
     L.c2a_debug_patch_bool_op.restype = ctypes.c_int
     L.c2a_debug_patch_bool_op.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint8]
     L.c2a_get_timings.restype = ctypes.c_int
@@ -202,6 +204,7 @@ class Backend:
                                "(this back end has no CPU fallback)")
         self.n = 0
         self.n_nodes = 0
+        self._n_in = self._n_out = 0
         self.wire_count = None
 
     # -- lifecycle -----------------------------------------------------------------------------
@@ -249,6 +252,7 @@ class Backend:
                                       _p(inn, ctypes.c_uint32), len(outn), _p(outn, ctypes.c_uint32))
         self._check(rc)
         self.n, self.n_nodes = len(lh), int(n_nodes)
+        self._n_in, self._n_out = len(inn), len(outn)
         self.wire_count = None
 
     def topo_sort(self, fetch: bool = True, serial: bool = False) -> Optional[np.ndarray]:
@@ -365,6 +369,25 @@ class Backend:
         chk, bad = ctypes.c_uint64(0), ctypes.c_uint64(0)
         self._check(self._lib.c2a_verify_boolify(self._ctx, int(seed), ctypes.byref(chk), ctypes.byref(bad)))
         return chk.value, bad.value
+
+    def eval(self, inputs, constants=None, width: int = 32, boolean: bool = False) -> np.ndarray:
+        """Run the circuit on caller-supplied values on the GPU (c2a_eval: the reference's simulation harness,
+        tests/integration.rs:191-237).  inputs: array [n_in] or [n_in, T] (T <= 64 vectors), in the order of load_gates'
+        input list; constants: {arithmetic wire: value}; returns [n_out, T] uint64.  boolean=True evaluates the circuit of
+        boolify() (same values in, same values out: bit-slicing happens on the device)."""
+        a = np.ascontiguousarray(np.asarray(inputs, dtype=np.uint64))
+        if a.ndim == 1:
+            a = a.reshape(-1, 1)
+        T = a.shape[1] if a.size else 1
+        cst = constants or {}
+        cw = np.ascontiguousarray(np.fromiter(cst.keys(), dtype=np.uint32, count=len(cst)))
+        cv = np.ascontiguousarray(np.fromiter((int(v) & 0xFFFFFFFFFFFFFFFF for v in cst.values()), dtype=np.uint64, count=len(cst)))
+        n_out = ctypes.c_uint32(0)
+        out = np.zeros((self._n_out, T), dtype=np.uint64)
+        self._check(self._lib.c2a_eval(self._ctx, 1 if boolean else 0, int(width), int(T), _p(a, ctypes.c_uint64) if a.size else None,
+                                       len(cst), _p(cw, ctypes.c_uint32) if len(cst) else None,
+                                       _p(cv, ctypes.c_uint64) if len(cst) else None, _p(out, ctypes.c_uint64) if out.size else None))
+        return out
 
     def debug_patch_bool_op(self, index: int, new_op: int):
         """Fault injection for the verifier's tests."""

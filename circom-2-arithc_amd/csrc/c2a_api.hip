@@ -92,7 +92,7 @@ struct c2a_ctx {
     DevBuf fmt_len, fmt_off, fmt_text, fmt_table, shard_cut, shard_qcut;
     u64 fmt_chunk_first = 0, fmt_chunk_cnt = 0;      // boolean gates held by the chunk buffers (c2a_boolify_chunk)
     bool fmt_chunk_valid = false;                    // ... of the circuit and plan now current (reset wherever the plan is)
-    DevBuf ev_produced, ev_spos, ev_aval, ev_bval, ev_lcount, ev_lbase, ev_lorder, cb_in0, cb_in1, cb_out, cb_op;
+    DevBuf ev_produced, ev_spos, ev_aval, ev_bval, ev_lcount, ev_lbase, ev_lorder, ev_bar, ev_io, cb_in0, cb_in1, cb_out, cb_op;
     bool bool_planned = false;
     std::vector<DevBuf*> all;
 
@@ -101,7 +101,7 @@ struct c2a_ctx {
                &gstat, &clist, &pctl, &pcold, &meta, &node, &child, &rflag, &ridx, &rlist, &next,
                &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
                &node_wire, &e_in0, &e_in1, &e_out, &e_op, &gs, &wcnt, &wfo, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &mb, &mb_seq, &mb_rd, &tsz, &asz, &goff,
-               &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &fmt_len, &fmt_off, &fmt_text, &fmt_table, &shard_cut, &shard_qcut, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &ev_lcount, &ev_lbase, &ev_lorder, &cb_in0, &cb_in1, &cb_out, &cb_op};
+               &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &fmt_len, &fmt_off, &fmt_text, &fmt_table, &shard_cut, &shard_qcut, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &ev_lcount, &ev_lbase, &ev_lorder, &ev_bar, &ev_io, &cb_in0, &cb_in1, &cb_out, &cb_op};
     }
 };
 
@@ -1260,6 +1260,50 @@ int c2a_checksum(c2a_ctx* c, int which, uint64_t* value) {
     return C2A_OK;
 }
 
+// level lists of the loaded circuit (gates of one reverse Kahn level are independent; producers sit in higher levels than
+// their consumers), the inverse of the sorted order, and the evaluation launch itself
+static int eval_levels(c2a_ctx* c) {
+    hipStream_t s = c->stream;
+    const u32 n = c->n, L = c->stats.levels;
+    ENSURE(c->ev_spos, (size_t)n * 4);
+    ENSURE(c->ev_lcount, ((size_t)L + 1) * 4); ENSURE(c->ev_lbase, ((size_t)L + 2) * 4); ENSURE(c->ev_lorder, (size_t)n * 4);
+    if (!n) return C2A_OK;
+    C2A_LAUNCH_NOSYNC(k_eval_inverse, grid_for(n, 4096), kThreads, s, n, c->sorted.as<u32>(), c->ev_spos.as<u32>());
+    HIP_TRY(hipMemsetAsync(c->ev_lcount.p, 0, ((size_t)L + 1) * 4, s));
+    C2A_LAUNCH_NOSYNC(k_level_hist, grid_for(n, 4096), kThreads, s, n, (const uint4*)c->meta.as<uint4>(), c->ev_lcount.as<u32>());
+    int r = scan_exclusive<u32>(c, c->ev_lcount.as<u32>(), c->ev_lbase.as<u32>(), L);
+    if (r) return r;
+    HIP_TRY(hipMemsetAsync(c->ev_lcount.p, 0, ((size_t)L + 1) * 4, s));
+    C2A_LAUNCH_NOSYNC(k_level_scatter, grid_for(n, 4096), kThreads, s, n, (const uint4*)c->meta.as<uint4>(),
+                      (const u32*)c->ev_lbase.as<u32>(), c->ev_lcount.as<u32>(), c->ev_lorder.as<u32>());
+    return C2A_OK;
+}
+
+static int eval_run(c2a_ctx* c, u32 mode, u32 width) {
+    hipStream_t s = c->stream;
+    if (!c->n) return C2A_OK;
+    EvalRun R;
+    R.levels = c->stats.levels; R.width = width; R.mode = mode;
+    R.lbase = c->ev_lbase.as<u32>(); R.order = c->ev_lorder.as<u32>(); R.spos = c->ev_spos.as<u32>();
+    R.e_in0 = c->e_in0.as<u32>(); R.e_in1 = c->e_in1.as<u32>(); R.e_out = c->e_out.as<u32>(); R.e_op = c->e_op.as<u8>();
+    R.goff = c->goff.as<u64>(); R.b_in0 = c->b_in0.as<u32>(); R.b_in1 = c->b_in1.as<u32>(); R.b_out = c->b_out.as<u32>(); R.b_op = c->b_op.as<u8>();
+    R.aval = c->ev_aval.as<u64>(); R.bval = c->ev_bval.as<u64>();
+    ENSURE(c->ev_bar, 64);
+    HIP_TRY(hipMemsetAsync(c->ev_bar.p, 0, 64, s));
+    R.bar = c->ev_bar.as<u32>();
+    // every workgroup waits for every other at the end of a level: the grid must be resident as a whole
+    u32 grid = 8;
+#ifndef C2A_EMULATE
+    {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_eval_run, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        grid = (u32)c->n_cu * (u32)std::min(per_cu, 4);
+    }
+#endif
+    C2A_LAUNCH_CONCURRENT(k_eval_run, grid, kThreads, s, R);
+    return C2A_OK;
+}
+
 int c2a_verify_boolify(c2a_ctx* c, uint64_t seed, uint64_t* n_checked, uint64_t* n_mismatch) {
     if (!c) return C2A_ERR_ARG;
     if (c->stage < ST_BOOLIFIED) return fail(c, C2A_ERR_STATE, "c2a_verify_boolify: call c2a_boolify first");
@@ -1270,45 +1314,18 @@ int c2a_verify_boolify(c2a_ctx* c, uint64_t seed, uint64_t* n_checked, uint64_t*
     const u32 n = c->n, wc = c->wire_count, width = c->binfo.width, M = c->binfo.m_wires;
     const u64 out_base = (u64)M * width + c->binfo.aux_total;
     ENSURE(c->ev_produced, wc);
-    ENSURE(c->ev_spos, (size_t)n * 4);
     ENSURE(c->ev_aval, (size_t)wc * 64 * 8);
     ENSURE(c->ev_bval, (size_t)c->binfo.wire_count * 8);
     HIP_TRY(hipMemsetAsync(c->ev_produced.p, 0, wc, s));
     ull* acc = reinterpret_cast<ull*>(c->scalars.as<u32>() + SC_TOTAL64);
     HIP_TRY(hipMemsetAsync(acc, 0, 8, s));
-    if (n) {
-        C2A_LAUNCH_NOSYNC(k_eval_mark_produced, grid_for(n, 4096), kThreads, s, n, c->e_out.as<u32>(), c->ev_produced.as<u8>());
-        C2A_LAUNCH_NOSYNC(k_eval_inverse, grid_for(n, 4096), kThreads, s, n, c->sorted.as<u32>(), c->ev_spos.as<u32>());
-    }
+    if (n) C2A_LAUNCH_NOSYNC(k_eval_mark_produced, grid_for(n, 4096), kThreads, s, n, c->e_out.as<u32>(), c->ev_produced.as<u8>());
     if (wc)
         C2A_LAUNCH_NOSYNC(k_eval_init, grid_for((u64)wc * 64, 8192), kThreads, s, wc, width, M, out_base, (u64)seed,
                           (const u8*)c->ev_produced.as<u8>(), c->ev_aval.as<u64>(), c->ev_bval.as<u64>());
-    // level lists (gates of one reverse Kahn level are independent), last level first: producers before consumers
-    const u32 L = c->stats.levels;
-    std::vector<u32> fb((size_t)L + 1, 0);
-    if (n) {
-        ENSURE(c->ev_lcount, ((size_t)L + 1) * 4); ENSURE(c->ev_lbase, ((size_t)L + 2) * 4); ENSURE(c->ev_lorder, (size_t)n * 4);
-        HIP_TRY(hipMemsetAsync(c->ev_lcount.p, 0, ((size_t)L + 1) * 4, s));
-        C2A_LAUNCH_NOSYNC(k_level_hist, grid_for(n, 4096), kThreads, s, n, (const uint4*)c->meta.as<uint4>(), c->ev_lcount.as<u32>());
-        int r = scan_exclusive<u32>(c, c->ev_lcount.as<u32>(), c->ev_lbase.as<u32>(), L);
-        if (r) return r;
-        HIP_TRY(hipMemsetAsync(c->ev_lcount.p, 0, ((size_t)L + 1) * 4, s));
-        C2A_LAUNCH_NOSYNC(k_level_scatter, grid_for(n, 4096), kThreads, s, n, (const uint4*)c->meta.as<uint4>(),
-                          (const u32*)c->ev_lbase.as<u32>(), c->ev_lcount.as<u32>(), c->ev_lorder.as<u32>());
-        HIP_TRY(hipMemcpyAsync(fb.data(), c->ev_lbase.p, ((size_t)L + 1) * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-    }
-    for (u32 lv = L; n && lv-- > 0;) {
-        const u32 lo = fb[lv], hi = fb[lv + 1];
-        if (hi <= lo || hi > n) continue;
-        const u32 cnt = hi - lo;
-        C2A_LAUNCH_NOSYNC(k_eval_level_arith, grid_for((u64)cnt * 64, 4096), kThreads, s, lo, cnt, width, c->ev_lorder.as<u32>(),
-                          c->ev_spos.as<u32>(), c->e_in0.as<u32>(), c->e_in1.as<u32>(), c->e_out.as<u32>(), c->e_op.as<u8>(),
-                          c->ev_aval.as<u64>());
-        C2A_LAUNCH_NOSYNC(k_eval_level_bool, grid_for(cnt, 4096), kThreads, s, lo, cnt, c->ev_lorder.as<u32>(), c->ev_spos.as<u32>(),
-                          (const u64*)c->goff.as<u64>(), c->b_in0.as<u32>(), c->b_in1.as<u32>(), c->b_out.as<u32>(),
-                          c->b_op.as<u8>(), c->ev_bval.as<u64>());
-    }
+    int r = eval_levels(c);
+    if (r) return r;
+    if ((r = eval_run(c, 3u, width))) return r;
     if (wc)
         C2A_LAUNCH_NOSYNC(k_eval_compare, grid_for((u64)wc * 64, 8192), kThreads, s, wc, width, M, out_base,
                           (const u64*)c->ev_aval.as<u64>(), (const u64*)c->ev_bval.as<u64>(), acc);
@@ -1317,6 +1334,60 @@ int c2a_verify_boolify(c2a_ctx* c, uint64_t seed, uint64_t* n_checked, uint64_t*
     HIP_TRY(hipStreamSynchronize(s));
     if (n_checked) *n_checked = (u64)wc * 64;
     if (n_mismatch) *n_mismatch = bad;
+    return C2A_OK;
+}
+
+int c2a_eval(c2a_ctx* c, int which, uint32_t width, uint32_t n_vectors, const uint64_t* inputs, uint32_t n_const,
+             const uint32_t* const_wires, const uint64_t* const_values, uint64_t* outputs) {
+    if (!c) return C2A_ERR_ARG;
+    if (which != 0 && which != 1) return fail(c, C2A_ERR_ARG, "c2a_eval: which must be 0 (arithmetic circuit) or 1 (boolean circuit)");
+    if (n_vectors == 0 || n_vectors > 64) return fail(c, C2A_ERR_ARG, "c2a_eval: 1..64 vectors per call");
+    if (c->stage < (which ? ST_BOOLIFIED : ST_EMITTED)) return fail(c, C2A_ERR_STATE, which ? "c2a_eval: call c2a_boolify first" : "c2a_eval: call c2a_emit_gates / c2a_build_circuit first");
+    if (which && !c->peers.empty()) return fail(c, C2A_ERR_STATE, "c2a_eval: the boolean circuit is spread over several devices (single-device context needed)");
+    if (!c->peel_meta_valid) return fail(c, C2A_ERR_STATE, "c2a_eval: needs the level data of c2a_topo_sort (not of c2a_topo_sort_serial)");
+    if (which) width = c->binfo.width;
+    if (width == 0 || width > 64) return fail(c, C2A_ERR_ARG, "c2a_eval: width must be in 1..64");
+    if ((c->n_in && !inputs) || (c->n_out && !outputs) || (n_const && (!const_wires || !const_values))) return fail(c, C2A_ERR_ARG, "c2a_eval: null value arrays");
+    const u32 wc = c->wire_count;
+    for (u32 i = 0; i < n_const; ++i)
+        if (const_wires[i] >= wc) return fail(c, C2A_ERR_ARG, "c2a_eval: constant wire id out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const u32 M = wc - c->n_out;
+    const u64 out_base = which ? (u64)c->binfo.m_wires * width + c->binfo.aux_total : 0;
+    const size_t in_words = (size_t)c->n_in * n_vectors, out_words = (size_t)c->n_out * n_vectors, cst_words = (size_t)n_const * n_vectors;
+    ENSURE(c->ev_io, (in_words + out_words + cst_words) * 8 + (size_t)n_const * 4 + 64);
+    u64* d_in = c->ev_io.as<u64>(); u64* d_out = d_in + in_words; u64* d_cv = d_out + out_words; u32* d_cw = reinterpret_cast<u32*>(d_cv + cst_words);
+    if (in_words) HIP_TRY(hipMemcpyAsync(d_in, inputs, in_words * 8, hipMemcpyHostToDevice, s));
+    std::vector<u64> cv(cst_words);                      // a constant holds its value in every vector
+    for (u32 i = 0; i < n_const; ++i) for (u32 t = 0; t < n_vectors; ++t) cv[(size_t)i * n_vectors + t] = const_values[i];
+    if (n_const) {
+        HIP_TRY(hipMemcpyAsync(d_cv, cv.data(), cst_words * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_cw, const_wires, (size_t)n_const * 4, hipMemcpyHostToDevice, s));
+    }
+    // every wire starts at 0 (a wire nothing drives stays 0), then the inputs and the constants
+    if (which) {
+        ENSURE(c->ev_bval, (size_t)c->binfo.wire_count * 8);
+        HIP_TRY(hipMemsetAsync(c->ev_bval.p, 0, (size_t)c->binfo.wire_count * 8, s));
+        if (c->n_in) C2A_LAUNCH_NOSYNC(k_eval_set_bool, grid_for((u64)c->n_in * width, 4096), kThreads, s, c->n_in, n_vectors, width, c->binfo.m_wires, out_base,
+                                       (const u32*)nullptr, (const u64*)d_in, c->ev_bval.as<u64>());
+        if (n_const) C2A_LAUNCH_NOSYNC(k_eval_set_bool, grid_for((u64)n_const * width, 4096), kThreads, s, n_const, n_vectors, width, c->binfo.m_wires, out_base,
+                                       (const u32*)d_cw, (const u64*)d_cv, c->ev_bval.as<u64>());
+    } else {
+        ENSURE(c->ev_aval, (size_t)wc * 64 * 8);
+        HIP_TRY(hipMemsetAsync(c->ev_aval.p, 0, (size_t)wc * 64 * 8, s));
+        if (c->n_in) C2A_LAUNCH_NOSYNC(k_eval_set_arith, grid_for(in_words, 4096), kThreads, s, c->n_in, n_vectors, width, (const u32*)nullptr, (const u64*)d_in, c->ev_aval.as<u64>());
+        if (n_const) C2A_LAUNCH_NOSYNC(k_eval_set_arith, grid_for(cst_words, 4096), kThreads, s, n_const, n_vectors, width, (const u32*)d_cw, (const u64*)d_cv, c->ev_aval.as<u64>());
+    }
+    int r = eval_levels(c);
+    if (r) return r;
+    if ((r = eval_run(c, which ? 2u : 1u, width))) return r;
+    if (c->n_out) {
+        C2A_LAUNCH_NOSYNC(k_eval_get, grid_for(out_words, 4096), kThreads, s, c->n_out, n_vectors, width, M, c->binfo.m_wires, out_base, which,
+                          (const u64*)c->ev_aval.as<u64>(), (const u64*)c->ev_bval.as<u64>(), d_out);
+        HIP_TRY(hipMemcpyAsync(outputs, d_out, out_words * 8, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
     return C2A_OK;
 }
 

@@ -719,6 +719,87 @@ __global__ void k_level_scatter(u32 n, const uint4* __restrict__ meta, const u32
     }
 }
 
+// ---- the whole evaluation as ONE launch: a grid-wide barrier between reverse Kahn levels instead of two launches per level
+// (10 000 launches for the 10 M-gate graph).  The values of a level are read by other workgroups — other XCDs, whose L2s
+// are not coherent with each other — in the next one, so values go through agent-scope accesses (the launch boundary used
+// to do that) and the barrier is a fence + a counter every workgroup bumps once per level.
+struct EvalRun {
+    u32 levels, width, mode;           // mode bit 0: the arithmetic circuit, bit 1: its boolean image
+    const u32* lbase; const u32* order; const u32* spos;
+    const u32* e_in0; const u32* e_in1; const u32* e_out; const u8* e_op;
+    const u64* goff; const u32* b_in0; const u32* b_in1; const u32* b_out; const u8* b_op;
+    u64* aval; u64* bval;
+    u32* bar;                          // barrier counter (zeroed before the launch)
+};
+__device__ __forceinline__ u64 ev_ld(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ev_st(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__global__ void __launch_bounds__(kThreads) k_eval_run(EvalRun R) {
+    const u64 mk = R.width >= 64 ? ~0ull : ((1ull << R.width) - 1ull);
+    u32 target = 0;
+    for (u32 lv = R.levels; lv-- > 0;) {
+        const u32 lo = R.lbase[lv], cnt = R.lbase[lv + 1] - lo;
+        if (R.mode & 1u)
+            for (u64 i = gtid(); i < (u64)cnt * 64; i += gstride()) {
+                const u32 p = R.spos[R.order[lo + (u32)(i >> 6)]], t = (u32)(i & 63);
+                ev_st(&R.aval[(u64)R.e_out[p] * 64 + t],
+                      eval_arith_op(R.e_op[p], ev_ld(&R.aval[(u64)R.e_in0[p] * 64 + t]), ev_ld(&R.aval[(u64)R.e_in1[p] * 64 + t]), R.width, mk));
+            }
+        if (R.mode & 2u)
+            for (u64 i = gtid(); i < cnt; i += gstride()) {
+                const u32 p = R.spos[R.order[lo + (u32)i]];
+                for (u64 k = R.goff[p]; k < R.goff[p + 1]; ++k) {        // (a gate's template reads wires the same lane wrote: program order)
+                    const u64 a = ev_ld(&R.bval[R.b_in0[k]]), b = ev_ld(&R.bval[R.b_in1[k]]);
+                    const u32 o = R.b_op[k];
+                    ev_st(&R.bval[R.b_out[k]], o == 0 ? (a ^ b) : (o == 1 ? (a & b) : ~a));
+                }
+            }
+        if (lv == 0) break;
+        // ---- every workgroup has finished the level before any starts the next
+        __threadfence();
+        __syncthreads();
+        target += gridDim.x;
+        if (threadIdx.x == 0) {
+            atomicAdd(R.bar, 1u);
+            while (__hip_atomic_load(R.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) peel_sleep(2);
+        }
+        __syncthreads();
+        __threadfence();
+    }
+}
+
+// caller-supplied values: inputs[i][t] for input wire i (wires 0 .. n_in-1, compiler.rs:388-395), vector t < n_vectors
+__global__ void k_eval_set_arith(u32 n_wires, u32 n_vectors, u32 width, const u32* __restrict__ wires, const u64* __restrict__ vals, u64* aval) {
+    const u64 mk = width >= 64 ? ~0ull : ((1ull << width) - 1ull);
+    for (u64 i = gtid(); i < (u64)n_wires * n_vectors; i += gstride()) {
+        const u32 k = (u32)(i / n_vectors), t = (u32)(i - (u64)k * n_vectors);
+        const u32 W = wires ? wires[k] : k;
+        aval[(u64)W * 64 + t] = vals[i] & mk;
+    }
+}
+// ... and their boolean image: bit b of the value of arithmetic wire W in vector t is bit t of boolean wire (W, b)
+__global__ void k_eval_set_bool(u32 n_wires, u32 n_vectors, u32 width, u32 M, u64 out_base, const u32* __restrict__ wires,
+                                const u64* __restrict__ vals, u64* bval) {
+    for (u64 i = gtid(); i < (u64)n_wires * width; i += gstride()) {
+        const u32 k = (u32)(i / width), bit = (u32)(i - (u64)k * width);
+        const u32 W = wires ? wires[k] : k;
+        u64 word = 0;
+        for (u32 t = 0; t < n_vectors; ++t) word |= ((vals[(u64)k * n_vectors + t] >> bit) & 1ull) << t;
+        bval[bool_wire(W, bit, width, M, out_base)] = word;
+    }
+}
+// the named outputs: the last n_out arithmetic wires (compiler.rs:445-449), as values
+__global__ void k_eval_get(u32 n_out, u32 n_vectors, u32 width, u32 first_wire, u32 M, u64 out_base, int boolean,
+                           const u64* __restrict__ aval, const u64* __restrict__ bval, u64* vals) {
+    for (u64 i = gtid(); i < (u64)n_out * n_vectors; i += gstride()) {
+        const u32 j = (u32)(i / n_vectors), t = (u32)(i - (u64)j * n_vectors);
+        const u32 W = first_wire + j;
+        u64 v = 0;
+        if (boolean) for (u32 bit = 0; bit < width; ++bit) v |= ((bval[bool_wire(W, bit, width, M, out_base)] >> t) & 1ull) << bit;
+        else v = aval[(u64)W * 64 + t];
+        vals[i] = v;
+    }
+}
+
 __global__ void k_eval_level_arith(u32 lo, u32 cnt, u32 width, const u32* __restrict__ order, const u32* __restrict__ spos,
                                    const u32* __restrict__ e_in0, const u32* __restrict__ e_in1, const u32* __restrict__ e_out,
                                    const u8* __restrict__ e_op, u64* aval) {

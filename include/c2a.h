@@ -189,6 +189,17 @@ int c2a_checksum(c2a_ctx* ctx, int which, uint64_t* value);
  * Needs ~8 B per (arithmetic wire x 64) + 8 B per boolean wire of scratch HBM; requires c2a_boolify.
  */
 int c2a_verify_boolify(c2a_ctx* ctx, uint64_t seed, uint64_t* n_checked, uint64_t* n_mismatch);
+/*
+ * == the reference's simulation harness with CALLER-SUPPLIED values (tests/integration.rs:191-237: named inputs in, named
+ * outputs out), level-parallel on the GPU.  which = 0: the arithmetic circuit of c2a_build_circuit, evaluated mod 2^width
+ * (tests/integration.rs:94-115 where that is defined, DESIGN.md §5.2 elsewhere);  1: the boolean circuit of c2a_boolify
+ * (width is the boolify width; the values are bit-sliced onto the boolean wires and read back from them).
+ * inputs[i * n_vectors + t]: value of input wire i (wires 0 .. n_in-1 in the order of c2a_load_gates' input list) in vector
+ * t;  n_const constants given as (ARITHMETIC wire id, value) — the host knows them from its name tables (ConstantInfo);
+ * outputs[j * n_vectors + t]: value of output j (the last n_out wires).  1 <= n_vectors <= 64.  Wires nothing drives are 0.
+ */
+int c2a_eval(c2a_ctx* ctx, int which, uint32_t width, uint32_t n_vectors, const uint64_t* inputs, uint32_t n_const,
+             const uint32_t* const_wires, const uint64_t* const_values, uint64_t* outputs);
 /* Fault injection for the tests of the verifier: overwrite the op of one boolean gate in HBM. */
 int c2a_debug_patch_bool_op(c2a_ctx* ctx, uint64_t index, uint8_t new_op);
 

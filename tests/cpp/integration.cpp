@@ -46,6 +46,19 @@ static std::map<std::string, uint32_t> run(const BristolCircuit& c, const std::m
     return out;
 }
 
+// the same harness on the GPU: c2a_eval on the circuit the back end still holds (named inputs in, named outputs out)
+static std::map<std::string, uint32_t> run_gpu(Backend& be, const BristolCircuit& c, const std::map<std::string, uint32_t>& inputs, bool boolean) {
+    const size_t n_in = c.info.input_name_to_wire_index.size(), n_out = c.info.output_name_to_wire_index.size();
+    std::vector<uint64_t> in(n_in, 0), out(n_out, 0), cv;
+    std::vector<uint32_t> cw;
+    for (auto& kv : inputs) in[c.info.input_name_to_wire_index.at(kv.first)] = kv.second;
+    for (auto& kv : c.info.constants) { cw.push_back((uint32_t)kv.second.wire_index); cv.push_back(std::stoull(kv.second.value)); }
+    be.check(c2a_eval(be.get(), boolean ? 1 : 0, 32, 1, in.data(), (uint32_t)cw.size(), cw.data(), cv.data(), out.data()));
+    std::map<std::string, uint32_t> r;
+    for (auto& kv : c.info.output_name_to_wire_index) r[kv.first] = (uint32_t)out[kv.second - (c.wire_count - n_out)];
+    return r;
+}
+
 // `out_k <== x_a op x_b`: random signal, gate, connection (process.rs:466-475, :266-269)
 static void binop(Compiler& ac, uint32_t& next_sid, AGateType op, uint32_t a, uint32_t b, uint32_t out_sid) {
     const uint32_t r = next_sid++;
@@ -62,6 +75,11 @@ static void simulation_test(const char* name, Backend& be, const std::function<v
     const BristolCircuit circuit = compiler.build_circuit();
     const auto outputs = run(circuit, inputs);
     for (auto& kv : expected) { CHECK(outputs.count(kv.first) == 1); CHECK(outputs.at(kv.first) == kv.second); }
+    const auto gpu = run_gpu(be, circuit, inputs, false);
+    for (auto& kv : expected) { CHECK(gpu.count(kv.first) == 1); CHECK(gpu.at(kv.first) == kv.second); }
+    boolify(compiler, circuit, 32);                         // --boolify-width 32: the boolean circuit gives the same answers
+    const auto gpu_b = run_gpu(be, circuit, inputs, true);
+    for (auto& kv : expected) { CHECK(gpu_b.count(kv.first) == 1); CHECK(gpu_b.at(kv.first) == kv.second); }
 }
 
 int main() {

@@ -29,6 +29,21 @@ def _compiler(fx, backend):
     return c
 
 
+def _gpu_io(circuit, be, inputs_by_name, expect_by_name, boolean=False, width=32):
+    """One IO case of the reference's harness (tests/integration.rs:191-237) through c2a_eval: named inputs in, named outputs out."""
+    n_in = len(circuit.info.input_name_to_wire_index)
+    n_out = len(circuit.info.output_name_to_wire_index)
+    vals = np.zeros(n_in, dtype=np.uint64)
+    for k, w in circuit.info.input_name_to_wire_index.items():
+        vals[w] = inputs_by_name.get(k, 0)
+    cst = {c.wire_index: int(c.value) for c in circuit.info.constants.values()}
+    out = be.eval(vals, cst, width=width, boolean=boolean)
+    assert out.shape == (n_out, 1)
+    for k, v in expect_by_name.items():
+        j = circuit.info.output_name_to_wire_index[k] - (circuit.wire_count - n_out)
+        assert int(out[j, 0]) == v, (k, boolean)
+
+
 @pytest.mark.parametrize("name", SCRIPTED)
 def test_integration_fixture(name, backend, orc):
     fx = FX[name]
@@ -53,6 +68,7 @@ def test_integration_fixture(name, backend, orc):
                               len(ins), len(case["outputs"]), ins, cst)
         for k, v in case["outputs"].items():
             assert int(vals[circuit.info.output_name_to_wire_index[k]]) == v, (k, case)
+        _gpu_io(circuit, comp.backend(), case["inputs"], case["outputs"])       # the same table through the GPU evaluator
     if "constants_exact" in exp:                                          # test_constant_sum
         assert consts == exp["constants_exact"]
     if "outputs_exact" in exp:                                            # test_direct_output
@@ -68,8 +84,10 @@ def test_integration_fixture(name, backend, orc):
                               len(ins), len(exp["io"]["outputs"]), ins, cst)
         for k, v in exp["io"]["outputs"].items():
             assert int(vals[circuit.info.output_name_to_wire_index[k]]) == v, k
+        _gpu_io(circuit, comp.backend(), exp["io"]["inputs"], exp["io"]["outputs"])
         # --boolify-width 32 (src/main.rs:30-32): same answers from the boolean circuit
         bi_circ = comp.boolify(circuit, 32)
+        _gpu_io(circuit, comp.backend(), exp["io"]["inputs"], exp["io"]["outputs"], boolean=True)
         bi = comp.backend().bool_info
         val = simulate_bool(orc, bi_circ.in0, bi_circ.in1, bi_circ.out, bi_circ.op, bi_circ.wire_count, 32,
                             lambda W, b: bi.wire(W, b), ins, cst)

@@ -84,6 +84,45 @@ def test_boolean_circuit_computes_the_arithmetic_circuit(backend, orc, c2a, widt
             assert got == int(vals[W, t]), (W, t)
 
 
+@pytest.mark.parametrize("width", [8, 32])
+def test_evaluator_with_caller_inputs(backend, orc, c2a, width):
+    """c2a_eval — the reference's simulation harness (tests/integration.rs:191-237: inputs in, outputs out) on the GPU: 64
+    caller-supplied vectors through the arithmetic circuit and through its boolean image give the oracle's outputs."""
+    mix = tuple(m for m in c2a.synth.MIX_ALL if m[0] != "APow") if width > 8 else c2a.synth.MIX_ALL
+    fg = c2a.synth.layered_dag(12, 14, n_in=8, n_const=3, window=3, mix=mix, seed=100 + width)
+    _load(backend, fg)
+    nw, wc = backend.assign_wires()
+    in0, in1, out, op = backend.emit_gates()
+    rng = np.random.default_rng(width)
+    mask = (1 << width) - 1
+    n_in, n_out = len(fg.input_nodes), len(fg.output_nodes)
+    T = 64
+    vals = np.zeros((wc, T), np.uint64)
+    ins = rng.integers(0, 2 ** 63, (n_in, T), dtype=np.uint64) & np.uint64(mask)
+    ins[:, :4] = [0, mask, 1, mask >> 1]
+    for i, nd in enumerate(fg.input_nodes):
+        assert int(nw[nd]) == i                              # inputs are wires 0 .. n_in-1 in list order
+        vals[i] = ins[i]
+    consts = {}
+    for k, nd in enumerate(fg.const_nodes):
+        if nw[nd] != 0xFFFFFFFF:
+            consts[int(nw[nd])] = (0x9E3779B97F4A7C15 * (k + 1)) & mask
+            vals[int(nw[nd])] = consts[int(nw[nd])]
+    circ = orc.ArithCircuit(sorted=np.empty(0, np.uint32), in0=in0, in1=in1, out=out, op=op, node_wire=np.empty(0, np.uint32),
+                            wire_count=wc, n_in=n_in, n_out=n_out)
+    orc.eval_arith(circ, width, vals)
+    want = vals[wc - n_out:]
+    got = backend.eval(ins, consts, width=width)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(backend.eval(ins[:, :5], consts, width=width), want[:, :5])     # fewer vectors
+    backend.boolify(width)
+    np.testing.assert_array_equal(backend.eval(ins, consts, boolean=True), want)
+    with pytest.raises(c2a.BackendError):
+        backend.eval(np.zeros((n_in, 65), np.uint64), consts, width=width)
+    with pytest.raises(c2a.BackendError):
+        backend.eval(ins, {wc + 5: 1}, width=width)
+
+
 def test_boolify_empty_circuit(backend):
     e = np.empty(0, np.uint32)
     backend.load_gates(e, e, e, np.empty(0, np.uint8), 4, [1], [2])
