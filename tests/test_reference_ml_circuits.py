@@ -1,0 +1,69 @@
+"""The larger real circuits the reference ships (tests/circuits/machine-learning/**) through the whole path: the call
+script its unroller makes (tests/golden/ml/*.json, derived from the .circom texts by make_ml_fixtures.py) -> the Compiler
+mirror -> the C ABI -> circuit, checked against the literal oracle (sorted order, wire numbering, emitted gates, name maps),
+the IO vectors through the GPU evaluator (c2a_eval) for the arithmetic circuit and its --boolify-width 32 image, and the
+bit-blast verified wire by wire (c2a_verify_boolify).  ml/_unsupported.json lists every other file of that tree and why it
+is not here (no main / main commented out upstream / a construct outside the front-end's subset)."""
+import glob
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+ML = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ml")
+NAMES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(ML, "*.json")) if not os.path.basename(p).startswith("_"))
+
+
+def test_every_file_of_the_tree_is_accounted_for():
+    uns = json.load(open(os.path.join(ML, "_unsupported.json")))
+    assert len(NAMES) == 3 and len(uns) + len(NAMES) == 42
+    assert all(("main" in why) or why.startswith("front-end:") for why in uns.values())
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_reference_ml_circuit(name, backend, orc):
+    comp_mod = importlib.import_module("circom-2-arithc_amd.compiler")
+    fx = json.load(open(os.path.join(ML, f"{name}.json")))
+    C = comp_mod.Compiler(backend)
+    lit = orc.CompilerModel()
+    for st in fx["script"]:
+        if st[0] == "signal":
+            C.add_signal(st[1], st[2], st[3]); lit.add_signal(st[1], st[2], st[3])
+        elif st[0] == "gate":
+            C.add_gate(st[1], st[2], st[3], st[4]); lit.add_gate(orc.OP[st[1]], st[2], st[3], st[4])
+        else:
+            C.add_connection(st[1], st[2]); lit.add_connection(st[1], st[2])
+    for p in fx["input_prefixes"]:
+        C.add_inputs(C.get_signals("0." + p)); lit.add_inputs(lit.get_signals("0." + p))
+    for p in fx["output_prefixes"]:
+        C.add_outputs(C.get_signals("0." + p)); lit.add_outputs(lit.get_signals("0." + p))
+    assert [list(g) for g in C.gates] == fx["gates"]
+    circ = C.build_circuit()
+    want = lit.build_circuit()
+    exp = fx["expect"]
+    assert circ.wire_count == want.wire_count == exp["wire_count"]
+    assert circ.sorted_gate_ids.tolist() == want.sorted_gate_ids == exp["sorted"]
+    got = [[int(a), int(b), int(o), comp_mod.OP_NAMES[int(p)]] for a, b, o, p in zip(circ.in0, circ.in1, circ.out, circ.op)]
+    assert got == [list(g) for g in want.gates] == exp["emitted"]
+    assert circ.info.input_name_to_wire_index == want.input_name_to_wire_index == exp["input_name_to_wire_index"]
+    assert circ.info.output_name_to_wire_index == want.output_name_to_wire_index == exp["output_name_to_wire_index"]
+    assert {k: [c.value, c.wire_index] for k, c in circ.info.constants.items()} == exp["constants"]
+    assert C.generate_circuit_report() == lit.generate_circuit_report()
+    # the IO vectors through the GPU evaluator: arithmetic circuit, then its boolean image
+    n_in, n_out = len(exp["input_name_to_wire_index"]), len(exp["output_name_to_wire_index"])
+    cases = exp["io_cases"]
+    ins = np.zeros((n_in, len(cases)), np.uint64)
+    outs = np.zeros((n_out, len(cases)), np.uint64)
+    for t, c in enumerate(cases):
+        for k, v in c["inputs"].items():
+            ins[exp["input_name_to_wire_index"][k], t] = v
+        for k, v in c["outputs"].items():
+            outs[exp["output_name_to_wire_index"][k] - (circ.wire_count - n_out), t] = v
+    cst = {c.wire_index: int(c.value) for c in circ.info.constants.values()}
+    np.testing.assert_array_equal(backend.eval(ins, cst, width=32), outs)
+    C.boolify(circ, 32, fetch=False)
+    np.testing.assert_array_equal(backend.eval(ins, cst, boolean=True), outs)
+    checked, bad = backend.verify_boolify(seed=7)
+    assert checked == circ.wire_count * 64 and bad == 0
