@@ -86,6 +86,7 @@ struct c2a_ctx {
     DevBuf prod1, dep0, dep1, cons_cnt, cons_off, eslot, aq_items, aq_pc, aq_seeds, aq_seed_cnt, fill, meta, node, child, gstat, clist, pctl, pcold;
     DevBuf rflag, ridx, rlist, next, owner, local, slist, snext, ssum, jnxt, jval, sorted;
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op, gs, wcnt, wfo;
+    u32 rb_edges = 0, rb_dup = 0, rb_nmid = 0, rb_err = 0;  // read-back slots (edge count, duplicate-writer flag, wires handed out, in/out clash)
     bool has_dup = false;          // two gates write one node (compiler.rs:403-406 keeps the last): the general numbering path
     DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof, mb, mb_seq, mb_rd;
     DevBuf tsz, asz, goff, aoff, tmpl, tables, b_in0, b_in1, b_out, b_op;
@@ -152,43 +153,27 @@ void rec(c2a_ctx* c, Ev e) {
     if (hipEventRecord(c->ev[e], c->stream) == hipSuccess) c->ev_valid[e] = true;
 }
 
+// one-launch exclusive scans (k_scan_1pass): NC sums of the functor's element values into out0 (/ out1), n + 1 entries each
+// (out[n] = the total); `epi` sees every element with its exclusive prefix.  Descriptors + tile counter live in scan_tmp.
+template <int NC, class F, typename TOut, class Epi>
+int scan_1pass(c2a_ctx* c, hipStream_t s, DevBuf& tmp, u64 n, F f, TOut* out0, TOut* out1, Epi epi) {
+    if (n == 0) {
+        HIP_TRY(hipMemsetAsync(out0, 0, sizeof(TOut), s));
+        if (NC > 1) HIP_TRY(hipMemsetAsync(out1, 0, sizeof(TOut), s));
+        return C2A_OK;
+    }
+    const u64 tiles = (n + kScanTile - 1) / kScanTile;
+    const size_t bytes = 64 + (size_t)tiles * NC * 8;
+    ENSURE(tmp, bytes);
+    HIP_TRY(hipMemsetAsync(tmp.p, 0, bytes, s));
+    C2A_LAUNCH((k_scan_1pass<NC, F, TOut, Epi>), (u32)tiles, kThreads, s, n, f, out0, out1, tmp.as<u64>() + 8, tmp.as<u32>(), epi);
+    return C2A_OK;
+}
+
 // exclusive scan of `in` (n entries, u32) into `out` (n+1 entries; out[n] = total).
 template <typename TOut>
 int scan_exclusive(c2a_ctx* c, const u32* in, TOut* out, u64 n) {
-    if (n == 0) {
-        HIP_TRY(hipMemsetAsync(out, 0, sizeof(TOut), c->stream));
-        return C2A_OK;
-    }
-    // level sizes
-    std::vector<u64> sizes;
-    u64 m = n;
-    while (true) {
-        m = (m + kScanTile - 1) / kScanTile;
-        sizes.push_back(m);
-        if (m == 1) break;
-    }
-    size_t total = 0;
-    for (u64 s : sizes) total += (size_t)s + 1;
-    ENSURE(c->scan_tmp, total * sizeof(TOut));
-    std::vector<TOut*> part(sizes.size());
-    {
-        TOut* base = c->scan_tmp.as<TOut>();
-        for (size_t l = 0; l < sizes.size(); ++l) { part[l] = base; base += sizes[l] + 1; }
-    }
-    // up-sweep
-    C2A_LAUNCH((k_scan_tile<u32, TOut>), (u32)sizes[0], kThreads, c->stream, in, out, part[0], n);
-    for (size_t l = 1; l < sizes.size(); ++l)
-        C2A_LAUNCH((k_scan_tile<TOut, TOut>), (u32)sizes[l], kThreads, c->stream, (const TOut*)part[l - 1], part[l - 1],
-                   part[l], sizes[l - 1]);
-    // part[last][0] = grand total (single tile at the top level; its tile-exclusive prefix is 0)
-    C2A_LAUNCH_NOSYNC((k_scan_total<TOut>), 1, 64, c->stream, out + n, (const TOut*)part.back());
-    // down-sweep: part[L-1] is already a full exclusive scan (the top level is a single tile)
-    for (int l = (int)sizes.size() - 2; l >= 1; --l)
-        C2A_LAUNCH_NOSYNC((k_scan_add<TOut>), grid_for(sizes[l - 1], 2048), kThreads, c->stream, part[l - 1],
-                          (const TOut*)part[l], sizes[l - 1]);
-    if (sizes[0] > 1)
-        C2A_LAUNCH_NOSYNC((k_scan_add<TOut>), grid_for(n, 4096), kThreads, c->stream, out, (const TOut*)part[0], n);
-    return C2A_OK;
+    return scan_1pass<1>(c, c->stream, c->scan_tmp, n, ScanFromU32{in}, out, (TOut*)nullptr, ScanNoEpilogue{});
 }
 
 int read_scalars(c2a_ctx* c, u32* host, int first, int count) {
@@ -207,8 +192,8 @@ int do_prep(c2a_ctx* c) {
     HIP_TRY(hipMemsetAsync(c->child.p, 0xFF, (size_t)n * 8, s));
     HIP_TRY(hipMemsetAsync(c->scalars.p, 0, SC_WORDS * 4, s));
     C2A_LAUNCH_NOSYNC(k_producer, G, kThreads, s, n, c->out.as<u32>(), c->prod1.as<u32>(), c->scalars.as<u32>() + SC_DUP);
-    C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->prod1.as<u32>(), c->dep0.as<u32>(),
-                      c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>());
+    C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->out.as<u32>(), c->op.as<u8>(), c->prod1.as<u32>(),
+                      c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>(), c->gate4.as<uint4>());
     int r = scan_exclusive<u32>(c, c->cons_cnt.as<u32>(), c->cons_off.as<u32>(), n);
     if (r) return r;
     C2A_LAUNCH_NOSYNC(k_gstat, G, kThreads, s, n, c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_off.as<u32>(),
@@ -292,9 +277,9 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
     cold.seeds = c->aq_seeds.as<u32>(); cold.seed_cnt = c->aq_seed_cnt.as<u32>();
     A.seeds_w = c->aq_seeds.as<u32>(); A.seed_cnt_w = c->aq_seed_cnt.as<u32>(); A.region_cap = cold.region_cap;
     // what only the edges of the launch touch travels as one small block in HBM (keeps the kernel's scalar registers free)
+    // (written by a one-thread launch that takes it by value: a copy from this stack object would need a host round trip)
     ENSURE(c->pcold, sizeof(PeelCold));
-    HIP_TRY(hipMemcpyAsync(c->pcold.p, &cold, sizeof(PeelCold), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));                // `cold` is a stack object
+    C2A_LAUNCH_NOSYNC(k_set_cold, 1, 1, s, c->pcold.as<PeelCold>(), cold);
     A.cold = c->pcold.as<PeelCold>();
     C2A_LAUNCH(k_peel_sinks, sink_blocks, kThreads, s, A);
     // (every wave of the launch is alive at once under emulation too, interleaved at the back-offs — in a shuffled order per
@@ -303,6 +288,8 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
     else C2A_LAUNCH_CONCURRENT((k_peel<false>), waves, 64, s, A);
     u32 t4[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(t4, c->pctl.p, sizeof(t4), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&c->rb_edges, c->cons_off.as<u32>() + n, 4, hipMemcpyDeviceToHost, s));      // (ride along: one round trip)
+    HIP_TRY(hipMemcpyAsync(&c->rb_dup, c->scalars.as<u32>() + SC_DUP, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (want_stats) {
         ull st[32];
@@ -423,6 +410,8 @@ int do_peel2(c2a_ctx* c, u32* peeled_out, bool* gave_up) {
     if (want_stats) HIP_TRY(hipEventRecord(e1, s));
     u32 t[24] = {0};
     HIP_TRY(hipMemcpyAsync(t, c->pctl.p, sizeof(t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&c->rb_edges, c->cons_off.as<u32>() + n, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&c->rb_dup, c->scalars.as<u32>() + SC_DUP, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (want_stats) {
         float ms = 0.f;
@@ -473,29 +462,25 @@ int do_order(c2a_ctx* c) {
     const u32 n = c->n;
     hipStream_t s = c->stream;
     const u32 G = grid_for(n, 4096);
-    C2A_LAUNCH(k_rootflag, grid_for(n, 1024), kThreads, s, n, c->meta.as<uint4>(), c->rflag.as<u32>(),
-               c->scalars.as<u32>() + SC_MAXDEPTH);
-    int r = scan_exclusive<u32>(c, c->rflag.as<u32>(), c->ridx.as<u32>(), n);
+    // DFS roots (tree nodes without a parent) in ascending gate id: flags, their scan and the root list in one launch
+    int r = scan_1pass<1>(c, s, c->scan_tmp, n, ScanRootFlag{c->meta.as<uint4>()}, c->ridx.as<u32>(), (u32*)nullptr, ScanRootList{c->rlist.as<u32>()});
     if (r) return r;
-    C2A_LAUNCH_NOSYNC(k_rootlist, G, kThreads, s, n, c->rflag.as<u32>(), c->ridx.as<u32>(), c->rlist.as<u32>());
-    u32 n_roots = 0;
-    HIP_TRY(hipMemcpyAsync(&n_roots, c->ridx.as<u32>() + n, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    c->stats.n_roots = n_roots;
-    C2A_LAUNCH_NOSYNC(k_euler_next, G, kThreads, s, n, c->meta.as<uint4>(), c->child.as<u32>(),
-                      c->ridx.as<u32>(), c->rlist.as<u32>(), n_roots, c->next.as<u32>());
+    C2A_LAUNCH(k_euler_next, G, kThreads, s, n, c->meta.as<uint4>(), c->child.as<u32>(),
+               c->ridx.as<u32>(), c->rlist.as<u32>(), (const u32*)(c->ridx.as<u32>() + n), c->next.as<u32>(), c->scalars.as<u32>() + SC_MAXDEPTH);
     const u32 m = 2 * n;
     u32* scount = c->scalars.as<u32>() + SC_SCOUNT;
     C2A_LAUNCH(k_rank_mark, std::max<u32>(1u, std::min<u32>(2048u, (m + kThreads * 8 - 1) / (kThreads * 8))), kThreads, s, m, c->rlist.as<u32>(), scount, c->slist.as<u32>(),
                       c->owner.as<u32>());
-    u32 sc[2] = {0, 0};                       // SC_MAXDEPTH, SC_SCOUNT are adjacent
+    u32 sc[3] = {0, 0, 0};                    // SC_MAXDEPTH, SC_SCOUNT are adjacent; the number of roots rides along
+    HIP_TRY(hipMemcpyAsync(&sc[2], c->ridx.as<u32>() + n, 4, hipMemcpyDeviceToHost, s));
     r = read_scalars(c, sc, SC_MAXDEPTH, 2);
     if (r) return r;
     const u32 S = sc[1];
     c->stats.max_depth = sc[0];
     c->stats.n_splitters = S;
+    c->stats.n_roots = sc[2];
     C2A_LAUNCH_NOSYNC(k_rank_walk, grid_for(S, 8192), kThreads, s, (const u32*)scount, c->rlist.as<u32>(), c->slist.as<u32>(),
-                      c->next.as<u32>(), c->owner.as<u32>(), c->local.as<u32>(), c->snext.as<u32>(), c->ssum.as<u32>());
+                      c->next.as<u32>(), (const u32*)c->owner.as<u32>(), c->local.as<u64>(), c->snext.as<u32>(), c->ssum.as<u32>());
     // pointer jumping, ping-pong between (snext,ssum) and (jnxt,jval)
     u32 rounds = 0;
     while ((1ull << rounds) < S) ++rounds;
@@ -506,8 +491,7 @@ int do_order(c2a_ctx* c) {
         std::swap(nx_a, nx_b);
         std::swap(vl_a, vl_b);
     }
-    C2A_LAUNCH_NOSYNC(k_rank_final, G, kThreads, s, n, c->owner.as<u32>(), c->local.as<u32>(),
-                      (const u32*)vl_a, c->sorted.as<u32>());
+    C2A_LAUNCH_NOSYNC(k_rank_final, G, kThreads, s, n, (const u64*)c->local.as<u64>(), (const u32*)vl_a, c->sorted.as<u32>());
     return C2A_OK;
 }
 
@@ -546,14 +530,8 @@ int do_topo_sort(c2a_ctx* c, u64* cycle_at) {
     r = do_peel(c, &peeled);
     if (r) return r;
     rec(c, EV_PEEL1);
-    {
-        u32 edges = 0, dup = 0;
-        HIP_TRY(hipMemcpyAsync(&edges, c->cons_off.as<u32>() + n, 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(&dup, c->scalars.as<u32>() + SC_DUP, 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        c->stats.n_edges = edges;
-        c->has_dup = dup != 0;
-    }
+    c->stats.n_edges = c->rb_edges;                  // (read back with the launch's own counters)
+    c->has_dup = c->rb_dup != 0;
     if (peeled != n) {
         // leftover gates sit on or above a dependency cycle: replay the reference's DFS for its message
         u32 status = 0;
@@ -572,7 +550,15 @@ int do_topo_sort(c2a_ctx* c, u64* cycle_at) {
     return C2A_OK;
 }
 
-int do_assign_wires(c2a_ctx* c) {
+// the two words do_assign_wires reads back (the stream must have been synchronized)
+int finish_wires(c2a_ctx* c) {
+    if (c->rb_err) { c->stage = ST_SORTED; return fail(c, C2A_ERR_INCONSISTENCY, "Inconsistency: a node is used for both input and output"); }
+    c->n_mid = c->rb_nmid;
+    c->wire_count = c->n_in + c->rb_nmid + c->n_out;
+    return C2A_OK;
+}
+
+int do_assign_wires(c2a_ctx* c, bool defer_readback = false) {
     if (c->stage < ST_SORTED) return fail(c, C2A_ERR_STATE, "c2a_assign_wires: call c2a_topo_sort first");
     const u32 n = c->n;
     hipStream_t s = c->stream;
@@ -594,7 +580,7 @@ int do_assign_wires(c2a_ctx* c) {
     int r;
     if (fast) {
         if (n) {
-            C2A_LAUNCH_NOSYNC(k_walk, G, kThreads, s, n, c->sorted.as<u32>(), (const uint4*)c->gate4.as<uint4>(), (const u32*)c->prod1.as<u32>(),
+            C2A_LAUNCH_NOSYNC(k_walk, G, kThreads, s, n, c->sorted.as<u32>(), (const uint4*)c->gate4.as<uint4>(),
                               (const u8*)c->nflag.as<u8>(), c->gs.as<uint4>(), c->wcnt.as<u32>(), c->wfo.as<u8>(), c->first.as<u32>());
             C2A_LAUNCH_NOSYNC(k_walk_nodes, GN, kThreads, s, c->n_nodes, (const u32*)c->prod1.as<u32>(), (const u8*)c->nflag.as<u8>(),
                               (const u32*)c->first.as<u32>(), c->wcnt.as<u32>());
@@ -628,15 +614,12 @@ int do_assign_wires(c2a_ctx* c) {
         C2A_LAUNCH_NOSYNC(k_assign_outputs, grid_for(c->n_out, 1024), kThreads, s, c->n_out, c->out_nodes.as<u32>(), c->n_in,
                           (const u32*)(c->widx.as<u32>() + n_scan), c->node_wire1.as<u32>());
     rec(c, EV_WIRES1);
-    u32 n_mid = 0, err = 0;
-    HIP_TRY(hipMemcpyAsync(&n_mid, c->widx.as<u32>() + n_scan, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&err, c->scalars.as<u32>() + SC_ERR, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&c->rb_nmid, c->widx.as<u32>() + n_scan, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&c->rb_err, c->scalars.as<u32>() + SC_ERR, 4, hipMemcpyDeviceToHost, s));
+    c->stage = ST_WIRED;                             // (the emission may be queued behind this; finish_wires() makes it official)
+    if (defer_readback) return C2A_OK;
     HIP_TRY(hipStreamSynchronize(s));
-    if (err) return fail(c, C2A_ERR_INCONSISTENCY, "Inconsistency: a node is used for both input and output");
-    c->n_mid = n_mid;
-    c->wire_count = c->n_in + n_mid + c->n_out;
-    c->stage = ST_WIRED;
-    return C2A_OK;
+    return finish_wires(c);
 }
 
 int do_emit(c2a_ctx* c) {
@@ -818,8 +801,6 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
         HIP_TRY(hipMemcpyAsync(c->out.p, out, n4, hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(c->op.p, op, n, hipMemcpyHostToDevice, s));
     }
-    if (n) C2A_LAUNCH_NOSYNC(k_pack_gates, grid_for(n, 4096), kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->out.as<u32>(),
-                             c->op.as<u8>(), c->gate4.as<uint4>());
     if (n_in) HIP_TRY(hipMemcpyAsync(c->in_nodes.p, input_nodes, (size_t)n_in * 4, hipMemcpyHostToDevice, s));
     if (n_out) HIP_TRY(hipMemcpyAsync(c->out_nodes.p, output_nodes, (size_t)n_out * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -854,8 +835,8 @@ int c2a_topo_sort_serial(c2a_ctx* c, uint32_t* sorted, uint64_t* cycle_at) {
     HIP_TRY(hipMemsetAsync(c->scalars.p, 0, SC_WORDS * 4, c->stream));
     const u32 G = grid_for(c->n, 4096);
     C2A_LAUNCH_NOSYNC(k_producer, G, kThreads, c->stream, c->n, c->out.as<u32>(), c->prod1.as<u32>(), c->scalars.as<u32>() + SC_DUP);
-    C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, c->stream, c->n, c->lh.as<u32>(), c->rh.as<u32>(), c->prod1.as<u32>(),
-                      c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>());
+    C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, c->stream, c->n, c->lh.as<u32>(), c->rh.as<u32>(), c->out.as<u32>(), c->op.as<u8>(), c->prod1.as<u32>(),
+                      c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>(), c->gate4.as<uint4>());
     u32 status = 0;
     u64 at = 0;
     int r = run_serial_dfs(c, &status, &at);
@@ -916,10 +897,11 @@ int c2a_build_circuit(c2a_ctx* c, uint64_t* cycle_at, uint32_t* wire_count) {
     int r = do_topo_sort(c, cycle_at);
     if (r) return r;
     c->ev_valid[EV_BUILD0] = true;
-    if ((r = do_assign_wires(c))) return r;
+    if ((r = do_assign_wires(c, true))) return r;    // (its read-back is picked up below: one host round trip for numbering + emission)
     if ((r = do_emit(c))) return r;
     rec(c, EV_BUILD1);
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((r = finish_wires(c))) return r;
     if (wire_count) *wire_count = c->wire_count;
     return C2A_OK;
 }
@@ -964,14 +946,9 @@ int bool_plan(c2a_ctx* c, uint32_t width) {
         c->bool_width = width;
     }
     rec(c, EV_BPREP0);
-    ENSURE(c->tsz, (size_t)n * 4); ENSURE(c->asz, (size_t)n * 4);
     ENSURE(c->goff, ((size_t)n + 1) * 8); ENSURE(c->aoff, ((size_t)n + 1) * 8);
-    if (n)
-        C2A_LAUNCH_NOSYNC(k_bool_sizes, grid_for(n, 4096), kThreads, s, n, c->e_op.as<u8>(),
-                          (const BoolTables*)c->tables.as<BoolTables>(), c->tsz.as<u32>(), c->asz.as<u32>());
-    int r = scan_exclusive<u64>(c, c->tsz.as<u32>(), c->goff.as<u64>(), n);
-    if (r) return r;
-    r = scan_exclusive<u64>(c, c->asz.as<u32>(), c->aoff.as<u64>(), n);
+    // template sizes and aux-wire counts straight from the op bytes, both scanned in one launch
+    int r = scan_1pass<2>(c, s, c->scan_tmp, n, ScanBoolSizes{c->e_op.as<u8>(), c->tables.as<BoolTables>()}, c->goff.as<u64>(), c->aoff.as<u64>(), ScanNoEpilogue{});
     if (r) return r;
     u64 totals[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(&totals[0], c->goff.as<u64>() + n, 8, hipMemcpyDeviceToHost, s));

@@ -25,53 +25,133 @@ constexpr int kThreads = 256;
 __device__ __forceinline__ u64 gtid() { return (u64)blockIdx.x * blockDim.x + threadIdx.x; }
 __device__ __forceinline__ u64 gstride() { return (u64)gridDim.x * blockDim.x; }
 
+}  // namespace c2a
+
+#include "c2a_peel.h"       // (also the agent-scope access helpers the scan below uses)
+#include "c2a_peel2.h"
+
+namespace c2a {
+
 // ------------------------------------------------------------------------------------------------
-// exclusive scan (u32 in -> TOut out), tile = 256 threads x 8 items, hierarchical over tile partials
+// exclusive scan in ONE launch (decoupled look-back): a workgroup takes the next tile of 256 x 16 elements, publishes the
+// tile's sum as soon as it has it, and finds its exclusive prefix by looking back over the descriptors of the tiles before
+// it (a sum that is already inclusive ends the walk).  NC sums are carried at once (the boolify plan scans the template
+// sizes and the aux-wire counts of the same gates together).  The element values come from a functor — a plain array, or
+// something computed on the fly (root flags from the tree records, template sizes from the op bytes) so that the flag array
+// of a three-kernel scan is never written —, and an epilogue sees every element with its exclusive prefix (the root list is
+// written there).  out[c][n] = the total.
 // ------------------------------------------------------------------------------------------------
-constexpr int kScanItems = 8;
+constexpr int kScanItems = 16;
 constexpr int kScanTile = kThreads * kScanItems;
+constexpr u64 kScanAgg = 1ull << 62, kScanPre = 2ull << 62, kScanVal = (1ull << 62) - 1ull;
 
-template <typename TIn, typename TOut>
-__global__ void __launch_bounds__(kThreads) k_scan_tile(const TIn* in, TOut* out, TOut* partials, u64 n) {
-    __shared__ TOut sh[kThreads];
-    const u32 tid = threadIdx.x;
-    const u64 base = (u64)blockIdx.x * kScanTile + (u64)tid * kScanItems;
-    TOut v[kScanItems];
-    TOut sum = 0;
-#pragma unroll
-    for (int i = 0; i < kScanItems; ++i) {
-        const u64 idx = base + i;
-        const TOut x = idx < n ? (TOut)in[idx] : (TOut)0;
-        v[i] = sum;
-        sum += x;
-    }
-    sh[tid] = sum;
+struct ScanNoEpilogue { __device__ __forceinline__ void operator()(u64, const u64*, const u64*) const {} };
+
+template <int NC, class F, typename TOut, class Epi>
+__global__ void __launch_bounds__(kThreads) k_scan_1pass(u64 n, F f, TOut* out0, TOut* out1, u64* desc, u32* counter, Epi epi) {
+    __shared__ u32 s_tile;
+    __shared__ u64 s_wave[NC][kThreads / 64];
+    __shared__ u64 s_excl[NC];
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    if (tid == 0) s_tile = atomicAdd(counter, 1u);
     __syncthreads();
-    for (u32 off = 1; off < (u32)kThreads; off <<= 1) {
-        const TOut t = tid >= off ? sh[tid - off] : (TOut)0;
-        __syncthreads();
-        sh[tid] += t;
-        __syncthreads();
+    const u32 tile = s_tile;
+    const u64 base = (u64)tile * kScanTile + (u64)tid * kScanItems;
+    u64 v[kScanItems][NC];
+    u64 sum[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) sum[c] = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        u64 x[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) x[c] = 0;
+        if (base + i < n) f(base + i, x);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { v[i][c] = x[c]; sum[c] += x[c]; }
     }
-    const TOut excl = sh[tid] - sum;
+    // inclusive scan of the per-thread sums inside the wave, then across the four waves
+    u64 inc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        u64 t = sum[c];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const u64 o = __shfl_up(t, off, 64);
+            if (lane >= (u32)off) t += o;
+        }
+        inc[c] = t;
+        if (lane == 63) s_wave[c][wv] = t;
+    }
+    __syncthreads();
+    u64 tile_total[NC], wave_base[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        u64 run = 0;
+        wave_base[c] = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) { if ((u32)w == wv) wave_base[c] = run; run += s_wave[c][w]; }
+        tile_total[c] = run;
+    }
+    // ---- the tile's exclusive prefix: wave 0 publishes the sum and looks back
+    if (wv == 0) {
+        u64 excl[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) excl[c] = 0;
+        if (tile == 0) {
+            if (lane == 0) for (int c = 0; c < NC; ++c) st_nw(&desc[(u64)tile * NC + c], kScanPre | tile_total[c]);
+        } else {
+            if (lane == 0) for (int c = 0; c < NC; ++c) st_nw(&desc[(u64)tile * NC + c], kScanAgg | tile_total[c]);
+            i64 look = (i64)tile - 1;               // lane l looks at tile look - l
+            for (;;) {
+                const i64 t = look - (i64)lane;
+                u64 d[NC];
+                bool ready = true;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) { d[c] = t >= 0 ? ld_nw(&desc[(u64)t * NC + c]) : kScanPre; ready = ready && (d[c] >> 62) != 0 && (d[c] >> 62) == (d[0] >> 62); }
+                // the window up to the first tile whose sum is inclusive must be all there; else look again
+                const u64 pre = __ballot(ready && (d[0] >> 62) == 2u);
+                const u64 notready = __ballot(!ready);
+                const u32 upto = pre ? (u32)__builtin_ctzll(pre) : 63u;              // lanes 0..upto are summed
+                const u64 need = upto == 63u ? ~0ull : ((2ull << upto) - 1ull);
+                if (notready & need) { peel_sleep(1); continue; }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    u64 x = lane <= upto ? (d[c] & kScanVal) : 0ull;
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+                    excl[c] += x;
+                }
+                if (pre) break;
+                look -= 64;
+            }
+            if (lane == 0) for (int c = 0; c < NC; ++c) st_nw(&desc[(u64)tile * NC + c], kScanPre | ((excl[c] + tile_total[c]) & kScanVal));
+        }
+        if (lane == 0) for (int c = 0; c < NC; ++c) s_excl[c] = excl[c];
+    }
+    __syncthreads();
+    u64 run[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) run[c] = s_excl[c] + wave_base[c] + inc[c] - sum[c];
 #pragma unroll
     for (int i = 0; i < kScanItems; ++i) {
         const u64 idx = base + i;
-        if (idx < n) out[idx] = excl + v[i];
+        if (idx < n) {
+            out0[idx] = (TOut)run[0];
+            if (NC > 1) out1[idx] = (TOut)run[NC - 1];
+            epi(idx, v[i], run);
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) run[c] += v[i][c];
     }
-    if (tid == kThreads - 1) partials[blockIdx.x] = sh[tid];
+    if ((u64)(tile + 1) * kScanTile >= n && tid == kThreads - 1) {      // the last tile: the totals
+        out0[n] = (TOut)(s_excl[0] + tile_total[0]);
+        if (NC > 1) out1[n] = (TOut)(s_excl[NC - 1] + tile_total[NC - 1]);
+    }
 }
 
-template <typename TOut>
-__global__ void k_scan_add(TOut* out, const TOut* partials, u64 n) {
-    for (u64 i = gtid(); i < n; i += gstride()) out[i] += partials[i / kScanTile];
-}
-
-// out[n] = grand total (the scanned array has n+1 entries)
-template <typename TOut>
-__global__ void k_scan_total(TOut* out_n, const TOut* total) {
-    if (gtid() == 0) *out_n = *total;
-}
+// element functors
+struct ScanFromU32 { const u32* in; __device__ __forceinline__ void operator()(u64 i, u64* x) const { x[0] = in[i]; } };
 
 // ------------------------------------------------------------------------------------------------
 // graph prep
@@ -87,10 +167,15 @@ __global__ void k_producer(u32 n, const u32* __restrict__ out, u32* prod1, u32* 
 
 // deps closure (compiler.rs:408-421) + consumer counts.  dep1 is dropped when equal to dep0: a second
 // visit of the same gate is a no-op in the DFS (topological_sort.rs:30-32).
-__global__ void k_deps(u32 n, const u32* __restrict__ lh, const u32* __restrict__ rh, const u32* __restrict__ prod1,
-                       u32* dep0, u32* dep1, u32* cons_cnt, u32* eslot) {
+// Also packs the payload as 16-byte records {lh, rh, out, op | lh node un-produced << 8 | rh node un-produced << 9}: the
+// numbering kernels visit gates in SORTED order, i.e. at random gate ids — one line per gate instead of four, and what they
+// want to know about the two input nodes (does any gate produce them?) comes along instead of costing two more random reads.
+__global__ void k_deps(u32 n, const u32* __restrict__ lh, const u32* __restrict__ rh, const u32* __restrict__ out, const u8* __restrict__ op,
+                       const u32* __restrict__ prod1, u32* dep0, u32* dep1, u32* cons_cnt, u32* eslot, uint4* gate4) {
     for (u64 g = gtid(); g < n; g += gstride()) {
-        const u32 p0 = prod1[lh[g]], p1 = prod1[rh[g]];
+        const u32 a = lh[g], b = rh[g];
+        const u32 p0 = prod1[a], p1 = prod1[b];
+        gate4[g] = make_uint4(a, b, out[g], (u32)op[g] | (p0 ? 0u : 0x100u) | (p1 ? 0u : 0x200u));
         const u32 d0 = p0 ? p0 - 1 : C2A_NONE;
         u32 d1 = p1 ? p1 - 1 : C2A_NONE;
         if (d1 == d0) d1 = C2A_NONE;
@@ -102,50 +187,28 @@ __global__ void k_deps(u32 n, const u32* __restrict__ lh, const u32* __restrict_
     }
 }
 
-}  // namespace c2a
-
-#include "c2a_peel.h"
-#include "c2a_peel2.h"
-
-namespace c2a {
 
 
 // ------------------------------------------------------------------------------------------------
 // post-order numbering: Euler tour of the DFS tree + list ranking (random splitters)
 // ------------------------------------------------------------------------------------------------
-// also collects the DFS-tree depth (stat) with one atomic per workgroup — never one per gate on a single word
-__global__ void __launch_bounds__(kThreads) k_rootflag(u32 n, const uint4* __restrict__ meta,
-                                                       u32* rflag, u32* maxdepth) {
-    __shared__ u32 s_max[kThreads];
-    u32 md = 0;
-    for (u64 g = gtid(); g < n; g += gstride()) {
-        const uint4 m = meta[g];
-        rflag[g] = m.x == C2A_NONE ? 1u : 0u;
-        md = m.y > md ? m.y : md;
-    }
-    s_max[threadIdx.x] = md;
-    __syncthreads();
-    for (u32 off = kThreads / 2; off; off >>= 1) {
-        if (threadIdx.x < off) { const u32 o = s_max[threadIdx.x + off]; if (o > s_max[threadIdx.x]) s_max[threadIdx.x] = o; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && s_max[0]) atomicMax(maxdepth, s_max[0]);
-}
-
-// DFS roots in ascending gate id (topological_sort.rs:11-13), as tree positions
-__global__ void k_rootlist(u32 n, const u32* __restrict__ rflag, const u32* __restrict__ ridx,
-                           u32* rlist) {
-    for (u64 g = gtid(); g < n; g += gstride())
-        if (rflag[g]) rlist[ridx[g]] = (u32)g;
-}
+// DFS roots = tree nodes without a parent, in ascending gate id (topological_sort.rs:11-13): the flag is computed where the
+// scan reads it, the root list is written where the scan knows a root's index
+struct ScanRootFlag { const uint4* meta; __device__ __forceinline__ void operator()(u64 g, u64* x) const { x[0] = meta[g].x == C2A_NONE ? 1u : 0u; } };
+struct ScanRootList { u32* rlist; __device__ __forceinline__ void operator()(u64 g, const u64* v, const u64* excl) const { if (v[0]) rlist[excl[0]] = (u32)g; } };
 
 // element 2x = enter(x), 2x+1 = exit(x); the tour visits label-0 child, label-1 child, then exits.
 // child[2p + l] was written by the peel when the child picked (p, l) as its parent (NONE otherwise).
-__global__ void k_euler_next(u32 n, const uint4* __restrict__ meta,
+// (also collects the depth of the DFS tree — a statistic — with one atomic per workgroup, never one per gate on a single word)
+__global__ void __launch_bounds__(kThreads) k_euler_next(u32 n, const uint4* __restrict__ meta,
                              const u32* __restrict__ child, const u32* __restrict__ ridx, const u32* __restrict__ rlist,
-                             u32 n_roots, u32* next) {
+                             const u32* __restrict__ n_roots_p, u32* next, u32* maxdepth) {
+    __shared__ u32 s_max[kThreads / 64];
+    const u32 n_roots = *n_roots_p;
+    u32 md = 0;
     for (u64 i = gtid(); i < n; i += gstride()) {
         const u32 x = (u32)i;
+        md = meta[x].y > md ? meta[x].y : md;
         const u32 c0 = child[2 * i], c1 = child[2 * i + 1];
         next[2 * i] = c0 != C2A_NONE ? 2 * c0 : (c1 != C2A_NONE ? 2 * c1 : 2 * x + 1);
         const uint4 m = meta[x];
@@ -158,6 +221,15 @@ __global__ void k_euler_next(u32 n, const uint4* __restrict__ meta,
             nx = s1 != C2A_NONE ? 2 * s1 : 2 * m.x + 1;
         }
         next[2 * i + 1] = nx;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const u32 o = __shfl_xor(md, off, 64); md = o > md ? o : md; }
+    if ((threadIdx.x & 63u) == 0) s_max[threadIdx.x >> 6] = md;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 m = 0;
+        for (int w = 0; w < kThreads / 64; ++w) m = s_max[w] > m ? s_max[w] : m;
+        if (m) atomicMax(maxdepth, m);
     }
 }
 
@@ -205,17 +277,17 @@ __global__ void __launch_bounds__(kThreads) k_rank_mark(u32 m, const u32* __rest
     }
 }
 
-// one thread per splitter walks its sublist: local[e] = number of exits before e inside the sublist
+// one thread per splitter walks its sublist.  Only EXIT elements are ranked in the end (sorted.push happens at an exit), so
+// only they get a record — ol[x] = sublist << 32 | exits before exit(x) inside the sublist: one random 8-byte write per node
+// instead of four 4-byte ones per node (owner[] keeps the index of the splitter elements only, written by k_rank_mark)
 __global__ void k_rank_walk(const u32* __restrict__ scount, const u32* __restrict__ rlist, const u32* __restrict__ slist,
-                            const u32* __restrict__ next, u32* owner, u32* local, u32* snext, u32* ssum) {
+                            const u32* __restrict__ next, const u32* __restrict__ owner, u64* ol, u32* snext, u32* ssum) {
     const u32 S = *scount;
     const u32 head = 2 * rlist[0];
     for (u64 k = gtid(); k < S; k += gstride()) {
         u32 e = slist[k], acc = 0;
         for (;;) {
-            local[e] = acc;
-            owner[e] = (u32)k;
-            acc += e & 1u;
+            if (e & 1u) { ol[e >> 1] = ((u64)k << 32) | acc; ++acc; }
             const u32 e2 = next[e];
             if (e2 == C2A_NONE) { snext[k] = C2A_NONE; break; }
             if (is_splitter(e2, head)) { snext[k] = owner[e2]; break; }
@@ -240,11 +312,10 @@ __global__ void k_rank_jump(const u32* __restrict__ scount, const u32* __restric
 }
 
 // sorted[post-order index of x] = gate(x)   (== sorted.push(i), topological_sort.rs:46)
-__global__ void k_rank_final(u32 n, const u32* __restrict__ owner,
-                             const u32* __restrict__ local, const u32* __restrict__ suffix, u32* sorted) {
+__global__ void k_rank_final(u32 n, const u64* __restrict__ ol, const u32* __restrict__ suffix, u32* sorted) {
     for (u64 x = gtid(); x < n; x += gstride()) {
-        const u32 e = 2 * (u32)x + 1;
-        const u32 post = (n - suffix[owner[e]]) + local[e];
+        const u64 r = ol[x];
+        const u32 post = (n - suffix[(u32)(r >> 32)]) + (u32)r;
         sorted[post] = (u32)x;
     }
 }
@@ -306,13 +377,6 @@ __global__ void k_mark_outputs(u32 n_out, const u32* __restrict__ out_nodes, u8*
         if (nflag[node] & 1u) atomicOr(err, 1u);    // compiler.rs:363-383
         else nflag[node] = 2;
     }
-}
-
-// the payload as 16-byte records {lh, rh, out, op}: the kernels below visit gates in SORTED order, i.e. at random
-// gate ids — one line per gate instead of four (built once per c2a_load_gates, outside any timed region)
-__global__ void k_pack_gates(u32 n, const u32* __restrict__ lh, const u32* __restrict__ rh, const u32* __restrict__ out,
-                             const u8* __restrict__ op, uint4* gate4) {
-    for (u64 g = gtid(); g < n; g += gstride()) gate4[g] = make_uint4(lh[g], rh[g], out[g], op[g]);
 }
 
 // One lane per sorted position handles its three walk entries [lh, rh, out] (compiler.rs:427-430): walk index 3*pos+k.
@@ -398,14 +462,14 @@ __global__ void k_emit(u32 n, const u32* __restrict__ sorted, const uint4* __res
 //   k_assign_fast   node_wire1[out] = n_in + widx[pos] + (cnt[pos] - 1) for fo[pos]
 //   k_assign_nodes  the un-produced nodes' wires (lh before rh inside one gate, compiler.rs:430)
 //   k_emit_fast     in0 / in1 by gather, out by formula, op from the record
-__global__ void k_walk(u32 n, const u32* __restrict__ sorted, const uint4* __restrict__ gate4, const u32* __restrict__ prod1,
+__global__ void k_walk(u32 n, const u32* __restrict__ sorted, const uint4* __restrict__ gate4,
                        const u8* __restrict__ nflag, uint4* gs, u32* cnt, u8* fo, u32* first) {
     for (u64 pos = gtid(); pos < n; pos += gstride()) {
         const uint4 g = gate4[sorted[pos]];
         gs[pos] = g;
         const u32 i = 3u * (u32)pos;
-        if (prod1[g.x] == 0) atomicMin(&first[g.x], i);
-        if (prod1[g.y] == 0) atomicMin(&first[g.y], i + 1);
+        if (g.w & 0x100u) atomicMin(&first[g.x], i);                              // (un-produced input nodes: flags packed by k_deps)
+        if (g.w & 0x200u) atomicMin(&first[g.y], i + 1);
         const u32 f = nflag[g.z] == 0 ? 1u : 0u;                                 // :431-438 for the out node
         cnt[pos] = f;
         fo[pos] = (u8)f;
@@ -463,13 +527,11 @@ struct BoolTables {
     u32 taux[20];    // AUX(op,w)
 };
 
-__global__ void k_bool_sizes(u32 n, const u8* __restrict__ e_op, const BoolTables* __restrict__ T, u32* tsz, u32* asz) {
-    for (u64 p = gtid(); p < n; p += gstride()) {
-        const u32 o = e_op[p];
-        tsz[p] = T->tsize[o];
-        asz[p] = T->taux[o];
-    }
-}
+// T(op, w) and AUX(op, w) of the gate at sorted position p, for the scan that places its boolean gates and aux wires
+struct ScanBoolSizes {
+    const u8* e_op; const BoolTables* T;
+    __device__ __forceinline__ void operator()(u64 p, u64* x) const { const u32 o = e_op[p]; x[0] = T->tsize[o]; x[1] = T->taux[o]; }
+};
 
 // cut[k] = first sorted position p with goff[p] >= G k / N (k = 0..N; cut[N] = n), qcut[k] = goff[cut[k]]: N ranges of
 // sorted positions holding (nearly) equal numbers of boolean gates

@@ -386,6 +386,8 @@ __global__ void __launch_bounds__(256) k_peel_sinks(PeelArgs A) {
     }
 }
 
+__global__ void k_set_cold(PeelCold* dst, PeelCold v) { *dst = v; }
+
 // everything issued for one gate at the top of its step; two of these swap roles (nothing is ever copied: a register
 // copy of a value still in flight is a use, and its wait would drain the step that was just issued)
 struct StepIO {

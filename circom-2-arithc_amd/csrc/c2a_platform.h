@@ -24,6 +24,7 @@
 typedef uint8_t u8;
 typedef uint32_t u32;
 typedef uint64_t u64;
+typedef int64_t i64;
 typedef unsigned long long ull;
 
 #define C2A_NONE 0xFFFFFFFFu

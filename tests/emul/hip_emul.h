@@ -359,7 +359,7 @@ inline void hipemuLaunchConcurrent(K kernel, dim3 grid, dim3 block, size_t, hipS
             const unsigned b = wv / wpb, lo = b * nthreads + (wv % wpb) * 64, hi = std::min(b * nthreads + nthreads, lo + 64);
             unsigned long long spins = 0;
             for (;;) {
-                if (++spins == 300000ull) {
+                if (++spins == 4000000000ull) {
                     std::fprintf(stderr, "hip_emul: block %u never steps aside (a polling loop without a back-off?) kinds:", b);
                     for (unsigned t = lo; t < hi; ++t) std::fprintf(stderr, " %d", fibers[t].done ? 9 : fibers[t].wait_kind);
                     std::fprintf(stderr, "\n");
