@@ -71,6 +71,7 @@ struct c2a_ctx {
     u32 peel2_lanes = 64;          // ... lanes of a claim wave that take part
     u32 peel2_mbcap = 4096;        // ... entries of a mailbox ring (a power of two)
     u32 mb_seq_cur = 0;            // which of the two mailbox sequence arrays holds the current numbers
+    bool peel_gave_up = false;     // the last dataflow launch ended by its watchdog (do_peel retries once on clean buffers)
     bool mb_dirty = true;          // mailboxes / sequence numbers must be zeroed (fresh buffers, or a run that failed)
 
     // problem
@@ -166,7 +167,7 @@ int scan_1pass(c2a_ctx* c, hipStream_t s, DevBuf& tmp, u64 n, F f, TOut* out0, T
     const size_t bytes = 64 + (size_t)tiles * NC * 8;
     ENSURE(tmp, bytes);
     HIP_TRY(hipMemsetAsync(tmp.p, 0, bytes, s));
-    C2A_LAUNCH((k_scan_1pass<NC, F, TOut, Epi>), (u32)tiles, kThreads, s, n, f, out0, out1, tmp.as<u64>() + 8, tmp.as<u32>(), epi);
+    C2A_LAUNCH((k_scan_1pass<NC, F, TOut, Epi>), (u32)tiles, kScanThreads, s, n, f, out0, out1, tmp.as<u64>() + 8, tmp.as<u32>(), epi);
     return C2A_OK;
 }
 
@@ -323,6 +324,7 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
         if (st[13]) std::fprintf(stderr, "[c2a peel stats] per chain step (ns): wait for tickets/static data/records %.0f, issue of the next step %.0f, tournament %.0f, record + stores %.0f | steps without a load %.1f %% | chain start (static loads) %.0f ns per chain\n",
                      st[9] * 10.0 / st[13], st[10] * 10.0 / st[13], st[11] * 10.0 / st[13], st[12] * 10.0 / st[13], 100.0 * st[14] / st[13], st[15] * 10.0 / (st[5] + st[0] + 1));
     }
+    c->peel_gave_up = t4[CTL_ABORT] != 0;
     if (t4[CTL_ABORT]) return fail(c, C2A_ERR_HIP, "dataflow peel: watchdog tripped (" + std::to_string(t4[CTL_ABORT]) + " waves gave up waiting)");
     c->node_clear = false;
     *peeled_out = t4[CTL_PROCESSED];
@@ -455,7 +457,16 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
         HIP_TRY(hipMemsetAsync(c->fill.p, 0, (size_t)c->n * 4, c->stream));
         HIP_TRY(hipMemsetAsync(c->child.p, 0xFF, (size_t)c->n * 8, c->stream));
     }
-    return do_peel_classic(c, peeled_out);
+    int r = do_peel_classic(c, peeled_out);
+    if (r == C2A_ERR_HIP && c->peel_gave_up) {
+        // the launch's watchdog tripped (a wave waited too long for a record or for global progress): once more on clean
+        // buffers — node records re-zeroed, tickets and child pointers reset — before this is reported as an error
+        std::fprintf(stderr, "[c2a] the dataflow peel gave up (%s); retrying once on clean buffers\n", c->err.c_str());
+        HIP_TRY(hipMemsetAsync(c->fill.p, 0, (size_t)c->n * 4, c->stream));
+        HIP_TRY(hipMemsetAsync(c->child.p, 0xFF, (size_t)c->n * 8, c->stream));
+        r = do_peel_classic(c, peeled_out);
+    }
+    return r;
 }
 
 int do_order(c2a_ctx* c) {

@@ -33,7 +33,7 @@ __device__ __forceinline__ u64 gstride() { return (u64)gridDim.x * blockDim.x; }
 namespace c2a {
 
 // ------------------------------------------------------------------------------------------------
-// exclusive scan in ONE launch (decoupled look-back): a workgroup takes the next tile of 256 x 16 elements, publishes the
+// exclusive scan in ONE launch (decoupled look-back): a workgroup takes the next tile of 1024 x 16 elements, publishes the
 // tile's sum as soon as it has it, and finds its exclusive prefix by looking back over the descriptors of the tiles before
 // it (a sum that is already inclusive ends the walk).  NC sums are carried at once (the boolify plan scans the template
 // sizes and the aux-wire counts of the same gates together).  The element values come from a functor — a plain array, or
@@ -42,15 +42,16 @@ namespace c2a {
 // written there).  out[c][n] = the total.
 // ------------------------------------------------------------------------------------------------
 constexpr int kScanItems = 16;
-constexpr int kScanTile = kThreads * kScanItems;
+constexpr int kScanThreads = 1024;          // fat tiles: the look-back is a chain over tiles (64 per round trip), 611 of them for 10 M elements
+constexpr int kScanTile = kScanThreads * kScanItems;
 constexpr u64 kScanAgg = 1ull << 62, kScanPre = 2ull << 62, kScanVal = (1ull << 62) - 1ull;
 
 struct ScanNoEpilogue { __device__ __forceinline__ void operator()(u64, const u64*, const u64*) const {} };
 
 template <int NC, class F, typename TOut, class Epi>
-__global__ void __launch_bounds__(kThreads) k_scan_1pass(u64 n, F f, TOut* out0, TOut* out1, u64* desc, u32* counter, Epi epi) {
+__global__ void __launch_bounds__(kScanThreads) k_scan_1pass(u64 n, F f, TOut* out0, TOut* out1, u64* desc, u32* counter, Epi epi) {
     __shared__ u32 s_tile;
-    __shared__ u64 s_wave[NC][kThreads / 64];
+    __shared__ u64 s_wave[NC][kScanThreads / 64];
     __shared__ u64 s_excl[NC];
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     if (tid == 0) s_tile = atomicAdd(counter, 1u);
@@ -90,7 +91,7 @@ __global__ void __launch_bounds__(kThreads) k_scan_1pass(u64 n, F f, TOut* out0,
         u64 run = 0;
         wave_base[c] = 0;
 #pragma unroll
-        for (int w = 0; w < kThreads / 64; ++w) { if ((u32)w == wv) wave_base[c] = run; run += s_wave[c][w]; }
+        for (int w = 0; w < kScanThreads / 64; ++w) { if ((u32)w == wv) wave_base[c] = run; run += s_wave[c][w]; }
         tile_total[c] = run;
     }
     // ---- the tile's exclusive prefix: wave 0 publishes the sum and looks back
@@ -114,7 +115,7 @@ __global__ void __launch_bounds__(kThreads) k_scan_1pass(u64 n, F f, TOut* out0,
                 const u64 notready = __ballot(!ready);
                 const u32 upto = pre ? (u32)__builtin_ctzll(pre) : 63u;              // lanes 0..upto are summed
                 const u64 need = upto == 63u ? ~0ull : ((2ull << upto) - 1ull);
-                if (notready & need) { peel_sleep(1); continue; }
+                if (notready & need) continue;                     // (looked at again at once: the tiles before this one are running)
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     u64 x = lane <= upto ? (d[c] & kScanVal) : 0ull;
@@ -144,7 +145,7 @@ __global__ void __launch_bounds__(kThreads) k_scan_1pass(u64 n, F f, TOut* out0,
 #pragma unroll
         for (int c = 0; c < NC; ++c) run[c] += v[i][c];
     }
-    if ((u64)(tile + 1) * kScanTile >= n && tid == kThreads - 1) {      // the last tile: the totals
+    if ((u64)(tile + 1) * kScanTile >= n && tid == kScanThreads - 1) {      // the last tile: the totals
         out0[n] = (TOut)(s_excl[0] + tile_total[0]);
         if (NC > 1) out1[n] = (TOut)(s_excl[NC - 1] + tile_total[NC - 1]);
     }

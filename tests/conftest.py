@@ -120,6 +120,31 @@ def backend_wave(request, c2a):
     be.close()
 
 
+# (library build, peel kernel: "classic" = the one-wave dataflow launch, "split" = the decoupled launch of c2a_peel2.h; under
+# emulation every wave of either launch is alive at once and C2A_EMUL_SEED shuffles the schedule per pass)
+PEEL_BACKENDS = [_variant("emul", "classic-s1"), _variant("emul", "classic-s2"), _variant("emul", "classic-s3"),
+                 _variant("emul", "split-s0"), _variant("emul", "split-s1"), _variant("emul", "split-s2"), _variant("hip", "split-s0")]
+
+
+@pytest.fixture(params=PEEL_BACKENDS)
+def backend_peel(request, c2a):
+    """Either peel kernel under a seeded random interleaving of its waves (emulation), and the decoupled launch on the GPU."""
+    kind, mode = request.param
+    peel, seed = mode.split("-s")
+    env = {"C2A_PEEL_MODE": peel}
+    with _Env(**env):
+        be = c2a.Backend(0, lib_path=request.getfixturevalue("emul_lib")) if kind == "emul" else c2a.Backend(0)
+    old = os.environ.get("C2A_EMUL_SEED")
+    if int(seed):
+        os.environ["C2A_EMUL_SEED"] = seed
+    yield be
+    be.close()
+    if old is None:
+        os.environ.pop("C2A_EMUL_SEED", None)
+    else:
+        os.environ["C2A_EMUL_SEED"] = old
+
+
 @pytest.fixture
 def hip_backend(c2a):
     be = c2a.Backend(0)

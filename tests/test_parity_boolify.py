@@ -255,6 +255,17 @@ def test_multi_device_boolify_equals_the_single_device_result(multi_backend, orc
             assert be.checksum(name) == backend_mod.checksum_host(arr), name
     with pytest.raises(c2a.BackendError):                   # the verifier wants the whole circuit on one device
         be.verify_boolify(1)
+    # circuit.txt of a circuit spread over several devices: streamed chunk by chunk, the text of the single-device writer
+    import io
+    bristol = __import__("importlib").import_module("circom-2-arithc_amd.bristol")
+    info_c = bristol.CircuitInfo({f"in{i}": i for i in range(info.n_in)}, {}, {f"out{i}": i for i in range(info.n_out)})
+    lazy = bristol.BristolCircuit(wire_count=info.wire_count, info=info_c, in0=np.empty(0, np.uint32), in1=np.empty(0, np.uint32),
+                                  out=np.empty(0, np.uint32), op=np.empty(0, np.uint8), op_names=bristol.BOOL_OP_NAMES if hasattr(bristol, "BOOL_OP_NAMES") else ["XOR", "AND", "INV"],
+                                  io_widths=([width] * info.n_in, [width] * info.n_out), unary_ops=(2,), gates_on_device=info.n_gates)
+    buf = io.BytesIO()
+    lazy.write_bristol_gpu(buf, be, chunk_gates=4096)
+    eb = orc.boolify(_oracle(orc, fg), width)
+    assert buf.getvalue() == orc.bristol_text_of(eb).encode()
 
 
 def test_verifier_refuses_stale_level_data(backend, c2a):

@@ -115,6 +115,25 @@ def test_layered_dags(backend, orc, c2a, layers, width, window):
     assert st["levels"] >= layers
 
 
+def test_peel_protocols_under_random_schedules(backend_peel, orc, c2a):
+    """The ticket / hand-off / termination protocol of the dataflow launch, and the claim-wave / mailbox protocol of the
+    decoupled launch, with every wave of the launch alive at once and taking turns in a shuffled order (the emulator's
+    concurrent launch, C2A_EMUL_SEED): the results do not depend on the interleaving.  Also cyclic inputs and duplicate writers."""
+    be = backend_peel
+    rng = np.random.default_rng(31337)
+    seen = {"ok": 0, "cyclic": 0, "inconsistent": 0, "cyclic-and-inconsistent": 0}
+    for trial in range(40):
+        p = random_gate_graph(rng, int(rng.integers(1, 70)), p_dup_out=0.1 if trial % 3 == 0 else 0.0, p_same=0.15,
+                              p_cycle=0.08 if trial % 4 == 0 else 0.0)
+        seen[_compare(be, orc, p, check_serial=False)] += 1
+    assert seen["ok"] > 10 and seen["cyclic"] > 0, seen
+    for layers, width, window, seed in ((30, 40, 4, 1), (150, 6, 64, 2), (8, 200, 3, 3)):
+        fg = c2a.synth.layered_dag(layers, width, n_in=16, n_const=3, window=window, mix=c2a.synth.MIX_ALL, seed=seed)
+        p = dict(lh=fg.lh, rh=fg.rh, out=fg.out, op=fg.op, n_nodes=fg.n_nodes, input_nodes=fg.input_nodes, output_nodes=fg.output_nodes)
+        assert _compare(be, orc, p, check_serial=False) == "ok"
+        assert _compare(be, orc, p, check_serial=False) == "ok"       # the same buffers again (run tags, mailbox sequence numbers)
+
+
 def test_deep_chain_exercises_path_string_chunks(backend, orc):
     """A 9000-deep dependency chain with side branches: tree depth > 4096, so path strings span three chunks and
     comparisons go through the chunk links (cprev), including the chunk-boundary ancestor cases."""
