@@ -176,6 +176,7 @@ def main():
     ap.add_argument("--no-artefacts", action="store_true", help="skip the circuit.txt formatting measurement")
     ap.add_argument("--check", action="store_true", help="verify the GPU result against the oracle even when the CPU baseline is skipped")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold single-shot measurement")
+    ap.add_argument("--no-prune", action="store_true", help="skip the optional prune pass report")
     ap.add_argument("--mode", choices=["shard", "replicas"], default="shard",
                     help="N>1: 'shard' (default) = ONE graph, sort replicated on every rank, boolify sharded by sorted-position "
                          "range (strong scaling, BASELINE's metric); 'replicas' = N independent graphs, one per GPU (throughput, weak)")
@@ -352,6 +353,25 @@ def main():
                                                                               "seconds": t_bool * bi.n_gates / max(1, cnt)}},
                      "note": "c2a_format_bristol: lengths + scan + print on the GPU, one D2H copy per chunk (PCIe-bound); file writing not included"}
 
+    # ---- the optional prune pass (outside the timed region and NOT the metric's path: c2a_boolify_prune — constant folding and
+    # dead-gate removal over the per-gate map, what the absent `boolify` crate is believed to do): how much smaller
+    # the circuit gets, and that it still computes the same outputs (64 random vectors through c2a_eval, both circuits)
+    prune = None
+    if world == 1 and not args.no_prune:
+        be.build_circuit()
+        be.boolify(args.width)
+        t0 = time.perf_counter()
+        pi = be.boolify_prune()
+        t_prune = time.perf_counter() - t0
+        rng = np.random.default_rng(7)
+        mask = (1 << args.width) - 1
+        vec = rng.integers(0, 2 ** 63, (len(fg.input_nodes), 64), dtype=np.uint64) & np.uint64(mask)
+        same = bool(np.array_equal(be.eval(vec, {}, boolean=True), be.eval(vec, {}, pruned=True)))
+        assert same, "the pruned circuit computes something else"
+        prune = {"gates_before": pi["n_gates_before"], "gates_after": pi["n_gates"], "folded": pi["n_folded"], "dead": pi["n_dead"],
+                 "kept_fraction": pi["n_gates"] / max(1, pi["n_gates_before"]), "seconds": t_prune,
+                 "outputs_equal_on_64_vectors": same}
+
     sort_ms = stages.get("build_total", 0.0)
     bool_ms = stages.get("boolify_total", 0.0) if not shard else ms_per_step - sort_ms
     # what strong scaling can reach at all: the sort is replicated, only the boolify part B divides by N (Amdahl)
@@ -386,6 +406,7 @@ def main():
         "stages_ms": stages,
         "per_rank": per_rank,
         "cold": cold,
+        "prune": prune,
         "setup_s": {"generate": gen_s, "h2d_and_alloc": h2d_s},
         "stats": stats,
         "checked": checked,

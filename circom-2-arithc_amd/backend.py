@@ -56,6 +56,11 @@ class _BoolInfo(ctypes.Structure):
                 ("m_wires", ctypes.c_uint32)]
 
 
+class _PruneInfo(ctypes.Structure):
+    _fields_ = [("n_gates", ctypes.c_uint64), ("n_gates_before", ctypes.c_uint64), ("n_folded", ctypes.c_uint64),
+                ("n_dead", ctypes.c_uint64), ("wire_count", ctypes.c_uint64), ("zero_wire", ctypes.c_uint32), ("one_wire", ctypes.c_uint32)]
+
+
 class _Timings(ctypes.Structure):
     _fields_ = [(k, ctypes.c_float) for k in ("prep", "peel", "order", "wires", "emit", "bool_prep", "bool_map",
                                               "build_total", "boolify_total")]
@@ -85,12 +90,12 @@ class BoolInfo:
         return np.where(W < M, W * w + bit, M * w + self.aux_total + (W - M) * w + bit)
 
 
-ABI_VERSION = 3          # == C2A_ABI_VERSION of include/c2a.h this binding was written against
+ABI_VERSION = 4          # == C2A_ABI_VERSION of include/c2a.h this binding was written against
 
 _EXPORTS = ["c2a_abi_version", "c2a_visible_devices", "c2a_create", "c2a_device_count", "c2a_format_bristol", "c2a_destroy", "c2a_last_error", "c2a_version", "c2a_load_gates", "c2a_topo_sort",
             "c2a_topo_sort_serial", "c2a_assign_wires", "c2a_emit_gates", "c2a_build_circuit", "c2a_boolify",
             "c2a_bool_read", "c2a_template_size", "c2a_checksum", "c2a_get_timings", "c2a_get_stats", "c2a_verify_boolify",
-            "c2a_debug_patch_bool_op", "c2a_boolify_plan", "c2a_boolify_chunk", "c2a_boolify_shard_range", "c2a_eval"]
+            "c2a_debug_patch_bool_op", "c2a_boolify_plan", "c2a_boolify_chunk", "c2a_boolify_shard_range", "c2a_eval", "c2a_boolify_prune", "c2a_pruned_read"]
 
 
 def library_path() -> str:
@@ -156,6 +161,10 @@ def load_library(lib_path: Optional[str] = None):
     L.c2a_checksum.argtypes = [vp, ctypes.c_int, u64p]
     L.c2a_verify_boolify.restype = ctypes.c_int
     L.c2a_verify_boolify.argtypes = [vp, ctypes.c_uint64, u64p, u64p]
+    L.c2a_boolify_prune.restype = ctypes.c_int
+    L.c2a_boolify_prune.argtypes = [vp, ctypes.POINTER(_PruneInfo)]
+    L.c2a_pruned_read.restype = ctypes.c_int
+    L.c2a_pruned_read.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64, u32p, u32p, u32p, u8p]
     L.c2a_eval.restype = ctypes.c_int
     L.c2a_eval.argtypes = [vp, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, u64p, ctypes.c_uint32, u32p, u64p, u64p]
     L.c2a_debug_patch_bool_op.restype = ctypes.c_int
@@ -370,7 +379,23 @@ class Backend:
         self._check(self._lib.c2a_verify_boolify(self._ctx, int(seed), ctypes.byref(chk), ctypes.byref(bad)))
         return chk.value, bad.value
 
-    def eval(self, inputs, constants=None, width: int = 32, boolean: bool = False) -> np.ndarray:
+    def boolify_prune(self) -> dict:
+        """The optional prune pass over the circuit of boolify() (constant folding + dead-gate removal); returns its counts."""
+        info = _PruneInfo()
+        self._check(self._lib.c2a_boolify_prune(self._ctx, ctypes.byref(info)))
+        self.prune_info = {k: int(getattr(info, k)) for k, _ in _PruneInfo._fields_}
+        return self.prune_info
+
+    def pruned_read(self, first: int = 0, count: Optional[int] = None):
+        if count is None:
+            count = self.prune_info["n_gates"] - first
+        in0, in1, out = (np.empty(count, dtype=np.uint32) for _ in range(3))
+        op = np.empty(count, dtype=np.uint8)
+        self._check(self._lib.c2a_pruned_read(self._ctx, int(first), int(count), _p(in0, ctypes.c_uint32), _p(in1, ctypes.c_uint32),
+                                              _p(out, ctypes.c_uint32), _p(op, ctypes.c_uint8)))
+        return in0, in1, out, op
+
+    def eval(self, inputs, constants=None, width: int = 32, boolean: bool = False, pruned: bool = False) -> np.ndarray:
         """Run the circuit on caller-supplied values on the GPU (c2a_eval: the reference's simulation harness,
         tests/integration.rs:191-237).  inputs: array [n_in] or [n_in, T] (T <= 64 vectors), in the order of load_gates'
         input list; constants: {arithmetic wire: value}; returns [n_out, T] uint64.  boolean=True evaluates the circuit of
@@ -384,7 +409,7 @@ class Backend:
         cv = np.ascontiguousarray(np.fromiter((int(v) & 0xFFFFFFFFFFFFFFFF for v in cst.values()), dtype=np.uint64, count=len(cst)))
         n_out = ctypes.c_uint32(0)
         out = np.zeros((self._n_out, T), dtype=np.uint64)
-        self._check(self._lib.c2a_eval(self._ctx, 1 if boolean else 0, int(width), int(T), _p(a, ctypes.c_uint64) if a.size else None,
+        self._check(self._lib.c2a_eval(self._ctx, 2 if pruned else (1 if boolean else 0), int(width), int(T), _p(a, ctypes.c_uint64) if a.size else None,
                                        len(cst), _p(cw, ctypes.c_uint32) if len(cst) else None,
                                        _p(cv, ctypes.c_uint64) if len(cst) else None, _p(out, ctypes.c_uint64) if out.size else None))
         return out

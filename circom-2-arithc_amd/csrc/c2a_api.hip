@@ -94,8 +94,11 @@ struct c2a_ctx {
     DevBuf fmt_len, fmt_off, fmt_text, fmt_table, shard_cut, shard_qcut;
     u64 fmt_chunk_first = 0, fmt_chunk_cnt = 0;      // boolean gates held by the chunk buffers (c2a_boolify_chunk)
     bool fmt_chunk_valid = false;                    // ... of the circuit and plan now current (reset wherever the plan is)
+    DevBuf pr_rep, pr_need, pr_tin0, pr_tin1, pr_top, pr_live, pr_goff, pr_counts, p_in0, p_in1, p_out, p_op;
     DevBuf ev_produced, ev_spos, ev_aval, ev_bval, ev_lcount, ev_lbase, ev_lorder, ev_bar, ev_io, cb_in0, cb_in1, cb_out, cb_op;
     bool bool_planned = false;
+    bool pruned = false;           // p_* hold the pruned image of the boolean circuit now in b_*
+    c2a_prune_info pinfo{};
     std::vector<DevBuf*> all;
 
     c2a_ctx() {
@@ -103,7 +106,7 @@ struct c2a_ctx {
                &gstat, &clist, &pctl, &pcold, &meta, &node, &child, &rflag, &ridx, &rlist, &next,
                &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
                &node_wire, &e_in0, &e_in1, &e_out, &e_op, &gs, &wcnt, &wfo, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &mb, &mb_seq, &mb_rd, &tsz, &asz, &goff,
-               &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &fmt_len, &fmt_off, &fmt_text, &fmt_table, &shard_cut, &shard_qcut, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &ev_lcount, &ev_lbase, &ev_lorder, &ev_bar, &ev_io, &cb_in0, &cb_in1, &cb_out, &cb_op};
+               &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &fmt_len, &fmt_off, &fmt_text, &fmt_table, &shard_cut, &shard_qcut, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &ev_lcount, &ev_lbase, &ev_lorder, &ev_bar, &ev_io, &pr_rep, &pr_need, &pr_tin0, &pr_tin1, &pr_top, &pr_live, &pr_goff, &pr_counts, &p_in0, &p_in1, &p_out, &p_op, &cb_in0, &cb_in1, &cb_out, &cb_op};
     }
 };
 
@@ -525,7 +528,7 @@ int run_serial_dfs(c2a_ctx* c, u32* status, u64* cycle_at) {
 int do_topo_sort(c2a_ctx* c, u64* cycle_at) {
     if (c->stage < ST_LOADED) return fail(c, C2A_ERR_STATE, "c2a_topo_sort: no gates loaded");
     c->stage = ST_LOADED;
-    c->bool_planned = false; c->fmt_chunk_valid = false;
+    c->bool_planned = false; c->fmt_chunk_valid = false; c->pruned = false;
     c->peel_meta_valid = false;
     const u32 n = c->n;
     std::memset(c->ev_valid, 0, sizeof(c->ev_valid));
@@ -773,7 +776,7 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
         if (output_nodes[i] >= n_nodes) return fail(c, C2A_ERR_ARG, "c2a_load_gates: output node id >= n_nodes");
     HIP_TRY(hipSetDevice(c->device));
     c->n = n; c->n_nodes = n_nodes; c->n_in = n_in; c->n_out = n_out;
-    c->bool_planned = false; c->fmt_chunk_valid = false; c->peel_meta_valid = false; c->stats = c2a_stats{}; c->binfo = c2a_bool_info{};
+    c->bool_planned = false; c->fmt_chunk_valid = false; c->pruned = false; c->peel_meta_valid = false; c->stats = c2a_stats{}; c->binfo = c2a_bool_info{};
     {   // the reference checks this BEFORE it sorts (compiler.rs:363-383 precede :408), so build_circuit must report it first
         std::vector<u32> a(input_nodes, input_nodes + n_in), b(output_nodes, output_nodes + n_out);
         std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
@@ -836,7 +839,7 @@ int c2a_topo_sort_serial(c2a_ctx* c, uint32_t* sorted, uint64_t* cycle_at) {
     if (c->stage < ST_LOADED) return fail(c, C2A_ERR_STATE, "c2a_topo_sort_serial: no gates loaded");
     HIP_TRY(hipSetDevice(c->device));
     c->stage = ST_LOADED;
-    c->bool_planned = false; c->fmt_chunk_valid = false; c->peel_meta_valid = false;
+    c->bool_planned = false; c->fmt_chunk_valid = false; c->pruned = false; c->peel_meta_valid = false;
     c->stats = c2a_stats{}; c->stats.n_gates = c->n;
     if (cycle_at) *cycle_at = 0;
     if (c->n == 0) { c->stage = ST_SORTED; return C2A_OK; }
@@ -934,7 +937,7 @@ namespace {
 int bool_plan(c2a_ctx* c, uint32_t width) {
     if (c->stage < ST_EMITTED) return fail(c, C2A_ERR_STATE, "c2a_boolify: call c2a_emit_gates / c2a_build_circuit first");
     if (width == 0 || width > 64) return fail(c, C2A_ERR_ARG, "c2a_boolify: width must be in 1..64");
-    c->bool_planned = false; c->fmt_chunk_valid = false;      // (until this plan is complete; the chunk buffers belong to the plan before)
+    c->bool_planned = false; c->fmt_chunk_valid = false; c->pruned = false;      // (until this plan is complete; the chunk buffers belong to the plan before)
     hipStream_t s = c->stream;
     const u32 n = c->n;
     // templates for this width (host-generated once per width, cached in HBM)
@@ -1325,10 +1328,87 @@ int c2a_verify_boolify(c2a_ctx* c, uint64_t seed, uint64_t* n_checked, uint64_t*
     return C2A_OK;
 }
 
+int c2a_boolify_prune(c2a_ctx* c, c2a_prune_info* info) {
+    if (!c) return C2A_ERR_ARG;
+    c->pruned = false;
+    if (c->stage < ST_BOOLIFIED) return fail(c, C2A_ERR_STATE, "c2a_boolify_prune: call c2a_boolify first");
+    if (!c->peers.empty()) return fail(c, C2A_ERR_STATE, "c2a_boolify_prune: needs the whole boolean circuit on one device (single-device context)");
+    if (!c->peel_meta_valid) return fail(c, C2A_ERR_STATE, "c2a_boolify_prune: needs the level data of c2a_topo_sort (not of c2a_topo_sort_serial)");
+    if (c->binfo.wire_count + 2 >= 0xFFFFFFFFull) return fail(c, C2A_ERR_OVERFLOW, "c2a_boolify_prune: no room for the two constant wires in u32");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const u32 n = c->n, width = c->binfo.width;
+    const u64 G = c->binfo.n_gates, wires = c->binfo.wire_count;
+    ENSURE(c->pr_rep, (wires + 2) * 4); ENSURE(c->pr_need, (wires + 2) * 4);
+    ENSURE(c->pr_tin0, G * 4 + 16); ENSURE(c->pr_tin1, G * 4 + 16); ENSURE(c->pr_top, G + 16);
+    ENSURE(c->pr_live, (size_t)n * 4 + 16); ENSURE(c->pr_goff, ((size_t)n + 1) * 4); ENSURE(c->pr_counts, 64); ENSURE(c->ev_bar, 64);
+    HIP_TRY(hipMemsetAsync(c->pr_counts.p, 0, 64, s));
+    C2A_LAUNCH_NOSYNC(k_prune_init, grid_for(wires + 2, 8192), kThreads, s, wires + 2, c->pr_rep.as<u32>(), c->pr_need.as<u32>());
+    int r = eval_levels(c);
+    if (r) return r;
+    PruneRun R;
+    R.levels = c->stats.levels; R.width = width; R.M = c->binfo.m_wires; R.n_out_wires = c->n_out * width;
+    R.out_base = (u64)c->binfo.m_wires * width + c->binfo.aux_total;
+    R.zero_wire = (u32)wires; R.one_wire = (u32)wires + 1;
+    R.lbase = c->ev_lbase.as<u32>(); R.order = c->ev_lorder.as<u32>(); R.spos = c->ev_spos.as<u32>();
+    R.goff = c->goff.as<u64>(); R.b_in0 = c->b_in0.as<u32>(); R.b_in1 = c->b_in1.as<u32>(); R.b_out = c->b_out.as<u32>(); R.b_op = c->b_op.as<u8>();
+    R.rep = c->pr_rep.as<u32>(); R.need = c->pr_need.as<u32>();
+    R.t_in0 = c->pr_tin0.as<u32>(); R.t_in1 = c->pr_tin1.as<u32>(); R.t_op = c->pr_top.as<u8>();
+    R.live_cnt = c->pr_live.as<u32>(); R.bar = c->ev_bar.as<u32>(); R.counts = c->pr_counts.as<ull>();
+    u32 grid = 8;
+#ifndef C2A_EMULATE
+    {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_prune_fold, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        grid = (u32)c->n_cu * (u32)std::min(per_cu, 4);
+    }
+#endif
+    if (n) {
+        HIP_TRY(hipMemsetAsync(c->ev_bar.p, 0, 64, s));
+        C2A_LAUNCH_CONCURRENT(k_prune_fold, grid, kThreads, s, R);
+        HIP_TRY(hipMemsetAsync(c->ev_bar.p, 0, 64, s));
+        C2A_LAUNCH_CONCURRENT(k_prune_live, grid, kThreads, s, R);
+    }
+    r = scan_exclusive<u32>(c, c->pr_live.as<u32>(), c->pr_goff.as<u32>(), n);
+    if (r) return r;
+    u32 kept = 0;
+    ull cnts[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(&kept, c->pr_goff.as<u32>() + n, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(cnts, c->pr_counts.p, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const u64 PG = (u64)kept + 2;
+    ENSURE(c->p_in0, PG * 4); ENSURE(c->p_in1, PG * 4); ENSURE(c->p_out, PG * 4); ENSURE(c->p_op, PG);
+    C2A_LAUNCH_NOSYNC(k_prune_consts, 1, 64, s, R.zero_wire, R.one_wire, c->p_in0.as<u32>(), c->p_in1.as<u32>(), c->p_out.as<u32>(), c->p_op.as<u8>());
+    if (n)
+        C2A_LAUNCH_NOSYNC(k_prune_compact, grid_for(n, 4096), kThreads, s, n, (const u64*)c->goff.as<u64>(), (const u32*)c->pr_goff.as<u32>(),
+                          (const u32*)c->pr_tin0.as<u32>(), (const u32*)c->pr_tin1.as<u32>(), (const u32*)c->b_out.as<u32>(), (const u8*)c->pr_top.as<u8>(),
+                          c->p_in0.as<u32>(), c->p_in1.as<u32>(), c->p_out.as<u32>(), c->p_op.as<u8>());
+    HIP_TRY(hipStreamSynchronize(s));
+    c->pinfo.n_gates = PG; c->pinfo.n_gates_before = G; c->pinfo.n_folded = cnts[0]; c->pinfo.n_dead = cnts[1];
+    c->pinfo.wire_count = wires + 2; c->pinfo.zero_wire = R.zero_wire; c->pinfo.one_wire = R.one_wire;
+    c->pruned = true;
+    if (info) *info = c->pinfo;
+    return C2A_OK;
+}
+
+int c2a_pruned_read(c2a_ctx* c, uint64_t first, uint64_t count, uint32_t* in0, uint32_t* in1, uint32_t* out, uint8_t* op) {
+    if (!c) return C2A_ERR_ARG;
+    if (!c->pruned || c->stage < ST_BOOLIFIED) return fail(c, C2A_ERR_STATE, "c2a_pruned_read: call c2a_boolify_prune first");
+    if (first + count > c->pinfo.n_gates) return fail(c, C2A_ERR_ARG, "c2a_pruned_read: range out of bounds");
+    HIP_TRY(hipSetDevice(c->device));
+    int r;
+    if ((r = copy_out(c, in0, c->p_in0.as<u32>() + first, count * 4)) || (r = copy_out(c, in1, c->p_in1.as<u32>() + first, count * 4)) ||
+        (r = copy_out(c, out, c->p_out.as<u32>() + first, count * 4)) || (r = copy_out(c, op, c->p_op.as<u8>() + first, count)))
+        return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return C2A_OK;
+}
+
 int c2a_eval(c2a_ctx* c, int which, uint32_t width, uint32_t n_vectors, const uint64_t* inputs, uint32_t n_const,
              const uint32_t* const_wires, const uint64_t* const_values, uint64_t* outputs) {
     if (!c) return C2A_ERR_ARG;
-    if (which != 0 && which != 1) return fail(c, C2A_ERR_ARG, "c2a_eval: which must be 0 (arithmetic circuit) or 1 (boolean circuit)");
+    if (which != 0 && which != 1 && which != 2) return fail(c, C2A_ERR_ARG, "c2a_eval: which must be 0 (arithmetic circuit), 1 (boolean circuit) or 2 (pruned boolean circuit)");
+    if (which == 2 && !c->pruned) return fail(c, C2A_ERR_STATE, "c2a_eval: call c2a_boolify_prune first");
     if (n_vectors == 0 || n_vectors > 64) return fail(c, C2A_ERR_ARG, "c2a_eval: 1..64 vectors per call");
     if (c->stage < (which ? ST_BOOLIFIED : ST_EMITTED)) return fail(c, C2A_ERR_STATE, which ? "c2a_eval: call c2a_boolify first" : "c2a_eval: call c2a_emit_gates / c2a_build_circuit first");
     if (which && !c->peers.empty()) return fail(c, C2A_ERR_STATE, "c2a_eval: the boolean circuit is spread over several devices (single-device context needed)");
@@ -1355,8 +1435,9 @@ int c2a_eval(c2a_ctx* c, int which, uint32_t width, uint32_t n_vectors, const ui
     }
     // every wire starts at 0 (a wire nothing drives stays 0), then the inputs and the constants
     if (which) {
-        ENSURE(c->ev_bval, (size_t)c->binfo.wire_count * 8);
-        HIP_TRY(hipMemsetAsync(c->ev_bval.p, 0, (size_t)c->binfo.wire_count * 8, s));
+        ENSURE(c->ev_bval, ((size_t)c->binfo.wire_count + 2) * 8);
+        HIP_TRY(hipMemsetAsync(c->ev_bval.p, 0, (size_t)c->binfo.wire_count * 8 + 8, s));       // (incl. the pruned circuit's ZERO wire)
+        HIP_TRY(hipMemsetAsync(c->ev_bval.as<u64>() + c->binfo.wire_count + 1, 0xFF, 8, s));    // (... and its ONE wire)
         if (c->n_in) C2A_LAUNCH_NOSYNC(k_eval_set_bool, grid_for((u64)c->n_in * width, 4096), kThreads, s, c->n_in, n_vectors, width, c->binfo.m_wires, out_base,
                                        (const u32*)nullptr, (const u64*)d_in, c->ev_bval.as<u64>());
         if (n_const) C2A_LAUNCH_NOSYNC(k_eval_set_bool, grid_for((u64)n_const * width, 4096), kThreads, s, n_const, n_vectors, width, c->binfo.m_wires, out_base,
@@ -1369,7 +1450,28 @@ int c2a_eval(c2a_ctx* c, int which, uint32_t width, uint32_t n_vectors, const ui
     }
     int r = eval_levels(c);
     if (r) return r;
-    if ((r = eval_run(c, which ? 2u : 1u, width))) return r;
+    if (which == 2) {
+        if (c->n) {
+            EvalRun R;
+            R.levels = c->stats.levels; R.width = width; R.mode = 2;
+            R.lbase = c->ev_lbase.as<u32>(); R.order = c->ev_lorder.as<u32>(); R.spos = c->ev_spos.as<u32>();
+            R.e_in0 = c->e_in0.as<u32>(); R.e_in1 = c->e_in1.as<u32>(); R.e_out = c->e_out.as<u32>(); R.e_op = c->e_op.as<u8>();
+            R.goff = c->goff.as<u64>(); R.b_in0 = c->p_in0.as<u32>(); R.b_in1 = c->p_in1.as<u32>(); R.b_out = c->p_out.as<u32>(); R.b_op = c->p_op.as<u8>();
+            R.aval = c->ev_aval.as<u64>(); R.bval = c->ev_bval.as<u64>();
+            ENSURE(c->ev_bar, 64);
+            HIP_TRY(hipMemsetAsync(c->ev_bar.p, 0, 64, s));
+            R.bar = c->ev_bar.as<u32>();
+            u32 grid = 8;
+#ifndef C2A_EMULATE
+            {
+                int per_cu = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_eval_pruned, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+                grid = (u32)c->n_cu * (u32)std::min(per_cu, 4);
+            }
+#endif
+            C2A_LAUNCH_CONCURRENT(k_eval_pruned, grid, kThreads, s, R, (const u32*)c->pr_goff.as<u32>());
+        }
+    } else if ((r = eval_run(c, which ? 2u : 1u, width))) return r;
     if (c->n_out) {
         C2A_LAUNCH_NOSYNC(k_eval_get, grid_for(out_words, 4096), kThreads, s, c->n_out, n_vectors, width, M, c->binfo.m_wires, out_base, which,
                           (const u64*)c->ev_aval.as<u64>(), (const u64*)c->ev_bval.as<u64>(), d_out);

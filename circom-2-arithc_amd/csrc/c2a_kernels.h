@@ -830,6 +830,156 @@ __global__ void __launch_bounds__(kThreads) k_eval_run(EvalRun R) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// optional PRUNE pass over the bit-blasted circuit (what the absent `boolify` crate is believed to do after its per-gate
+// blast, SURVEY C.2: constant folding + removal of logic no output reaches).  Not the metric's path: the frozen per-gate map
+//  stays what c2a_boolify returns; this rewrites it into a smaller, functionally equal circuit.
+//   rep[w]   what boolean wire w is known to be: 0 / 1 = the constant, x + 2 = the same as wire x (itself: a real wire)
+//   fold     forward over the reverse Kahn levels (producers first), a lane per arithmetic gate walks its template in order:
+//            XOR(a,a) = 0, XOR(a,0) = a, XOR(a,1) = INV a, AND(a,a) = a, AND(a,0) = 0, AND(a,1) = a, INV of a constant;
+//            a gate that drives a circuit OUTPUT wire always stays (constants reach it through the two constant wires)
+//   live     backward (consumers first), templates in reverse: a kept gate is live if its out wire is a circuit output or
+//            is read by a live gate
+//   compact  live gates of every arithmetic gate, in order, behind the two gates that make the constant wires
+// ------------------------------------------------------------------------------------------------
+struct PruneRun {
+    u32 levels, width, M, n_out_wires;
+    u64 out_base;                      // first boolean wire of the circuit outputs (n_out arithmetic wires x width)
+    u32 zero_wire, one_wire;           // the two constant wires (new: wire_count, wire_count + 1)
+    const u32* lbase; const u32* order; const u32* spos;
+    const u64* goff; const u32* b_in0; const u32* b_in1; const u32* b_out; const u8* b_op;
+    u32* rep;                          // [wires + 2]
+    u32* need;                         // [wires + 2]
+    u32* t_in0; u32* t_in1; u8* t_op;  // [G] rewritten gates (t_op 0xFF: folded away; bit 7 set after `live`: dead)
+    u32* live_cnt;                     // [n] live gates per arithmetic gate (sorted position)
+    u32* bar;
+    ull* counts;                       // [0] folded, [1] dead
+};
+__device__ __forceinline__ u32 ev_ld32(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ev_st32(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void grid_barrier(u32* bar, u32& target) {
+    __threadfence();
+    __syncthreads();
+    target += gridDim.x;
+    if (threadIdx.x == 0) {
+        atomicAdd(bar, 1u);
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) peel_sleep(2);
+    }
+    __syncthreads();
+    __threadfence();
+}
+__global__ void __launch_bounds__(kThreads) k_prune_fold(PruneRun R) {
+    u32 target = 0;
+    u64 folded = 0;
+    const u64 out_end = R.out_base + (u64)R.n_out_wires;
+    for (u32 lv = R.levels; lv-- > 0;) {
+        const u32 lo = R.lbase[lv], cnt = R.lbase[lv + 1] - lo;
+        for (u64 i = gtid(); i < cnt; i += gstride()) {
+            const u32 p = R.spos[R.order[lo + (u32)i]];
+            for (u64 k = R.goff[p]; k < R.goff[p + 1]; ++k) {
+                const u32 op = R.b_op[k], out = R.b_out[k];
+                const u32 a = ev_ld32(&R.rep[R.b_in0[k]]);
+                const u32 b = op == 2u ? a : ev_ld32(&R.rep[R.b_in1[k]]);
+                u32 r = 0xFFFFFFFFu, nop = op, na = a, nb = b;                 // r: the folded value (a rep), or "keep"
+                if (op == 0u) {            // XOR
+                    if (a == b) r = 0u; else if (a == 0u) r = b; else if (b == 0u) r = a;
+                    else if (a == 1u) { nop = 2u; na = b; nb = b; } else if (b == 1u) { nop = 2u; nb = a; }
+                } else if (op == 1u) {     // AND
+                    if (a == b) r = a; else if (a == 0u || b == 0u) r = 0u; else if (a == 1u) r = b; else if (b == 1u) r = a;
+                } else {                   // INV
+                    if (a <= 1u) r = 1u - a;
+                }
+                const bool is_output = (u64)out >= R.out_base && (u64)out < out_end;
+                if (r != 0xFFFFFFFFu && !is_output) {
+                    ev_st32(&R.rep[out], r);
+                    R.t_op[k] = 0xFFu;
+                    ++folded;
+                } else {
+                    // stays a gate (an output wire must be driven): its inputs by what they are known to be
+                    if (r != 0xFFFFFFFFu) { nop = op; na = a; nb = b; }
+                    const u32 wa = na == 0u ? R.zero_wire : (na == 1u ? R.one_wire : na - 2u);
+                    const u32 wb = nb == 0u ? R.zero_wire : (nb == 1u ? R.one_wire : nb - 2u);
+                    R.t_in0[k] = wa; R.t_in1[k] = nop == 2u ? wa : wb; R.t_op[k] = (u8)nop;
+                    ev_st32(&R.rep[out], out + 2u);
+                }
+            }
+        }
+        if (lv == 0) break;
+        grid_barrier(R.bar, target);
+    }
+    if (folded) atomicAdd(&R.counts[0], (ull)folded);
+}
+__global__ void __launch_bounds__(kThreads) k_prune_live(PruneRun R) {
+    u32 target = 0;
+    u64 dead = 0;
+    const u64 out_end = R.out_base + (u64)R.n_out_wires;
+    for (u32 lv = 0; lv < R.levels; ++lv) {
+        const u32 lo = R.lbase[lv], cnt = R.lbase[lv + 1] - lo;
+        for (u64 i = gtid(); i < cnt; i += gstride()) {
+            const u32 p = R.spos[R.order[lo + (u32)i]];
+            u32 live = 0;
+            for (u64 k = R.goff[p + 1]; k-- > R.goff[p];) {
+                const u32 op = R.t_op[k];
+                if (op == 0xFFu) continue;
+                const u32 out = R.b_out[k];
+                const bool is_output = (u64)out >= R.out_base && (u64)out < out_end;
+                if (is_output || ev_ld32(&R.need[out]) != 0u) {
+                    ++live;
+                    ev_st32(&R.need[R.t_in0[k]], 1u);
+                    if (op != 2u) ev_st32(&R.need[R.t_in1[k]], 1u);
+                } else {
+                    R.t_op[k] = (u8)(op | 0x80u);
+                    ++dead;
+                }
+            }
+            R.live_cnt[p] = live;
+        }
+        if (lv + 1 == R.levels) break;
+        grid_barrier(R.bar, target);
+    }
+    if (dead) atomicAdd(&R.counts[1], (ull)dead);
+}
+__global__ void k_prune_init(u64 n_wires, u32* rep, u32* need) {
+    for (u64 w = gtid(); w < n_wires; w += gstride()) { rep[w] = (u32)w + 2u; need[w] = 0u; }
+}
+// the live gates of every arithmetic gate, in order, from position 2 on (0, 1: the gates that make the constant wires)
+__global__ void k_prune_compact(u32 n, const u64* __restrict__ goff, const u32* __restrict__ pgoff, const u32* __restrict__ t_in0,
+                                const u32* __restrict__ t_in1, const u32* __restrict__ b_out, const u8* __restrict__ t_op,
+                                u32* p_in0, u32* p_in1, u32* p_out, u8* p_op) {
+    for (u64 p = gtid(); p < n; p += gstride()) {
+        u64 q = 2ull + pgoff[p];
+        for (u64 k = goff[p]; k < goff[p + 1]; ++k) {
+            const u32 op = t_op[k];
+            if (op & 0x80u) continue;                  // folded (0xFF) or dead (bit 7)
+            p_in0[q] = t_in0[k]; p_in1[q] = t_in1[k]; p_out[q] = b_out[k]; p_op[q] = (u8)op;
+            ++q;
+        }
+    }
+}
+__global__ void k_prune_consts(u32 zero_wire, u32 one_wire, u32* p_in0, u32* p_in1, u32* p_out, u8* p_op) {
+    if (gtid() == 0) {
+        p_in0[0] = 0; p_in1[0] = 0; p_out[0] = zero_wire; p_op[0] = 0;          // ZERO = XOR(wire 0, wire 0)
+        p_in0[1] = zero_wire; p_in1[1] = zero_wire; p_out[1] = one_wire; p_op[1] = 2;   // ONE = INV(ZERO)
+    }
+}
+// the pruned circuit on values: the per-gate ranges are pgoff (+ 2), the two constant wires are set by the caller
+__global__ void __launch_bounds__(kThreads) k_eval_pruned(EvalRun R, const u32* __restrict__ pgoff) {
+    u32 target = 0;
+    for (u32 lv = R.levels; lv-- > 0;) {
+        const u32 lo = R.lbase[lv], cnt = R.lbase[lv + 1] - lo;
+        for (u64 i = gtid(); i < cnt; i += gstride()) {
+            const u32 p = R.spos[R.order[lo + (u32)i]];
+            for (u64 k = 2ull + pgoff[p]; k < 2ull + pgoff[p + 1]; ++k) {
+                const u64 a = ev_ld(&R.bval[R.b_in0[k]]), b = ev_ld(&R.bval[R.b_in1[k]]);
+                const u32 o = R.b_op[k];
+                ev_st(&R.bval[R.b_out[k]], o == 0 ? (a ^ b) : (o == 1 ? (a & b) : ~a));
+            }
+        }
+        if (lv == 0) break;
+        grid_barrier(R.bar, target);
+    }
+}
+
 // caller-supplied values: inputs[i][t] for input wire i (wires 0 .. n_in-1, compiler.rs:388-395), vector t < n_vectors
 __global__ void k_eval_set_arith(u32 n_wires, u32 n_vectors, u32 width, const u32* __restrict__ wires, const u64* __restrict__ vals, u64* aval) {
     const u64 mk = width >= 64 ? ~0ull : ((1ull << width) - 1ull);

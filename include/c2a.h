@@ -99,7 +99,7 @@ const char* c2a_last_error(const c2a_ctx* ctx);
 const char* c2a_version(void);
 /* Bumped whenever a signature or a struct layout of this header changes (round 2 changed c2a_create and c2a_stats without
  * a signal): a binding built against another header must refuse to go on.  c2a_abi_version() == C2A_ABI_VERSION. */
-#define C2A_ABI_VERSION 3
+#define C2A_ABI_VERSION 4
 int c2a_abi_version(void);
 
 /*
@@ -190,10 +190,30 @@ int c2a_checksum(c2a_ctx* ctx, int which, uint64_t* value);
  */
 int c2a_verify_boolify(c2a_ctx* ctx, uint64_t seed, uint64_t* n_checked, uint64_t* n_mismatch);
 /*
+ * OPTIONAL prune pass over the circuit of c2a_boolify (single-device context): what the `boolify` crate is believed to do
+ * after its per-gate blast — constant folding (XOR(a,a) = 0, XOR(a,0) = a, XOR(a,1) = INV a, AND(a,a) = a,
+ * AND(a,0) = 0, AND(a,1) = a, INV of a constant) and removal of gates no circuit output depends on.  The frozen per-gate map
+ * stays what c2a_boolify returns (and what the metric measures); this produces a second, smaller, functionally equal circuit:
+ * gates 0 and 1 make the two constant wires (zero_wire = XOR(w0, w0), one_wire = INV zero_wire), the live gates follow in
+ * the order of the original; wires keep their ids (wire_count grows by the two constants).  c2a_eval(which = 2) runs it.
+ */
+typedef struct c2a_prune_info {
+    uint64_t n_gates;          /* gates of the pruned circuit (incl. the two constant gates) */
+    uint64_t n_gates_before;   /* gates of the circuit of c2a_boolify */
+    uint64_t n_folded;         /* gates replaced by a constant or by another wire */
+    uint64_t n_dead;           /* gates that no output depends on */
+    uint64_t wire_count;       /* boolean wire_count + 2 */
+    uint32_t zero_wire, one_wire;
+} c2a_prune_info;
+int c2a_boolify_prune(c2a_ctx* ctx, c2a_prune_info* info);
+int c2a_pruned_read(c2a_ctx* ctx, uint64_t first, uint64_t count, uint32_t* in0, uint32_t* in1, uint32_t* out, uint8_t* op);
+
+/*
  * == the reference's simulation harness with CALLER-SUPPLIED values (tests/integration.rs:191-237: named inputs in, named
  * outputs out), level-parallel on the GPU.  which = 0: the arithmetic circuit of c2a_build_circuit, evaluated mod 2^width
  * (tests/integration.rs:94-115 where that is defined, DESIGN.md §5.2 elsewhere);  1: the boolean circuit of c2a_boolify
- * (width is the boolify width; the values are bit-sliced onto the boolean wires and read back from them).
+ * (width is the boolify width; the values are bit-sliced onto the boolean wires and read back from them);  2: the pruned
+ * circuit of c2a_boolify_prune, same convention.
  * inputs[i * n_vectors + t]: value of input wire i (wires 0 .. n_in-1 in the order of c2a_load_gates' input list) in vector
  * t;  n_const constants given as (ARITHMETIC wire id, value) — the host knows them from its name tables (ConstantInfo);
  * outputs[j * n_vectors + t]: value of output j (the last n_out wires).  1 <= n_vectors <= 64.  Wires nothing drives are 0.

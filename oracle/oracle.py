@@ -641,3 +641,72 @@ def circuit_info_json(circ: BristolCircuit, bool_width: Optional[int] = None, bo
         "constants": {k: {"value": c.value, "wire_index": m(c.wire_index)} for k, c in sorted(circ.constants.items())},
         "output_name_to_wire_index": {k: m(v) for k, v in sorted(circ.output_name_to_wire_index.items())},
     }, indent=2)
+
+
+# ---------------------------------------------------------------------------------------------
+# optional prune pass over a bit-blasted circuit (constant folding + dead-gate removal): the checker's sequential twin of
+# c2a_boolify_prune.  The boolean circuit is in topological order, so one forward sweep over the gates folds, one backward
+# sweep marks what the outputs depend on.  (What the real `boolify` crate does here is unknown — SURVEY C.2 — so this, like
+# the bit-blast itself, is a frozen rule set written twice, not a pinned parity.)
+# ---------------------------------------------------------------------------------------------
+def prune_bool(bc: BoolCircuit, out_base: int):
+    """bc: BoolCircuit with n_out / width set; out_base: first boolean wire of the circuit outputs.
+    Returns (in0, in1, out, op) of the pruned circuit (gates 0, 1 make the constant wires) and a dict of counts."""
+    G = len(bc.op)
+    zero_wire, one_wire = bc.wire_count, bc.wire_count + 1
+    out_end = out_base + bc.n_out * bc.width
+    rep = {}                                   # wire -> 0 / 1 / other wire + 2 (absent: itself)
+
+    def R(w):
+        return rep.get(w, w + 2)
+    kept = []                                  # (in0, in1, out, op) or None
+    folded = 0
+    in0, in1, out, op = bc.in0.tolist(), bc.in1.tolist(), bc.out.tolist(), bc.op.tolist()
+    for k in range(G):
+        o, a = op[k], R(in0[k])
+        b = a if o == 2 else R(in1[k])
+        r, nop, na, nb = None, o, a, b
+        if o == 0:
+            if a == b: r = 0
+            elif a == 0: r = b
+            elif b == 0: r = a
+            elif a == 1: nop, na, nb = 2, b, b
+            elif b == 1: nop, nb = 2, a
+        elif o == 1:
+            if a == b: r = a
+            elif a == 0 or b == 0: r = 0
+            elif a == 1: r = b
+            elif b == 1: r = a
+        else:
+            if a <= 1: r = 1 - a
+        is_output = out_base <= out[k] < out_end
+        if r is not None and not is_output:
+            rep[out[k]] = r
+            kept.append(None)
+            folded += 1
+        else:
+            if r is not None:
+                nop, na, nb = o, a, b
+            wa = zero_wire if na == 0 else (one_wire if na == 1 else na - 2)
+            wb = zero_wire if nb == 0 else (one_wire if nb == 1 else nb - 2)
+            kept.append((wa, wa if nop == 2 else wb, out[k], nop))
+            rep[out[k]] = out[k] + 2
+    need = set()
+    dead = 0
+    live = [False] * G
+    for k in range(G - 1, -1, -1):
+        g = kept[k]
+        if g is None:
+            continue
+        if out_base <= g[2] < out_end or g[2] in need:
+            live[k] = True
+            need.add(g[0])
+            if g[3] != 2:
+                need.add(g[1])
+        else:
+            dead += 1
+    res = [(0, 0, zero_wire, 0), (zero_wire, zero_wire, one_wire, 2)] + [kept[k] for k in range(G) if live[k]]
+    arr = np.array(res, dtype=np.int64).reshape(-1, 4)
+    return ((arr[:, 0].astype(np.uint32), arr[:, 1].astype(np.uint32), arr[:, 2].astype(np.uint32), arr[:, 3].astype(np.uint8)),
+            {"n_gates": len(res), "n_gates_before": G, "n_folded": folded, "n_dead": dead, "wire_count": bc.wire_count + 2,
+             "zero_wire": zero_wire, "one_wire": one_wire})

@@ -123,6 +123,40 @@ def test_evaluator_with_caller_inputs(backend, orc, c2a, width):
         backend.eval(ins, {wc + 5: 1}, width=width)
 
 
+@pytest.mark.parametrize("width", [3, 8, 32])
+def test_prune_pass(backend, orc, c2a, width):
+    """c2a_boolify_prune (optional: constant folding + dead-gate removal, SURVEY C.2's second half of `boolify`): gate for
+    gate the oracle's sequential twin, fewer gates than the per-gate map, and the same outputs on 64 vectors (c2a_eval)."""
+    mix = tuple(m for m in c2a.synth.MIX_ALL if m[0] != "APow") if width > 8 else c2a.synth.MIX_ALL
+    fg = c2a.synth.layered_dag(9, 15, n_in=8, n_const=3, window=3, mix=mix, seed=400 + width)
+    _load(backend, fg)
+    nw, wc = backend.assign_wires()
+    backend.emit_gates()
+    arith = _oracle(orc, fg)
+    info = backend.boolify(width)
+    eb = orc.boolify(arith, width)
+    want, wcnt = orc.prune_bool(eb, int(info.wire(wc - len(fg.output_nodes))))
+    pi = backend.boolify_prune()
+    assert {k: pi[k] for k in wcnt} == wcnt
+    assert pi["n_gates"] - 2 + pi["n_folded"] + pi["n_dead"] == info.n_gates and pi["n_gates"] < info.n_gates
+    got = backend.pruned_read()
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a, b)
+    # same function: 64 vectors through the arithmetic circuit, the per-gate map and the pruned circuit
+    rng = np.random.default_rng(width)
+    mask = (1 << width) - 1
+    ins = rng.integers(0, 2 ** 63, (len(fg.input_nodes), 64), dtype=np.uint64) & np.uint64(mask)
+    ins[:, :4] = [0, mask, 1, mask >> 1]
+    consts = {int(nw[nd]): (0x9E3779B97F4A7C15 * (k + 1)) & mask for k, nd in enumerate(fg.const_nodes) if nw[nd] != 0xFFFFFFFF}
+    ref = backend.eval(ins, consts, width=width)
+    np.testing.assert_array_equal(backend.eval(ins, consts, boolean=True), ref)
+    np.testing.assert_array_equal(backend.eval(ins, consts, pruned=True), ref)
+    # a new boolify invalidates the pruned circuit
+    backend.boolify(width)
+    with pytest.raises(c2a.BackendError):
+        backend.pruned_read(0, 1)
+
+
 def test_boolify_empty_circuit(backend):
     e = np.empty(0, np.uint32)
     backend.load_gates(e, e, e, np.empty(0, np.uint8), 4, [1], [2])
