@@ -326,6 +326,8 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
                      (double)(st[7] & 0xFFFFFFFFull) * 10.0 / st[13], (double)(st[7] >> 32) * 10.0 / st[13], st[16] * 10.0 / st[13]);
         if (st[13]) std::fprintf(stderr, "[c2a peel stats] per chain step (ns): wait for tickets/static data/records %.0f, issue of the next step %.0f, tournament %.0f, record + stores %.0f | steps without a load %.1f %% | chain start (static loads) %.0f ns per chain\n",
                      st[9] * 10.0 / st[13], st[10] * 10.0 / st[13], st[11] * 10.0 / st[13], st[12] * 10.0 / st[13], 100.0 * st[14] / st[13], st[15] * 10.0 / (st[5] + st[0] + 1));
+        if (st[13]) std::fprintf(stderr, "[c2a peel stats] of the tournament phase: %.0f ns per step go to writing hand-off entries (%.0f ns per entry, its wait for the tickets included); %.2f %% of the steps read the consumer list itself (cold)\n",
+                     st[17] * 10.0 / st[13], st[17] * 10.0 / (st[2] + 1), 100.0 * st[18] / st[13]);
     }
     c->peel_gave_up = t4[CTL_ABORT] != 0;
     if (t4[CTL_ABORT]) return fail(c, C2A_ERR_HIP, "dataflow peel: watchdog tripped (" + std::to_string(t4[CTL_ABORT]) + " waves gave up waiting)");

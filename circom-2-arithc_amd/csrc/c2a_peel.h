@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
     u32 st_pops = 0, st_polls = 0, st_push = 0, st_seeds = 0;
     ull st_busy = 0, st_idle = 0, st_t0 = STATS ? c2a_now() : 0;
     ull ph_w1 = 0, ph_w2 = 0, ph_w3 = 0;
-    ull ph_a = 0, ph_b = 0, ph_c = 0, ph_d = 0, ph_steps = 0, ph_noload = 0, ph_start = 0;      // STATS: phase times of the chain step
+    ull ph_a = 0, ph_b = 0, ph_c = 0, ph_d = 0, ph_steps = 0, ph_noload = 0, ph_start = 0, ph_push = 0, ph_cold = 0;      // STATS: phase times of the chain step
     for (;;) {
         // ---- next piece of work: the seed pool, then the hand-off slots
         u32 g = C2A_NONE;
@@ -736,6 +736,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                 }
             }
             if (gave_up) { if (lane == 0) atomicAdd(&A.ctl[CTL_ABORT], 1u); wave_join(); return true; }      // a record never arrived: fail loudly
+            const ull ph2a = STATS ? c2a_now() : 0;
             if (rmask == 3u) {
                 // the entry: lanes 8..15 hold the pushed gate's static records, lanes 32..38 its first consumers
                 C2A_PIN(push_t);                                    // (both atomics are back)
@@ -787,7 +788,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                 const ull ph4 = c2a_now();
                 ++ph_steps;
                 if (cur.take == 0) ++ph_noload;
-                ph_a += ph1 - ph0; ph_b += ph2 - ph1; ph_c += ph3 - ph2; ph_d += ph4 - ph3;
+                ph_a += ph1 - ph0; ph_b += ph2 - ph1; ph_c += ph3 - ph2; ph_d += ph4 - ph3; ph_push += ph3 - ph2a; ph_cold += cur.more ? 1 : 0;
             }
             if (nxt == C2A_NONE) return true;                       // the chain ends here
             // what the next step reuses: this gate as the first candidate of nxt (same DFS root: ch_root stays)
@@ -820,6 +821,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                 atomicAdd(&stats[7], ph_w1 | (ph_w2 << 32)); atomicAdd(&stats[16], ph_w3);
                 atomicAdd(&stats[9], ph_a); atomicAdd(&stats[10], ph_b); atomicAdd(&stats[11], ph_c); atomicAdd(&stats[12], ph_d);
                 atomicAdd(&stats[13], ph_steps); atomicAdd(&stats[14], ph_noload); atomicAdd(&stats[15], ph_start);
+                atomicAdd(&stats[17], ph_push); atomicAdd(&stats[18], ph_cold);
             }
         }
     }
