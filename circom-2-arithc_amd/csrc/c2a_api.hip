@@ -94,9 +94,10 @@ struct c2a_ctx {
     DevBuf fmt_len, fmt_off, fmt_text, fmt_table, shard_cut, shard_qcut;
     u64 fmt_chunk_first = 0, fmt_chunk_cnt = 0;      // boolean gates held by the chunk buffers (c2a_boolify_chunk)
     bool fmt_chunk_valid = false;                    // ... of the circuit and plan now current (reset wherever the plan is)
-    DevBuf pr_rep, pr_need, pr_tin0, pr_tin1, pr_top, pr_live, pr_goff, pr_counts, p_in0, p_in1, p_out, p_op;
+    DevBuf g_in0, g_in1, g_out, g_op, pr_rep, pr_need, pr_tin0, pr_tin1, pr_top, pr_live, pr_goff, pr_counts, p_in0, p_in1, p_out, p_op;
     DevBuf ev_produced, ev_spos, ev_aval, ev_bval, ev_lcount, ev_lbase, ev_lorder, ev_bar, ev_io, cb_in0, cb_in1, cb_out, cb_op;
     bool bool_planned = false;
+    bool gathered = false;         // multi-device: g_* hold the whole boolean circuit of the last c2a_boolify on the primary device
     bool pruned = false;           // p_* hold the pruned image of the boolean circuit now in b_*
     c2a_prune_info pinfo{};
     std::vector<DevBuf*> all;
@@ -106,7 +107,7 @@ struct c2a_ctx {
                &gstat, &clist, &pctl, &pcold, &meta, &node, &child, &rflag, &ridx, &rlist, &next,
                &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
                &node_wire, &e_in0, &e_in1, &e_out, &e_op, &gs, &wcnt, &wfo, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &mb, &mb_seq, &mb_rd, &tsz, &asz, &goff,
-               &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &fmt_len, &fmt_off, &fmt_text, &fmt_table, &shard_cut, &shard_qcut, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &ev_lcount, &ev_lbase, &ev_lorder, &ev_bar, &ev_io, &pr_rep, &pr_need, &pr_tin0, &pr_tin1, &pr_top, &pr_live, &pr_goff, &pr_counts, &p_in0, &p_in1, &p_out, &p_op, &cb_in0, &cb_in1, &cb_out, &cb_op};
+               &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &fmt_len, &fmt_off, &fmt_text, &fmt_table, &shard_cut, &shard_qcut, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &ev_lcount, &ev_lbase, &ev_lorder, &ev_bar, &ev_io, &g_in0, &g_in1, &g_out, &g_op, &pr_rep, &pr_need, &pr_tin0, &pr_tin1, &pr_top, &pr_live, &pr_goff, &pr_counts, &p_in0, &p_in1, &p_out, &p_op, &cb_in0, &cb_in1, &cb_out, &cb_op};
     }
 };
 
@@ -530,7 +531,7 @@ int run_serial_dfs(c2a_ctx* c, u32* status, u64* cycle_at) {
 int do_topo_sort(c2a_ctx* c, u64* cycle_at) {
     if (c->stage < ST_LOADED) return fail(c, C2A_ERR_STATE, "c2a_topo_sort: no gates loaded");
     c->stage = ST_LOADED;
-    c->bool_planned = false; c->fmt_chunk_valid = false; c->pruned = false;
+    c->bool_planned = false; c->fmt_chunk_valid = false; c->pruned = false; c->gathered = false;
     c->peel_meta_valid = false;
     const u32 n = c->n;
     std::memset(c->ev_valid, 0, sizeof(c->ev_valid));
@@ -778,7 +779,7 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
         if (output_nodes[i] >= n_nodes) return fail(c, C2A_ERR_ARG, "c2a_load_gates: output node id >= n_nodes");
     HIP_TRY(hipSetDevice(c->device));
     c->n = n; c->n_nodes = n_nodes; c->n_in = n_in; c->n_out = n_out;
-    c->bool_planned = false; c->fmt_chunk_valid = false; c->pruned = false; c->peel_meta_valid = false; c->stats = c2a_stats{}; c->binfo = c2a_bool_info{};
+    c->bool_planned = false; c->fmt_chunk_valid = false; c->pruned = false; c->gathered = false; c->peel_meta_valid = false; c->stats = c2a_stats{}; c->binfo = c2a_bool_info{};
     {   // the reference checks this BEFORE it sorts (compiler.rs:363-383 precede :408), so build_circuit must report it first
         std::vector<u32> a(input_nodes, input_nodes + n_in), b(output_nodes, output_nodes + n_out);
         std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
@@ -841,7 +842,7 @@ int c2a_topo_sort_serial(c2a_ctx* c, uint32_t* sorted, uint64_t* cycle_at) {
     if (c->stage < ST_LOADED) return fail(c, C2A_ERR_STATE, "c2a_topo_sort_serial: no gates loaded");
     HIP_TRY(hipSetDevice(c->device));
     c->stage = ST_LOADED;
-    c->bool_planned = false; c->fmt_chunk_valid = false; c->pruned = false; c->peel_meta_valid = false;
+    c->bool_planned = false; c->fmt_chunk_valid = false; c->pruned = false; c->gathered = false; c->peel_meta_valid = false;
     c->stats = c2a_stats{}; c->stats.n_gates = c->n;
     if (cycle_at) *cycle_at = 0;
     if (c->n == 0) { c->stage = ST_SORTED; return C2A_OK; }
@@ -939,7 +940,7 @@ namespace {
 int bool_plan(c2a_ctx* c, uint32_t width) {
     if (c->stage < ST_EMITTED) return fail(c, C2A_ERR_STATE, "c2a_boolify: call c2a_emit_gates / c2a_build_circuit first");
     if (width == 0 || width > 64) return fail(c, C2A_ERR_ARG, "c2a_boolify: width must be in 1..64");
-    c->bool_planned = false; c->fmt_chunk_valid = false; c->pruned = false;      // (until this plan is complete; the chunk buffers belong to the plan before)
+    c->bool_planned = false; c->fmt_chunk_valid = false; c->pruned = false; c->gathered = false;      // (until this plan is complete; the chunk buffers belong to the plan before)
     hipStream_t s = c->stream;
     const u32 n = c->n;
     // templates for this width (host-generated once per width, cached in HBM)
@@ -1253,6 +1254,35 @@ int c2a_checksum(c2a_ctx* c, int which, uint64_t* value) {
     return C2A_OK;
 }
 
+// The whole boolean circuit on the primary device: what c2a_boolify left there, or — on a multi-device context, where every
+// device keeps the gates of its own range — a gathered copy (peer copies, made once per c2a_boolify, on the first call of
+// something that needs all of it: the evaluator, the verifier, the prune pass, which = 1 of the text formatter).
+struct BoolView { const u32* in0; const u32* in1; const u32* out; const u8* op; };
+static int full_bool(c2a_ctx* c, BoolView* v) {
+    if (c->peers.empty()) { *v = BoolView{c->b_in0.as<u32>(), c->b_in1.as<u32>(), c->b_out.as<u32>(), c->b_op.as<u8>()}; return C2A_OK; }
+    const u64 G = c->binfo.n_gates;
+    if (!c->gathered) {
+        ENSURE(c->g_in0, G * 4 + 16); ENSURE(c->g_in1, G * 4 + 16); ENSURE(c->g_out, G * 4 + 16); ENSURE(c->g_op, G + 16);
+        const u64 g0 = c->shard0_qhi;
+        HIP_TRY(hipMemcpyAsync(c->g_in0.p, c->b_in0.p, g0 * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->g_in1.p, c->b_in1.p, g0 * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->g_out.p, c->b_out.p, g0 * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->g_op.p, c->b_op.p, g0, hipMemcpyDeviceToDevice, c->stream));
+        for (PeerDev& P : c->peers) {
+            const u64 cntq = P.q_hi - P.q_lo, skip = P.q_lo - P.q_bias;
+            if (!cntq) continue;
+            HIP_TRY(hipMemcpyPeerAsync(c->g_in0.as<u32>() + P.q_lo, c->device, P.b_in0.as<u32>() + skip, P.device, cntq * 4, c->stream));
+            HIP_TRY(hipMemcpyPeerAsync(c->g_in1.as<u32>() + P.q_lo, c->device, P.b_in1.as<u32>() + skip, P.device, cntq * 4, c->stream));
+            HIP_TRY(hipMemcpyPeerAsync(c->g_out.as<u32>() + P.q_lo, c->device, P.b_out.as<u32>() + skip, P.device, cntq * 4, c->stream));
+            HIP_TRY(hipMemcpyPeerAsync(c->g_op.as<u8>() + P.q_lo, c->device, P.b_op.as<u8>() + skip, P.device, cntq, c->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->gathered = true;
+    }
+    *v = BoolView{c->g_in0.as<u32>(), c->g_in1.as<u32>(), c->g_out.as<u32>(), c->g_op.as<u8>()};
+    return C2A_OK;
+}
+
 // level lists of the loaded circuit (gates of one reverse Kahn level are independent; producers sit in higher levels than
 // their consumers), the inverse of the sorted order, and the evaluation launch itself
 static int eval_levels(c2a_ctx* c) {
@@ -1279,7 +1309,9 @@ static int eval_run(c2a_ctx* c, u32 mode, u32 width) {
     R.levels = c->stats.levels; R.width = width; R.mode = mode;
     R.lbase = c->ev_lbase.as<u32>(); R.order = c->ev_lorder.as<u32>(); R.spos = c->ev_spos.as<u32>();
     R.e_in0 = c->e_in0.as<u32>(); R.e_in1 = c->e_in1.as<u32>(); R.e_out = c->e_out.as<u32>(); R.e_op = c->e_op.as<u8>();
-    R.goff = c->goff.as<u64>(); R.b_in0 = c->b_in0.as<u32>(); R.b_in1 = c->b_in1.as<u32>(); R.b_out = c->b_out.as<u32>(); R.b_op = c->b_op.as<u8>();
+    BoolView bv{nullptr, nullptr, nullptr, nullptr};
+    if (mode & 2u) { int rv = full_bool(c, &bv); if (rv) return rv; }
+    R.goff = c->goff.as<u64>(); R.b_in0 = bv.in0; R.b_in1 = bv.in1; R.b_out = bv.out; R.b_op = bv.op;
     R.aval = c->ev_aval.as<u64>(); R.bval = c->ev_bval.as<u64>();
     ENSURE(c->ev_bar, 64);
     HIP_TRY(hipMemsetAsync(c->ev_bar.p, 0, 64, s));
@@ -1300,7 +1332,6 @@ static int eval_run(c2a_ctx* c, u32 mode, u32 width) {
 int c2a_verify_boolify(c2a_ctx* c, uint64_t seed, uint64_t* n_checked, uint64_t* n_mismatch) {
     if (!c) return C2A_ERR_ARG;
     if (c->stage < ST_BOOLIFIED) return fail(c, C2A_ERR_STATE, "c2a_verify_boolify: call c2a_boolify first");
-    if (!c->peers.empty()) return fail(c, C2A_ERR_STATE, "c2a_verify_boolify: needs the whole boolean circuit on one device (single-device context)");
     if (!c->peel_meta_valid) return fail(c, C2A_ERR_STATE, "c2a_verify_boolify: needs the level data of c2a_topo_sort (not of c2a_topo_sort_serial)");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
@@ -1334,7 +1365,6 @@ int c2a_boolify_prune(c2a_ctx* c, c2a_prune_info* info) {
     if (!c) return C2A_ERR_ARG;
     c->pruned = false;
     if (c->stage < ST_BOOLIFIED) return fail(c, C2A_ERR_STATE, "c2a_boolify_prune: call c2a_boolify first");
-    if (!c->peers.empty()) return fail(c, C2A_ERR_STATE, "c2a_boolify_prune: needs the whole boolean circuit on one device (single-device context)");
     if (!c->peel_meta_valid) return fail(c, C2A_ERR_STATE, "c2a_boolify_prune: needs the level data of c2a_topo_sort (not of c2a_topo_sort_serial)");
     if (c->binfo.wire_count + 2 >= 0xFFFFFFFFull) return fail(c, C2A_ERR_OVERFLOW, "c2a_boolify_prune: no room for the two constant wires in u32");
     HIP_TRY(hipSetDevice(c->device));
@@ -1353,7 +1383,9 @@ int c2a_boolify_prune(c2a_ctx* c, c2a_prune_info* info) {
     R.out_base = (u64)c->binfo.m_wires * width + c->binfo.aux_total;
     R.zero_wire = (u32)wires; R.one_wire = (u32)wires + 1;
     R.lbase = c->ev_lbase.as<u32>(); R.order = c->ev_lorder.as<u32>(); R.spos = c->ev_spos.as<u32>();
-    R.goff = c->goff.as<u64>(); R.b_in0 = c->b_in0.as<u32>(); R.b_in1 = c->b_in1.as<u32>(); R.b_out = c->b_out.as<u32>(); R.b_op = c->b_op.as<u8>();
+    BoolView bv;
+    if ((r = full_bool(c, &bv))) return r;
+    R.goff = c->goff.as<u64>(); R.b_in0 = bv.in0; R.b_in1 = bv.in1; R.b_out = bv.out; R.b_op = bv.op;
     R.rep = c->pr_rep.as<u32>(); R.need = c->pr_need.as<u32>();
     R.t_in0 = c->pr_tin0.as<u32>(); R.t_in1 = c->pr_tin1.as<u32>(); R.t_op = c->pr_top.as<u8>();
     R.live_cnt = c->pr_live.as<u32>(); R.bar = c->ev_bar.as<u32>(); R.counts = c->pr_counts.as<ull>();
@@ -1383,7 +1415,7 @@ int c2a_boolify_prune(c2a_ctx* c, c2a_prune_info* info) {
     C2A_LAUNCH_NOSYNC(k_prune_consts, 1, 64, s, R.zero_wire, R.one_wire, c->p_in0.as<u32>(), c->p_in1.as<u32>(), c->p_out.as<u32>(), c->p_op.as<u8>());
     if (n)
         C2A_LAUNCH_NOSYNC(k_prune_compact, grid_for(n, 4096), kThreads, s, n, (const u64*)c->goff.as<u64>(), (const u32*)c->pr_goff.as<u32>(),
-                          (const u32*)c->pr_tin0.as<u32>(), (const u32*)c->pr_tin1.as<u32>(), (const u32*)c->b_out.as<u32>(), (const u8*)c->pr_top.as<u8>(),
+                          (const u32*)c->pr_tin0.as<u32>(), (const u32*)c->pr_tin1.as<u32>(), bv.out, (const u8*)c->pr_top.as<u8>(),
                           c->p_in0.as<u32>(), c->p_in1.as<u32>(), c->p_out.as<u32>(), c->p_op.as<u8>());
     HIP_TRY(hipStreamSynchronize(s));
     c->pinfo.n_gates = PG; c->pinfo.n_gates_before = G; c->pinfo.n_folded = cnts[0]; c->pinfo.n_dead = cnts[1];
@@ -1413,7 +1445,6 @@ int c2a_eval(c2a_ctx* c, int which, uint32_t width, uint32_t n_vectors, const ui
     if (which == 2 && !c->pruned) return fail(c, C2A_ERR_STATE, "c2a_eval: call c2a_boolify_prune first");
     if (n_vectors == 0 || n_vectors > 64) return fail(c, C2A_ERR_ARG, "c2a_eval: 1..64 vectors per call");
     if (c->stage < (which ? ST_BOOLIFIED : ST_EMITTED)) return fail(c, C2A_ERR_STATE, which ? "c2a_eval: call c2a_boolify first" : "c2a_eval: call c2a_emit_gates / c2a_build_circuit first");
-    if (which && !c->peers.empty()) return fail(c, C2A_ERR_STATE, "c2a_eval: the boolean circuit is spread over several devices (single-device context needed)");
     if (!c->peel_meta_valid) return fail(c, C2A_ERR_STATE, "c2a_eval: needs the level data of c2a_topo_sort (not of c2a_topo_sort_serial)");
     if (which) width = c->binfo.width;
     if (width == 0 || width > 64) return fail(c, C2A_ERR_ARG, "c2a_eval: width must be in 1..64");
@@ -1498,8 +1529,13 @@ int c2a_format_bristol(c2a_ctx* c, int which, uint64_t first, uint64_t count, ch
         in0 = c->e_in0.as<u32>(); in1 = c->e_in1.as<u32>(); out = c->e_out.as<u32>(); op = c->e_op.as<u8>(); total = c->n; break;
     case 1:
         if (c->stage < ST_BOOLIFIED) return fail(c, C2A_ERR_STATE, "c2a_format_bristol: call c2a_boolify first");
-        if (!c->peers.empty()) return fail(c, C2A_ERR_STATE, "c2a_format_bristol: the boolean circuit is spread over several devices; format it chunk by chunk (which = 2)");
-        in0 = c->b_in0.as<u32>(); in1 = c->b_in1.as<u32>(); out = c->b_out.as<u32>(); op = c->b_op.as<u8>(); total = c->binfo.n_gates; break;
+        {   // (a multi-device context gathers the circuit on the primary device once per c2a_boolify)
+            BoolView bv;
+            int rv = full_bool(c, &bv);
+            if (rv) return rv;
+            in0 = bv.in0; in1 = bv.in1; out = bv.out; op = bv.op; total = c->binfo.n_gates;
+        }
+        break;
     case 2: {
         if (!c->bool_planned || !c->fmt_chunk_valid) return fail(c, C2A_ERR_STATE, "c2a_format_bristol: call c2a_boolify_chunk first");
         const u64 lead = c->fmt_chunk_first - (c->fmt_chunk_first & ~3ull);

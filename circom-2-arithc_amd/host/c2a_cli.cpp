@@ -14,6 +14,7 @@
 // `--host-writer` uses the host writer instead (the two are byte-identical: tests/test_cpp_host.py).
 #include <cstdio>
 #include <cstdlib>
+#include <filesystem>
 #include <fstream>
 #include <iostream>
 #include <sstream>
@@ -75,7 +76,7 @@ int main(int argc, char** argv) {
         BristolCircuit circuit = compiler.build_circuit();                                                    // main.rs:28
         if (boolify_width) circuit = boolify(compiler, circuit, *boolify_width, /*fetch=*/host_writer);       // main.rs:30-32
         if (!output.empty() && output.back() != '/') output += '/';
-        std::system(("mkdir -p '" + output + "'").c_str());                                                   // main.rs:25-26
+        std::filesystem::create_directories(output);                                                          // main.rs:25-26 (fs::create_dir_all)
         {
             std::ofstream f(output + "circuit.txt", std::ios::binary);                                        // main.rs:34-35
             if (host_writer) circuit.write_bristol(f); else circuit.write_bristol_gpu(f, backend.get());

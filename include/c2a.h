@@ -167,8 +167,8 @@ int c2a_boolify_shard_range(c2a_ctx* ctx, uint32_t k, uint32_t n_shards, uint64_
 /*
  * == the gate lines of BristolCircuit::write_bristol (src/main.rs:34-35; crate absent: Bristol-fashion text per SURVEY C.2),
  * printed on the GPU: "2 1 <in0> <in1> <out> <OP>\n", "1 1 <in0> <out> INV\n" for the one-input op.  Gates
- * [first, first + count) of  which = 0: the arithmetic circuit (c2a_emit_gates);  1: the boolean circuit (c2a_boolify,
- * single-device context);  2: the chunk of the last c2a_boolify_chunk.  text == NULL only queries *written (bytes).
+ * [first, first + count) of  which = 0: the arithmetic circuit (c2a_emit_gates);  1: the boolean circuit (c2a_boolify; a
+ * multi-device context gathers it on the primary device first, once);  2: the chunk of the last c2a_boolify_chunk.  text == NULL only queries *written (bytes).
  * The header lines (gate / wire counts, io widths) are the host's: it knows the name tables.
  */
 int c2a_format_bristol(c2a_ctx* ctx, int which, uint64_t first, uint64_t count, char* text, uint64_t capacity, uint64_t* written);
@@ -190,7 +190,7 @@ int c2a_checksum(c2a_ctx* ctx, int which, uint64_t* value);
  */
 int c2a_verify_boolify(c2a_ctx* ctx, uint64_t seed, uint64_t* n_checked, uint64_t* n_mismatch);
 /*
- * OPTIONAL prune pass over the circuit of c2a_boolify (single-device context): what the `boolify` crate is believed to do
+ * OPTIONAL prune pass over the circuit of c2a_boolify: what the `boolify` crate is believed to do
  * after its per-gate blast — constant folding (XOR(a,a) = 0, XOR(a,0) = a, XOR(a,1) = INV a, AND(a,a) = a,
  * AND(a,0) = 0, AND(a,1) = a, INV of a constant) and removal of gates no circuit output depends on.  The frozen per-gate map
  * stays what c2a_boolify returns (and what the metric measures); this produces a second, smaller, functionally equal circuit:

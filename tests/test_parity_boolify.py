@@ -287,8 +287,17 @@ def test_multi_device_boolify_equals_the_single_device_result(multi_backend, orc
         backend_mod = __import__("importlib").import_module("circom-2-arithc_amd.backend")
         for name, arr in (("bool_in0", exp.in0), ("bool_in1", exp.in1), ("bool_out", exp.out), ("bool_op", exp.op)):
             assert be.checksum(name) == backend_mod.checksum_host(arr), name
-    with pytest.raises(c2a.BackendError):                   # the verifier wants the whole circuit on one device
-        be.verify_boolify(1)
+    # what needs the whole circuit in one place — the verifier, the evaluator, the prune pass, the text of a gate range —
+    # gathers it on the primary device once (peer copies) and gives the single-device answers
+    checked, bad = be.verify_boolify(1)
+    assert bad == 0 and checked > 0
+    pi = be.boolify_prune()
+    want, wcnt = orc.prune_bool(exp, int(info.wire(_oracle(orc, fg).wire_count - len(fg.output_nodes))))
+    assert {k: pi[k] for k in wcnt} == wcnt
+    for g, e in zip(be.pruned_read(), want):
+        np.testing.assert_array_equal(g, e)
+    lines = orc.bristol_text_of(exp).encode().split(b"\n")[4:]
+    assert be.format_bristol(1, n // 3, 50) == b"\n".join(lines[n // 3:n // 3 + 50]) + b"\n"
     # circuit.txt of a circuit spread over several devices: streamed chunk by chunk, the text of the single-device writer
     import io
     bristol = __import__("importlib").import_module("circom-2-arithc_amd.bristol")
