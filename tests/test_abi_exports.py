@@ -36,6 +36,18 @@ def test_product_library_exports_every_symbol(c2a):
     assert (g.value, a.value) == (32, 0)
 
 
+def test_abi_version_is_one_number_everywhere(c2a):
+    """include/c2a.h, the built library and the ctypes binding agree on C2A_ABI_VERSION (a signature change must
+    be a loud load-time error, not undefined behaviour), and the device query works without a GPU."""
+    import importlib
+    src = open(os.path.join(ROOT, "include", "c2a.h")).read()
+    header = int(re.search(r"#define\s+C2A_ABI_VERSION\s+(\d+)", src).group(1))
+    backend_mod = importlib.import_module("circom-2-arithc_amd.backend")
+    lib = ctypes.CDLL(c2a.library_path())
+    assert lib.c2a_abi_version() == header == backend_mod.ABI_VERSION
+    assert c2a.visible_devices() >= 0
+
+
 def test_no_gpu_means_loud_failure(c2a):
     """On a box without a GPU the product path must raise, never fall back."""
     import shutil
