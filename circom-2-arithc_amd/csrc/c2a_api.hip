@@ -192,11 +192,9 @@ int do_prep(c2a_ctx* c) {
     hipStream_t s = c->stream;
     const u32 G = grid_for(n, 4096);
     HIP_TRY(hipMemsetAsync(c->prod1.p, 0, (size_t)c->n_nodes * 4, s));
-    HIP_TRY(hipMemsetAsync(c->cons_cnt.p, 0, (size_t)n * 4, s));
-    HIP_TRY(hipMemsetAsync(c->fill.p, 0, (size_t)n * 4, s));
-    HIP_TRY(hipMemsetAsync(c->child.p, 0xFF, (size_t)n * 8, s));
     HIP_TRY(hipMemsetAsync(c->scalars.p, 0, SC_WORDS * 4, s));
-    C2A_LAUNCH_NOSYNC(k_producer, G, kThreads, s, n, c->out.as<u32>(), c->prod1.as<u32>(), c->scalars.as<u32>() + SC_DUP);
+    C2A_LAUNCH_NOSYNC(k_producer, G, kThreads, s, n, c->out.as<u32>(), c->prod1.as<u32>(), c->scalars.as<u32>() + SC_DUP,
+                      c->cons_cnt.as<u32>(), c->fill.as<u32>(), c->child.as<uint2>());
     C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->out.as<u32>(), c->op.as<u8>(), c->prod1.as<u32>(),
                       c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>(), c->gate4.as<uint4>());
     int r = scan_exclusive<u32>(c, c->cons_cnt.as<u32>(), c->cons_off.as<u32>(), n);
@@ -581,10 +579,8 @@ int do_assign_wires(c2a_ctx* c, bool defer_readback = false) {
     hipStream_t s = c->stream;
     const u64 m = (u64)n * 3;
     rec(c, EV_WIRES0);
-    HIP_TRY(hipMemsetAsync(c->node_wire1.p, 0, (size_t)c->n_nodes * 4, s));
-    HIP_TRY(hipMemsetAsync(c->nflag.p, 0, (size_t)c->n_nodes, s));
-    HIP_TRY(hipMemsetAsync(c->first.p, 0xFF, (size_t)c->n_nodes * 4, s));
-    HIP_TRY(hipMemsetAsync(c->scalars.as<u32>() + SC_ERR, 0, 4, s));
+    C2A_LAUNCH_NOSYNC(k_node_init, grid_for(std::max<u32>(1u, c->n_nodes), 4096), kThreads, s, c->n_nodes, c->node_wire1.as<u32>(), c->nflag.as<u8>(),
+                      c->first.as<u32>(), c->scalars.as<u32>() + SC_ERR);
     if (c->n_in)
         C2A_LAUNCH_NOSYNC(k_mark_inputs, grid_for(c->n_in, 1024), kThreads, s, c->n_in, c->in_nodes.as<u32>(),
                           c->node_wire1.as<u32>(), c->nflag.as<u8>());
@@ -848,10 +844,10 @@ int c2a_topo_sort_serial(c2a_ctx* c, uint32_t* sorted, uint64_t* cycle_at) {
     if (c->n == 0) { c->stage = ST_SORTED; return C2A_OK; }
     // the deps closure only (no peel)
     HIP_TRY(hipMemsetAsync(c->prod1.p, 0, (size_t)c->n_nodes * 4, c->stream));
-    HIP_TRY(hipMemsetAsync(c->cons_cnt.p, 0, (size_t)c->n * 4, c->stream));
     HIP_TRY(hipMemsetAsync(c->scalars.p, 0, SC_WORDS * 4, c->stream));
     const u32 G = grid_for(c->n, 4096);
-    C2A_LAUNCH_NOSYNC(k_producer, G, kThreads, c->stream, c->n, c->out.as<u32>(), c->prod1.as<u32>(), c->scalars.as<u32>() + SC_DUP);
+    C2A_LAUNCH_NOSYNC(k_producer, G, kThreads, c->stream, c->n, c->out.as<u32>(), c->prod1.as<u32>(), c->scalars.as<u32>() + SC_DUP,
+                      c->cons_cnt.as<u32>(), (u32*)nullptr, (uint2*)nullptr);
     C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, c->stream, c->n, c->lh.as<u32>(), c->rh.as<u32>(), c->out.as<u32>(), c->op.as<u8>(), c->prod1.as<u32>(),
                       c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>(), c->gate4.as<uint4>());
     u32 status = 0;

@@ -161,9 +161,14 @@ struct ScanFromU32 { const u32* in; __device__ __forceinline__ void operator()(u
 // prod1 holds gate id + 1 (0 = no producer); must be zeroed.
 // *dup is raised when two gates write one node (the reference keeps the last writer, compiler.rs:403-406): the wire
 // numbering then takes its general path (first-seen by atomicMin over every reference)
-__global__ void k_producer(u32 n, const u32* __restrict__ out, u32* prod1, u32* dup) {
-    for (u64 g = gtid(); g < n; g += gstride())
+// (also resets what the rest of the sort keeps per gate — consumer count, claim tickets, tree children —: three coalesced
+// stores here instead of three clears of their own)
+__global__ void k_producer(u32 n, const u32* __restrict__ out, u32* prod1, u32* dup, u32* cons_cnt, u32* fill, uint2* child) {
+    for (u64 g = gtid(); g < n; g += gstride()) {
+        cons_cnt[g] = 0u;
+        if (fill) { fill[g] = 0u; child[g] = make_uint2(C2A_NONE, C2A_NONE); }
         if (atomicMax(&prod1[out[g]], (u32)g + 1) != 0) *dup = 1u;
+    }
 }
 
 // deps closure (compiler.rs:408-421) + consumer counts.  dep1 is dropped when equal to dep0: a second
@@ -363,6 +368,11 @@ __global__ void k_serial_dfs(u32 n, const u32* __restrict__ dep0, const u32* __r
 // wire numbering (compiler.rs:388-449) and gate emission (compiler.rs:451-464)
 // node_wire1[node] = wire id + 1 (0 = none); nflag bit0 = input node, bit1 = output node.
 // ------------------------------------------------------------------------------------------------
+// the per-node state of the wire numbering in one launch (was three clears): no wire, no IO flag, not seen yet
+__global__ void k_node_init(u32 n_nodes, u32* node_wire1, u8* nflag, u32* first, u32* err) {
+    if (gtid() == 0) *err = 0u;
+    for (u64 v = gtid(); v < n_nodes; v += gstride()) { node_wire1[v] = 0u; nflag[v] = 0; first[v] = 0xFFFFFFFFu; }
+}
 __global__ void k_mark_inputs(u32 n_in, const u32* __restrict__ in_nodes, u32* node_wire1, u8* nflag) {
     for (u64 i = gtid(); i < n_in; i += gstride()) {
         const u32 node = in_nodes[i];
