@@ -89,7 +89,7 @@ struct c2a_ctx {
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op, gs, wcnt, wfo;
     u32 rb_edges = 0, rb_dup = 0, rb_nmid = 0, rb_err = 0;  // read-back slots (edge count, duplicate-writer flag, wires handed out, in/out clash)
     bool has_dup = false;          // two gates write one node (compiler.rs:403-406 keeps the last): the general numbering path
-    DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof, mb, mb_seq, mb_rd;
+    DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof, peel_trace, mb, mb_seq, mb_rd;
     DevBuf tsz, asz, goff, aoff, tmpl, tables, b_in0, b_in1, b_out, b_op;
     DevBuf fmt_len, fmt_off, fmt_text, fmt_table, shard_cut, shard_qcut;
     u64 fmt_chunk_first = 0, fmt_chunk_cnt = 0;      // boolean gates held by the chunk buffers (c2a_boolify_chunk)
@@ -106,7 +106,7 @@ struct c2a_ctx {
         all = {&lh, &rh, &out, &op, &gate4, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &aq_items, &aq_pc, &aq_seeds, &aq_seed_cnt, &fill,
                &gstat, &clist, &pctl, &pcold, &meta, &node, &child, &rflag, &ridx, &rlist, &next,
                &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
-               &node_wire, &e_in0, &e_in1, &e_out, &e_op, &gs, &wcnt, &wfo, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &mb, &mb_seq, &mb_rd, &tsz, &asz, &goff,
+               &node_wire, &e_in0, &e_in1, &e_out, &e_op, &gs, &wcnt, &wfo, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &peel_trace, &mb, &mb_seq, &mb_rd, &tsz, &asz, &goff,
                &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &fmt_len, &fmt_off, &fmt_text, &fmt_table, &shard_cut, &shard_qcut, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &ev_lcount, &ev_lbase, &ev_lorder, &ev_bar, &ev_io, &g_in0, &g_in1, &g_out, &g_op, &pr_rep, &pr_need, &pr_tin0, &pr_tin1, &pr_top, &pr_live, &pr_goff, &pr_counts, &p_in0, &p_in1, &p_out, &p_op, &cb_in0, &cb_in1, &cb_out, &cb_op};
     }
 };
@@ -265,11 +265,17 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
     HIP_TRY(hipMemsetAsync(c->aq_pc.p, 0, (size_t)A.n_fifos * kPcStride * 8, s));
     HIP_TRY(hipMemsetAsync(c->pctl.p, 0, (size_t)CTL_WORDS * 4, s));
     A.fifo = c->aq_items.as<u64>(); A.q_pc = c->aq_pc.as<u64>(); A.ctl = c->pctl.as<u32>();
-    cold.stats = nullptr; cold.q_time = nullptr; cold.p_time = nullptr;
+    cold.stats = nullptr; cold.q_time = nullptr; cold.p_time = nullptr; cold.t_trace = nullptr;
+    const char* trace_dir = want_stats ? std::getenv("C2A_PEEL_TRACE") : nullptr;
     if (want_stats) {
         ENSURE(c->peel_prof, 256 + 2 * slots * 8);
         HIP_TRY(hipMemsetAsync(c->peel_prof.p, 0, 256 + 2 * slots * 8, s));
         cold.stats = c->peel_prof.as<ull>(); cold.q_time = c->peel_prof.as<ull>() + 32; cold.p_time = cold.q_time + slots;
+        if (trace_dir) {
+            ENSURE(c->peel_trace, (size_t)n * 24);
+            HIP_TRY(hipMemsetAsync(c->peel_trace.p, 0, (size_t)n * 24, s));
+            cold.t_trace = c->peel_trace.as<ull>();
+        }
     }
     // seed regions: one per workgroup of the sinks pass; a workgroup sees at most gates_per_block gates, each claims <= 2 producers
     const u32 sink_blocks = grid_for(n, c->peel_sinks_blocks);
@@ -320,6 +326,16 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
             const char* names[] = {"<0.5", "<1", "<1.5", "<2", "<3", "<4", "<6", "<8", "<16", ">=16"};
             for (int k = 0; k < 10; ++k) std::fprintf(stderr, " %s us: %llu", names[k], hist[k]);
             std::fprintf(stderr, " (receiver waiting before the push was decided: %llu)\n", late);
+        }
+        if (trace_dir) {
+            // per gate: step start (<< 2 | how it came) and record stored (100 MHz clock), + the tree records, for tools/peel_trace.py
+            std::vector<ull> tr((size_t)n * 3);
+            std::vector<u32> mt((size_t)n * 4);
+            HIP_TRY(hipMemcpy(tr.data(), c->peel_trace.p, (size_t)n * 24, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(mt.data(), c->meta.p, (size_t)n * 16, hipMemcpyDeviceToHost));
+            const std::string base(trace_dir);
+            if (FILE* f = std::fopen((base + "/peel_trace.bin").c_str(), "wb")) { std::fwrite(tr.data(), 8, tr.size(), f); std::fclose(f); }
+            if (FILE* f = std::fopen((base + "/peel_meta.bin").c_str(), "wb")) { std::fwrite(mt.data(), 4, mt.size(), f); std::fclose(f); }
         }
         if (st[13]) std::fprintf(stderr, "[c2a peel stats] wait at the top of a step (ns): ticket %.0f, then static data %.0f, then records %.0f\n",
                      (double)(st[7] & 0xFFFFFFFFull) * 10.0 / st[13], (double)(st[7] >> 32) * 10.0 / st[13], st[16] * 10.0 / st[13]);

@@ -93,6 +93,7 @@ struct PeelCold {
     ull* stats;                // optional diagnostics (32 words), nullptr normally
     ull* q_time;               // with stats: when the push of every hand-off entry was decided ...
     ull* p_time;               // ... and when the receiver had it ready to issue
+    ull* t_trace;              // with stats + C2A_PEEL_TRACE: three words per gate (step start << 2 | how it came; record stored; phases: tools/peel_trace.py)
 };
 
 struct PeelArgs {
@@ -431,6 +432,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
     for (;;) {
         // ---- next piece of work: the seed pool, then the hand-off slots
         u32 g = C2A_NONE;
+        u32 came = 0;                        // STATS: 1 popped from a hand-off array, 2 a seed (0: chain step)
         uint4 gi, gi2;
         u32 cl0 = 0, cl0_base = 0, cl0_cap = 64;       // g's consumers: one per lane from lane cl0_base on, cl0_cap lanes
         ull pop_slot = ~0ull;                // STATS: slot of the popped entry
@@ -445,7 +447,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                 if (r >= uniform(C->n_regions)) { seeds_left = false; break; }
                 region = r; idx = 0; region_cnt = uniform(C->seed_cnt[r]);
             }
-            if (seeds_left) { g = uniform(C->seeds[(u64)region * uniform(C->region_cap) + idx]); ++idx; if (STATS) ++st_seeds; }
+            if (seeds_left) { g = uniform(C->seeds[(u64)region * uniform(C->region_cap) + idx]); ++idx; if (STATS) { ++st_seeds; came = 2; } }
         }
         const ull ph_s0 = STATS ? c2a_now() : 0;
         if (g != C2A_NONE) {
@@ -548,7 +550,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             if (STATS) { const ull tt = c2a_now(); st_idle += tt - st_t0; st_t0 = tt; }
             if (!got) break;
             if (slot_i == held_slot) held = 0;
-            if (STATS) { pop_slot = slot_i; ++st_pops; }
+            if (STATS) { pop_slot = slot_i; ++st_pops; came = 1; }
             const u32 pv = (u32)v;
             gi = make_uint4(rdlane(pv, 0), rdlane(pv, 1), rdlane(pv, 2), rdlane(pv, 3));
             gi2 = make_uint4(rdlane(pv, 4), rdlane(pv, 5), rdlane(pv, 6), rdlane(pv, 7));
@@ -786,6 +788,14 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             if ((processed & 63u) == 0 && lane == 0) atomicAdd(&A.ctl[CTL_HEARTBEAT], 1u);
             if (STATS) {
                 const ull ph4 = c2a_now();
+                if (A.cold->t_trace && lane == 0) {
+                    A.cold->t_trace[3 * (u64)gc] = (ph0 << 2) | came; A.cold->t_trace[3 * (u64)gc + 1] = ph4;
+                    // what the step was made of: top wait, issue, tournament, stores (ticks, 12 bits each) | pushed << 48 | records loaded ahead << 49 | cold << 52
+                    const ull c12 = 0xFFFull;
+                    A.cold->t_trace[3 * (u64)gc + 2] = ((ph1 - ph0) & c12) | (((ph2 - ph1) & c12) << 12) | (((ph3 - ph2) & c12) << 24) | (((ph4 - ph3) & c12) << 36) |
+                                                       ((ull)(rmask == 3u) << 48) | ((ull)cur.take << 49) | ((ull)(cur.more != 0) << 52);
+                }
+                came = 0;
                 ++ph_steps;
                 if (cur.take == 0) ++ph_noload;
                 ph_a += ph1 - ph0; ph_b += ph2 - ph1; ph_c += ph3 - ph2; ph_d += ph4 - ph3; ph_push += ph3 - ph2a; ph_cold += cur.more ? 1 : 0;
