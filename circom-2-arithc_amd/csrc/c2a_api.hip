@@ -552,7 +552,7 @@ int do_topo_sort(c2a_ctx* c, u64* cycle_at) {
     c->stats = c2a_stats{};
     c->stats.n_gates = n;
     if (cycle_at) *cycle_at = 0;
-    if (n == 0) { c->stage = ST_SORTED; return C2A_OK; }
+    if (n == 0) { c->stage = ST_SORTED; c->peel_meta_valid = true; return C2A_OK; }      // (no gates: no levels, and that is valid level data)
     rec(c, EV_PREP0);
     int r = do_prep(c);
     if (r) return r;

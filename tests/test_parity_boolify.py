@@ -163,6 +163,13 @@ def test_boolify_empty_circuit(backend):
     assert backend.build_circuit() == 2
     info = backend.boolify(16)
     assert (info.n_gates, info.wire_count, info.aux_total) == (0, 32, 0)
+    # the evaluator, the verifier and the prune pass on a circuit without gates: the output is a wire nothing drives (0)
+    assert backend.eval(np.array([[5, 9]], np.uint64), {}, width=16).tolist() == [[0, 0]]
+    assert backend.eval(np.array([[5, 9]], np.uint64), {}, boolean=True).tolist() == [[0, 0]]
+    assert backend.verify_boolify(3) == (2 * 64, 0)
+    pi = backend.boolify_prune()
+    assert (pi["n_gates"], pi["n_folded"], pi["n_dead"]) == (2, 0, 0)          # just the two constant gates
+    assert backend.eval(np.array([[5, 9]], np.uint64), {}, pruned=True).tolist() == [[0, 0]]
 
 
 def test_call_order_is_enforced(backend, c2a):
