@@ -202,16 +202,26 @@ def main():
 
     dist = None
     torch = None
+    # TESTS ONLY (tests/test_multi_rank_gloo.py): the path of the emulated library — the N-rank flow of this very function then
+    # runs on CPUs (gloo, no torch.cuda), so that what the driver launches on 2-8 GPUs has been executed before it gets there
+    test_lib = os.environ.get("C2A_BENCH_TEST_LIB")
     # one rank per GPU under torch.distributed.run; a 1-rank launch takes the same path (RANK is set by the launcher)
     if world > 1 or ("RANK" in os.environ and os.environ.get("C2A_BENCH_PLAIN") is None and "TORCHELASTIC_RUN_ID" in os.environ):
         import torch
         import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if test_lib:
+            dist.init_process_group("gloo")
+        else:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    sync_device = "cuda" if (dist is not None and not test_lib) else None
 
     c2a = importlib.import_module("circom-2-arithc_amd")
     synth = c2a.synth
+
+    def new_backend():
+        return c2a.Backend(0, lib_path=test_lib) if test_lib else c2a.Backend(local_rank)
 
     shard = args.mode == "shard" and world > 1
     replicas = args.mode == "replicas" and world > 1
@@ -223,7 +233,7 @@ def main():
     cold = None
     if world == 1 and not args.no_cold:        # (first thing on the device: nothing of this process is resident yet)
         t0 = time.perf_counter()
-        be2 = c2a.Backend(local_rank)
+        be2 = new_backend()
         t1 = time.perf_counter()
         be2.load_gates(fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes)
         t2 = time.perf_counter()
@@ -238,7 +248,7 @@ def main():
                         "rate with the input resident"}
         be2.close()
 
-    be = c2a.Backend(local_rank)
+    be = new_backend()
     t0 = time.time()
     be.load_gates(fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes)
     h2d_s = time.time() - t0
@@ -260,7 +270,7 @@ def main():
         for k, v in be.timings().items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
 
-    elapsed = timed_region(step, timed_step, args.steps, args.warmup, dist, torch, "cuda" if dist is not None else None)
+    elapsed = timed_region(step, timed_step, args.steps, args.warmup, dist, torch, sync_device)
     info = last.get("info")
 
     steps = max(1, args.steps)

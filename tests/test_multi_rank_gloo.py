@@ -87,3 +87,32 @@ def test_two_ranks_shard_step_equals_the_whole_circuit(emul_lib, orc, c2a):
     import bench
     assert bench.whole_job_rate(1, 1000, 3, 2.0) == 1500.0   # shard mode: one graph whatever N is
     assert bench.whole_job_rate(2, 1000, 3, 2.0) == 3000.0   # replicas mode: N graphs
+
+
+def test_bench_main_runs_its_two_rank_flow_on_cpus(emul_lib, tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` — the launch line of the driver's scaling run —
+    executed end to end on CPUs (the emulated library + gloo through bench.py's test-only hook): both ranks sort the same graph,
+    bit-blast their own range, check their results against the oracle, and rank 0 prints the one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, C2A_BENCH_TEST_LIB=emul_lib, MASTER_ADDR="127.0.0.1")
+    port = 29700 + (os.getpid() % 1500)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--layers", "14", "--layer-width", "24", "--cpu-sample-layers", "4", "--cpu-bool-slice", "60", "--width", "8"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.split("\n") if ln.startswith("{")]
+    assert len(lines) == 1                                  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong" and d["unit"] == "gates/s"
+    assert d["config"]["n_gates"] == 14 * 24 and d["value"] > 0
+    assert d["checked"].startswith("every one of the 2 ranks")
+    assert len(d["per_rank"]) == 2 and all(r["checked"] for r in d["per_rank"])
+    (lo0, n0), (lo1, n1) = d["per_rank"][0]["shard"], d["per_rank"][1]["shard"]
+    assert lo0 == 0 and lo1 == n0 and n0 + n1 == 14 * 24     # two ranges that tile the sorted positions
+    b = d["config"]["strong_scaling_bound"]["speedup_at_n_gpus"]
+    assert 1.0 <= b["2"] <= b["8"] < 8.0
+    assert d["cpu_baseline"]["kind"] == "port" and d["roofline"]["bound"] == "hbm"
