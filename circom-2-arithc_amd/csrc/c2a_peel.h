@@ -182,6 +182,12 @@ __device__ __forceinline__ void peel_sleep(int units) {
 // Where one lane does something and the wave then LEAVES a loop (break / return), the lanes must be seen to meet again
 // first: otherwise the compiler threads the jump into both sides of the `if (lane == 0)`, the loop exit becomes a join of
 // a divergent branch, and every value carried around that loop is handled as divergent (vector registers, masked code).
+template <int P> __device__ __forceinline__ void wave_priority_() {
+#ifndef C2A_EMULATE
+    __builtin_amdgcn_s_setprio(P);
+#endif
+}
+#define wave_priority(p) wave_priority_<p>()
 __device__ __forceinline__ void wave_join() {
 #ifndef C2A_EMULATE
     __builtin_amdgcn_wave_barrier();
@@ -626,6 +632,8 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
         // one step: `cur` is in hand (issued one step ago), `nx` receives the next one.  true = the chain ends (or abort)
         auto step = [&](StepIO& cur, StepIO& nx) -> bool {
             const ull ph0 = STATS ? c2a_now() : 0;
+            // (two waves share a SIMD's issue slots: from here to the issue of the next step — the claim path — this one goes first)
+            wave_priority(3);
             // ---- everything of THIS step (issued one step ago) is needed now, and is pinned HERE: a register of `cur` that
             // the compiler still counts as in flight further down would put its wait behind the issue of the next step
             C2A_PIN(cur.kfill);
@@ -663,6 +671,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                 // the consumers of nxt are already here (lanes 32 j0 ... of the prefetched lists) unless it has more than 32
                 issue(nx, gi.x, gi.y, gi.w, gi2.x, gi2.y, gi2.z, gi2.w, cur.clp, 32u * j0, 32u, true, gc);
             }
+            wave_priority(0);
             const ull ph2 = STATS ? c2a_now() : 0;
             // ---- tournament of THIS gate
             u32 level = own_valid ? own_level + 1u : 0u;
