@@ -84,7 +84,7 @@ struct c2a_ctx {
 
     // device buffers
     DevBuf lh, rh, out, op, gate4, in_nodes, out_nodes;
-    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, eslot, aq_items, aq_pc, aq_seeds, aq_seed_cnt, fill, meta, node, child, gstat, clist, pctl, pcold;
+    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, eslot, aq_items, aq_pc, aq_seeds, aq_seeds1, aq_seed_cnt, fill, meta, node, child, gstat, clist, pctl, pcold;
     DevBuf rflag, ridx, rlist, next, owner, local, slist, snext, ssum, jnxt, jval, sorted;
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op, gs, wcnt, wfo;
     u32 rb_edges = 0, rb_dup = 0, rb_nmid = 0, rb_err = 0;  // read-back slots (edge count, duplicate-writer flag, wires handed out, in/out clash)
@@ -103,7 +103,7 @@ struct c2a_ctx {
     std::vector<DevBuf*> all;
 
     c2a_ctx() {
-        all = {&lh, &rh, &out, &op, &gate4, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &aq_items, &aq_pc, &aq_seeds, &aq_seed_cnt, &fill,
+        all = {&lh, &rh, &out, &op, &gate4, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &aq_items, &aq_pc, &aq_seeds, &aq_seeds1, &aq_seed_cnt, &fill,
                &gstat, &clist, &pctl, &pcold, &meta, &node, &child, &rflag, &ridx, &rlist, &next,
                &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
                &node_wire, &e_in0, &e_in1, &e_out, &e_op, &gs, &wcnt, &wfo, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &peel_trace, &mb, &mb_seq, &mb_rd, &tsz, &asz, &goff,
@@ -280,17 +280,22 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
     // seed regions: one per workgroup of the sinks pass; a workgroup sees at most gates_per_block gates, each claims <= 2 producers
     const u32 sink_blocks = grid_for(n, c->peel_sinks_blocks);
     const u64 gates_per_block = ((u64)n + (u64)sink_blocks * kThreads - 1) / ((u64)sink_blocks * kThreads) * kThreads;
-    cold.n_regions = sink_blocks; cold.region_cap = (u32)(2 * gates_per_block);
-    ENSURE(c->aq_seeds, (size_t)cold.n_regions * cold.region_cap * 4); ENSURE(c->aq_seed_cnt, (size_t)cold.n_regions * 4);
-    HIP_TRY(hipMemsetAsync(c->aq_seed_cnt.p, 0, (size_t)cold.n_regions * 4, s));
-    cold.seeds = c->aq_seeds.as<u32>(); cold.seed_cnt = c->aq_seed_cnt.as<u32>();
-    A.seeds_w = c->aq_seeds.as<u32>(); A.seed_cnt_w = c->aq_seed_cnt.as<u32>(); A.region_cap = cold.region_cap;
+    const u32 sink_cap = (u32)(2 * gates_per_block);
+    ENSURE(c->aq_seeds, (size_t)sink_blocks * sink_cap * 4); ENSURE(c->aq_seed_cnt, (size_t)2 * sink_blocks * 4);
+    HIP_TRY(hipMemsetAsync(c->aq_seed_cnt.p, 0, (size_t)2 * sink_blocks * 4, s));
+    A.seeds_w = c->aq_seeds.as<u32>(); A.seed_cnt_w = c->aq_seed_cnt.as<u32>(); A.region_cap = sink_cap;
+    // ... what those claim is done by k_peel_level1 (a wave per gate, region by region), and what THAT claims — at most two
+    // producers per gate again — starts the chains of the dataflow launch
+    cold.n_regions = sink_blocks; cold.region_cap = 2 * sink_cap;
+    ENSURE(c->aq_seeds1, (size_t)sink_blocks * cold.region_cap * 4);
+    cold.seeds = c->aq_seeds1.as<u32>(); cold.seed_cnt = c->aq_seed_cnt.as<u32>() + sink_blocks;
     // what only the edges of the launch touch travels as one small block in HBM (keeps the kernel's scalar registers free)
     // (written by a one-thread launch that takes it by value: a copy from this stack object would need a host round trip)
     ENSURE(c->pcold, sizeof(PeelCold));
     C2A_LAUNCH_NOSYNC(k_set_cold, 1, 1, s, c->pcold.as<PeelCold>(), cold);
     A.cold = c->pcold.as<PeelCold>();
     C2A_LAUNCH(k_peel_sinks, sink_blocks, kThreads, s, A);
+    C2A_LAUNCH(k_peel_level1, sink_blocks, kThreads, s, A, (const u32*)A.seeds_w, (const u32*)A.seed_cnt_w, sink_cap, c->aq_seeds1.as<u32>(), c->aq_seed_cnt.as<u32>() + sink_blocks, cold.region_cap);
     // (every wave of the launch is alive at once under emulation too, interleaved at the back-offs — in a shuffled order per
     // C2A_EMUL_SEED: the ticket / hand-off / termination protocol is exercised without a GPU)
     if (want_stats) C2A_LAUNCH_CONCURRENT((k_peel<true>), waves, 64, s, A);
@@ -343,6 +348,7 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
                      st[9] * 10.0 / st[13], st[10] * 10.0 / st[13], st[11] * 10.0 / st[13], st[12] * 10.0 / st[13], 100.0 * st[14] / st[13], st[15] * 10.0 / (st[5] + st[0] + 1));
         if (st[13]) std::fprintf(stderr, "[c2a peel stats] of the tournament phase: %.0f ns per step go to writing hand-off entries (%.0f ns per entry, its wait for the tickets included); %.2f %% of the steps read the consumer list itself (cold)\n",
                      st[17] * 10.0 / st[13], st[17] * 10.0 / (st[2] + 1), 100.0 * st[18] / st[13]);
+        if (st[2]) std::fprintf(stderr, "[c2a peel stats] per hand-off entry: %.0f ns waiting for its two tickets, %.0f ns writing it\n", st[19] * 10.0 / st[2], (st[17] - st[19]) * 10.0 / st[2]);
     }
     c->peel_gave_up = t4[CTL_ABORT] != 0;
     if (t4[CTL_ABORT]) return fail(c, C2A_ERR_HIP, "dataflow peel: watchdog tripped (" + std::to_string(t4[CTL_ABORT]) + " waves gave up waiting)");

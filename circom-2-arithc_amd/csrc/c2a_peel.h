@@ -208,6 +208,16 @@ template <class T> __device__ __forceinline__ T* own_sgprs(T* p) {
     return (T*)q;
 #endif
 }
+// A pointer READ FROM MEMORY, as a wave-uniform global pointer (STATS only).
+__device__ __forceinline__ ull* uniform_ptr(ull* p) {
+#ifdef C2A_EMULATE
+    return p;
+#else
+    const u64 v = (u64)p;
+    const u64 u = (u64)(u32)__builtin_amdgcn_readfirstlane((u32)v) | ((u64)(u32)__builtin_amdgcn_readfirstlane((u32)(v >> 32)) << 32);
+    return (ull*)(__attribute__((address_space(1))) ull*)u;
+#endif
+}
 __device__ __forceinline__ u32 own_sgpr(u32 v) {
 #ifdef C2A_EMULATE
     return v;
@@ -393,6 +403,62 @@ __global__ void __launch_bounds__(256) k_peel_sinks(PeelArgs A) {
     }
 }
 
+// ---- the gates the sinks pass claimed (level 1: every consumer is a sink), all at once: a wave per gate, one step each.  In
+// the dataflow launch each of them would start a chain with three dependent round trips in front of its first step (measured
+// on the 10 M-gate graph: 450 000 such starts kept all 2 048 waves busy for the first 1.3 ms, and the hand-off entries of
+// that time — the critical path among them — waited for its end).  Here their tournament is a minimum: a sink's path is
+// [sink], so the smallest (consumer id, edge label) wins, if that id is smaller than the gate's own (else the gate is a DFS
+// root itself).  Workgroup b takes region b of the sinks pass and writes the producers it claims into ITS region of `out`:
+// the seeds of the dataflow launch.
+__global__ void __launch_bounds__(256) k_peel_level1(PeelArgs A, const u32* __restrict__ in, const u32* __restrict__ in_cnt, u32 in_cap,
+                                                     u32* out, u32* out_cnt, u32 out_cap) {
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const u32 cnt = in_cnt[blockIdx.x];
+    const u32* src = in + (u64)blockIdx.x * in_cap;
+    u32* dst = out + (u64)blockIdx.x * out_cap;
+    u32* counter = &out_cnt[blockIdx.x];
+    const u64 tag = A.epoch ? kTagBit : 0ull;
+    for (u32 i = wave; i < cnt; i += 4) {
+        const u32 g = src[i];
+        const uint4 gi = A.gstat[2 * (u64)g], gi2 = A.gstat[2 * (u64)g + 1];
+        // the smallest consumer, then the smaller label: one key
+        u64 best = ~0ull;
+        for (u32 eb = lane; eb < gi.w; eb += 64) {
+            const u32 e = A.clist[gi.z + eb];
+            const u64 key = ((u64)(e & kIdMask) << 1) | (e >> 31);
+            best = key < best ? key : best;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { const u64 o = __shfl_xor(best, off, 64); best = o < best ? o : best; }
+        const u32 c = (u32)(best >> 1), el = (u32)(best & 1ull);
+        const bool has = c < g;                      // (else every consumer belongs to a later DFS root: [g] itself)
+        const u32 ch = has ? c : C2A_NONE, depth = has ? 1u : 0u, root = has ? c : g, label = has ? el : 0u;
+        u64 w = tag;
+        if (lane == 0) w |= hdr0_word(root, depth);
+        else if (lane == 1) w |= hdr1_word(1u, C2A_NONE);
+        else if (lane == 2) w |= (u64)depth;         // (position in the chunk: bit 1 of word 0 comes next — the same number)
+        else if (lane == kHdrWords) w |= (u64)label;
+        A.node[(u64)g * kNodeWords + lane] = w;
+        u32 claimed = C2A_NONE;
+        if (lane == 0) {
+            A.meta[g] = make_uint4(ch, depth, root, label | (1u << 1));
+            if (has) A.child[2 * (u64)ch + label] = g;
+        }
+        if (lane < 2) {
+            const u32 d = lane ? gi.y : gi.x, dc = lane ? gi2.w : gi2.y;
+            if (d != C2A_NONE && (dc == 1u || atomicAdd(&A.fill[d], 1u) + 1u == dc)) claimed = d;
+        }
+        const u64 mask = __ballot(claimed != C2A_NONE);
+        if (mask) {
+            u32 b = 0;
+            if (lane == (u32)ctz64(mask)) b = atomicAdd(counter, (u32)__popcll(mask));
+            b = __shfl(b, (int)ctz64(mask), 64);
+            if (claimed != C2A_NONE) dst[b + (u32)__popcll(mask & ((1ull << lane) - 1ull))] = claimed;
+        }
+    }
+    if (threadIdx.x == 0 && cnt) { atomicAdd(&A.ctl[CTL_PROCESSED], cnt); atomicMax(&A.ctl[CTL_MAXLEVEL], 1u); }
+}
+
 __global__ void k_set_cold(PeelCold* dst, PeelCold v) { *dst = v; }
 
 // everything issued for one gate at the top of its step; two of these swap roles (nothing is ever copied: a register
@@ -434,7 +500,11 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
     u32 st_pops = 0, st_polls = 0, st_push = 0, st_seeds = 0;
     ull st_busy = 0, st_idle = 0, st_t0 = STATS ? c2a_now() : 0;
     ull ph_w1 = 0, ph_w2 = 0, ph_w3 = 0;
-    ull ph_a = 0, ph_b = 0, ph_c = 0, ph_d = 0, ph_steps = 0, ph_noload = 0, ph_start = 0, ph_push = 0, ph_cold = 0;      // STATS: phase times of the chain step
+    // STATS: the diagnostic arrays, read once (a load through A.cold inside a step would put its round trip into the step)
+    ull* const dq_time = STATS ? uniform_ptr(A.cold->q_time) : nullptr;
+    ull* const dp_time = STATS ? uniform_ptr(A.cold->p_time) : nullptr;
+    ull* const dt_trace = STATS ? uniform_ptr(A.cold->t_trace) : nullptr;
+    ull ph_a = 0, ph_b = 0, ph_c = 0, ph_d = 0, ph_steps = 0, ph_noload = 0, ph_start = 0, ph_push = 0, ph_cold = 0, ph_pwait = 0;      // STATS: phase times of the chain step
     for (;;) {
         // ---- next piece of work: the seed pool, then the hand-off slots
         u32 g = C2A_NONE;
@@ -571,7 +641,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
         if (STATS) {
             const ull tn = c2a_now();
             ph_start += tn - ph_s0;
-            if (pop_slot != ~0ull && lane == 0) A.cold->p_time[pop_slot] = tn;
+            if (pop_slot != ~0ull && lane == 0) dp_time[pop_slot] = tn;
         }
 
         // issue everything the step of a gate needs from memory.  scl: the gate's consumer list, one entry per lane from
@@ -751,12 +821,13 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             if (rmask == 3u) {
                 // the entry: lanes 8..15 hold the pushed gate's static records, lanes 32..38 its first consumers
                 C2A_PIN(push_t);                                    // (both atomics are back)
+                if (STATS) ph_pwait += c2a_now() - ph2a;
                 const u64 t = (u64)push_f * A.q_cap + rdlane(push_t, 0);
                 // nobody was in line for this entry: tell the reserve
                 if (rdlane(push_c, 0) <= rdlane(push_t, 0)) { if (lane == 0) atomicAdd(&A.ctl[CTL_DEMAND + (me & (kAcctShards - 1u)) * kAcctStride], 1u); wave_join(); }
                 u64* slot = A.fifo + t * kSlotWords;
                 const u64 rt = (u64)A.run << 32;
-                if (STATS && lane == 0) A.cold->q_time[t] = ph0;
+                if (STATS && lane == 0) dq_time[t] = ph0;
                 if (lane >= 8 && lane < 16) st_nw(slot + (lane - 8), rt | cur.gw);
                 if (lane >= 32 && lane < 40) st_nw(slot + (lane - 24), rt | (lane == 39 ? g_dep1 : cur.clp));
                 wave_join();
@@ -797,11 +868,11 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             if ((processed & 63u) == 0 && lane == 0) atomicAdd(&A.ctl[CTL_HEARTBEAT], 1u);
             if (STATS) {
                 const ull ph4 = c2a_now();
-                if (A.cold->t_trace && lane == 0) {
-                    A.cold->t_trace[3 * (u64)gc] = (ph0 << 2) | came; A.cold->t_trace[3 * (u64)gc + 1] = ph4;
+                if (dt_trace && lane == 0) {
+                    dt_trace[3 * (u64)gc] = (ph0 << 2) | came; dt_trace[3 * (u64)gc + 1] = ph4;
                     // what the step was made of: top wait, issue, tournament, stores (ticks, 12 bits each) | pushed << 48 | records loaded ahead << 49 | cold << 52
                     const ull c12 = 0xFFFull;
-                    A.cold->t_trace[3 * (u64)gc + 2] = ((ph1 - ph0) & c12) | (((ph2 - ph1) & c12) << 12) | (((ph3 - ph2) & c12) << 24) | (((ph4 - ph3) & c12) << 36) |
+                    dt_trace[3 * (u64)gc + 2] = ((ph1 - ph0) & c12) | (((ph2 - ph1) & c12) << 12) | (((ph3 - ph2) & c12) << 24) | (((ph4 - ph3) & c12) << 36) |
                                                        ((ull)(rmask == 3u) << 48) | ((ull)cur.take << 49) | ((ull)(cur.more != 0) << 52);
                 }
                 came = 0;
@@ -840,7 +911,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                 atomicAdd(&stats[7], ph_w1 | (ph_w2 << 32)); atomicAdd(&stats[16], ph_w3);
                 atomicAdd(&stats[9], ph_a); atomicAdd(&stats[10], ph_b); atomicAdd(&stats[11], ph_c); atomicAdd(&stats[12], ph_d);
                 atomicAdd(&stats[13], ph_steps); atomicAdd(&stats[14], ph_noload); atomicAdd(&stats[15], ph_start);
-                atomicAdd(&stats[17], ph_push); atomicAdd(&stats[18], ph_cold);
+                atomicAdd(&stats[17], ph_push); atomicAdd(&stats[18], ph_cold); atomicAdd(&stats[19], ph_pwait);
             }
         }
     }
