@@ -806,8 +806,75 @@ struct EvalRun {
 };
 __device__ __forceinline__ u64 ev_ld(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ev_st(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// ---- a boolean template on ONE WAVE, 64 of its gates at a time (a lane per gate).  The gates of a template are in
+// dependency order and read each other's wires: a lane that reads the out wire of an EARLIER lane of its chunk (dep: which) takes
+// the value from that lane's register once that lane is done — rounds of "every lane whose producers are done" until the chunk
+// is; a ripple-carry chain makes that as many rounds as the chunk is deep, a bitwise template one — and everything else comes
+// from memory, all lanes at once.  (One lane walking its template gate by gate — the first version — paid two dependent
+// round trips per gate: 560 us per level of the 10 M-gate graph, 2.8 s for a pass over its 742 M boolean gates.)
+// Every store this wave has issued is performed (and nothing is moved across by the compiler).  The values of these passes
+// travel by agent-scope loads and stores, which no cache holds back; a full agent-scope fence (__threadfence) would also write
+// back and invalidate the XCD's L2 — once per wave — and that, not the work, was what a level cost (measured: 230 us per level
+// of 2 000 gates with __threadfence between the chunks of a template).
+__device__ __forceinline__ void store_fence() {
+#ifdef C2A_EMULATE
+    __threadfence();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+}
+// between two chunks of a template: what the lanes stored is there for what the lanes load next (under emulation the lanes of
+// a wave are fibers that only meet at wave-level intrinsics: they have to meet here)
+__device__ __forceinline__ void chunk_fence() {
+    store_fence();
+#ifdef C2A_EMULATE
+    (void)__ballot(1);
+#endif
+}
+struct ChunkDeps { int d0, d1; };
+// which earlier lane of the chunk (nv lanes hold gates) drives this lane's inputs; -1: nobody here (out wires are unique)
+__device__ __forceinline__ ChunkDeps chunk_deps(u32 in0, u32 in1, u32 out, u32 nv, u32 lane) {
+    ChunkDeps d{-1, -1};
+    for (u32 i = 0; i + 1 < nv; ++i) {
+        const u32 oi = rdlane(out, i);
+        if (i < lane) { if (in0 == oi) d.d0 = (int)i; if (in1 == oi) d.d1 = (int)i; }
+    }
+    return d;
+}
+// gates [k0, k1) on wire values (64 vectors per wire, one bit each)
+__device__ __forceinline__ void eval_template_wave(u64 k0, u64 k1, const u32* __restrict__ g_in0, const u32* __restrict__ g_in1,
+                                                   const u32* __restrict__ g_out, const u8* __restrict__ g_op, u64* bval, u32 lane) {
+    for (u64 base = k0; base < k1; base += 64) {
+        const u32 nv = k1 - base < 64 ? (u32)(k1 - base) : 64u;
+        const bool valid = lane < nv;
+        u32 i0 = 0xFFFFFFFFu, i1 = 0xFFFFFFFFu, o = 0xFFFFFFFEu, op = 2;
+        if (valid) { i0 = g_in0[base + lane]; i1 = g_in1[base + lane]; o = g_out[base + lane]; op = g_op[base + lane]; }
+        ChunkDeps d = chunk_deps(i0, i1, o, nv, lane);
+        if (op == 2u) d.d1 = -1;
+        const u64 a_mem = valid && d.d0 < 0 ? ev_ld(&bval[i0]) : 0ull;
+        const u64 b_mem = valid && op != 2u && d.d1 < 0 ? ev_ld(&bval[i1]) : 0ull;
+        bool done = !valid;
+        u64 v = 0;
+        for (;;) {
+            const u64 dm = __ballot(done);
+            if (dm == ~0ull) break;
+            const u64 av = __shfl(v, d.d0 < 0 ? (int)lane : d.d0, 64), bv = __shfl(v, d.d1 < 0 ? (int)lane : d.d1, 64);
+            if (!done && (d.d0 < 0 || ((dm >> d.d0) & 1ull)) && (d.d1 < 0 || ((dm >> d.d1) & 1ull))) {
+                const u64 a = d.d0 < 0 ? a_mem : av, b = d.d1 < 0 ? b_mem : bv;
+                v = op == 0u ? (a ^ b) : (op == 1u ? (a & b) : ~a);
+                done = true;
+            }
+        }
+        if (valid) ev_st(&bval[o], v);
+        if (base + 64 < k1) chunk_fence();       // (the next chunk reads these wires from memory)
+    }
+}
 __global__ void __launch_bounds__(kThreads) k_eval_run(EvalRun R) {
     const u64 mk = R.width >= 64 ? ~0ull : ((1ull << R.width) - 1ull);
+    const u32 lane = threadIdx.x & 63u;
+    const u64 wave = gtid() >> 6, n_waves = gstride() >> 6;
     u32 target = 0;
     for (u32 lv = R.levels; lv-- > 0;) {
         const u32 lo = R.lbase[lv], cnt = R.lbase[lv + 1] - lo;
@@ -818,17 +885,13 @@ __global__ void __launch_bounds__(kThreads) k_eval_run(EvalRun R) {
                       eval_arith_op(R.e_op[p], ev_ld(&R.aval[(u64)R.e_in0[p] * 64 + t]), ev_ld(&R.aval[(u64)R.e_in1[p] * 64 + t]), R.width, mk));
             }
         if (R.mode & 2u)
-            for (u64 i = gtid(); i < cnt; i += gstride()) {
+            for (u64 i = wave; i < cnt; i += n_waves) {
                 const u32 p = R.spos[R.order[lo + (u32)i]];
-                for (u64 k = R.goff[p]; k < R.goff[p + 1]; ++k) {        // (a gate's template reads wires the same lane wrote: program order)
-                    const u64 a = ev_ld(&R.bval[R.b_in0[k]]), b = ev_ld(&R.bval[R.b_in1[k]]);
-                    const u32 o = R.b_op[k];
-                    ev_st(&R.bval[R.b_out[k]], o == 0 ? (a ^ b) : (o == 1 ? (a & b) : ~a));
-                }
+                eval_template_wave(R.goff[p], R.goff[p + 1], R.b_in0, R.b_in1, R.b_out, R.b_op, R.bval, lane);
             }
         if (lv == 0) break;
         // ---- every workgroup has finished the level before any starts the next
-        __threadfence();
+        store_fence();
         __syncthreads();
         target += gridDim.x;
         if (threadIdx.x == 0) {
@@ -836,7 +899,7 @@ __global__ void __launch_bounds__(kThreads) k_eval_run(EvalRun R) {
             while (__hip_atomic_load(R.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) peel_sleep(2);
         }
         __syncthreads();
-        __threadfence();
+        store_fence();
     }
 }
 
@@ -868,7 +931,7 @@ struct PruneRun {
 __device__ __forceinline__ u32 ev_ld32(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ev_st32(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void grid_barrier(u32* bar, u32& target) {
-    __threadfence();
+    store_fence();
     __syncthreads();
     target += gridDim.x;
     if (threadIdx.x == 0) {
@@ -876,42 +939,66 @@ __device__ __forceinline__ void grid_barrier(u32* bar, u32& target) {
         while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) peel_sleep(2);
     }
     __syncthreads();
-    __threadfence();
+    store_fence();
 }
+// (both passes: a wave per arithmetic gate, its template 64 gates at a time like eval_template_wave)
 __global__ void __launch_bounds__(kThreads) k_prune_fold(PruneRun R) {
+    const u32 lane = threadIdx.x & 63u;
+    const u64 wave = gtid() >> 6, n_waves = gstride() >> 6;
     u32 target = 0;
     u64 folded = 0;
     const u64 out_end = R.out_base + (u64)R.n_out_wires;
     for (u32 lv = R.levels; lv-- > 0;) {
         const u32 lo = R.lbase[lv], cnt = R.lbase[lv + 1] - lo;
-        for (u64 i = gtid(); i < cnt; i += gstride()) {
+        for (u64 i = wave; i < cnt; i += n_waves) {
             const u32 p = R.spos[R.order[lo + (u32)i]];
-            for (u64 k = R.goff[p]; k < R.goff[p + 1]; ++k) {
-                const u32 op = R.b_op[k], out = R.b_out[k];
-                const u32 a = ev_ld32(&R.rep[R.b_in0[k]]);
-                const u32 b = op == 2u ? a : ev_ld32(&R.rep[R.b_in1[k]]);
-                u32 r = 0xFFFFFFFFu, nop = op, na = a, nb = b;                 // r: the folded value (a rep), or "keep"
-                if (op == 0u) {            // XOR
-                    if (a == b) r = 0u; else if (a == 0u) r = b; else if (b == 0u) r = a;
-                    else if (a == 1u) { nop = 2u; na = b; nb = b; } else if (b == 1u) { nop = 2u; nb = a; }
-                } else if (op == 1u) {     // AND
-                    if (a == b) r = a; else if (a == 0u || b == 0u) r = 0u; else if (a == 1u) r = b; else if (b == 1u) r = a;
-                } else {                   // INV
-                    if (a <= 1u) r = 1u - a;
-                }
+            const u64 k0 = R.goff[p], k1 = R.goff[p + 1];
+            for (u64 base = k0; base < k1; base += 64) {
+                const u32 nv = k1 - base < 64 ? (u32)(k1 - base) : 64u;
+                const bool valid = lane < nv;
+                const u64 k = base + lane;
+                u32 i0 = 0xFFFFFFFFu, i1 = 0xFFFFFFFFu, out = 0xFFFFFFFEu, op = 2;
+                if (valid) { i0 = R.b_in0[k]; i1 = R.b_in1[k]; out = R.b_out[k]; op = R.b_op[k]; }
+                ChunkDeps d = chunk_deps(i0, i1, out, nv, lane);
+                if (op == 2u) d.d1 = -1;
+                const u32 a_mem = valid && d.d0 < 0 ? ev_ld32(&R.rep[i0]) : 0u;
+                const u32 b_mem = valid && op != 2u && d.d1 < 0 ? ev_ld32(&R.rep[i1]) : 0u;
                 const bool is_output = (u64)out >= R.out_base && (u64)out < out_end;
-                if (r != 0xFFFFFFFFu && !is_output) {
-                    ev_st32(&R.rep[out], r);
-                    R.t_op[k] = 0xFFu;
-                    ++folded;
-                } else {
-                    // stays a gate (an output wire must be driven): its inputs by what they are known to be
-                    if (r != 0xFFFFFFFFu) { nop = op; na = a; nb = b; }
-                    const u32 wa = na == 0u ? R.zero_wire : (na == 1u ? R.one_wire : na - 2u);
-                    const u32 wb = nb == 0u ? R.zero_wire : (nb == 1u ? R.one_wire : nb - 2u);
-                    R.t_in0[k] = wa; R.t_in1[k] = nop == 2u ? wa : wb; R.t_op[k] = (u8)nop;
-                    ev_st32(&R.rep[out], out + 2u);
+                bool done = !valid;
+                u32 v = 0;                                   // what the out wire is known to be (a rep)
+                for (;;) {
+                    const u64 dm = __ballot(done);
+                    if (dm == ~0ull) break;
+                    const u32 av = __shfl(v, d.d0 < 0 ? (int)lane : d.d0, 64), bv = __shfl(v, d.d1 < 0 ? (int)lane : d.d1, 64);
+                    if (!done && (d.d0 < 0 || ((dm >> d.d0) & 1ull)) && (d.d1 < 0 || ((dm >> d.d1) & 1ull))) {
+                        const u32 a = d.d0 < 0 ? a_mem : av;
+                        const u32 b = op == 2u ? a : (d.d1 < 0 ? b_mem : bv);
+                        u32 r = 0xFFFFFFFFu, nop = op, na = a, nb = b;                 // r: the folded value (a rep), or "keep"
+                        if (op == 0u) {            // XOR
+                            if (a == b) r = 0u; else if (a == 0u) r = b; else if (b == 0u) r = a;
+                            else if (a == 1u) { nop = 2u; na = b; nb = b; } else if (b == 1u) { nop = 2u; nb = a; }
+                        } else if (op == 1u) {     // AND
+                            if (a == b) r = a; else if (a == 0u || b == 0u) r = 0u; else if (a == 1u) r = b; else if (b == 1u) r = a;
+                        } else {                   // INV
+                            if (a <= 1u) r = 1u - a;
+                        }
+                        if (r != 0xFFFFFFFFu && !is_output) {
+                            v = r;
+                            R.t_op[k] = 0xFFu;
+                            ++folded;
+                        } else {
+                            // stays a gate (an output wire must be driven): its inputs by what they are known to be
+                            if (r != 0xFFFFFFFFu) { nop = op; na = a; nb = b; }
+                            const u32 wa = na == 0u ? R.zero_wire : (na == 1u ? R.one_wire : na - 2u);
+                            const u32 wb = nb == 0u ? R.zero_wire : (nb == 1u ? R.one_wire : nb - 2u);
+                            R.t_in0[k] = wa; R.t_in1[k] = nop == 2u ? wa : wb; R.t_op[k] = (u8)nop;
+                            v = out + 2u;
+                        }
+                        done = true;
+                    }
                 }
+                if (valid) ev_st32(&R.rep[out], v);
+                if (base + 64 < k1) chunk_fence();
             }
         }
         if (lv == 0) break;
@@ -920,29 +1007,50 @@ __global__ void __launch_bounds__(kThreads) k_prune_fold(PruneRun R) {
     if (folded) atomicAdd(&R.counts[0], (ull)folded);
 }
 __global__ void __launch_bounds__(kThreads) k_prune_live(PruneRun R) {
+    const u32 lane = threadIdx.x & 63u;
+    const u64 wave = gtid() >> 6, n_waves = gstride() >> 6;
     u32 target = 0;
     u64 dead = 0;
     const u64 out_end = R.out_base + (u64)R.n_out_wires;
     for (u32 lv = 0; lv < R.levels; ++lv) {
         const u32 lo = R.lbase[lv], cnt = R.lbase[lv + 1] - lo;
-        for (u64 i = gtid(); i < cnt; i += gstride()) {
+        for (u64 i = wave; i < cnt; i += n_waves) {
             const u32 p = R.spos[R.order[lo + (u32)i]];
-            u32 live = 0;
-            for (u64 k = R.goff[p + 1]; k-- > R.goff[p];) {
-                const u32 op = R.t_op[k];
-                if (op == 0xFFu) continue;
-                const u32 out = R.b_out[k];
+            const u64 k0 = R.goff[p], k1 = R.goff[p + 1];
+            u32 live_total = 0;
+            // chunks from the last to the first; inside a chunk a gate is needed by the live gates behind it that read its wire
+            for (u64 base = k0 + ((k1 - k0 - 1) & ~63ull); k1 > k0; base -= 64) {
+                const u32 nv = k1 - base < 64 ? (u32)(k1 - base) : 64u;
+                const u64 k = base + lane;
+                u32 op = 0xFFu, out = 0xFFFFFFFEu, t0 = 0xFFFFFFFFu, t1 = 0xFFFFFFFFu;
+                if (lane < nv) { op = R.t_op[k]; out = R.b_out[k]; }
+                const bool kept = op != 0xFFu;
+                if (kept) { t0 = R.t_in0[k]; t1 = op == 2u ? t0 : R.t_in1[k]; }
+                u64 readers = 0;
+                for (u32 j = 1; j < nv; ++j) {
+                    const u32 r0 = rdlane(t0, j), r1 = rdlane(t1, j);
+                    if (j > lane && (out == r0 || out == r1)) readers |= 1ull << j;      // (lanes that hold no kept gate read wire 0xFFFFFFFF)
+                }
                 const bool is_output = (u64)out >= R.out_base && (u64)out < out_end;
-                if (is_output || ev_ld32(&R.need[out]) != 0u) {
-                    ++live;
-                    ev_st32(&R.need[R.t_in0[k]], 1u);
-                    if (op != 2u) ev_st32(&R.need[R.t_in1[k]], 1u);
-                } else {
+                bool live = kept && (is_output || ev_ld32(&R.need[out]) != 0u);
+                for (;;) {
+                    const u64 lm = __ballot(live);
+                    const bool wake = kept && !live && (readers & lm) != 0ull;
+                    if (!__ballot(wake)) break;
+                    live = live || wake;
+                }
+                if (live) {
+                    ev_st32(&R.need[t0], 1u);
+                    if (op != 2u) ev_st32(&R.need[t1], 1u);
+                } else if (kept) {
                     R.t_op[k] = (u8)(op | 0x80u);
                     ++dead;
                 }
+                live_total += (u32)__popcll(__ballot(live));
+                if (base == k0) break;
+                chunk_fence();
             }
-            R.live_cnt[p] = live;
+            if (lane == 0) R.live_cnt[p] = live_total;
         }
         if (lv + 1 == R.levels) break;
         grid_barrier(R.bar, target);
@@ -974,16 +1082,14 @@ __global__ void k_prune_consts(u32 zero_wire, u32 one_wire, u32* p_in0, u32* p_i
 }
 // the pruned circuit on values: the per-gate ranges are pgoff (+ 2), the two constant wires are set by the caller
 __global__ void __launch_bounds__(kThreads) k_eval_pruned(EvalRun R, const u32* __restrict__ pgoff) {
+    const u32 lane = threadIdx.x & 63u;
+    const u64 wave = gtid() >> 6, n_waves = gstride() >> 6;
     u32 target = 0;
     for (u32 lv = R.levels; lv-- > 0;) {
         const u32 lo = R.lbase[lv], cnt = R.lbase[lv + 1] - lo;
-        for (u64 i = gtid(); i < cnt; i += gstride()) {
+        for (u64 i = wave; i < cnt; i += n_waves) {
             const u32 p = R.spos[R.order[lo + (u32)i]];
-            for (u64 k = 2ull + pgoff[p]; k < 2ull + pgoff[p + 1]; ++k) {
-                const u64 a = ev_ld(&R.bval[R.b_in0[k]]), b = ev_ld(&R.bval[R.b_in1[k]]);
-                const u32 o = R.b_op[k];
-                ev_st(&R.bval[R.b_out[k]], o == 0 ? (a ^ b) : (o == 1 ? (a & b) : ~a));
-            }
+            eval_template_wave(2ull + pgoff[p], 2ull + pgoff[p + 1], R.b_in0, R.b_in1, R.b_out, R.b_op, R.bval, lane);
         }
         if (lv == 0) break;
         grid_barrier(R.bar, target);
