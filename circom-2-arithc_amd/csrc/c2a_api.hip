@@ -55,6 +55,7 @@ struct c2a_ctx {
     Stage stage = ST_EMPTY;
     int n_cu = 256;
     u32 bool_chunk = 256;          // arithmetic gates per k_boolify workgroup: 128, 256 (measured best) or 512
+    u32 peel_seed_chunk = 8;       // dataflow launch: seeds a wave takes at a time (1: the one counter they all hit costs 1.4 ms; 8 and 32 are equal)
     u32 peel_sinks_blocks = 4096;  // grid cap of the sinks pass (latency-bound per thread: two dependent round trips per sink)
     u32 peel_waves = 8;            // dataflow launch: single-wave workgroups per CU (clamped by the occupancy query)
     u32 peel_fifos = 64;           // dataflow launch: hand-off arrays (a power of two <= 64)
@@ -84,7 +85,7 @@ struct c2a_ctx {
 
     // device buffers
     DevBuf lh, rh, out, op, gate4, in_nodes, out_nodes;
-    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, eslot, aq_items, aq_pc, aq_seeds, aq_seeds1, aq_seed_cnt, fill, meta, node, child, gstat, clist, pctl, pcold;
+    DevBuf prod1, dep0, dep1, cons_cnt, cons_off, eslot, aq_items, aq_pc, aq_seeds, aq_seeds1, aq_seed_flat, aq_seed_cnt, fill, meta, node, child, gstat, clist, pctl, pcold;
     DevBuf rflag, ridx, rlist, next, owner, local, slist, snext, ssum, jnxt, jval, sorted;
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op, gs, wcnt, wfo;
     u32 rb_edges = 0, rb_dup = 0, rb_nmid = 0, rb_err = 0;  // read-back slots (edge count, duplicate-writer flag, wires handed out, in/out clash)
@@ -103,7 +104,7 @@ struct c2a_ctx {
     std::vector<DevBuf*> all;
 
     c2a_ctx() {
-        all = {&lh, &rh, &out, &op, &gate4, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &aq_items, &aq_pc, &aq_seeds, &aq_seeds1, &aq_seed_cnt, &fill,
+        all = {&lh, &rh, &out, &op, &gate4, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &aq_items, &aq_pc, &aq_seeds, &aq_seeds1, &aq_seed_flat, &aq_seed_cnt, &fill,
                &gstat, &clist, &pctl, &pcold, &meta, &node, &child, &rflag, &ridx, &rlist, &next,
                &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
                &node_wire, &e_in0, &e_in1, &e_out, &e_op, &gs, &wcnt, &wfo, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &peel_trace, &mb, &mb_seq, &mb_rd, &tsz, &asz, &goff,
@@ -281,21 +282,24 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
     const u32 sink_blocks = grid_for(n, c->peel_sinks_blocks);
     const u64 gates_per_block = ((u64)n + (u64)sink_blocks * kThreads - 1) / ((u64)sink_blocks * kThreads) * kThreads;
     const u32 sink_cap = (u32)(2 * gates_per_block);
-    ENSURE(c->aq_seeds, (size_t)sink_blocks * sink_cap * 4); ENSURE(c->aq_seed_cnt, (size_t)2 * sink_blocks * 4);
-    HIP_TRY(hipMemsetAsync(c->aq_seed_cnt.p, 0, (size_t)2 * sink_blocks * 4, s));
+    ENSURE(c->aq_seeds, (size_t)sink_blocks * sink_cap * 4); ENSURE(c->aq_seed_cnt, ((size_t)2 * sink_blocks + 16) * 4);
+    HIP_TRY(hipMemsetAsync(c->aq_seed_cnt.p, 0, ((size_t)2 * sink_blocks + 16) * 4, s));
     A.seeds_w = c->aq_seeds.as<u32>(); A.seed_cnt_w = c->aq_seed_cnt.as<u32>(); A.region_cap = sink_cap;
     // ... what those claim is done by k_peel_level1 (a wave per gate, region by region), and what THAT claims — at most two
     // producers per gate again — starts the chains of the dataflow launch
-    cold.n_regions = sink_blocks; cold.region_cap = 2 * sink_cap;
-    ENSURE(c->aq_seeds1, (size_t)sink_blocks * cold.region_cap * 4);
-    cold.seeds = c->aq_seeds1.as<u32>(); cold.seed_cnt = c->aq_seed_cnt.as<u32>() + sink_blocks;
+    // (collected per workgroup first, then moved to ONE list the waves of the launch take seed_chunk at a time; its length
+    // stays on the device: the word behind the 2 x sink_blocks region counts)
+    const u32 l1_cap = 2 * sink_cap;
+    ENSURE(c->aq_seeds1, (size_t)sink_blocks * l1_cap * 4); ENSURE(c->aq_seed_flat, ((size_t)n + 64) * 4);
+    cold.seeds = c->aq_seed_flat.as<u32>(); cold.seed_total = c->aq_seed_cnt.as<u32>() + 2 * sink_blocks; cold.seed_chunk = c->peel_seed_chunk;
     // what only the edges of the launch touch travels as one small block in HBM (keeps the kernel's scalar registers free)
     // (written by a one-thread launch that takes it by value: a copy from this stack object would need a host round trip)
     ENSURE(c->pcold, sizeof(PeelCold));
     C2A_LAUNCH_NOSYNC(k_set_cold, 1, 1, s, c->pcold.as<PeelCold>(), cold);
     A.cold = c->pcold.as<PeelCold>();
     C2A_LAUNCH(k_peel_sinks, sink_blocks, kThreads, s, A);
-    C2A_LAUNCH(k_peel_level1, sink_blocks, kThreads, s, A, (const u32*)A.seeds_w, (const u32*)A.seed_cnt_w, sink_cap, c->aq_seeds1.as<u32>(), c->aq_seed_cnt.as<u32>() + sink_blocks, cold.region_cap);
+    C2A_LAUNCH(k_peel_level1, sink_blocks, kThreads, s, A, (const u32*)A.seeds_w, (const u32*)A.seed_cnt_w, sink_cap, c->aq_seeds1.as<u32>(), c->aq_seed_cnt.as<u32>() + sink_blocks, l1_cap,
+               c->aq_seed_flat.as<u32>(), c->aq_seed_cnt.as<u32>() + 2 * sink_blocks);
     // (every wave of the launch is alive at once under emulation too, interleaved at the back-offs — in a shuffled order per
     // C2A_EMUL_SEED: the ticket / hand-off / termination protocol is exercised without a GPU)
     if (want_stats) C2A_LAUNCH_CONCURRENT((k_peel<true>), waves, 64, s, A);
@@ -723,6 +727,7 @@ int c2a_create(int n_devices, const int* device_ids, c2a_ctx** out) {
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
         c->n_cu = prop.multiProcessorCount;
     if (const char* e = std::getenv("C2A_BOOL_CHUNK")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 128 || v == 256 || v == 512) c->bool_chunk = v; }
+    if (const char* e = std::getenv("C2A_PEEL_SEED_CHUNK")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 4096) c->peel_seed_chunk = v; }
     if (const char* e = std::getenv("C2A_PEEL_SINKS_BLOCKS")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 16) c->peel_sinks_blocks = v; }
     if (const char* e = std::getenv("C2A_PEEL_WAVES")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 32) c->peel_waves = v; }
     if (const char* e = std::getenv("C2A_PEEL_RESERVE")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v <= 32) c->peel_reserve = v; }

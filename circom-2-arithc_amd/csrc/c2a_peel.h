@@ -87,9 +87,9 @@ constexpr u32 kAcctStride = 32;
 
 // what only the edges of the launch touch (kept out of the kernel's scalar registers)
 struct PeelCold {
-    const u32* seeds;          // [n_regions][region_cap] producers claimed by the sinks pass
-    const u32* seed_cnt;       // [n_regions]
-    u32 n_regions, region_cap;
+    const u32* seeds;          // [*seed_total] the gates the launch starts chains from (claimed by k_peel_level1), one flat list
+    const u32* seed_total;     // how many (device side: the host never learns it)
+    u32 seed_chunk;            // a wave takes this many at a time
     ull* stats;                // optional diagnostics (32 words), nullptr normally
     ull* q_time;               // with stats: when the push of every hand-off entry was decided ...
     ull* p_time;               // ... and when the receiver had it ready to issue
@@ -408,10 +408,13 @@ __global__ void __launch_bounds__(256) k_peel_sinks(PeelArgs A) {
 // on the 10 M-gate graph: 450 000 such starts kept all 2 048 waves busy for the first 1.3 ms, and the hand-off entries of
 // that time — the critical path among them — waited for its end).  Here their tournament is a minimum: a sink's path is
 // [sink], so the smallest (consumer id, edge label) wins, if that id is smaller than the gate's own (else the gate is a DFS
-// root itself).  Workgroup b takes region b of the sinks pass and writes the producers it claims into ITS region of `out`:
-// the seeds of the dataflow launch.
+// root itself).  Workgroup b takes region b of the sinks pass, collects the producers it claims in ITS region of `out`, and
+// at its end moves them to one flat list (a single reservation per workgroup): the seeds of the dataflow launch, which its
+// waves take a few at a time — a wave that owned a whole region would start the region's last seed only after the chains of
+// all the others (measured: the critical path began 0.9 ms into the launch, with idle waves all around).
 __global__ void __launch_bounds__(256) k_peel_level1(PeelArgs A, const u32* __restrict__ in, const u32* __restrict__ in_cnt, u32 in_cap,
-                                                     u32* out, u32* out_cnt, u32 out_cap) {
+                                                     u32* out, u32* out_cnt, u32 out_cap, u32* flat, u32* flat_total) {
+    __shared__ u32 s_base, s_cnt;
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const u32 cnt = in_cnt[blockIdx.x];
     const u32* src = in + (u64)blockIdx.x * in_cap;
@@ -457,6 +460,13 @@ __global__ void __launch_bounds__(256) k_peel_level1(PeelArgs A, const u32* __re
         }
     }
     if (threadIdx.x == 0 && cnt) { atomicAdd(&A.ctl[CTL_PROCESSED], cnt); atomicMax(&A.ctl[CTL_MAXLEVEL], 1u); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_cnt = atomicAdd(counter, 0u);          // (the waves counted by atomics: read it the same way)
+        s_base = s_cnt ? atomicAdd(flat_total, s_cnt) : 0u;
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < s_cnt; i += 256) flat[s_base + i] = __hip_atomic_load(&dst[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 __global__ void k_set_cold(PeelCold* dst, PeelCold v) { *dst = v; }
@@ -516,14 +526,16 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             // (pointers read from memory are generic pointers, and a load through one counts as divergent: every value
             // read through A.cold is declared wave-uniform by hand)
             const PeelCold* C = A.cold;
+            const u32 chunk = uniform(C->seed_chunk);
             while (idx >= region_cnt) {
                 u32 r = 0;
                 if (lane == 0) r = atomicAdd(&A.ctl[CTL_SEEDNEXT], 1u); wave_join();
                 r = rdlane(r, 0);
-                if (r >= uniform(C->n_regions)) { seeds_left = false; break; }
-                region = r; idx = 0; region_cnt = uniform(C->seed_cnt[r]);
+                const u32 total = uniform(*C->seed_total);
+                if ((u64)r * chunk >= total) { seeds_left = false; break; }
+                region = r; idx = 0; region_cnt = total - r * chunk < chunk ? total - r * chunk : chunk;
             }
-            if (seeds_left) { g = uniform(C->seeds[(u64)region * uniform(C->region_cap) + idx]); ++idx; if (STATS) { ++st_seeds; came = 2; } }
+            if (seeds_left) { g = uniform(C->seeds[(u64)region * chunk + idx]); ++idx; if (STATS) { ++st_seeds; came = 2; } }
         }
         const ull ph_s0 = STATS ? c2a_now() : 0;
         if (g != C2A_NONE) {
