@@ -186,6 +186,25 @@ def test_call_order_is_enforced(backend, c2a):
         backend.boolify(65)
 
 
+def test_evaluator_template_chunks_and_more_gates_than_waves(backend, c2a):
+    """The evaluator runs a template on one wave, 64 boolean gates at a time, values forwarded between the lanes of a chunk and
+    through memory between chunks.  One level of 40 independent gates of every template length — among them the dividers,
+    whose last chunk holds a single gate (8 193 = 128 x 64 + 1) — on more gates than the emulated launch has waves, so that
+    waves run a second template after a long first one: every wire must agree with the arithmetic circuit."""
+    ops = [o for o in range(20) if o != 11]
+    n = 40
+    lh = np.array([1 + (k % 3) for k in range(n)], np.uint32)
+    rh = np.array([2 + (k % 5) for k in range(n)], np.uint32)
+    out = (10 + np.arange(n)).astype(np.uint32)
+    op = np.array([ops[(7 * k) % len(ops)] for k in range(n)], np.uint8)
+    backend.load_gates(lh, rh, out, op, 10 + n + 1, list(range(1, 8)), list(out[-3:]))
+    backend.build_circuit()
+    backend.boolify(32)
+    for seed in (1, 2, 3):
+        checked, bad = backend.verify_boolify(seed=seed)
+        assert checked == backend.wire_count * 64 and bad == 0
+
+
 @pytest.mark.parametrize("width", [1, 8, 32, 64])
 def test_gpu_verifier_agrees_and_detects_faults(backend, c2a, width):
     """c2a_verify_boolify = the reference's simulation harness (tests/integration.rs:191-237) as kernels: every

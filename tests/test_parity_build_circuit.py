@@ -258,6 +258,40 @@ def test_dataflow_peel_shapes(backend, orc, shape):
     assert _compare(backend, orc, p, check_serial=False) == "ok"
 
 
+@pytest.mark.parametrize("case", ["own-root", "both-edges-one-sink", "many-sinks", "mixed"])
+def test_level_one_gates(backend, orc, case):
+    """The gates whose consumers are all sinks are done by a kernel of their own (k_peel_level1: the tournament is a minimum
+    over (consumer id, edge label), won only by a consumer with a smaller id than the gate's own).  Its cases one by one:
+    a gate all of whose consumers have larger ids (a DFS root itself), a sink that reads the same gate on both inputs
+    (label 0 wins), a gate with more sink consumers than a wave has lanes, and all of it mixed with deeper gates."""
+    rng = np.random.default_rng(5)
+    if case == "own-root":
+        # gate 0 writes node 10; gates 1..3 (sinks, larger ids) read it
+        lh = np.array([1, 10, 10, 2], np.uint32); rh = np.array([2, 1, 10, 10], np.uint32); out = np.array([10, 11, 12, 13], np.uint32)
+    elif case == "both-edges-one-sink":
+        # gate 3 writes node 10; sink 0 reads it on both inputs, sink 1 on its right input only
+        lh = np.array([10, 1, 2, 1], np.uint32); rh = np.array([10, 10, 1, 2], np.uint32); out = np.array([11, 12, 13, 10], np.uint32)
+    elif case == "many-sinks":
+        # gate 150 writes node 10; 200 sinks around it read it (ids below AND above its own), some on both inputs
+        n = 201
+        lh = np.full(n, 1, np.uint32); rh = np.full(n, 10, np.uint32); out = (20 + np.arange(n)).astype(np.uint32)
+        lh[::7] = 10
+        lh[150], rh[150], out[150] = 1, 2, 10
+    else:
+        # three layers: inputs -> 40 gates -> 40 gates -> 120 sinks, ids permuted
+        n = 200
+        lh = np.empty(n, np.uint32); rh = np.empty(n, np.uint32); out = (100 + np.arange(n)).astype(np.uint32)
+        lh[:40] = rng.integers(1, 9, 40); rh[:40] = rng.integers(1, 9, 40)
+        lh[40:80] = 100 + rng.integers(0, 40, 40); rh[40:80] = 100 + rng.integers(0, 40, 40)
+        lh[80:] = 100 + rng.integers(40, 80, 120); rh[80:] = 100 + rng.integers(0, 80, 120)
+        perm = rng.permutation(n)
+        lh, rh, out = lh[perm], rh[perm], out[perm]
+    n = len(lh)
+    p = dict(lh=lh, rh=rh, out=out, op=rng.integers(0, 20, n).astype(np.uint8), n_nodes=int(out.max()) + 2,
+             input_nodes=np.arange(1, 9, dtype=np.uint32), output_nodes=np.array([int(out.max())], np.uint32))
+    assert _compare(backend, orc, p) == "ok"
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("layers,width,window,seed", [(1500, 200, 8, 11), (300, 1000, 64, 12), (6000, 50, 2, 13), (60, 5000, 30, 14)])
 def test_dataflow_peel_mid_size_full_compare(hip_backend, orc, c2a, layers, width, window, seed):
