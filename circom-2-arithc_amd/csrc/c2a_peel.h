@@ -403,7 +403,9 @@ __global__ void __launch_bounds__(256) k_peel_sinks(PeelArgs A) {
     }
 }
 
-// ---- the gates the sinks pass claimed (level 1: every consumer is a sink), all at once: a wave per gate, one step each.  In
+// ---- the gates the sinks pass claimed (level 1: every consumer is a sink), all at once, one step each (a lane per gate decides, a
+// wave per gate writes its record: a wave per gate for both took 0.30 ms — 27 gates one after the other per wave, four dependent
+// round trips each).  In
 // the dataflow launch each of them would start a chain with three dependent round trips in front of its first step (measured
 // on the 10 M-gate graph: 450 000 such starts kept all 2 048 waves busy for the first 1.3 ms, and the hand-off entries of
 // that time — the critical path among them — waited for its end).  Here their tournament is a minimum: a sink's path is
@@ -414,6 +416,8 @@ __global__ void __launch_bounds__(256) k_peel_sinks(PeelArgs A) {
 // all the others (measured: the critical path began 0.9 ms into the launch, with idle waves all around).
 __global__ void __launch_bounds__(256) k_peel_level1(PeelArgs A, const u32* __restrict__ in, const u32* __restrict__ in_cnt, u32 in_cap,
                                                      u32* out, u32* out_cnt, u32 out_cap, u32* flat, u32* flat_total) {
+    // what a lane decided about its gate, for the wave that writes the records
+    __shared__ u32 s_g[256], s_root[256], s_dl[256];         // gate (C2A_NONE: none), DFS root, depth | label << 1
     __shared__ u32 s_base, s_cnt;
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const u32 cnt = in_cnt[blockIdx.x];
@@ -421,43 +425,59 @@ __global__ void __launch_bounds__(256) k_peel_level1(PeelArgs A, const u32* __re
     u32* dst = out + (u64)blockIdx.x * out_cap;
     u32* counter = &out_cnt[blockIdx.x];
     const u64 tag = A.epoch ? kTagBit : 0ull;
-    for (u32 i = wave; i < cnt; i += 4) {
-        const u32 g = src[i];
-        const uint4 gi = A.gstat[2 * (u64)g], gi2 = A.gstat[2 * (u64)g + 1];
-        // the smallest consumer, then the smaller label: one key
-        u64 best = ~0ull;
-        for (u32 eb = lane; eb < gi.w; eb += 64) {
-            const u32 e = A.clist[gi.z + eb];
-            const u64 key = ((u64)(e & kIdMask) << 1) | (e >> 31);
-            best = key < best ? key : best;
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { const u64 o = __shfl_xor(best, off, 64); best = o < best ? o : best; }
-        const u32 c = (u32)(best >> 1), el = (u32)(best & 1ull);
-        const bool has = c < g;                      // (else every consumer belongs to a later DFS root: [g] itself)
-        const u32 ch = has ? c : C2A_NONE, depth = has ? 1u : 0u, root = has ? c : g, label = has ? el : 0u;
-        u64 w = tag;
-        if (lane == 0) w |= hdr0_word(root, depth);
-        else if (lane == 1) w |= hdr1_word(1u, C2A_NONE);
-        else if (lane == 2) w |= (u64)depth;         // (position in the chunk: bit 1 of word 0 comes next — the same number)
-        else if (lane == kHdrWords) w |= (u64)label;
-        A.node[(u64)g * kNodeWords + lane] = w;
-        u32 claimed = C2A_NONE;
-        if (lane == 0) {
+    const u64 lt_mask = (1ull << lane) - 1ull;
+    for (u32 base = 0; base < cnt; base += 256) {
+        // ---- a LANE per gate: the smallest (consumer, label), the tree entry, the tickets of its producers (every load of a
+        // gate waits for the one before: 256 gates wait together)
+        const u32 i = base + threadIdx.x;
+        u32 g = C2A_NONE, rdy[2] = {C2A_NONE, C2A_NONE};
+        if (i < cnt) {
+            g = src[i];
+            const uint4 gi = A.gstat[2 * (u64)g], gi2 = A.gstat[2 * (u64)g + 1];
+            u64 best = ~0ull;
+            for (u32 e_i = 0; e_i < gi.w; ++e_i) {
+                const u32 e = A.clist[gi.z + e_i];
+                const u64 key = ((u64)(e & kIdMask) << 1) | (e >> 31);
+                best = key < best ? key : best;
+            }
+            const u32 c = (u32)(best >> 1), el = (u32)(best & 1ull);
+            const bool has = c < g;                  // (else every consumer belongs to a later DFS root: [g] itself)
+            const u32 ch = has ? c : C2A_NONE, depth = has ? 1u : 0u, root = has ? c : g, label = has ? el : 0u;
             A.meta[g] = make_uint4(ch, depth, root, label | (1u << 1));
             if (has) A.child[2 * (u64)ch + label] = g;
+            s_root[threadIdx.x] = root; s_dl[threadIdx.x] = depth | (label << 1);
+            const u32 deps[2] = {gi.x, gi.y}, cnts[2] = {gi2.y, gi2.w};
+#pragma unroll
+            for (u32 l = 0; l < 2; ++l) {
+                const u32 d = deps[l];
+                if (d != C2A_NONE && (cnts[l] == 1u || atomicAdd(&A.fill[d], 1u) + 1u == cnts[l])) rdy[l] = d;
+            }
         }
-        if (lane < 2) {
-            const u32 d = lane ? gi.y : gi.x, dc = lane ? gi2.w : gi2.y;
-            if (d != C2A_NONE && (dc == 1u || atomicAdd(&A.fill[d], 1u) + 1u == dc)) claimed = d;
+        s_g[threadIdx.x] = g;
+#pragma unroll
+        for (u32 l = 0; l < 2; ++l) {
+            const u64 mask = __ballot(rdy[l] != C2A_NONE);
+            if (mask) {
+                u32 b = 0;
+                if (lane == (u32)ctz64(mask)) b = atomicAdd(counter, (u32)__popcll(mask));      // this workgroup's own counter
+                b = __shfl(b, (int)ctz64(mask), 64);
+                if (rdy[l] != C2A_NONE) dst[b + (u32)__popcll(mask & lt_mask)] = rdy[l];
+            }
         }
-        const u64 mask = __ballot(claimed != C2A_NONE);
-        if (mask) {
-            u32 b = 0;
-            if (lane == (u32)ctz64(mask)) b = atomicAdd(counter, (u32)__popcll(mask));
-            b = __shfl(b, (int)ctz64(mask), 64);
-            if (claimed != C2A_NONE) dst[b + (u32)__popcll(mask & ((1ull << lane) - 1ull))] = claimed;
+        __syncthreads();
+        // ---- a WAVE per record: 64 words, one store
+        for (u32 j = wave; j < 256; j += 4) {
+            const u32 gj = s_g[j];
+            if (gj == C2A_NONE) break;               // (the gates of a batch are its first lanes)
+            const u32 root = s_root[j], dl = s_dl[j], depth = dl & 1u, label = dl >> 1;
+            u64 w = tag;
+            if (lane == 0) w |= hdr0_word(root, depth);
+            else if (lane == 1) w |= hdr1_word(1u, C2A_NONE);
+            else if (lane == 2) w |= (u64)depth;     // (position in the chunk: bit 1 of word 0 comes next — the same number)
+            else if (lane == kHdrWords) w |= (u64)label;
+            A.node[(u64)gj * kNodeWords + lane] = w;
         }
+        __syncthreads();
     }
     if (threadIdx.x == 0 && cnt) { atomicAdd(&A.ctl[CTL_PROCESSED], cnt); atomicMax(&A.ctl[CTL_MAXLEVEL], 1u); }
     __syncthreads();
