@@ -285,6 +285,7 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
     ENSURE(c->aq_seeds, (size_t)sink_blocks * sink_cap * 4); ENSURE(c->aq_seed_cnt, ((size_t)2 * sink_blocks + 16) * 4);
     HIP_TRY(hipMemsetAsync(c->aq_seed_cnt.p, 0, ((size_t)2 * sink_blocks + 16) * 4, s));
     A.seeds_w = c->aq_seeds.as<u32>(); A.seed_cnt_w = c->aq_seed_cnt.as<u32>(); A.region_cap = sink_cap;
+    A.proc_word = CTL_PROC; A.proc_mask = kAcctShards - 1u;
     // ... what those claim is done by k_peel_level1 (a wave per gate, region by region), and what THAT claims — at most two
     // producers per gate again — starts the chains of the dataflow launch
     // (collected per workgroup first, then moved to ONE list the waves of the launch take seed_chunk at a time; its length
@@ -305,10 +306,14 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
     if (want_stats) C2A_LAUNCH_CONCURRENT((k_peel<true>), waves, 64, s, A);
     else C2A_LAUNCH_CONCURRENT((k_peel<false>), waves, 64, s, A);
     u32 t4[4] = {0, 0, 0, 0};
+    static_assert(CTL_PROCESSED == 0 && CTL_MAXLEVEL == 1, "t4[0], t4[1] are filled from the shards below");
+    std::vector<u32> acct((size_t)kAcctShards * kAcctStride);
     HIP_TRY(hipMemcpyAsync(t4, c->pctl.p, sizeof(t4), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(acct.data(), c->pctl.as<u32>() + CTL_PROC, acct.size() * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&c->rb_edges, c->cons_off.as<u32>() + n, 4, hipMemcpyDeviceToHost, s));      // (ride along: one round trip)
     HIP_TRY(hipMemcpyAsync(&c->rb_dup, c->scalars.as<u32>() + SC_DUP, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    for (u32 k = 0; k < kAcctShards; ++k) { t4[CTL_PROCESSED] += acct[(size_t)k * kAcctStride]; t4[CTL_MAXLEVEL] = std::max(t4[CTL_MAXLEVEL], acct[(size_t)k * kAcctStride + 1]); }
     if (want_stats) {
         ull st[32];
         HIP_TRY(hipMemcpy(st, c->peel_prof.p, 256, hipMemcpyDeviceToHost));
@@ -421,7 +426,7 @@ int do_peel2(c2a_ctx* c, u32* peeled_out, bool* gave_up) {
     std::memset(&S, 0, sizeof(S));
     S.epoch = c->peel_epoch; S.n = n; S.gstat = c->gstat.as<uint4>(); S.node = c->node.as<u64>(); S.fill = c->fill.as<u32>();
     S.meta = c->meta.as<uint4>(); S.ctl = c->pctl.as<u32>();
-    S.seeds_w = c->aq_seeds.as<u32>(); S.seed_cnt_w = c->aq_seed_cnt.as<u32>(); S.region_cap = region_cap;
+    S.seeds_w = c->aq_seeds.as<u32>(); S.seed_cnt_w = c->aq_seed_cnt.as<u32>(); S.region_cap = region_cap; S.proc_word = P2_PROCESSED; S.proc_mask = 0;
     Peel2Args A;
     A.epoch = c->peel_epoch; A.n = n; A.gstat = c->gstat.as<uint4>(); A.clist = c->clist.as<u32>(); A.node = c->node.as<u64>();
     A.fill = c->fill.as<u32>(); A.meta = c->meta.as<uint4>(); A.child = c->child.as<u32>();

@@ -78,7 +78,11 @@ constexpr u32 kPollLimit = 1u << 21;        // ~1 s of polling for a record: giv
 constexpr u32 kWatchdogChecks = 1u << 15;   // idle-side checks (one per 32 polls, ~100 us apart) without global progress
 // control block (u32 words; every hot word on its own 128-byte line)
 enum PeelCtl { CTL_PROCESSED = 0, CTL_MAXLEVEL = 1, CTL_ABORT = 2, CTL_REREADS = 3, CTL_DONE = 4, CTL_HEARTBEAT = 32, CTL_SEEDNEXT = 64,
-               CTL_BEGIN = 128, CTL_END = CTL_BEGIN + 64 * 32, CTL_DEMAND = CTL_END + 64 * 32, CTL_WORDS = CTL_DEMAND + 64 * 32 };
+               CTL_BEGIN = 128, CTL_END = CTL_BEGIN + 64 * 32, CTL_DEMAND = CTL_END + 64 * 32,
+               // gates done (word 0) and the highest level seen (word 1), in kAcctShards parts like BEGIN / END: thousands of
+               // workgroups (sinks pass, level-1 pass) and every wave of the launch report here as they leave, and atomics on
+               // ONE word go one at a time, ~10 ns each (measured: 4 096 workgroups x 3 such atomics were 120 us of k_peel_level1)
+               CTL_PROC = CTL_DEMAND + 64 * 32, CTL_WORDS = CTL_PROC + 64 * 32 };
 constexpr u32 kPcStride = 16;               // u64 words between two hand-off arrays' ticket words (128 bytes)
 constexpr u32 kSlotWords = 16;              // a hand-off entry: words 0..7 gstat[2g], gstat[2g + 1]; 8..14 first consumers; 15 gate id
 constexpr u32 kSlotCons = 7;
@@ -116,6 +120,7 @@ struct PeelArgs {
     const PeelCold* cold;
     // the sinks pass only
     u32* seeds_w; u32* seed_cnt_w; u32 region_cap;
+    u32 proc_word, proc_mask;  // sinks pass: its count of gates done goes to ctl[proc_word + (workgroup & proc_mask) * kAcctStride]
 };
 
 __device__ __forceinline__ u32 chunk_of(u32 depth) { return depth ? (depth - 1) / kChunkBits : 0u; }
@@ -399,7 +404,7 @@ __global__ void __launch_bounds__(256) k_peel_sinks(PeelArgs A) {
     __syncthreads();
     if (threadIdx.x == 0) {
         const u32 t = s_done[0] + s_done[1] + s_done[2] + s_done[3];
-        if (t) atomicAdd(&A.ctl[CTL_PROCESSED], t);
+        if (t) atomicAdd(&A.ctl[A.proc_word + (blockIdx.x & A.proc_mask) * kAcctStride], t);
     }
 }
 
@@ -479,7 +484,10 @@ __global__ void __launch_bounds__(256) k_peel_level1(PeelArgs A, const u32* __re
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0 && cnt) { atomicAdd(&A.ctl[CTL_PROCESSED], cnt); atomicMax(&A.ctl[CTL_MAXLEVEL], 1u); }
+    if (threadIdx.x == 0 && cnt) {
+        u32* acct = &A.ctl[CTL_PROC + (blockIdx.x & (kAcctShards - 1u)) * kAcctStride];
+        atomicAdd(acct, cnt); atomicMax(acct + 1, 1u);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         s_cnt = atomicAdd(counter, 0u);          // (the waves counted by atomics: read it the same way)
@@ -932,8 +940,9 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
         }
     }
     if (lane == 0) {
-        if (processed) atomicAdd(&A.ctl[CTL_PROCESSED], processed);
-        if (max_level) atomicMax(&A.ctl[CTL_MAXLEVEL], max_level);
+        u32* acct = &A.ctl[CTL_PROC + (me & (kAcctShards - 1u)) * kAcctStride];
+        if (processed) atomicAdd(acct, processed);
+        if (max_level) atomicMax(acct + 1, max_level);
         if (STATS) {
             ull* stats = A.cold->stats;
             if (stats) {
