@@ -235,7 +235,9 @@ __global__ void __launch_bounds__(kThreads) k_euler_next(u32 n, const uint4* __r
     if (threadIdx.x == 0) {
         u32 m = 0;
         for (int w = 0; w < kThreads / 64; ++w) m = s_max[w] > m ? s_max[w] : m;
-        if (m) atomicMax(maxdepth, m);
+        // (a look first: the maximum only grows, so a workgroup that sees a value >= its own has nothing to add — atomics on
+        // one word go one at a time, and there are thousands of workgroups)
+        if (m && m > __hip_atomic_load(maxdepth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxdepth, m);
     }
 }
 
@@ -244,15 +246,38 @@ __global__ void __launch_bounds__(kThreads) k_euler_next(u32 n, const uint4* __r
 #endif
 __device__ __forceinline__ bool is_splitter(u32 e, u32 head) { return e == head || ((e * 0x9E3779B1u) >> C2A_SPLIT_SHIFT) == 0u; }
 
-// splitter compaction, 8 elements per lane: one atomic and three barriers per 2048 elements
+// splitter compaction, 8 elements per lane.  Which elements are splitters is a hash of the element number — nothing is read —
+// so a workgroup first COUNTS the splitters of its whole share (a run of whole 2 048-element tiles), reserves their places
+// with ONE atomic, and then hands the places out tile by tile.  (One reservation per tile was 9 766 returning atomics on one
+// word for the 10 M-gate graph, and those go one at a time, ~10 ns each: 100 of the kernel's 118 us.)
 __global__ void __launch_bounds__(kThreads) k_rank_mark(u32 m, const u32* __restrict__ rlist, u32* scount, u32* slist,
                                                         u32* owner) {
     __shared__ u32 s_w[kThreads / 64];
     __shared__ u32 s_base;
     const u32 head = 2 * rlist[0];
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    for (u64 base = (u64)blockIdx.x * (kThreads * 8); base < m; base += (u64)gridDim.x * (kThreads * 8)) {
-        const u64 e0 = base + (u64)tid * 8;
+    constexpr u64 T = (u64)kThreads * 8;
+    const u64 tiles = ((u64)m + T - 1) / T, per = (tiles + gridDim.x - 1) / gridDim.x;
+    const u64 t0 = (u64)blockIdx.x * per, t1 = t0 + per < tiles ? t0 + per : tiles;
+    u32 mine = 0;
+    for (u64 t = t0; t < t1; ++t) {
+        const u64 e0 = t * T + (u64)tid * 8;
+#pragma unroll
+        for (u32 k = 0; k < 8; ++k) mine += (e0 + k < m && is_splitter((u32)(e0 + k), head)) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
+    if (lane == 0) s_w[wv] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        u32 run = 0;
+        for (int w = 0; w < kThreads / 64; ++w) run += s_w[w];
+        s_base = run ? atomicAdd(scount, run) : 0u;
+    }
+    __syncthreads();
+    u32 place = s_base;                          // where this workgroup's next splitter goes
+    for (u64 t = t0; t < t1; ++t) {
+        const u64 e0 = t * T + (u64)tid * 8;
         u32 bits = 0, cnt = 0;
 #pragma unroll
         for (u32 k = 0; k < 8; ++k) {
@@ -267,19 +292,17 @@ __global__ void __launch_bounds__(kThreads) k_rank_mark(u32 m, const u32* __rest
             const u32 o = __shfl_up(inc, off, 64);
             if (lane >= (u32)off) inc += o;
         }
+        __syncthreads();                         // (s_w of the tile before has been read by everybody)
         if (lane == 63) s_w[wv] = inc;
         __syncthreads();
-        if (tid == 0) {
-            u32 run = 0;
-            for (int w = 0; w < kThreads / 64; ++w) { const u32 t = s_w[w]; s_w[w] = run; run += t; }
-            s_base = run ? atomicAdd(scount, run) : 0u;
-        }
-        __syncthreads();
-        u32 pos = s_base + s_w[wv] + inc - cnt;
+        u32 before = 0, total = 0;
+#pragma unroll
+        for (u32 w = 0; w < kThreads / 64; ++w) { const u32 v = s_w[w]; before += w < wv ? v : 0u; total += v; }
+        u32 pos = place + before + inc - cnt;
 #pragma unroll
         for (u32 k = 0; k < 8; ++k)
             if (bits & (1u << k)) { slist[pos] = (u32)(e0 + k); owner[e0 + k] = pos; ++pos; }
-        __syncthreads();
+        place += total;
     }
 }
 
