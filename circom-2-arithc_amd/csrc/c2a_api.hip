@@ -88,6 +88,8 @@ struct c2a_ctx {
     DevBuf prod1, dep0, dep1, cons_cnt, cons_off, eslot, aq_items, aq_pc, aq_seeds, aq_seeds1, aq_seed_flat, aq_seed_cnt, fill, meta, node, child, gstat, clist, pctl, pcold;
     DevBuf rflag, ridx, rlist, next, owner, local, slist, snext, ssum, jnxt, jval, sorted;
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op, gs, wcnt, wfo;
+    u32* hrb = nullptr;            // 256 words of host memory the device writes the end-of-stage numbers to (k_post_*) ...
+    u32* hrb_dev = nullptr;        // ... as the device sees it.  Words 0-7: peel, 8-15: order, 16-23: wires, 24-31: boolify
     u32 rb_edges = 0, rb_dup = 0, rb_nmid = 0, rb_err = 0;  // read-back slots (edge count, duplicate-writer flag, wires handed out, in/out clash)
     bool has_dup = false;          // two gates write one node (compiler.rs:403-406 keeps the last): the general numbering path
     DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof, peel_trace, mb, mb_seq, mb_rd;
@@ -305,15 +307,11 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
     // C2A_EMUL_SEED: the ticket / hand-off / termination protocol is exercised without a GPU)
     if (want_stats) C2A_LAUNCH_CONCURRENT((k_peel<true>), waves, 64, s, A);
     else C2A_LAUNCH_CONCURRENT((k_peel<false>), waves, 64, s, A);
-    u32 t4[4] = {0, 0, 0, 0};
-    static_assert(CTL_PROCESSED == 0 && CTL_MAXLEVEL == 1, "t4[0], t4[1] are filled from the shards below");
-    std::vector<u32> acct((size_t)kAcctShards * kAcctStride);
-    HIP_TRY(hipMemcpyAsync(t4, c->pctl.p, sizeof(t4), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(acct.data(), c->pctl.as<u32>() + CTL_PROC, acct.size() * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&c->rb_edges, c->cons_off.as<u32>() + n, 4, hipMemcpyDeviceToHost, s));      // (ride along: one round trip)
-    HIP_TRY(hipMemcpyAsync(&c->rb_dup, c->scalars.as<u32>() + SC_DUP, 4, hipMemcpyDeviceToHost, s));
+    static_assert(CTL_PROCESSED == 0 && CTL_MAXLEVEL == 1 && CTL_ABORT == 2 && CTL_REREADS == 3, "the order k_post_peel writes them in");
+    C2A_LAUNCH(k_post_peel, 1, 64, s, c->hrb_dev, (const u32*)c->pctl.as<u32>(), (const u32*)(c->cons_off.as<u32>() + n), (const u32*)(c->scalars.as<u32>() + SC_DUP));
     HIP_TRY(hipStreamSynchronize(s));
-    for (u32 k = 0; k < kAcctShards; ++k) { t4[CTL_PROCESSED] += acct[(size_t)k * kAcctStride]; t4[CTL_MAXLEVEL] = std::max(t4[CTL_MAXLEVEL], acct[(size_t)k * kAcctStride + 1]); }
+    const u32 t4[4] = {c->hrb[0], c->hrb[1], c->hrb[2], c->hrb[3]};
+    c->rb_edges = c->hrb[4]; c->rb_dup = c->hrb[5];      // (ride along: one round trip)
     if (want_stats) {
         ull st[32];
         HIP_TRY(hipMemcpy(st, c->peel_prof.p, 256, hipMemcpyDeviceToHost));
@@ -517,10 +515,10 @@ int do_order(c2a_ctx* c) {
     u32* scount = c->scalars.as<u32>() + SC_SCOUNT;
     C2A_LAUNCH(k_rank_mark, std::max<u32>(1u, std::min<u32>(2048u, (m + kThreads * 8 - 1) / (kThreads * 8))), kThreads, s, m, c->rlist.as<u32>(), scount, c->slist.as<u32>(),
                       c->owner.as<u32>());
-    u32 sc[3] = {0, 0, 0};                    // SC_MAXDEPTH, SC_SCOUNT are adjacent; the number of roots rides along
-    HIP_TRY(hipMemcpyAsync(&sc[2], c->ridx.as<u32>() + n, 4, hipMemcpyDeviceToHost, s));
-    r = read_scalars(c, sc, SC_MAXDEPTH, 2);
-    if (r) return r;
+    static_assert(SC_SCOUNT == SC_MAXDEPTH + 1, "read as a pair");
+    C2A_LAUNCH_NOSYNC(k_post_words, 1, 64, s, c->hrb_dev + 8, (const u32*)(c->scalars.as<u32>() + SC_MAXDEPTH), 2u, (const u32*)(c->ridx.as<u32>() + n), 1u, (const u32*)nullptr, 0u);
+    HIP_TRY(hipStreamSynchronize(s));
+    const u32 sc[3] = {c->hrb[8], c->hrb[9], c->hrb[10]};      // depth of the DFS forest, splitters, roots
     const u32 S = sc[1];
     c->stats.max_depth = sc[0];
     c->stats.n_splitters = S;
@@ -598,6 +596,7 @@ int do_topo_sort(c2a_ctx* c, u64* cycle_at) {
 
 // the two words do_assign_wires reads back (the stream must have been synchronized)
 int finish_wires(c2a_ctx* c) {
+    c->rb_nmid = c->hrb[16]; c->rb_err = c->hrb[17];      // (k_post_words of do_assign_wires; the stream has drained since)
     if (c->rb_err) { c->stage = ST_SORTED; return fail(c, C2A_ERR_INCONSISTENCY, "Inconsistency: a node is used for both input and output"); }
     c->n_mid = c->rb_nmid;
     c->wire_count = c->n_in + c->rb_nmid + c->n_out;
@@ -658,8 +657,7 @@ int do_assign_wires(c2a_ctx* c, bool defer_readback = false) {
         C2A_LAUNCH_NOSYNC(k_assign_outputs, grid_for(c->n_out, 1024), kThreads, s, c->n_out, c->out_nodes.as<u32>(), c->n_in,
                           (const u32*)(c->widx.as<u32>() + n_scan), c->node_wire1.as<u32>());
     rec(c, EV_WIRES1);
-    HIP_TRY(hipMemcpyAsync(&c->rb_nmid, c->widx.as<u32>() + n_scan, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&c->rb_err, c->scalars.as<u32>() + SC_ERR, 4, hipMemcpyDeviceToHost, s));
+    C2A_LAUNCH_NOSYNC(k_post_words, 1, 64, s, c->hrb_dev + 16, (const u32*)(c->widx.as<u32>() + n_scan), 1u, (const u32*)(c->scalars.as<u32>() + SC_ERR), 1u, (const u32*)nullptr, 0u);
     c->stage = ST_WIRED;                             // (the emission may be queued behind this; finish_wires() makes it official)
     if (defer_readback) return C2A_OK;
     HIP_TRY(hipStreamSynchronize(s));
@@ -749,6 +747,13 @@ int c2a_create(int n_devices, const int* device_ids, c2a_ctx** out) {
 #endif
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return C2A_ERR_HIP; }
     if (hipStreamCreate(&c->aux) != hipSuccess) { c->aux = hipStream_t{}; c2a_destroy(c); return C2A_ERR_HIP; }
+    {
+        void* h = nullptr; void* d = nullptr;
+        if (hipHostMalloc(&h, 256 * sizeof(u32), hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { c2a_destroy(c); return C2A_ERR_HIP; }
+        c->hrb = static_cast<u32*>(h);
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { c2a_destroy(c); return C2A_ERR_HIP; }
+        c->hrb_dev = static_cast<u32*>(d);
+    }
     for (int i = 0; i < EV_COUNT; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) { c2a_destroy(c); return C2A_ERR_HIP; }
     // devices 1..N-1: one stream each (the same device may be listed twice: it then simply gets two shards)
@@ -778,6 +783,7 @@ void c2a_destroy(c2a_ctx* c) {
     for (int i = 0; i < EV_COUNT; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->hrb) (void)hipHostFree(c->hrb);
     delete c;
 }
 
@@ -995,10 +1001,9 @@ int bool_plan(c2a_ctx* c, uint32_t width) {
     // template sizes and aux-wire counts straight from the op bytes, both scanned in one launch
     int r = scan_1pass<2>(c, s, c->scan_tmp, n, ScanBoolSizes{c->e_op.as<u8>(), c->tables.as<BoolTables>()}, c->goff.as<u64>(), c->aoff.as<u64>(), ScanNoEpilogue{});
     if (r) return r;
-    u64 totals[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(&totals[0], c->goff.as<u64>() + n, 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&totals[1], c->aoff.as<u64>() + n, 8, hipMemcpyDeviceToHost, s));
+    C2A_LAUNCH_NOSYNC(k_post_words, 1, 64, s, c->hrb_dev + 24, reinterpret_cast<const u32*>(c->goff.as<u64>() + n), 2u, reinterpret_cast<const u32*>(c->aoff.as<u64>() + n), 2u, (const u32*)nullptr, 0u);
     HIP_TRY(hipStreamSynchronize(s));
+    const u64 totals[2] = {(u64)c->hrb[24] | ((u64)c->hrb[25] << 32), (u64)c->hrb[26] | ((u64)c->hrb[27] << 32)};
     const u64 G = totals[0], AUX = totals[1];
     const u64 wires = (u64)c->wire_count * width + AUX;
     if (wires >= 0xFFFFFFFFull) return fail(c, C2A_ERR_OVERFLOW, "c2a_boolify: boolean wire ids exceed u32");

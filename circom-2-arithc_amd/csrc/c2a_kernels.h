@@ -726,6 +726,23 @@ __global__ void k_fmt_write(u64 n, const u32* __restrict__ in0, const u32* __res
     }
 }
 
+// ---- what the host wants to know at the end of a stage, gathered into ONE place it can read (host memory mapped into the
+// device's address space: after the stream has drained the words are simply there).  Every small device-to-host copy is a
+// command of its own, ~20 us behind the one before; a step had ten of them.
+__global__ void k_post_words(u32* dst, const u32* a, u32 na, const u32* b, u32 nb, const u32* c3, u32 nc) {
+    for (u32 i = threadIdx.x; i < na; i += blockDim.x) dst[i] = a[i];
+    for (u32 i = threadIdx.x; i < nb; i += blockDim.x) dst[na + i] = b[i];
+    for (u32 i = threadIdx.x; i < nc; i += blockDim.x) dst[na + nb + i] = c3[i];
+}
+// the peel: gates done and the highest level (summed / maximised over their kAcctShards parts), gave up, re-reads, edges, duplicate writers
+__global__ void k_post_peel(u32* dst, const u32* ctl, const u32* edges, const u32* dup) {
+    const u32 t = threadIdx.x;            // (one wave)
+    u32 done = t < kAcctShards ? ctl[CTL_PROC + t * kAcctStride] : 0u, lvl = t < kAcctShards ? ctl[CTL_PROC + t * kAcctStride + 1] : 0u;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { done += __shfl_xor(done, off, 64); const u32 o = __shfl_xor(lvl, off, 64); lvl = o > lvl ? o : lvl; }
+    if (t == 0) { dst[0] = done; dst[1] = lvl; dst[2] = ctl[CTL_ABORT]; dst[3] = ctl[CTL_REREADS]; dst[4] = *edges; dst[5] = *dup; }
+}
+
 // order-sensitive 64-bit checksum of a u32 stream: sum over i of mix(i, v[i]) (commutative combine of
 // position-salted hashes => parallel, deterministic).  Used by the full-size parity tests.
 __device__ __forceinline__ u64 mix64(u64 x) {
