@@ -248,6 +248,10 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
     A.epoch = c->peel_epoch;
     u32 n_primary = 0;
     const u32 waves = peel_grid(c, want_stats, &n_primary);
+    // the waves' dummy ticket words behind fill[n] (c2a_peel.h, SCALAR TICKETS): zero, and they stay zero (only 0 is ever
+    // added); a ticket word is addressed by a 32-bit byte offset from fill
+    if (waves > kFillDummyWaves || n >= (1u << 30)) { c->err = "peel: grid or gate count beyond the ticket words' addressing"; return C2A_ERR_ARG; }
+    HIP_TRY(hipMemsetAsync(c->fill.as<u32>() + n, 0, (size_t)kFillDummyStride * kFillDummyWaves * 4, s));
     // hand-off arrays: every slot is used once per run (no wrap-around).  A wave spreads its pushes round robin, so an
     // array receives at most pushes / n_fifos + waves entries, and a wave holds at most one unserved consumer ticket
     A.n_fifos = c->peel_fifos;
@@ -827,7 +831,7 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     ENSURE(c->lh, n4); ENSURE(c->rh, n4); ENSURE(c->out, n4); ENSURE(c->op, n); ENSURE(c->gate4, (size_t)n * 16);
     ENSURE(c->in_nodes, (size_t)n_in * 4); ENSURE(c->out_nodes, (size_t)n_out * 4);
     ENSURE(c->prod1, nn4); ENSURE(c->dep0, n4); ENSURE(c->dep1, n4); ENSURE(c->cons_cnt, n4);
-    ENSURE(c->cons_off, n4 + 4); ENSURE(c->eslot, 2 * n4); ENSURE(c->fill, n4);
+    ENSURE(c->cons_off, n4 + 4); ENSURE(c->eslot, 2 * n4); ENSURE(c->fill, n4 + (size_t)kFillDummyStride * kFillDummyWaves * 4);
     ENSURE(c->meta, (size_t)n * 16); ENSURE(c->gstat, (size_t)n * 32); ENSURE(c->clist, 2 * n4 + 64 * 4);
     ENSURE(c->node, (size_t)n * kNodeWords * 8); ENSURE(c->child, 2 * n4);
     // a new graph needs clean node records (5 GB at 10 M gates, ~0.75 ms of HBM writes): cleared here, on a stream of its own,

@@ -88,6 +88,8 @@ constexpr u32 kSlotWords = 16;              // a hand-off entry: words 0..7 gsta
 constexpr u32 kSlotCons = 7;
 constexpr u32 kAcctShards = 64;             // BEGIN / END are kept in this many parts, kAcctStride words (128 bytes) apart
 constexpr u32 kAcctStride = 32;
+constexpr u32 kFillDummyStride = 32;        // u32 words between two waves' dummy ticket words behind fill[n]
+constexpr u32 kFillDummyWaves = 8192;       // ... of at most this many waves (256 CUs x 32)
 
 // what only the edges of the launch touch (kept out of the kernel's scalar registers)
 struct PeelCold {
@@ -232,11 +234,121 @@ __device__ __forceinline__ u32 own_sgpr(u32 v) {
     return q;
 #endif
 }
+// Branch weights for the block layout: a TAKEN branch costs a wave its instruction buffer (~16+ clocks against 4 for one
+// that falls through), and a chain step runs some fifty branches — the hot path should fall through, the cold code
+// (re-reads, deep trees, the cold list loop, giving up) sit out of line.
+#ifndef C2A_HINTS
+#define C2A_HINTS 1
+#endif
+#if C2A_HINTS
+#define C2A_LIKELY(x) __builtin_expect(!!(x), 1)
+#define C2A_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#else
+#define C2A_LIKELY(x) (x)
+#define C2A_UNLIKELY(x) (x)
+#endif
 // the compiler must treat v as used (and redefined) here: pins the wait for a pending load to this point
 #ifdef C2A_EMULATE
 #define C2A_PIN(v) ((void)0)
 #else
 #define C2A_PIN(v) asm volatile("" : "+v"(v) :: "memory")
+#endif
+
+// SCALAR TICKETS.  A returning atomic of ONE lane does not need the vector memory path: gfx950 still has the scalar-memory
+// atomics of the gfx9 family (s_atomic_add ... glc; executed in L2 like the vector ones, exact next to them on the same
+// word — tools/ubench/satomic.hip).  Measured on MI355X, scattered words, 2 048 waves: 520 ns against 880 ns for a one-lane
+// global_atomic_add, and they are counted by lgkmcnt, NOT by vmcnt: waiting for a ticket does not wait for vector loads
+// issued after it (vmcnt is in order, and where the number of loads behind the atomic depends on a branch the compiler
+// waits for the smallest count: the wait for a hand-off ticket was a wait for the next step's static loads).
+// The compiler knows no scalar atomics, so they are inline assembly, and it cannot know that their result registers are
+// in flight: a copy or a spill of one before the wait would read garbage.  Hence the results land in FIXED registers
+// s97..s101 that the compiler never touches — the kernel is compiled with amdgpu_num_sgpr: registers beyond that budget
+// are RESERVED in the allocator (SIRegisterInfo::getReservedRegs) — and are read (s_mov) only after the wait.  The
+// clobber lists make the kernel descriptor cover them (tests/test_abi_exports.py reads it back from the built library).
+//   s100, s101   the two fill[] tickets of the step in flight (ONE pair: a step reads it at its top, then issues the next)
+//   s[98:99]     hand-off: tickets taken so far on the array, producer side | consumer side (the pre-op value)
+//   s97          hand-off: BEGIN unit counted (value unused: the wait is what matters)
+// Under emulation the "registers" are a small array per lane and the atomics go through lane 0.
+// (C2A_SFILL: 0 vector fill[] tickets, 1 scalar through C++ helpers, 2 scalar, hand-written; C2A_SPUSH: the hand-off's two
+// atomics scalar.  Same-box A/B, peel stage: 0/0 10.42 ms, 1/1 10.61 (the helpers' branches and spills cost more than the
+// shorter round trip brings), 2/1 10.28; with the branch weights below 0/0 9.97, 2/1 9.70 — the default)
+#ifndef C2A_SPUSH
+#define C2A_SPUSH 1
+#endif
+#ifndef C2A_SFILL
+#define C2A_SFILL 2
+#endif
+#if C2A_SPUSH && C2A_SFILL
+constexpr int kSregBase = 97, kSregBegin = 97, kSregPush = 98, kSregFill0 = 100, kSregFill1 = 101;
+#define C2A_SREG_BUDGET 103      /* 6 of the budget are VCC, FLAT_SCRATCH, XNACK_MASK: s0..s96 for the compiler */
+#define C2A_SREG_CLOBBERS "s97", "s98", "s99", "s100", "s101"
+#elif C2A_SPUSH
+constexpr int kSregBase = 99, kSregBegin = 99, kSregPush = 100, kSregFill0 = 100, kSregFill1 = 101;
+#define C2A_SREG_BUDGET 105
+#define C2A_SREG_CLOBBERS "s99", "s100", "s101"
+#else
+constexpr int kSregBase = 100, kSregFill0 = 100, kSregFill1 = 101;
+#define C2A_SREG_BUDGET 106
+#define C2A_SREG_CLOBBERS "s100", "s101"
+#endif
+#ifdef C2A_EMULATE
+#define C2A_PEEL_KERNEL_ATTR
+struct SRegs { u32 r[8]; };
+template <int R> __device__ __forceinline__ void sreg_add32(SRegs& sr, u32* p, u32 v) {
+    u32 t = 0;
+    if ((threadIdx.x & 63u) == 0) t = atomicAdd(p, v);
+    sr.r[R - kSregBase] = (u32)__shfl((int)t, 0, 64);
+}
+template <int R> __device__ __forceinline__ void sreg_add64(SRegs& sr, u64* p, u64 v) {
+    ull t = 0;
+    if ((threadIdx.x & 63u) == 0) t = atomicAdd(reinterpret_cast<ull*>(p), (ull)v);
+    sr.r[R - kSregBase] = (u32)__shfl((int)(u32)t, 0, 64); sr.r[R - kSregBase + 1] = (u32)__shfl((int)(u32)(t >> 32), 0, 64);
+}
+template <int R> __device__ __forceinline__ void sreg_set(SRegs& sr, u32 v) { sr.r[R - kSregBase] = v; }
+template <int R> __device__ __forceinline__ u32 sreg_get(const SRegs& sr) { return sr.r[R - kSregBase]; }
+__device__ __forceinline__ void sreg_wait() {}
+// the fill[] ticket of one producer, branch-free: a producer with other consumers (cnt > 1) takes a ticket on its own
+// word; any other adds 0 to this wave's DUMMY word behind fill[n] (always 0: "ticket 0 of cnt" reads as the last one
+// for cnt 1 and as nothing for cnt 0)
+template <int R> __device__ __forceinline__ void sfill_take(SRegs& sr, u32* fill, u32 dep, u32 cnt, u32 dummy_idx) {
+    u32 t = 0;
+    if ((threadIdx.x & 63u) == 0) t = atomicAdd(&fill[cnt > 1u ? dep : dummy_idx], cnt > 1u ? 1u : 0u);
+    sr.r[R - kSregBase] = (u32)__shfl((int)t, 0, 64);
+}
+template <int R0, int R1> __device__ __forceinline__ u32 sfill_claims(const SRegs& sr, u32 cnt0, u32 cnt1) {
+    return (sr.r[R0 - kSregBase] + 1u == cnt0 ? 1u : 0u) | (sr.r[R1 - kSregBase] + 1u == cnt1 ? 2u : 0u);
+}
+#else
+#define C2A_PEEL_KERNEL_ATTR __attribute__((amdgpu_num_sgpr(C2A_SREG_BUDGET)))
+struct SRegs {};
+template <int R> __device__ __forceinline__ void sreg_add32(SRegs&, u32* p, u32 v) {
+    typedef __attribute__((address_space(1))) u32* G;
+    asm volatile("s_mov_b32 s%c2, %1\n\ts_atomic_add s%c2, %0, 0x0 glc" :: "s"((G)p), "s"(v), "n"(R) : "memory", C2A_SREG_CLOBBERS);
+}
+template <int R> __device__ __forceinline__ void sreg_add64(SRegs&, u64* p, u64 v) {
+    typedef __attribute__((address_space(1))) u64* G;
+    static_assert((R & 1) == 0, "an aligned register pair");
+    asm volatile("s_mov_b64 s[%c2:%c3], %1\n\ts_atomic_add_x2 s[%c2:%c3], %0, 0x0 glc" :: "s"((G)p), "s"(v), "n"(R), "n"(R + 1) : "memory", C2A_SREG_CLOBBERS);
+}
+template <int R> __device__ __forceinline__ void sreg_set(SRegs&, u32 v) { asm volatile("s_mov_b32 s%c1, %0" :: "s"(v), "n"(R) : C2A_SREG_CLOBBERS); }
+template <int R> __device__ __forceinline__ u32 sreg_get(const SRegs&) { u32 v; asm volatile("s_mov_b32 %0, s%c1" : "=s"(v) : "n"(R)); return v; }
+__device__ __forceinline__ void sreg_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// (five scalar instructions, no branch; the word's byte offset goes in a register: fill[] stays below 4 GB — n < 2^30,
+// checked by the host)
+template <int R> __device__ __forceinline__ void sfill_take(SRegs&, u32* fill, u32 dep, u32 cnt, u32 dummy_idx) {
+    typedef __attribute__((address_space(1))) u32* G;
+    u32 off;
+    asm volatile("s_cmp_gt_u32 %2, 1\n\ts_cselect_b32 s%c5, 1, 0\n\ts_cselect_b32 %0, %3, %4\n\ts_lshl_b32 %0, %0, 2\n\ts_atomic_add s%c5, %1, %0 glc"
+                 : "=&s"(off) : "s"((G)fill), "s"(uniform(cnt)), "s"(uniform(dep)), "s"(uniform(dummy_idx)), "n"(R) : "memory", "scc", C2A_SREG_CLOBBERS);
+}
+// both tickets are back: bit l = producer l is claimed (its ticket was the last of cnt)
+template <int R0, int R1> __device__ __forceinline__ u32 sfill_claims(const SRegs&, u32 cnt0, u32 cnt1) {
+    u32 r, t;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_add_u32 %0, s%c4, 1\n\ts_cmp_eq_u32 %0, %2\n\ts_cselect_b32 %0, 1, 0\n\t"
+                 "s_add_u32 %1, s%c5, 1\n\ts_cmp_eq_u32 %1, %3\n\ts_cselect_b32 %1, 2, 0\n\ts_or_b32 %0, %0, %1"
+                 : "=&s"(r), "=&s"(t) : "s"(uniform(cnt0)), "s"(uniform(cnt1)), "n"(R0), "n"(R1) : "memory", "scc");
+    return r;
+}
 #endif
 
 __device__ __forceinline__ ull ld_word_time(const ull* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -502,8 +614,12 @@ __global__ void k_set_cold(PeelCold* dst, PeelCold v) { *dst = v; }
 // everything issued for one gate at the top of its step; two of these swap roles (nothing is ever copied: a register
 // copy of a value still in flight is a use, and its wait would drain the step that was just issued)
 struct StepIO {
+#if !C2A_SFILL
     u32 kfill;                 // lane l < 2: ticket taken on producer l
     u32 dcnt;                  // lane l < 2: consumers of producer l (0: no such producer)
+#endif
+    u32 cnt0, cnt1;            // consumers of producer 0 / 1 (0: no such producer); the tickets taken on them are in the
+                               // fixed scalar registers of this set (SCALAR TICKETS above)
     u32 gw;                    // lane 8 l + j (l < 2, j < 8): word j of the two gstat records of producer l
     u32 clp;                   // lanes 0..31: producer 0's consumers, 32..63: producer 1's
     u32 e0, e1, e2, e3, take;  // consumer | label << 31 of the (up to four) records in flight
@@ -512,8 +628,10 @@ struct StepIO {
 };
 
 // the dataflow launch: 64-thread workgroups (one wave each)
+template <int SET> struct StepSet { static constexpr int value = SET; };
 template <bool STATS>
-__global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
+__global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in) {
+    SRegs sr;
     PeelArgs A = A_in;
     A.gstat = own_sgprs(A_in.gstat); A.clist = own_sgprs(A_in.clist); A.node = own_sgprs(A_in.node); A.fill = own_sgprs(A_in.fill);
     A.meta = own_sgprs(A_in.meta); A.child = own_sgprs(A_in.child); A.fifo = own_sgprs(A_in.fifo); A.q_pc = own_sgprs(A_in.q_pc);
@@ -528,6 +646,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
         C2A_PIN(r);
     }
     const u32 epoch = A.epoch;
+    const u32 dummy_idx = A.n + me * kFillDummyStride; (void)dummy_idx;      // this wave's dummy ticket word (a line of its own behind fill[n])
     bool seeds_left = true;
     u32 region = 0, idx = 0, region_cnt = 0;
     u32 push_rr = me, pop_rr = me * 7u;      // round-robin cursors over the hand-off arrays
@@ -686,12 +805,27 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
 
         // issue everything the step of a gate needs from memory.  scl: the gate's consumer list, one entry per lane from
         // lane cbase on, when it fits ccap lanes (else nothing is loaded ahead and the step reads the list itself)
-        auto issue = [&](StepIO& S, u32 dep0, u32 dep1, u32 n_cons, u32 off0, u32 cnt0, u32 off1, u32 cnt1, u32 scl, u32 cbase, u32 ccap,
+        auto issue = [&](auto set, StepIO& S, u32 dep0, u32 dep1, u32 n_cons, u32 off0, u32 cnt0, u32 off1, u32 cnt1, u32 scl, u32 cbase, u32 ccap,
                          bool have_own, u32 own_id) {
-            const u32 dl = wrlane_c<1>(dep1, wrlane_c<0>(dep0, C2A_NONE));
-            const u32 dcnt = wrlane_c<1>(cnt1, wrlane_c<0>(cnt0, 0u));       // (0 where there is no producer: gstat holds 0 then)
-            S.kfill = 0; S.dcnt = dcnt;
-            if (dcnt > 1u) S.kfill = atomicAdd(&A.fill[dl], 1u);         // (a ticket is needed where there is a producer with other consumers)
+            // (ONE pair of ticket registers: the step reads the pair at its top, before it issues the next step into it)
+            constexpr int R0 = kSregFill0, R1 = kSregFill1; (void)set;
+            S.cnt0 = cnt0; S.cnt1 = cnt1;                                // (0 where there is no producer: gstat holds 0 then)
+            // a ticket is needed where there is a producer with other consumers (else the register says 0: with cnt 1 that
+            // reads as "the last ticket", with cnt 0 as "nothing claimed")
+#if C2A_SFILL == 2
+            sfill_take<R0>(sr, A.fill, dep0, cnt0, dummy_idx);
+            sfill_take<R1>(sr, A.fill, dep1, cnt1, dummy_idx);
+#elif C2A_SFILL
+            if (cnt0 > 1u) sreg_add32<R0>(sr, &A.fill[dep0], 1u); else sreg_set<R0>(sr, 0u);
+            if (cnt1 > 1u) sreg_add32<R1>(sr, &A.fill[dep1], 1u); else sreg_set<R1>(sr, 0u);
+#else
+            {
+                const u32 dl = wrlane_c<1>(dep1, wrlane_c<0>(dep0, C2A_NONE));
+                const u32 dcnt = wrlane_c<1>(cnt1, wrlane_c<0>(cnt0, 0u));
+                S.kfill = 0; S.dcnt = dcnt;
+                if (dcnt > 1u) S.kfill = atomicAdd(&A.fill[dl], 1u);
+            }
+#endif
             // static data of both producers, one word per lane, BRANCH-FREE (clamped index, result discarded where there
             // is nothing to load)
             {
@@ -710,7 +844,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             const bool in_lanes = n_cons <= ccap;
             u64 smask = __ballot(in_lanes && lane - cbase < n_cons && !(have_own && (scl & kIdMask) == own_id));
             S.take = 0;                  // (e0 / e1 stay undefined like w0 / w1: they are only looked at under take)
-            if (smask) {
+            if (C2A_LIKELY(smask != 0)) {
                 S.e0 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 1;
                 S.w0 = ld_nw(&A.node[(u64)(S.e0 & kIdMask) * kNodeWords + lane]);
                 if (smask) {
@@ -718,10 +852,10 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                     S.w1 = ld_nw(&A.node[(u64)(S.e1 & kIdMask) * kNodeWords + lane]);
                     // (a third and a fourth: one gate in six has more than two other consumers, and the cold loop below costs it
                     // two dependent round trips per candidate)
-                    if (smask) {
+                    if (C2A_UNLIKELY(smask != 0)) {
                         S.e2 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 3;
                         S.w2 = ld_nw(&A.node[(u64)(S.e2 & kIdMask) * kNodeWords + lane]);
-                        if (smask) {
+                        if (C2A_UNLIKELY(smask != 0)) {
                             S.e3 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 4;
                             S.w3 = ld_nw(&A.node[(u64)(S.e3 & kIdMask) * kNodeWords + lane]);
                         }
@@ -731,7 +865,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             S.more = (!in_lanes || smask != 0) ? 1u : 0u;
         };
         StepIO S0, S1;
-        issue(S0, gi.x, gi.y, gi.w, gi2.x, gi2.y, gi2.z, gi2.w, cl0, cl0_base, cl0_cap, false, 0u);
+        issue(StepSet<0>(), S0, gi.x, gi.y, gi.w, gi2.x, gi2.y, gi2.z, gi2.w, cl0, cl0_base, cl0_cap, false, 0u);
         // The champion of a gate's tournament so far (wave-uniform); ch == NONE: the virtual-root candidate [g].  The gate
         // just finished stays in these registers as the first candidate of the next one: it is the champion to beat unless
         // its DFS root is not smaller than the next gate's own id (then the step starts from [g])
@@ -740,13 +874,21 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
         u32 own_valid = 0, own_node = 0, own_level = 0;      // the gate just finished (a consumer of the gate in hand)
 
         // one step: `cur` is in hand (issued one step ago), `nx` receives the next one.  true = the chain ends (or abort)
-        auto step = [&](StepIO& cur, StepIO& nx) -> bool {
+        auto step = [&](auto cur_set, auto nx_set, StepIO& cur, StepIO& nx) -> bool {
+            constexpr int RC0 = kSregFill0, RC1 = kSregFill1; (void)cur_set;
             const ull ph0 = STATS ? c2a_now() : 0;
             // (two waves share a SIMD's issue slots: from here to the issue of the next step — the claim path — this one goes first)
             wave_priority(3);
             // ---- everything of THIS step (issued one step ago) is needed now, and is pinned HERE: a register of `cur` that
             // the compiler still counts as in flight further down would put its wait behind the issue of the next step
+#if C2A_SFILL == 2
+            const u32 rmask = sfill_claims<RC0, RC1>(sr, cur.cnt0, cur.cnt1);
+#elif C2A_SFILL
+            sreg_wait();
+            const u32 k0 = sreg_get<RC0>(sr), k1 = sreg_get<RC1>(sr);
+#else
             C2A_PIN(cur.kfill);
+#endif
             const ull ph0a = STATS ? c2a_now() : 0;
             C2A_PIN(cur.gw);
             C2A_PIN(cur.clp);
@@ -755,15 +897,20 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             if (STATS) { const ull ph0c = c2a_now(); ph_w1 += ph0a - ph0; ph_w2 += ph0b - ph0a; ph_w3 += ph0c - ph0b; }
             // (the next gate's static records are written over gi / gi2 below: what the rest of this step needs of its own)
             const u32 gc = g, g_dep0 = gi.x, g_dep1 = gi.y, g_off = gi.z, g_cnt = gi.w;
-            // lane l < 2 claimed producer l when its ticket was the last of dcnt (no ticket was taken for a single-consumer
-            // producer: kfill 0, dcnt 1; no producer: dcnt 0 — the one comparison covers all three)
+            // producer l is claimed when its ticket was the last of cnt (no ticket was taken for a single-consumer producer:
+            // 0 of 1; no producer: cnt 0 — the one comparison covers all three)
+#if C2A_SFILL == 2
+#elif C2A_SFILL
+            const u32 rmask = (k0 + 1u == cur.cnt0 ? 1u : 0u) | (k1 + 1u == cur.cnt1 ? 2u : 0u);
+#else
             const u32 rmask = (u32)__ballot(cur.kfill + 1u == cur.dcnt) & 3u;
+#endif
             const ull ph1 = STATS ? c2a_now() : 0;
             // ---- go on with the first claimed producer: issue its step now; a second one goes to whoever has no work: its
             // producer ticket is taken here and its entry stored after the tournament (the ticket is back by then)
             u32 nxt = C2A_NONE, nxt_label = 0;
             u32 push_t = 0, push_c = 0, push_f = 0;
-            if (rmask) {
+            if (C2A_LIKELY(rmask != 0)) {
                 const u32 j0 = (rmask & 1u) ? 0u : 1u;
                 nxt = j0 ? g_dep1 : g_dep0; nxt_label = j0;
                 const u32 gsel = j0 ? row_shl8(cur.gw) : cur.gw;         // lanes 0..7: the static records of nxt
@@ -774,12 +921,17 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                     // one of the hand-off arrays: the ticket now, the entry after the tournament; BEGIN counts the entry
                     // before anybody can see it
                     push_f = (push_rr++) & (A.n_fifos - 1u);
+#if C2A_SPUSH
+                    sreg_add64<kSregPush>(sr, &A.q_pc[(u64)push_f * kPcStride], 1ull);
+                    sreg_add32<kSregBegin>(sr, &A.ctl[CTL_BEGIN + (me & (kAcctShards - 1u)) * kAcctStride], 1u);
+#else
                     if (lane == 0) { const ull pc = atomicAdd(reinterpret_cast<ull*>(&A.q_pc[(u64)push_f * kPcStride]), 1ull); push_t = (u32)pc; push_c = (u32)(pc >> 32); }
                     if (lane == 1) push_t = atomicAdd(&A.ctl[CTL_BEGIN + (me & (kAcctShards - 1u)) * kAcctStride], 1u);
                     wave_join();
+#endif
                 }
                 // the consumers of nxt are already here (lanes 32 j0 ... of the prefetched lists) unless it has more than 32
-                issue(nx, gi.x, gi.y, gi.w, gi2.x, gi2.y, gi2.z, gi2.w, cur.clp, 32u * j0, 32u, true, gc);
+                issue(nx_set, nx, gi.x, gi.y, gi.w, gi2.x, gi2.y, gi2.z, gi2.w, cur.clp, 32u * j0, 32u, true, gc);
             }
             wave_priority(0);
             const ull ph2 = STATS ? c2a_now() : 0;
@@ -791,7 +943,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             auto candidate = [&](u64& w, u32 e) {             // (w by reference: the cold path mends it in place, no copy)
                 const u32 c = e & kIdMask, el = e >> 31;
                 u64 badm = __ballot((u32)(w >> 63) != epoch);
-                if (badm) {
+                if (C2A_UNLIKELY(badm != 0)) {
                     // not all there: a sink (header words only: its string is empty whatever its string words hold) or a
                     // record that is still on its way
                     if ((badm & 7ull) != 0 || (u32)rdlane64(w, 0) != 0u) {
@@ -812,7 +964,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                 u32 less;                     // (0 / 1 in a scalar register: a bool merged over branches becomes a lane mask)
                 if (croot != ch_root) {
                     less = croot < ch_root ? 1u : 0u;                                // a larger DFS root loses at once (also to [g] itself)
-                } else if ((cdepth > ch_depth ? cdepth : ch_depth) < kChunkBits) {
+                } else if (C2A_LIKELY((cdepth > ch_depth ? cdepth : ch_depth) < kChunkBits)) {
                     // neither path is a prefix of the other (that would be a cycle), and the same node with the other label
                     // differs in the appended bit: the first differing bit decides
                     const u64 d = x ^ ch_x;
@@ -829,18 +981,18 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                 if (less) { ch = c; ch_el = el; ch_root = croot; ch_depth = cdepth; ch_pos = cpos; ch_w = w; ch_x = x; }
             };
             // the (up to two) records loaded ahead ...
-            if (cur.take >= 1) {
+            if (C2A_LIKELY(cur.take >= 1)) {
                 candidate(cur.w0, cur.e0);
                 if (cur.take >= 2) {
                     candidate(cur.w1, cur.e1);
-                    if (cur.take >= 3) {
+                    if (C2A_UNLIKELY(cur.take >= 3)) {
                         candidate(cur.w2, cur.e2);
-                        if (cur.take >= 4) candidate(cur.w3, cur.e3);
+                        if (C2A_UNLIKELY(cur.take >= 4)) candidate(cur.w3, cur.e3);
                     }
                 }
             }
             // ... then — cold — the consumer list itself, one record at a time, when it holds more than that
-            if (cur.more && !gave_up) {
+            if (C2A_UNLIKELY(cur.more && !gave_up)) {
                 for (u32 eb = 0; eb < g_cnt && !gave_up; eb += 64) {
                     u32 blk = A.clist[g_off + eb + lane];
                     C2A_PIN(blk);                                // (consumed here, like w below)
@@ -856,15 +1008,21 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                     }
                 }
             }
-            if (gave_up) { if (lane == 0) atomicAdd(&A.ctl[CTL_ABORT], 1u); wave_join(); return true; }      // a record never arrived: fail loudly
+            if (C2A_UNLIKELY(gave_up != 0)) { if (lane == 0) atomicAdd(&A.ctl[CTL_ABORT], 1u); wave_join(); return true; }      // a record never arrived: fail loudly
             const ull ph2a = STATS ? c2a_now() : 0;
             if (rmask == 3u) {
                 // the entry: lanes 8..15 hold the pushed gate's static records, lanes 32..38 its first consumers
+#if C2A_SPUSH
+                sreg_wait();                                        // (both atomics are back: the unit is in BEGIN before the entry can be seen)
+                push_t = sreg_get<kSregPush>(sr); push_c = sreg_get<kSregPush + 1>(sr);
+#else
                 C2A_PIN(push_t);                                    // (both atomics are back)
+                push_t = rdlane(push_t, 0); push_c = rdlane(push_c, 0);
+#endif
                 if (STATS) ph_pwait += c2a_now() - ph2a;
-                const u64 t = (u64)push_f * A.q_cap + rdlane(push_t, 0);
+                const u64 t = (u64)push_f * A.q_cap + push_t;
                 // nobody was in line for this entry: tell the reserve
-                if (rdlane(push_c, 0) <= rdlane(push_t, 0)) { if (lane == 0) atomicAdd(&A.ctl[CTL_DEMAND + (me & (kAcctShards - 1u)) * kAcctStride], 1u); wave_join(); }
+                if (push_c <= push_t) { if (lane == 0) atomicAdd(&A.ctl[CTL_DEMAND + (me & (kAcctShards - 1u)) * kAcctStride], 1u); wave_join(); }
                 u64* slot = A.fifo + t * kSlotWords;
                 const u64 rt = (u64)A.run << 32;
                 if (STATS && lane == 0) dq_time[t] = ph0;
@@ -876,10 +1034,10 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             // ---- the node: its string is the champion's string with the label appended — the register built above
             u32 depth = 0, my_label = 0, cprev = C2A_NONE, my_pos = 0;
             u64 str = 0;
-            if (ch != C2A_NONE) {
+            if (C2A_LIKELY(ch != C2A_NONE)) {
                 depth = ch_depth + 1; my_label = ch_el;
                 u32 wi = ch_pos >> 8, bp = ch_pos & 255u;
-                if (wi >= kStrWords) {           // the parent filled its chunk: a fresh one, the parent is its anchor
+                if (C2A_UNLIKELY(wi >= kStrWords)) {           // the parent filled its chunk: a fresh one, the parent is its anchor
                     cprev = ch; wi = 0; bp = 0;
                     str = lane == kHdrWords ? (u64)my_label : 0ull;
                 } else {
@@ -887,7 +1045,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                     str = ch_x;
                 }
                 ++bp;
-                if (bp == kWordBits) { bp = 0; ++wi; }
+                if (C2A_UNLIKELY(bp == kWordBits)) { bp = 0; ++wi; }
                 my_pos = (wi << 8) | bp;
             }
             max_level = level > max_level ? level : max_level;
@@ -905,7 +1063,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             const u64 my_w = (u64)w_lo | ((u64)w_hi << 32);
             st_nw(&A.node[(u64)gc * kNodeWords + lane], my_w);
             ++processed;
-            if ((processed & 63u) == 0 && lane == 0) atomicAdd(&A.ctl[CTL_HEARTBEAT], 1u);
+            if (C2A_UNLIKELY((processed & 63u) == 0) && lane == 0) atomicAdd(&A.ctl[CTL_HEARTBEAT], 1u);
             if (STATS) {
                 const ull ph4 = c2a_now();
                 if (dt_trace && lane == 0) {
@@ -920,7 +1078,7 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
                 if (cur.take == 0) ++ph_noload;
                 ph_a += ph1 - ph0; ph_b += ph2 - ph1; ph_c += ph3 - ph2; ph_d += ph4 - ph3; ph_push += ph3 - ph2a; ph_cold += cur.more ? 1 : 0;
             }
-            if (nxt == C2A_NONE) return true;                       // the chain ends here
+            if (C2A_UNLIKELY(nxt == C2A_NONE)) return true;         // the chain ends here
             // what the next step reuses: this gate as the first candidate of nxt (same DFS root: ch_root stays)
             own_valid = 1; own_node = gc; own_level = level;
             ch_x = str;
@@ -930,8 +1088,8 @@ __global__ void __launch_bounds__(64) k_peel(PeelArgs A_in) {
             return false;
         };
         for (;;) {
-            if (step(S0, S1)) break;
-            if (step(S1, S0)) break;
+            if (step(StepSet<0>(), StepSet<1>(), S0, S1)) break;
+            if (step(StepSet<1>(), StepSet<0>(), S1, S0)) break;
         }
         if ((++iters & 63u) == 0) {                                 // somebody gave up (watchdog): leave, the host reports it
             u32 ab = 0;

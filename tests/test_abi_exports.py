@@ -65,3 +65,26 @@ def test_product_package_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("no oracle", "").replace("No oracle", "") or f == "synth.py", \
                     os.path.join(dirpath, f)
+
+
+def test_peel_kernel_allocation_covers_its_fixed_scalar_registers(c2a, tmp_path):
+    """k_peel lands the results of its scalar atomics in FIXED registers s97..s101, outside the compiler's budget
+    (amdgpu_num_sgpr; csrc/c2a_peel.h, SCALAR TICKETS).  The hardware only gives a wave the registers its kernel descriptor
+    asks for: the descriptor of both instantiations must cover s0..s101 (102 + VCC, FLAT_SCRATCH, XNACK_MASK = 108)."""
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip("ROCm LLVM tools not found")
+    fb, co = str(tmp_path / "fatbin"), str(tmp_path / "code.o")
+    subprocess.check_call([tools[0], "-O", "binary", "--only-section=.hip_fatbin", c2a.library_path(), fb])
+    subprocess.check_call([tools[1], "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fb}", f"--output={co}", "--unbundle"])
+    notes = subprocess.check_output([tools[2], "--notes", co], text=True)
+    seen = 0
+    for block in notes.split("- .agpr_count")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        if "k_peelILb" in name:
+            assert int(re.search(r"\.sgpr_count:\s+(\d+)", block).group(1)) >= 108, name
+            seen += 1
+    assert seen == 2
