@@ -257,6 +257,7 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
     A.n_fifos = c->peel_fifos;
     A.q_cap = n / A.n_fifos + 2 * waves + 64;
     const size_t slots = (size_t)A.n_fifos * A.q_cap;
+    if (slots >= (1ull << 32)) { c->err = "peel: hand-off slots beyond 32-bit addressing"; return C2A_ERR_ARG; }
     // (slots are never cleared between runs: every word of an entry carries the number of the run that wrote it)
     if (c->aq_items.cap < slots * kSlotWords * 8 || c->peel_run == 0xFFFFFFFFu) {
         ENSURE(c->aq_items, slots * kSlotWords * 8);
@@ -267,6 +268,7 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
     A.n_primary = n_primary;
     A.reserve_min = 4;
     if (const char* e = std::getenv("C2A_PEEL_RESERVE_MIN")) A.reserve_min = std::max<u32>(1u, (u32)std::strtoul(e, nullptr, 10));
+    if (waves <= n_primary) A.reserve_min = 0;       // no reserve waves: pushers need not count the entries nobody was in line for
     ENSURE(c->aq_pc, (size_t)A.n_fifos * kPcStride * 8);
     ENSURE(c->pctl, (size_t)CTL_WORDS * 4);
     HIP_TRY(hipMemsetAsync(c->aq_pc.p, 0, (size_t)A.n_fifos * kPcStride * 8, s));

@@ -250,8 +250,10 @@ __device__ __forceinline__ u32 own_sgpr(u32 v) {
 // the compiler must treat v as used (and redefined) here: pins the wait for a pending load to this point
 #ifdef C2A_EMULATE
 #define C2A_PIN(v) ((void)0)
+#define C2A_OPAQUE(v) ((void)0)
 #else
 #define C2A_PIN(v) asm volatile("" : "+v"(v) :: "memory")
+#define C2A_OPAQUE(v) asm volatile("" : "+v"(v))      /* the compiler knows nothing about v from here on (no hoisting of what is computed from it) */
 #endif
 
 // SCALAR TICKETS.  A returning atomic of ONE lane does not need the vector memory path: gfx950 still has the scalar-memory
@@ -646,6 +648,10 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
         C2A_PIN(r);
     }
     const u32 epoch = A.epoch;
+    // byte offset of the word of a hand-off entry that this lane writes: lanes 8..15 words 0..7 (the pushed gate's static
+    // records), lanes 32..39 words 8..15 (its first consumers, its id)
+    const u32 ent_off = (lane >= 8u && lane < 16u) ? (lane - 8u) * 8u : ((lane >= 32u && lane < 40u) ? (lane - 24u) * 8u : C2A_NONE);
+    const u32 no_demand = A.reserve_min ? 0u : C2A_NONE;      // (one compare at the pusher: all ones = never tell anybody)
     const u32 dummy_idx = A.n + me * kFillDummyStride; (void)dummy_idx;      // this wave's dummy ticket word (a line of its own behind fill[n])
     bool seeds_left = true;
     u32 region = 0, idx = 0, region_cnt = 0;
@@ -1020,14 +1026,19 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                 push_t = rdlane(push_t, 0); push_c = rdlane(push_c, 0);
 #endif
                 if (STATS) ph_pwait += c2a_now() - ph2a;
-                const u64 t = (u64)push_f * A.q_cap + push_t;
-                // nobody was in line for this entry: tell the reserve
-                if (push_c <= push_t) { if (lane == 0) atomicAdd(&A.ctl[CTL_DEMAND + (me & (kAcctShards - 1u)) * kAcctStride], 1u); wave_join(); }
-                u64* slot = A.fifo + t * kSlotWords;
-                const u64 rt = (u64)A.run << 32;
+                const u32 t = push_f * A.q_cap + push_t;            // (all slots together stay below 2^32: the host checks)
+                // nobody was in line for this entry: tell the reserve (reserve_min is 0 when the launch has none)
+                if (C2A_UNLIKELY((push_c | no_demand) <= push_t)) { if (lane == 0) atomicAdd(&A.ctl[CTL_DEMAND + (me & (kAcctShards - 1u)) * kAcctStride], 1u); wave_join(); }
                 if (STATS && lane == 0) dq_time[t] = ph0;
-                if (lane >= 8 && lane < 16) st_nw(slot + (lane - 8), rt | cur.gw);
-                if (lane >= 32 && lane < 40) st_nw(slot + (lane - 24), rt | (lane == 39 ? g_dep1 : cur.clp));
+                // ONE masked store: a lane knows which word of the entry is its own (ent_off, set up once per wave)
+                // (the two lane masks are made HERE, a compare each: as loop invariants they would live in scalar register pairs,
+                // i.e. be spilled and fetched back, two lane reads and an exec shuffle apiece)
+                u32 ln = lane, eo = ent_off;
+                C2A_OPAQUE(ln); C2A_OPAQUE(eo);
+                const u32 c39 = wrlane_c<39>(g_dep1, cur.clp);
+                const u32 lo = ln < 32u ? cur.gw : c39;
+                char* slot = reinterpret_cast<char*>(A.fifo + (u64)t * kSlotWords);
+                if (eo != C2A_NONE) st_nw(reinterpret_cast<u64*>(slot + eo), ((u64)A.run << 32) | lo);
                 wave_join();
             }
             const ull ph3 = STATS ? c2a_now() : 0;
