@@ -250,7 +250,7 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
     const u32 waves = peel_grid(c, want_stats, &n_primary);
     // the waves' dummy ticket words behind fill[n] (c2a_peel.h, SCALAR TICKETS): zero, and they stay zero (only 0 is ever
     // added); a ticket word is addressed by a 32-bit byte offset from fill
-    if (waves > kFillDummyWaves || n >= (1u << 30)) { c->err = "peel: grid or gate count beyond the ticket words' addressing"; return C2A_ERR_ARG; }
+    if (waves > kFillDummyWaves || n >= (1u << 29)) { c->err = "peel: grid or gate count beyond the ticket words' addressing"; return C2A_ERR_ARG; }
     HIP_TRY(hipMemsetAsync(c->fill.as<u32>() + n, 0, (size_t)kFillDummyStride * kFillDummyWaves * 4, s));
     // hand-off arrays: every slot is used once per run (no wrap-around).  A wave spreads its pushes round robin, so an
     // array receives at most pushes / n_fifos + waves entries, and a wave holds at most one unserved consumer ticket

@@ -237,6 +237,9 @@ __device__ __forceinline__ u32 own_sgpr(u32 v) {
 // Branch weights for the block layout: a TAKEN branch costs a wave its instruction buffer (~16+ clocks against 4 for one
 // that falls through), and a chain step runs some fifty branches — the hot path should fall through, the cold code
 // (re-reads, deep trees, the cold list loop, giving up) sit out of line.
+#ifndef C2A_ISSUE_MASKS
+#define C2A_ISSUE_MASKS 0
+#endif
 #ifndef C2A_HINTS
 #define C2A_HINTS 1
 #endif
@@ -292,6 +295,27 @@ constexpr int kSregBase = 99, kSregBegin = 99, kSregPush = 100, kSregFill0 = 100
 constexpr int kSregBase = 100, kSregFill0 = 100, kSregFill1 = 101;
 #define C2A_SREG_BUDGET 106
 #define C2A_SREG_CLOBBERS "s100", "s101"
+#endif
+// SCALAR STORES for one-lane stores of wave-uniform data (s_store_dword[x4]: gfx9 family, still there on gfx950).  They go
+// through the scalar data cache, which is WRITE-BACK: nothing is visible to anybody else until s_dcache_wb — fine for data
+// that only later launches read, provided every wave writes the cache back before it ends (tools/ubench/sstore.hip: 0 of
+// 3.3 M results wrong with the write-back, 75 % lost without; neighbouring words written on different CUs both survive).
+#ifdef C2A_EMULATE
+__device__ __forceinline__ void sstore_x4(uint4* p, u32 a, u32 b, u32 c, u32 d) { if ((threadIdx.x & 63u) == 0) *p = make_uint4(a, b, c, d); }
+__device__ __forceinline__ void sstore_x1(u32* p, u32 a) { if ((threadIdx.x & 63u) == 0) *p = a; }
+__device__ __forceinline__ void sstore_flush() {}
+#else
+typedef u32 c2a_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void sstore_x4(uint4* p, u32 a, u32 b, u32 c, u32 d) {
+    typedef __attribute__((address_space(1))) uint4* G;
+    c2a_v4u q = {uniform(a), uniform(b), uniform(c), uniform(d)};
+    asm volatile("s_store_dwordx4 %0, %1, 0x0" :: "s"(q), "s"((G)p) : "memory");
+}
+__device__ __forceinline__ void sstore_x1(u32* p, u32 a) {
+    typedef __attribute__((address_space(1))) u32* G;
+    asm volatile("s_store_dword %0, %1, 0x0" :: "s"(uniform(a)), "s"((G)p) : "memory");
+}
+__device__ __forceinline__ void sstore_flush() { asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory"); }
 #endif
 #ifdef C2A_EMULATE
 #define C2A_PEEL_KERNEL_ATTR
@@ -835,11 +859,22 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             // static data of both producers, one word per lane, BRANCH-FREE (clamped index, result discarded where there
             // is nothing to load)
             {
+#if C2A_ISSUE_MASKS
+                u32 ln = lane; C2A_OPAQUE(ln);                          // (lane masks made on the spot: see the hand-off entry)
+                const u32 dw = (ln & 8u) ? dep1 : dep0;
+                S.gw = reinterpret_cast<const u32*>(A.gstat)[8 * (u64)(dw != C2A_NONE ? dw : 0u) + (ln & 7u)];
+#else
                 const u32 dw = (lane & 8u) ? dep1 : dep0;
                 S.gw = reinterpret_cast<const u32*>(A.gstat)[8 * (u64)(dw != C2A_NONE ? dw : 0u) + (lane & 7u)];
+#endif
             }
             {
+#if C2A_ISSUE_MASKS
+                u32 ln = lane; C2A_OPAQUE(ln);
+                const u32 half = ln >> 5, i = ln & 31u;
+#else
                 const u32 half = lane >> 5, i = lane & 31u;
+#endif
                 const u32 poff = half ? off1 : off0;
                 S.clp = A.clist[poff + i];                               // (clist is padded by 64 entries: lanes beyond the list read
                                                                          // somebody else's entries, which nobody looks at)
@@ -1060,11 +1095,10 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                 my_pos = (wi << 8) | bp;
             }
             max_level = level > max_level ? level : max_level;
-            if (lane == 0) {
-                A.meta[gc] = make_uint4(ch, depth, ch_root, my_label | (level << 1));
-                if (ch != C2A_NONE) A.child[2 * (u64)ch + my_label] = gc;
-            }
-            wave_join();
+            // the tree entry and the child link: wave-uniform data, read by later launches only — SCALAR stores (no exec
+            // shuffle, no moves into vector registers; written back at the end of the wave: sstore_flush)
+            sstore_x4(&A.meta[gc], ch, depth, ch_root, my_label | (level << 1));
+            if (C2A_LIKELY(ch != C2A_NONE)) sstore_x1(&A.child[2 * (u64)ch + my_label], gc);
             // (the three header words go into lanes 0..2 with v_writelane: a lane == k ladder is masked code)
             const u32 tag_hi = epoch << 31;
             u32 w_lo = (u32)str, w_hi = (u32)(str >> 32) | tag_hi;
@@ -1108,6 +1142,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             if (rdlane(ab, 0)) break;
         }
     }
+    sstore_flush();
     if (lane == 0) {
         u32* acct = &A.ctl[CTL_PROC + (me & (kAcctShards - 1u)) * kAcctStride];
         if (processed) atomicAdd(acct, processed);
