@@ -434,6 +434,7 @@ __device__ __attribute__((noinline)) u64 peel_reread(const u64* node_base, u32 e
         u64 badm = __ballot((u32)(w >> 63) != epoch);
         if ((u32)rdlane64(w, 0) == 0u) badm &= 7ull;
         if (badm == 0 || ++polls > kPollLimit) break;
+        if ((polls & 63u) == 1u && __ballot(ld_a32(&ctl[CTL_ABORT]) != 0u) != 0ull) break;       // the launch is being given up: nobody waits any more
         peel_sleep(polls < 8 ? 4 : 16);
         w = ld_nw(p);
     }
@@ -979,7 +980,6 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             // ---- tournament of THIS gate
             u32 level = own_valid ? own_level + 1u : 0u;
             if (!(own_valid && ch_root < gc)) { ch = C2A_NONE; ch_el = 0; ch_root = gc; ch_depth = 0; ch_pos = 0; ch_w = 0; ch_x = 0; }
-            u32 gave_up = 0;
             // one candidate: its record must be all there (else read it again: out of line), then it meets the champion
             auto candidate = [&](u64& w, u32 e) {             // (w by reference: the cold path mends it in place, no copy)
                 const u32 c = e & kIdMask, el = e >> 31;
@@ -990,7 +990,10 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                     if ((badm & 7ull) != 0 || (u32)rdlane64(w, 0) != 0u) {
                         w = peel_reread(A.node, epoch, A.ctl, c, w, lane);
                         badm = __ballot((u32)(w >> 63) != epoch);
-                        if ((badm & 7ull) != 0 || (badm != 0 && (u32)rdlane64(w, 0) != 0u)) { gave_up = 1; return; }
+                        // It never arrived (or the launch is being given up already): fail loudly — ABORT tells the host, which
+                        // discards the run — and leave the candidate out.  The chain goes on (no flag to carry through the hot
+                        // path); once ABORT is up no re-read waits any more, chains run out and waiting waves leave.
+                        if ((badm & 7ull) != 0 || (badm != 0 && (u32)rdlane64(w, 0) != 0u)) { if (lane == 0) atomicAdd(&A.ctl[CTL_ABORT], 1u); wave_join(); return; }
                     }
                     if ((u32)(w >> 63) != epoch) w = (u64)epoch << 63;       // (string words of a depth-0 record)
                 }
@@ -1002,24 +1005,25 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                 // the candidate's string with its edge label appended (meaningful while the chunk has room: cpos < kStrWords << 8)
                 u64 x = w & kPayload;
                 if (lane == kHdrWords + (cpos >> 8)) x |= (u64)el << (cpos & 255u);
-                u32 less;                     // (0 / 1 in a scalar register: a bool merged over branches becomes a lane mask)
+                // (the new champion is taken INSIDE each branch: a 0 / 1 merged over the branches becomes a lane mask, a scalar
+                // pair that is set, combined and tested with four instructions per branch)
+                auto take = [&]() { ch = c; ch_el = el; ch_root = croot; ch_depth = cdepth; ch_pos = cpos; ch_w = w; ch_x = x; };
                 if (croot != ch_root) {
-                    less = croot < ch_root ? 1u : 0u;                                // a larger DFS root loses at once (also to [g] itself)
+                    if (croot < ch_root) take();                                     // a larger DFS root loses at once (also to [g] itself)
                 } else if (C2A_LIKELY((cdepth > ch_depth ? cdepth : ch_depth) < kChunkBits)) {
                     // neither path is a prefix of the other (that would be a cycle), and the same node with the other label
                     // differs in the appended bit: the first differing bit decides
                     const u64 d = x ^ ch_x;
                     const u64 bal = __ballot(d != 0) & ~7ull;
                     const u32 L = ctz64(bal);
-                    less = (u32)(~(rdlane64(x, L) >> ctz64(rdlane64(d, L)))) & 1u;
+                    if (((u32)(rdlane64(x, L) >> ctz64(rdlane64(d, L))) & 1u) == 0u) take();
                 } else if (c == ch) {
-                    less = el < ch_el ? 1u : 0u;
+                    if (el < ch_el) take();
                 } else {
                     // (the result of an out-of-line call counts as divergent; left like that, every value that depends on the
                     // champion would move to vector registers and the whole tournament would be compiled as divergent code)
-                    less = uniform(deep_less(A.node, epoch, A.ctl, c, el, cdepth, w, ch, ch_el, ch_depth, ch_w, lane) ? 1u : 0u);
+                    if (uniform(deep_less(A.node, epoch, A.ctl, c, el, cdepth, w, ch, ch_el, ch_depth, ch_w, lane) ? 1u : 0u)) take();
                 }
-                if (less) { ch = c; ch_el = el; ch_root = croot; ch_depth = cdepth; ch_pos = cpos; ch_w = w; ch_x = x; }
             };
             // the (up to two) records loaded ahead ...
             if (C2A_LIKELY(cur.take >= 1)) {
@@ -1033,14 +1037,14 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                 }
             }
             // ... then — cold — the consumer list itself, one record at a time, when it holds more than that
-            if (C2A_UNLIKELY(cur.more && !gave_up)) {
-                for (u32 eb = 0; eb < g_cnt && !gave_up; eb += 64) {
+            if (C2A_UNLIKELY(cur.more != 0)) {
+                for (u32 eb = 0; eb < g_cnt; eb += 64) {
                     u32 blk = A.clist[g_off + eb + lane];
                     C2A_PIN(blk);                                // (consumed here, like w below)
                     u64 smask = __ballot(eb + lane < g_cnt && !(own_valid && (blk & kIdMask) == own_node) &&
                                          !(cur.take >= 1 && blk == cur.e0) && !(cur.take >= 2 && blk == cur.e1) &&
                                          !(cur.take >= 3 && blk == cur.e2) && !(cur.take >= 4 && blk == cur.e3));
-                    while (smask && !gave_up) {
+                    while (smask) {
                         const u32 e = rdlane(blk, ctz64(smask));
                         smask &= smask - 1;
                         u64 w = ld_nw(&A.node[(u64)(e & kIdMask) * kNodeWords + lane]);
@@ -1049,7 +1053,6 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                     }
                 }
             }
-            if (C2A_UNLIKELY(gave_up != 0)) { if (lane == 0) atomicAdd(&A.ctl[CTL_ABORT], 1u); wave_join(); return true; }      // a record never arrived: fail loudly
             const ull ph2a = STATS ? c2a_now() : 0;
             if (rmask == 3u) {
                 // the entry: lanes 8..15 hold the pushed gate's static records, lanes 32..38 its first consumers
@@ -1094,7 +1097,6 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                 if (C2A_UNLIKELY(bp == kWordBits)) { bp = 0; ++wi; }
                 my_pos = (wi << 8) | bp;
             }
-            max_level = level > max_level ? level : max_level;
             // the tree entry and the child link: wave-uniform data, read by later launches only — SCALAR stores (no exec
             // shuffle, no moves into vector registers; written back at the end of the wave: sstore_flush)
             sstore_x4(&A.meta[gc], ch, depth, ch_root, my_label | (level << 1));
@@ -1123,7 +1125,8 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                 if (cur.take == 0) ++ph_noload;
                 ph_a += ph1 - ph0; ph_b += ph2 - ph1; ph_c += ph3 - ph2; ph_d += ph4 - ph3; ph_push += ph3 - ph2a; ph_cold += cur.more ? 1 : 0;
             }
-            if (C2A_UNLIKELY(nxt == C2A_NONE)) return true;         // the chain ends here
+            // (levels grow along a chain: its last step has the highest)
+            if (C2A_UNLIKELY(nxt == C2A_NONE)) { max_level = level > max_level ? level : max_level; return true; }      // the chain ends here
             // what the next step reuses: this gate as the first candidate of nxt (same DFS root: ch_root stays)
             own_valid = 1; own_node = gc; own_level = level;
             ch_x = str;
