@@ -700,7 +700,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
         uint4 gi, gi2;
         u32 cl0 = 0, cl0_base = 0, cl0_cap = 64;       // g's consumers: one per lane from lane cl0_base on, cl0_cap lanes
         ull pop_slot = ~0ull;                // STATS: slot of the popped entry
-        if (seeds_left) {
+        if (C2A_UNLIKELY(seeds_left)) {
             // (pointers read from memory are generic pointers, and a load through one counts as divergent: every value
             // read through A.cold is declared wave-uniform by hand)
             const PeelCold* C = A.cold;
@@ -716,7 +716,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             if (seeds_left) { g = uniform(C->seeds[(u64)region * chunk + idx]); ++idx; if (STATS) { ++st_seeds; came = 2; } }
         }
         const ull ph_s0 = STATS ? c2a_now() : 0;
-        if (g != C2A_NONE) {
+        if (C2A_UNLIKELY(g != C2A_NONE)) {
             // static data of a seed (a chain step gets all of this prefetched by the step before; a popped gate brings it
             // along); consumed HERE, in scalar registers where wave-uniform: a load still pending at the loop header would
             // cost every chain step a wait
@@ -730,7 +730,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             // those were returning atomics, waited for)
             if (lane == 0) atomicAdd(&A.ctl[CTL_END + (me & (kAcctShards - 1u)) * kAcctStride], 1u); wave_join();
             // ---- a consumer ticket — kept until it is served, whatever else this wave does meanwhile — and the slot it names
-            if (!held && me >= A.n_primary) {
+            if (C2A_UNLIKELY(!held && me >= A.n_primary)) {
                 // A RESERVE wave (C2A_PEEL_RESERVE per CU, off by default) stays out of the lines — every wave in line makes
                 // the others' polls and the ticket lines slower, and 8 waves per CU are enough for a graph 2 000 gates wide —
                 // until enough pushers have found a line EMPTY: then the launch is short of waves, not of work
@@ -750,11 +750,18 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                 if (leave) break;
                 // (after 128 looks it joins a line anyway: ending, and picking up a stranded entry, never depends on others)
             }
-            if (!held) {
+            if (C2A_LIKELY(!held)) {
                 const u32 f = (pop_rr++) & (A.n_fifos - 1u);
+#if C2A_SPUSH
+                // (a scalar ticket here too — nothing else is in flight in those registers while a wave has no work)
+                sreg_add64<kSregPush>(sr, &A.q_pc[(u64)f * kPcStride], 1ull << 32);
+                sreg_wait();
+                held_slot = (u64)f * A.q_cap + sreg_get<kSregPush + 1>(sr);
+#else
                 u64 pc = 0;
                 if (lane == 0) pc = atomicAdd(reinterpret_cast<ull*>(&A.q_pc[(u64)f * kPcStride]), 1ull << 32); wave_join();
                 held_slot = (u64)f * A.q_cap + rdlane((u32)(pc >> 32), 0);
+#endif
                 held = 1;
             }
             u64 slot_i = held_slot;          // the slot this wave watches: its own, or (see below) one that is served already
@@ -765,7 +772,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                 v = ld_nw(A.fifo + slot_i * kSlotWords + (lane & (kSlotWords - 1u)));
                 if (((u32)__ballot((u32)(v >> 32) == A.run) & 0xFFFFu) == 0xFFFFu) { got = true; break; }
                 ++polls;
-                if ((polls & 31u) == 0) {
+                if (C2A_UNLIKELY((polls & 31u) == 0)) {
                     // cheap and frequent: has somebody seen the end (or given up)?  is the launch still making progress?
                     u32 c3 = 0;
                     if (lane < 3) c3 = ld_a32(&A.ctl[lane == 0 ? CTL_ABORT : (lane == 1 ? CTL_DONE : CTL_HEARTBEAT)]); wave_join();
@@ -814,7 +821,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             }
             if (STATS) st_polls += polls;
             if (STATS) { const ull tt = c2a_now(); st_idle += tt - st_t0; st_t0 = tt; }
-            if (!got) break;
+            if (C2A_UNLIKELY(!got)) break;
             if (slot_i == held_slot) held = 0;
             if (STATS) { pop_slot = slot_i; ++st_pops; came = 1; }
             const u32 pv = (u32)v;
@@ -911,9 +918,11 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
         // The champion of a gate's tournament so far (wave-uniform); ch == NONE: the virtual-root candidate [g].  The gate
         // just finished stays in these registers as the first candidate of the next one: it is the champion to beat unless
         // its DFS root is not smaller than the next gate's own id (then the step starts from [g])
-        u32 ch = C2A_NONE, ch_el = 0, ch_root = 0, ch_depth = 0, ch_pos = 0;
+        u32 ch = C2A_NONE, ch_el = 0, ch_root = C2A_NONE, ch_depth = 0, ch_pos = 0;
         u64 ch_w = 0, ch_x = 0;              // the champion's record / its string with the edge label appended
-        u32 own_valid = 0, own_node = 0, own_level = 0;      // the gate just finished (a consumer of the gate in hand)
+        // the gate just finished (a consumer of the gate in hand); at the start of a chain there is none: no gate has id NONE,
+        // level NONE + 1 is 0, and a champion root of NONE (above) is smaller than no gate id — no flag to test
+        u32 own_node = C2A_NONE, own_level = C2A_NONE;
 
         // one step: `cur` is in hand (issued one step ago), `nx` receives the next one.  true = the chain ends (or abort)
         auto step = [&](auto cur_set, auto nx_set, StepIO& cur, StepIO& nx) -> bool {
@@ -978,8 +987,8 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             wave_priority(0);
             const ull ph2 = STATS ? c2a_now() : 0;
             // ---- tournament of THIS gate
-            u32 level = own_valid ? own_level + 1u : 0u;
-            if (!(own_valid && ch_root < gc)) { ch = C2A_NONE; ch_el = 0; ch_root = gc; ch_depth = 0; ch_pos = 0; ch_w = 0; ch_x = 0; }
+            u32 level = own_level + 1u;
+            if (!(ch_root < gc)) { ch = C2A_NONE; ch_el = 0; ch_root = gc; ch_depth = 0; ch_pos = 0; ch_w = 0; ch_x = 0; }
             // one candidate: its record must be all there (else read it again: out of line), then it meets the champion
             auto candidate = [&](u64& w, u32 e) {             // (w by reference: the cold path mends it in place, no copy)
                 const u32 c = e & kIdMask, el = e >> 31;
@@ -1008,7 +1017,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                 // (the new champion is taken INSIDE each branch: a 0 / 1 merged over the branches becomes a lane mask, a scalar
                 // pair that is set, combined and tested with four instructions per branch)
                 auto take = [&]() { ch = c; ch_el = el; ch_root = croot; ch_depth = cdepth; ch_pos = cpos; ch_w = w; ch_x = x; };
-                if (croot != ch_root) {
+                if (C2A_UNLIKELY(croot != ch_root)) {      // (the first few DFS roots own nearly everything below them)
                     if (croot < ch_root) take();                                     // a larger DFS root loses at once (also to [g] itself)
                 } else if (C2A_LIKELY((cdepth > ch_depth ? cdepth : ch_depth) < kChunkBits)) {
                     // neither path is a prefix of the other (that would be a cycle), and the same node with the other label
@@ -1041,7 +1050,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                 for (u32 eb = 0; eb < g_cnt; eb += 64) {
                     u32 blk = A.clist[g_off + eb + lane];
                     C2A_PIN(blk);                                // (consumed here, like w below)
-                    u64 smask = __ballot(eb + lane < g_cnt && !(own_valid && (blk & kIdMask) == own_node) &&
+                    u64 smask = __ballot(eb + lane < g_cnt && !((blk & kIdMask) == own_node) &&
                                          !(cur.take >= 1 && blk == cur.e0) && !(cur.take >= 2 && blk == cur.e1) &&
                                          !(cur.take >= 3 && blk == cur.e2) && !(cur.take >= 4 && blk == cur.e3));
                     while (smask) {
@@ -1128,7 +1137,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             // (levels grow along a chain: its last step has the highest)
             if (C2A_UNLIKELY(nxt == C2A_NONE)) { max_level = level > max_level ? level : max_level; return true; }      // the chain ends here
             // what the next step reuses: this gate as the first candidate of nxt (same DFS root: ch_root stays)
-            own_valid = 1; own_node = gc; own_level = level;
+            own_node = gc; own_level = level;
             ch_x = str;
             if (lane == kHdrWords + (my_pos >> 8)) ch_x |= (u64)nxt_label << (my_pos & 255u);
             ch = gc; ch_el = nxt_label; ch_depth = depth; ch_pos = my_pos; ch_w = my_w;
@@ -1139,7 +1148,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             if (step(StepSet<0>(), StepSet<1>(), S0, S1)) break;
             if (step(StepSet<1>(), StepSet<0>(), S1, S0)) break;
         }
-        if ((++iters & 63u) == 0) {                                 // somebody gave up (watchdog): leave, the host reports it
+        if (C2A_UNLIKELY((++iters & 63u) == 0)) {                   // somebody gave up (watchdog): leave, the host reports it
             u32 ab = 0;
             if (lane == 0) ab = ld_a32(&A.ctl[CTL_ABORT]); wave_join();
             if (rdlane(ab, 0)) break;
