@@ -725,6 +725,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             cl0 = A.clist[gi.z + lane];                                      // clist is padded by 64 entries
             C2A_PIN(cl0);
         } else {
+            wave_priority(0);
             if (STATS) { const ull t = c2a_now(); st_busy += t - st_t0; st_t0 = t; }
             // ---- this unit of work is over: END counts it (every entry this wave pushed meanwhile is in BEGIN already:
             // those were returning atomics, waited for)
@@ -984,7 +985,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                 // the consumers of nxt are already here (lanes 32 j0 ... of the prefetched lists) unless it has more than 32
                 issue(nx_set, nx, gi.x, gi.y, gi.w, gi2.x, gi2.y, gi2.z, gi2.w, cur.clp, 32u * j0, 32u, true, gc);
             }
-            wave_priority(0);
+            wave_priority(1);
             const ull ph2 = STATS ? c2a_now() : 0;
             // ---- tournament of THIS gate
             u32 level = own_level + 1u;
