@@ -649,9 +649,9 @@ struct StepIO {
                                // fixed scalar registers of this set (SCALAR TICKETS above)
     u32 gw;                    // lane 8 l + j (l < 2, j < 8): word j of the two gstat records of producer l
     u32 clp;                   // lanes 0..31: producer 0's consumers, 32..63: producer 1's
-    u32 e0, e1, e2, e3, take;  // consumer | label << 31 of the (up to four) records in flight
+    u32 e0, e1, e2, e3, e4, e5, take;  // consumer | label << 31 of the (up to six) records in flight
     u32 more;                  // the consumer list holds candidates beyond those (the step reads the list itself: cold)
-    u64 w0, w1, w2, w3;        // this lane's word of those records
+    u64 w0, w1, w2, w3, w4, w5;        // this lane's word of those records
 };
 
 // the dataflow launch: 64-thread workgroups (one wave each)
@@ -908,6 +908,15 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                         if (C2A_UNLIKELY(smask != 0)) {
                             S.e3 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 4;
                             S.w3 = ld_nw(&A.node[(u64)(S.e3 & kIdMask) * kNodeWords + lane]);
+                            // (a fifth and a sixth: one gate in 45 — but one step in 15 of the critical path — has more than four)
+                            if (C2A_UNLIKELY(smask != 0)) {
+                                S.e4 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 5;
+                                S.w4 = ld_nw(&A.node[(u64)(S.e4 & kIdMask) * kNodeWords + lane]);
+                                if (smask) {
+                                    S.e5 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 6;
+                                    S.w5 = ld_nw(&A.node[(u64)(S.e5 & kIdMask) * kNodeWords + lane]);
+                                }
+                            }
                         }
                     }
                 }
@@ -945,7 +954,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             C2A_PIN(cur.gw);
             C2A_PIN(cur.clp);
             const ull ph0b = STATS ? c2a_now() : 0;
-            C2A_PIN(cur.w0); C2A_PIN(cur.w1); C2A_PIN(cur.w2); C2A_PIN(cur.w3);
+            C2A_PIN(cur.w0); C2A_PIN(cur.w1); C2A_PIN(cur.w2); C2A_PIN(cur.w3); C2A_PIN(cur.w4); C2A_PIN(cur.w5);
             if (STATS) { const ull ph0c = c2a_now(); ph_w1 += ph0a - ph0; ph_w2 += ph0b - ph0a; ph_w3 += ph0c - ph0b; }
             // (the next gate's static records are written over gi / gi2 below: what the rest of this step needs of its own)
             const u32 gc = g, g_dep0 = gi.x, g_dep1 = gi.y, g_off = gi.z, g_cnt = gi.w;
@@ -1047,7 +1056,13 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                     candidate(cur.w1, cur.e1);
                     if (C2A_UNLIKELY(cur.take >= 3)) {
                         candidate(cur.w2, cur.e2);
-                        if (C2A_UNLIKELY(cur.take >= 4)) candidate(cur.w3, cur.e3);
+                        if (C2A_UNLIKELY(cur.take >= 4)) {
+                            candidate(cur.w3, cur.e3);
+                            if (cur.take >= 5) {
+                                candidate(cur.w4, cur.e4);
+                                if (cur.take >= 6) candidate(cur.w5, cur.e5);
+                            }
+                        }
                     }
                 }
             }
@@ -1058,7 +1073,8 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                     C2A_PIN(blk);                                // (consumed here, like w below)
                     u64 smask = __ballot(eb + lane < g_cnt && !((blk & kIdMask) == own_node) &&
                                          !(cur.take >= 1 && blk == cur.e0) && !(cur.take >= 2 && blk == cur.e1) &&
-                                         !(cur.take >= 3 && blk == cur.e2) && !(cur.take >= 4 && blk == cur.e3));
+                                         !(cur.take >= 3 && blk == cur.e2) && !(cur.take >= 4 && blk == cur.e3) &&
+                                         !(cur.take >= 5 && blk == cur.e4) && !(cur.take >= 6 && blk == cur.e5));
                     while (smask) {
                         const u32 e = rdlane(blk, ctz64(smask));
                         smask &= smask - 1;
