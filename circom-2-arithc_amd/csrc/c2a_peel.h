@@ -649,9 +649,9 @@ struct StepIO {
                                // fixed scalar registers of this set (SCALAR TICKETS above)
     u32 gw;                    // lane 8 l + j (l < 2, j < 8): word j of the two gstat records of producer l
     u32 clp;                   // lanes 0..31: producer 0's consumers, 32..63: producer 1's
-    u32 e0, e1, e2, e3, e4, e5, take;  // consumer | label << 31 of the (up to six) records in flight
+    u32 e0, e1, e2, e3, e4, e5, e6, e7, take;  // consumer | label << 31 of the (up to six) records in flight
     u32 more;                  // the consumer list holds candidates beyond those (the step reads the list itself: cold)
-    u64 w0, w1, w2, w3, w4, w5;        // this lane's word of those records
+    u64 w0, w1, w2, w3, w4, w5, w6, w7;        // this lane's word of those records
 };
 
 // the dataflow launch: 64-thread workgroups (one wave each)
@@ -915,6 +915,14 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                                 if (smask) {
                                     S.e5 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 6;
                                     S.w5 = ld_nw(&A.node[(u64)(S.e5 & kIdMask) * kNodeWords + lane]);
+                                    if (smask) {
+                                        S.e6 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 7;
+                                        S.w6 = ld_nw(&A.node[(u64)(S.e6 & kIdMask) * kNodeWords + lane]);
+                                        if (smask) {
+                                            S.e7 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 8;
+                                            S.w7 = ld_nw(&A.node[(u64)(S.e7 & kIdMask) * kNodeWords + lane]);
+                                        }
+                                    }
                                 }
                             }
                         }
@@ -954,7 +962,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             C2A_PIN(cur.gw);
             C2A_PIN(cur.clp);
             const ull ph0b = STATS ? c2a_now() : 0;
-            C2A_PIN(cur.w0); C2A_PIN(cur.w1); C2A_PIN(cur.w2); C2A_PIN(cur.w3); C2A_PIN(cur.w4); C2A_PIN(cur.w5);
+            C2A_PIN(cur.w0); C2A_PIN(cur.w1); C2A_PIN(cur.w2); C2A_PIN(cur.w3); C2A_PIN(cur.w4); C2A_PIN(cur.w5); C2A_PIN(cur.w6); C2A_PIN(cur.w7);
             if (STATS) { const ull ph0c = c2a_now(); ph_w1 += ph0a - ph0; ph_w2 += ph0b - ph0a; ph_w3 += ph0c - ph0b; }
             // (the next gate's static records are written over gi / gi2 below: what the rest of this step needs of its own)
             const u32 gc = g, g_dep0 = gi.x, g_dep1 = gi.y, g_off = gi.z, g_cnt = gi.w;
@@ -1060,7 +1068,13 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                             candidate(cur.w3, cur.e3);
                             if (cur.take >= 5) {
                                 candidate(cur.w4, cur.e4);
-                                if (cur.take >= 6) candidate(cur.w5, cur.e5);
+                                if (cur.take >= 6) {
+                                    candidate(cur.w5, cur.e5);
+                                    if (cur.take >= 7) {
+                                        candidate(cur.w6, cur.e6);
+                                        if (cur.take >= 8) candidate(cur.w7, cur.e7);
+                                    }
+                                }
                             }
                         }
                     }
@@ -1074,7 +1088,8 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                     u64 smask = __ballot(eb + lane < g_cnt && !((blk & kIdMask) == own_node) &&
                                          !(cur.take >= 1 && blk == cur.e0) && !(cur.take >= 2 && blk == cur.e1) &&
                                          !(cur.take >= 3 && blk == cur.e2) && !(cur.take >= 4 && blk == cur.e3) &&
-                                         !(cur.take >= 5 && blk == cur.e4) && !(cur.take >= 6 && blk == cur.e5));
+                                         !(cur.take >= 5 && blk == cur.e4) && !(cur.take >= 6 && blk == cur.e5) &&
+                                         !(cur.take >= 7 && blk == cur.e6) && !(cur.take >= 8 && blk == cur.e7));
                     while (smask) {
                         const u32 e = rdlane(blk, ctz64(smask));
                         smask &= smask - 1;
@@ -1149,7 +1164,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                     // what the step was made of: top wait, issue, tournament, stores (ticks, 12 bits each) | pushed << 48 | records loaded ahead << 49 | cold << 52
                     const ull c12 = 0xFFFull;
                     dt_trace[3 * (u64)gc + 2] = ((ph1 - ph0) & c12) | (((ph2 - ph1) & c12) << 12) | (((ph3 - ph2) & c12) << 24) | (((ph4 - ph3) & c12) << 36) |
-                                                       ((ull)(rmask == 3u) << 48) | ((ull)cur.take << 49) | ((ull)(cur.more != 0) << 52);
+                                                       ((ull)(rmask == 3u) << 48) | ((ull)(cur.take < 7 ? cur.take : 7) << 49) | ((ull)(cur.more != 0) << 52);
                 }
                 came = 0;
                 ++ph_steps;
