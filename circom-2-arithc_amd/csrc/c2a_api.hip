@@ -56,6 +56,7 @@ struct c2a_ctx {
     int n_cu = 256;
     u32 bool_chunk = 256;          // arithmetic gates per k_boolify workgroup: 128, 256 (measured best) or 512
     u32 peel_seed_chunk = 8;       // dataflow launch: seeds a wave takes at a time (1: the one counter they all hit costs 1.4 ms; 8 and 32 are equal)
+    u32 peel_shallow = 4;          // levels behind the sinks done a whole level at once before the dataflow launch (>= 1, <= 48)
     u32 peel_sinks_blocks = 4096;  // grid cap of the sinks pass (latency-bound per thread: two dependent round trips per sink)
     u32 peel_waves = 8;            // dataflow launch: single-wave workgroups per CU (clamped by the occupancy query)
     u32 peel_fifos = 64;           // dataflow launch: hand-off arrays (a power of two <= 64)
@@ -290,25 +291,34 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
     const u32 sink_blocks = grid_for(n, c->peel_sinks_blocks);
     const u64 gates_per_block = ((u64)n + (u64)sink_blocks * kThreads - 1) / ((u64)sink_blocks * kThreads) * kThreads;
     const u32 sink_cap = (u32)(2 * gates_per_block);
-    ENSURE(c->aq_seeds, (size_t)sink_blocks * sink_cap * 4); ENSURE(c->aq_seed_cnt, ((size_t)2 * sink_blocks + 16) * 4);
-    HIP_TRY(hipMemsetAsync(c->aq_seed_cnt.p, 0, ((size_t)2 * sink_blocks + 16) * 4, s));
+    // (region counts of the sinks pass and of every shallow pass behind it, then the length of the flat seed list)
+    const u32 shallow = c->peel_shallow;
+    const u32 l1_cap = 2 * sink_cap;
+    const size_t cnt_words = (size_t)(shallow + 1) * sink_blocks + 16;
+    ENSURE(c->aq_seeds, (size_t)sink_blocks * l1_cap * 4); ENSURE(c->aq_seed_cnt, cnt_words * 4);
+    HIP_TRY(hipMemsetAsync(c->aq_seed_cnt.p, 0, cnt_words * 4, s));
     A.seeds_w = c->aq_seeds.as<u32>(); A.seed_cnt_w = c->aq_seed_cnt.as<u32>(); A.region_cap = sink_cap;
     A.proc_word = CTL_PROC; A.proc_mask = kAcctShards - 1u;
-    // ... what those claim is done by k_peel_level1 (a wave per gate, region by region), and what THAT claims — at most two
-    // producers per gate again — starts the chains of the dataflow launch
-    // (collected per workgroup first, then moved to ONE list the waves of the launch take seed_chunk at a time; its length
-    // stays on the device: the word behind the 2 x sink_blocks region counts)
-    const u32 l1_cap = 2 * sink_cap;
+    // ... what those claim is done by k_peel_shallow, a whole level at once (level 1, 2, ... `peel_shallow`: far wider than the
+    // body of the graph), and what the LAST of these passes claims starts the chains of the dataflow launch (collected per
+    // workgroup first, then moved to ONE list the waves of the launch take seed_chunk at a time; its length stays on the
+    // device: the word behind the region counts)
     ENSURE(c->aq_seeds1, (size_t)sink_blocks * l1_cap * 4); ENSURE(c->aq_seed_flat, ((size_t)n + 64) * 4);
-    cold.seeds = c->aq_seed_flat.as<u32>(); cold.seed_total = c->aq_seed_cnt.as<u32>() + 2 * sink_blocks; cold.seed_chunk = c->peel_seed_chunk;
+    cold.seeds = c->aq_seed_flat.as<u32>(); cold.seed_total = c->aq_seed_cnt.as<u32>() + (size_t)(shallow + 1) * sink_blocks; cold.seed_chunk = c->peel_seed_chunk;
     // what only the edges of the launch touch travels as one small block in HBM (keeps the kernel's scalar registers free)
     // (written by a one-thread launch that takes it by value: a copy from this stack object would need a host round trip)
     ENSURE(c->pcold, sizeof(PeelCold));
     C2A_LAUNCH_NOSYNC(k_set_cold, 1, 1, s, c->pcold.as<PeelCold>(), cold);
     A.cold = c->pcold.as<PeelCold>();
     C2A_LAUNCH(k_peel_sinks, sink_blocks, kThreads, s, A);
-    C2A_LAUNCH(k_peel_level1, sink_blocks, kThreads, s, A, (const u32*)A.seeds_w, (const u32*)A.seed_cnt_w, sink_cap, c->aq_seeds1.as<u32>(), c->aq_seed_cnt.as<u32>() + sink_blocks, l1_cap,
-               c->aq_seed_flat.as<u32>(), c->aq_seed_cnt.as<u32>() + 2 * sink_blocks);
+    // (the passes take turns on two region buffers; the sinks pass wrote the first with regions of sink_cap words)
+    for (u32 lvl = 1; lvl <= shallow; ++lvl) {
+        u32* cnts = c->aq_seed_cnt.as<u32>();
+        const u32* in = (lvl & 1u) ? c->aq_seeds.as<u32>() : c->aq_seeds1.as<u32>();
+        u32* out = (lvl & 1u) ? c->aq_seeds1.as<u32>() : c->aq_seeds.as<u32>();
+        C2A_LAUNCH(k_peel_shallow, sink_blocks, kThreads, s, A, lvl, lvl == shallow ? 1u : 0u, in, (const u32*)(cnts + (size_t)(lvl - 1) * sink_blocks), lvl == 1 ? sink_cap : l1_cap,
+                   out, cnts + (size_t)lvl * sink_blocks, l1_cap, c->aq_seed_flat.as<u32>(), cnts + (size_t)(shallow + 1) * sink_blocks);
+    }
     // (every wave of the launch is alive at once under emulation too, interleaved at the back-offs — in a shuffled order per
     // C2A_EMUL_SEED: the ticket / hand-off / termination protocol is exercised without a GPU)
     if (want_stats) C2A_LAUNCH_CONCURRENT((k_peel<true>), waves, 64, s, A);
@@ -737,6 +747,7 @@ int c2a_create(int n_devices, const int* device_ids, c2a_ctx** out) {
         c->n_cu = prop.multiProcessorCount;
     if (const char* e = std::getenv("C2A_BOOL_CHUNK")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 128 || v == 256 || v == 512) c->bool_chunk = v; }
     if (const char* e = std::getenv("C2A_PEEL_SEED_CHUNK")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 4096) c->peel_seed_chunk = v; }
+    if (const char* e = std::getenv("C2A_PEEL_SHALLOW")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 48) c->peel_shallow = v; }
     if (const char* e = std::getenv("C2A_PEEL_SINKS_BLOCKS")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 16) c->peel_sinks_blocks = v; }
     if (const char* e = std::getenv("C2A_PEEL_WAVES")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 32) c->peel_waves = v; }
     if (const char* e = std::getenv("C2A_PEEL_RESERVE")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v <= 32) c->peel_reserve = v; }

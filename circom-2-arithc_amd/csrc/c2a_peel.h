@@ -425,6 +425,14 @@ __device__ __forceinline__ bool str_less_len(u64 wa, u32 lena, u32 la, u64 wb, u
     if (lena < lenb) return la < str_bit(wb, lena);
     return str_bit(wa, lenb) < lb;
 }
+// The lanes of a record that must be there for a node of this depth (in its current chunk): the header words, the string
+// words that hold its bits, and the word its child's label goes to.  Everything beyond is zero padding whether it has been
+// written or not — a sink's record is its three header words, a record of the shallow passes its first sixteen.
+__device__ __forceinline__ u64 needed_lanes(u32 depth) {
+    if (depth == 0u) return 7ull;
+    const u32 top = kHdrWords + chunk_len(depth) / kWordBits;      // (the label of a child goes to bit chunk_len of the chunk)
+    return top >= 63u ? ~0ull : (2ull << top) - 1ull;
+}
 // A candidate's record was not (all) there when its load arrived: read it again until it is (a sink's record has header
 // words only).  Gives up after kPollLimit polls: the caller sees the stale tag.
 __device__ __attribute__((noinline)) u64 peel_reread(const u64* node_base, u32 epoch, u32* ctl, u32 c, u64 w, u32 lane) {
@@ -432,7 +440,7 @@ __device__ __attribute__((noinline)) u64 peel_reread(const u64* node_base, u32 e
     u32 polls = 0;
     for (;;) {
         u64 badm = __ballot((u32)(w >> 63) != epoch);
-        if ((u32)rdlane64(w, 0) == 0u) badm &= 7ull;
+        if ((badm & 1ull) == 0) badm &= needed_lanes((u32)rdlane64(w, 0));          // (word 0 is there: its depth says what else must be)
         if (badm == 0 || ++polls > kPollLimit) break;
         if ((polls & 63u) == 1u && __ballot(ld_a32(&ctl[CTL_ABORT]) != 0u) != 0ull) break;       // the launch is being given up: nobody waits any more
         peel_sleep(polls < 8 ? 4 : 16);
@@ -547,49 +555,81 @@ __global__ void __launch_bounds__(256) k_peel_sinks(PeelArgs A) {
     }
 }
 
-// ---- the gates the sinks pass claimed (level 1: every consumer is a sink), all at once, one step each (a lane per gate decides, a
-// wave per gate writes its record: a wave per gate for both took 0.30 ms — 27 gates one after the other per wave, four dependent
-// round trips each).  In
-// the dataflow launch each of them would start a chain with three dependent round trips in front of its first step (measured
-// on the 10 M-gate graph: 450 000 such starts kept all 2 048 waves busy for the first 1.3 ms, and the hand-off entries of
-// that time — the critical path among them — waited for its end).  Here their tournament is a minimum: a sink's path is
-// [sink], so the smallest (consumer id, edge label) wins, if that id is smaller than the gate's own (else the gate is a DFS
-// root itself).  Workgroup b takes region b of the sinks pass, collects the producers it claims in ITS region of `out`, and
-// at its end moves them to one flat list (a single reservation per workgroup): the seeds of the dataflow launch, which its
-// waves take a few at a time — a wave that owned a whole region would start the region's last seed only after the chains of
-// all the others (measured: the critical path began 0.9 ms into the launch, with idle waves all around).
-__global__ void __launch_bounds__(256) k_peel_level1(PeelArgs A, const u32* __restrict__ in, const u32* __restrict__ in_cnt, u32 in_cap,
-                                                     u32* out, u32* out_cnt, u32 out_cap, u32* flat, u32* flat_total) {
+// ---- the first few levels behind the sinks, a whole level at once.  Level 1 (every consumer is a sink: 450 000 gates of the
+// headline graph), 2 (175 000), 3 (73 000), 4 (33 000) ... are far WIDER than the body of the graph (2 000 per level): in the
+// dataflow launch each of their gates would start a chain — three dependent round trips before its first step — and those
+// starts kept all 2 048 waves busy for the launch's first 0.5 ms while the hand-off entries of that time, the critical path
+// among them, waited for its end (tools/peel_trace.py: the path began 0.54 ms into the launch).  Down here the paths are
+// short — a gate of level L is at most L deep, its string fits ONE word — so a LANE decides a gate: its key is (DFS root,
+// bit-reversed string with the edge label appended), the smallest key among its consumers wins (reversed, the first bit of
+// a string is the most significant: integer order = lexicographic order; neither path is a prefix of the other, so zero
+// padding decides nothing), if that root is smaller than the gate's own id (else the gate is a DFS root itself).  A wave
+// per gate then writes the 64-word record.  Workgroup b takes region b of the pass before, collects the producers it claims
+// in ITS region of `out` (no shared counter; a region that is full sends the rest straight to the flat list: any claimed
+// gate may start a chain at any time), and the LAST pass moves its regions to one flat list (a single reservation per
+// workgroup): the seeds of the dataflow launch, which its waves take a few at a time.
+__device__ __forceinline__ u64 c2a_brev64(u64 x) {
+#ifdef C2A_EMULATE
+    u64 r = 0;
+    for (int i = 0; i < 64; ++i) { r = (r << 1) | (x & 1ull); x >>= 1; }
+    return r;
+#else
+    return __brevll(x);
+#endif
+}
+__global__ void __launch_bounds__(256) k_peel_shallow(PeelArgs A, u32 lvl, u32 last, const u32* __restrict__ in, const u32* __restrict__ in_cnt, u32 in_cap,
+                                                      u32* out, u32* out_cnt, u32 out_cap, u32* flat, u32* flat_total) {
     // what a lane decided about its gate, for the wave that writes the records
-    __shared__ u32 s_g[256], s_root[256], s_dl[256];         // gate (C2A_NONE: none), DFS root, depth | label << 1
+    __shared__ u32 s_g[256], s_root[256], s_depth[256];       // gate (C2A_NONE: none), DFS root, depth
+    __shared__ u64 s_str[256];                                // its string (one word: depth <= lvl)
     __shared__ u32 s_base, s_cnt;
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const u32 cnt = in_cnt[blockIdx.x];
+    const u32 cnt = in_cnt[blockIdx.x] < in_cap ? in_cnt[blockIdx.x] : in_cap;      // (what did not fit went to the flat list)
     const u32* src = in + (u64)blockIdx.x * in_cap;
     u32* dst = out + (u64)blockIdx.x * out_cap;
     u32* counter = &out_cnt[blockIdx.x];
     const u64 tag = A.epoch ? kTagBit : 0ull;
     const u64 lt_mask = (1ull << lane) - 1ull;
     for (u32 base = 0; base < cnt; base += 256) {
-        // ---- a LANE per gate: the smallest (consumer, label), the tree entry, the tickets of its producers (every load of a
-        // gate waits for the one before: 256 gates wait together)
+        // ---- a LANE per gate: the smallest key, the tree entry, the tickets of its producers (every load of a gate waits
+        // for the one before: 256 gates wait together)
         const u32 i = base + threadIdx.x;
         u32 g = C2A_NONE, rdy[2] = {C2A_NONE, C2A_NONE};
         if (i < cnt) {
             g = src[i];
             const uint4 gi = A.gstat[2 * (u64)g], gi2 = A.gstat[2 * (u64)g + 1];
-            u64 best = ~0ull;
-            for (u32 e_i = 0; e_i < gi.w; ++e_i) {
+            u32 b_root = C2A_NONE, b_c = C2A_NONE, b_el = 0, b_depth = 0;
+            u64 b_rev = 0, b_x = 0;
+            // (records of the passes before: plain loads; a sink's record has header words only — its string is empty.  The
+            // loads of up to eight consumers go out TOGETHER, list entries, then header words, then strings: three round
+            // trips per gate instead of three per consumer)
+            auto meet = [&](u32 e, u64 h0w, u64 sw) {
+                const u32 c = e & kIdMask, el = e >> 31;
+                const u64 h0 = h0w & kPayload;
+                const u32 croot = hdr_hi(h0), cdepth = (u32)h0;
+                const u64 x = (cdepth ? (sw & kPayload) : 0ull) | ((u64)el << cdepth);
+                const u64 rev = c2a_brev64(x);
+                if (croot < b_root || (croot == b_root && rev < b_rev)) { b_root = croot; b_rev = rev; b_c = c; b_el = el; b_depth = cdepth; b_x = x; }
+            };
+            constexpr u32 kTogether = 8;
+            u32 ee[kTogether]; u64 hh[kTogether], ss[kTogether];
+#pragma unroll
+            for (u32 k = 0; k < kTogether; ++k) ee[k] = k < gi.w ? A.clist[gi.z + k] : 0u;
+#pragma unroll
+            for (u32 k = 0; k < kTogether; ++k) hh[k] = k < gi.w ? A.node[(u64)(ee[k] & kIdMask) * kNodeWords] : 0ull;
+#pragma unroll
+            for (u32 k = 0; k < kTogether; ++k) ss[k] = k < gi.w ? A.node[(u64)(ee[k] & kIdMask) * kNodeWords + kHdrWords] : 0ull;
+#pragma unroll
+            for (u32 k = 0; k < kTogether; ++k) if (k < gi.w) meet(ee[k], hh[k], ss[k]);
+            for (u32 e_i = kTogether; e_i < gi.w; ++e_i) {
                 const u32 e = A.clist[gi.z + e_i];
-                const u64 key = ((u64)(e & kIdMask) << 1) | (e >> 31);
-                best = key < best ? key : best;
+                meet(e, A.node[(u64)(e & kIdMask) * kNodeWords], A.node[(u64)(e & kIdMask) * kNodeWords + kHdrWords]);
             }
-            const u32 c = (u32)(best >> 1), el = (u32)(best & 1ull);
-            const bool has = c < g;                  // (else every consumer belongs to a later DFS root: [g] itself)
-            const u32 ch = has ? c : C2A_NONE, depth = has ? 1u : 0u, root = has ? c : g, label = has ? el : 0u;
-            A.meta[g] = make_uint4(ch, depth, root, label | (1u << 1));
+            const bool has = b_root < g;             // (else every consumer belongs to a later DFS root: [g] itself)
+            const u32 ch = has ? b_c : C2A_NONE, depth = has ? b_depth + 1u : 0u, root = has ? b_root : g, label = has ? b_el : 0u;
+            A.meta[g] = make_uint4(ch, depth, root, label | (lvl << 1));
             if (has) A.child[2 * (u64)ch + label] = g;
-            s_root[threadIdx.x] = root; s_dl[threadIdx.x] = depth | (label << 1);
+            s_root[threadIdx.x] = root; s_depth[threadIdx.x] = depth; s_str[threadIdx.x] = has ? b_x : 0ull;
             const u32 deps[2] = {gi.x, gi.y}, cnts[2] = {gi2.y, gi2.w};
 #pragma unroll
             for (u32 l = 0; l < 2; ++l) {
@@ -605,31 +645,38 @@ __global__ void __launch_bounds__(256) k_peel_level1(PeelArgs A, const u32* __re
                 u32 b = 0;
                 if (lane == (u32)ctz64(mask)) b = atomicAdd(counter, (u32)__popcll(mask));      // this workgroup's own counter
                 b = __shfl(b, (int)ctz64(mask), 64);
-                if (rdy[l] != C2A_NONE) dst[b + (u32)__popcll(mask & lt_mask)] = rdy[l];
+                if (rdy[l] != C2A_NONE) {
+                    const u32 at = b + (u32)__popcll(mask & lt_mask);
+                    if (at < out_cap) dst[at] = rdy[l];
+                    else flat[atomicAdd(flat_total, 1u)] = rdy[l];          // (the region is full: a seed of the launch right away)
+                }
             }
         }
         __syncthreads();
-        // ---- a WAVE per record: 64 words, one store
-        for (u32 j = wave; j < 256; j += 4) {
+        // ---- sixteen lanes per record: its first LINE (header + 13 string words; readers take the rest for zero padding:
+        // needed_lanes) — a quarter of the bytes of a whole record, and these passes are bound by what they write
+        for (u32 j = threadIdx.x >> 4; j < 256; j += 16) {
             const u32 gj = s_g[j];
             if (gj == C2A_NONE) break;               // (the gates of a batch are its first lanes)
-            const u32 root = s_root[j], dl = s_dl[j], depth = dl & 1u, label = dl >> 1;
+            const u32 root = s_root[j], depth = s_depth[j], l16 = threadIdx.x & 15u;
             u64 w = tag;
-            if (lane == 0) w |= hdr0_word(root, depth);
-            else if (lane == 1) w |= hdr1_word(1u, C2A_NONE);
-            else if (lane == 2) w |= (u64)depth;     // (position in the chunk: bit 1 of word 0 comes next — the same number)
-            else if (lane == kHdrWords) w |= (u64)label;
-            A.node[(u64)gj * kNodeWords + lane] = w;
+            if (l16 == 0) w |= hdr0_word(root, depth);
+            else if (l16 == 1) w |= hdr1_word(lvl, C2A_NONE);
+            else if (l16 == 2) w |= (u64)depth;      // (where a child's label goes: word 0, bit `depth` — depth < 63 down here)
+            else if (l16 == kHdrWords) w |= s_str[j];
+            A.node[(u64)gj * kNodeWords + l16] = w;
         }
         __syncthreads();
     }
     if (threadIdx.x == 0 && cnt) {
         u32* acct = &A.ctl[CTL_PROC + (blockIdx.x & (kAcctShards - 1u)) * kAcctStride];
-        atomicAdd(acct, cnt); atomicMax(acct + 1, 1u);
+        atomicAdd(acct, cnt); atomicMax(acct + 1, lvl);
     }
+    if (!last) return;
     __syncthreads();
     if (threadIdx.x == 0) {
-        s_cnt = atomicAdd(counter, 0u);          // (the waves counted by atomics: read it the same way)
+        const u32 c0 = atomicAdd(counter, 0u);   // (the waves counted by atomics: read it the same way)
+        s_cnt = c0 < out_cap ? c0 : out_cap;
         s_base = s_cnt ? atomicAdd(flat_total, s_cnt) : 0u;
     }
     __syncthreads();
@@ -1012,9 +1059,10 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                 const u32 c = e & kIdMask, el = e >> 31;
                 u64 badm = __ballot((u32)(w >> 63) != epoch);
                 if (C2A_UNLIKELY(badm != 0)) {
-                    // not all there: a sink (header words only: its string is empty whatever its string words hold) or a
-                    // record that is still on its way
-                    if ((badm & 7ull) != 0 || (u32)rdlane64(w, 0) != 0u) {
+                    // not all there: a short record (a sink: header words only; a gate of the shallow passes: one line — what
+                    // lies beyond the lanes its depth needs is zero padding whatever those words hold) or a record that is still
+                    // on its way
+                    if ((badm & 1ull) != 0 || (badm & needed_lanes((u32)rdlane64(w, 0))) != 0) {
                         w = peel_reread(A.node, epoch, A.ctl, c, w, lane);
                         badm = __ballot((u32)(w >> 63) != epoch);
                         // It never arrived (or the launch is being given up already): fail loudly — ABORT tells the host, which
@@ -1022,12 +1070,12 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                         // path); once ABORT is up no re-read waits any more, chains run out and waiting waves leave.
                         // (left out = replaced by a record that loses to everything: DFS root 2^31 - 1, no gate has that id.  No early
                         // exit from the candidate: what merges behind this cold block is the record alone, no flag — 8.95 -> 8.58 ms)
-                        if ((badm & 7ull) != 0 || (badm != 0 && (u32)rdlane64(w, 0) != 0u)) {
+                        if ((badm & 1ull) != 0 || (badm & needed_lanes((u32)rdlane64(w, 0))) != 0) {
                             if (lane == 0) atomicAdd(&A.ctl[CTL_ABORT], 1u); wave_join();
                             w = ((u64)epoch << 63) | (lane == 0 ? (u64)kIdMask << 32 : 0ull);
                         }
                     }
-                    if ((u32)(w >> 63) != epoch) w = (u64)epoch << 63;       // (string words of a depth-0 record)
+                    if ((u32)(w >> 63) != epoch) w = (u64)epoch << 63;       // (the zero padding of a short record)
                 }
                 const u64 h0 = rdlane64(w, 0);
                 const u32 croot = hdr_hi(h0), cdepth = (u32)h0;
