@@ -81,7 +81,7 @@ enum PeelCtl { CTL_PROCESSED = 0, CTL_MAXLEVEL = 1, CTL_ABORT = 2, CTL_REREADS =
                CTL_BEGIN = 128, CTL_END = CTL_BEGIN + 64 * 32, CTL_DEMAND = CTL_END + 64 * 32,
                // gates done (word 0) and the highest level seen (word 1), in kAcctShards parts like BEGIN / END: thousands of
                // workgroups (sinks pass, level-1 pass) and every wave of the launch report here as they leave, and atomics on
-               // ONE word go one at a time, ~10 ns each (measured: 4 096 workgroups x 3 such atomics were 120 us of k_peel_level1)
+               // ONE word go one at a time, ~10 ns each (measured: 4 096 workgroups x 3 such atomics were 120 us of the level-1 pass)
                CTL_PROC = CTL_DEMAND + 64 * 32, CTL_WORDS = CTL_PROC + 64 * 32 };
 constexpr u32 kPcStride = 16;               // u64 words between two hand-off arrays' ticket words (128 bytes)
 constexpr u32 kSlotWords = 16;              // a hand-off entry: words 0..7 gstat[2g], gstat[2g + 1]; 8..14 first consumers; 15 gate id
@@ -93,7 +93,7 @@ constexpr u32 kFillDummyWaves = 8192;       // ... of at most this many waves (2
 
 // what only the edges of the launch touch (kept out of the kernel's scalar registers)
 struct PeelCold {
-    const u32* seeds;          // [*seed_total] the gates the launch starts chains from (claimed by k_peel_level1), one flat list
+    const u32* seeds;          // [*seed_total] the gates the launch starts chains from (claimed by the last k_peel_shallow pass), one flat list
     const u32* seed_total;     // how many (device side: the host never learns it)
     u32 seed_chunk;            // a wave takes this many at a time
     ull* stats;                // optional diagnostics (32 words), nullptr normally

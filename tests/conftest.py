@@ -145,6 +145,21 @@ def backend_peel(request, c2a):
         os.environ["C2A_EMUL_SEED"] = old
 
 
+# (library build, levels behind the sinks done a whole level at once before the dataflow launch: k_peel_shallow)
+SHALLOW_BACKENDS = [_variant("emul", "s1"), _variant("emul", "s2"), _variant("emul", "s16"), _variant("emul", "s48"),
+                    _variant("hip", "s1"), _variant("hip", "s3"), _variant("hip", "s48")]
+
+
+@pytest.fixture(params=SHALLOW_BACKENDS)
+def backend_shallow(request, c2a):
+    """The peel with 1 .. 48 bulk passes in front of the dataflow launch: short records, region overflow, strings up to 48 bits."""
+    kind, mode = request.param
+    with _Env(C2A_PEEL_SHALLOW=int(mode[1:])):
+        be = c2a.Backend(0, lib_path=request.getfixturevalue("emul_lib")) if kind == "emul" else c2a.Backend(0)
+    yield be
+    be.close()
+
+
 @pytest.fixture
 def hip_backend(c2a):
     be = c2a.Backend(0)

@@ -260,7 +260,7 @@ def test_dataflow_peel_shapes(backend, orc, shape):
 
 @pytest.mark.parametrize("case", ["own-root", "both-edges-one-sink", "many-sinks", "mixed"])
 def test_level_one_gates(backend, orc, case):
-    """The gates whose consumers are all sinks are done by a kernel of their own (k_peel_level1: the tournament is a minimum
+    """The gates whose consumers are all sinks are done by a kernel of their own (k_peel_shallow, level 1: the tournament is a minimum
     over (consumer id, edge label), won only by a consumer with a smaller id than the gate's own).  Its cases one by one:
     a gate all of whose consumers have larger ids (a DFS root itself), a sink that reads the same gate on both inputs
     (label 0 wins), a gate with more sink consumers than a wave has lanes, and all of it mixed with deeper gates."""
@@ -290,6 +290,64 @@ def test_level_one_gates(backend, orc, case):
     p = dict(lh=lh, rh=rh, out=out, op=rng.integers(0, 20, n).astype(np.uint8), n_nodes=int(out.max()) + 2,
              input_nodes=np.arange(1, 9, dtype=np.uint32), output_nodes=np.array([int(out.max())], np.uint32))
     assert _compare(backend, orc, p) == "ok"
+
+
+@pytest.mark.parametrize("case", ["layered", "binary-tree", "chain-of-pairs", "fan"])
+def test_shallow_passes(backend_shallow, orc, c2a, case):
+    """k_peel_shallow does the first levels behind the sinks a whole level at once (a lane per gate, integer keys, one-line
+    records) with 1, 2, 3, 16 or 48 passes in front of the dataflow launch: a layered random graph (the passes end in the
+    middle of it, or swallow it whole); a complete binary tree under ONE sink (levels double inside one region: it overflows
+    into the flat seed list); a 40-level ladder whose paths need 40 string bits with both labels; a gate with 300 consumers."""
+    rng = np.random.default_rng(17)
+    if case == "layered":
+        fg = c2a.synth.layered_dag(30, 40, n_in=16, n_const=2, window=4, seed=21)
+        p = dict(lh=fg.lh, rh=fg.rh, out=fg.out, op=fg.op, n_nodes=fg.n_nodes, input_nodes=fg.input_nodes, output_nodes=fg.output_nodes)
+    elif case == "binary-tree":
+        depth = 13                                            # gate k reads the outputs of gates 2k+1, 2k+2; gate 0 is the only sink
+        n = (1 << depth) - 1
+        ids = rng.permutation(n)                              # (gate ids permuted: the DFS order is not the creation order)
+        lh = np.empty(n, np.uint32); rh = np.empty(n, np.uint32); out = np.empty(n, np.uint32)
+        for k in range(n):
+            g = ids[k]
+            out[g] = 100 + k
+            if 2 * k + 2 < n:
+                lh[g], rh[g] = 100 + 2 * k + 1, 100 + 2 * k + 2
+            else:
+                lh[g], rh[g] = 1, 2
+        p = dict(lh=lh, rh=rh, out=out, op=rng.integers(0, 20, n).astype(np.uint8), n_nodes=100 + n + 1,
+                 input_nodes=np.array([1, 2], np.uint32), output_nodes=np.array([100], np.uint32))
+    elif case == "chain-of-pairs":
+        # level k holds two gates; each reads both gates of level k + 1 (left / right swapped for the second): every path bit
+        # pattern of length <= 40 is in play, and every gate has two consumers whose strings share long prefixes
+        L = 40
+        n = 2 * L
+        ids = rng.permutation(n)
+        lh = np.empty(n, np.uint32); rh = np.empty(n, np.uint32); out = np.empty(n, np.uint32)
+        for k in range(L):
+            for j in range(2):
+                g = ids[2 * k + j]
+                out[g] = 100 + 2 * k + j
+                if k + 1 < L:
+                    a, b = 100 + 2 * (k + 1), 100 + 2 * (k + 1) + 1
+                    lh[g], rh[g] = (a, b) if j == 0 else (b, a)
+                else:
+                    lh[g], rh[g] = 1, 2
+        p = dict(lh=lh, rh=rh, out=out, op=rng.integers(0, 20, n).astype(np.uint8), n_nodes=100 + n + 1,
+                 input_nodes=np.array([1, 2], np.uint32), output_nodes=np.array([100, 101], np.uint32))
+    else:
+        # one gate with 300 consumers of level 1 (each read by a sink of its own): more than the eight loaded together
+        n = 1 + 300 + 300
+        lh = np.empty(n, np.uint32); rh = np.empty(n, np.uint32); out = (100 + np.arange(n)).astype(np.uint32)
+        lh[0], rh[0] = 1, 2
+        for k in range(300):
+            lh[1 + k], rh[1 + k] = (100, 1) if k % 3 else (2, 100)
+            lh[301 + k], rh[301 + k] = 100 + 1 + k, 100 + 1 + (k * 7) % 300
+        perm = rng.permutation(n)
+        inv = np.empty(n, np.int64); inv[perm] = np.arange(n)
+        lh, rh, out = lh[perm], rh[perm], out[perm]
+        p = dict(lh=lh, rh=rh, out=out, op=rng.integers(0, 20, n).astype(np.uint8), n_nodes=100 + n + 1,
+                 input_nodes=np.array([1, 2], np.uint32), output_nodes=np.array([int(out.max())], np.uint32))
+    assert _compare(backend_shallow, orc, p) == "ok"
 
 
 @pytest.mark.gpu
