@@ -1110,7 +1110,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                 candidate(cur.w0, cur.e0);
                 if (cur.take >= 2) {
                     candidate(cur.w1, cur.e1);
-                    if (C2A_UNLIKELY(cur.take >= 3)) {
+                    if (cur.take >= 3) {
                         candidate(cur.w2, cur.e2);
                         if (C2A_UNLIKELY(cur.take >= 4)) {
                             candidate(cur.w3, cur.e3);
