@@ -161,6 +161,17 @@ __device__ __forceinline__ u32 row_shl8(u32 v) {
     return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x108, 0xF, 0xF, false);
 #endif
 }
+// a (all lanes) if the wave-uniform j is not 0, else b — without a branch
+__device__ __forceinline__ u32 select_uniform(u32 j, u32 a, u32 b) {
+#ifdef C2A_EMULATE
+    return j ? a : b;
+#else
+    const u64 m = 0ull - (u64)(j & 1u);
+    u32 r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+#endif
+}
 __device__ __forceinline__ u32 uniform(u32 v) {
 #ifdef C2A_EMULATE
     return v;
@@ -330,6 +341,8 @@ template <int R> __device__ __forceinline__ void sreg_add64(SRegs& sr, u64* p, u
     if ((threadIdx.x & 63u) == 0) t = atomicAdd(reinterpret_cast<ull*>(p), (ull)v);
     sr.r[R - kSregBase] = (u32)__shfl((int)(u32)t, 0, 64); sr.r[R - kSregBase + 1] = (u32)__shfl((int)(u32)(t >> 32), 0, 64);
 }
+template <int R> __device__ __forceinline__ void sreg_inc64(SRegs& sr, u64* p) { sreg_add64<R>(sr, p, 1ull); }
+template <int R> __device__ __forceinline__ void sreg_inc32(SRegs& sr, u32* p) { sreg_add32<R>(sr, p, 1u); }
 template <int R> __device__ __forceinline__ void sreg_set(SRegs& sr, u32 v) { sr.r[R - kSregBase] = v; }
 template <int R> __device__ __forceinline__ u32 sreg_get(const SRegs& sr) { return sr.r[R - kSregBase]; }
 __device__ __forceinline__ void sreg_wait() {}
@@ -355,6 +368,17 @@ template <int R> __device__ __forceinline__ void sreg_add64(SRegs&, u64* p, u64 
     typedef __attribute__((address_space(1))) u64* G;
     static_assert((R & 1) == 0, "an aligned register pair");
     asm volatile("s_mov_b64 s[%c2:%c3], %1\n\ts_atomic_add_x2 s[%c2:%c3], %0, 0x0 glc" :: "s"((G)p), "s"(v), "n"(R), "n"(R + 1) : "memory", C2A_SREG_CLOBBERS);
+}
+// (+ 1 on the low word of a pair / on a word: the constant goes in as an immediate — as an operand the compiler puts it in a
+// register first, one more move on the claim path)
+template <int R> __device__ __forceinline__ void sreg_inc64(SRegs&, u64* p) {
+    typedef __attribute__((address_space(1))) u64* G;
+    static_assert((R & 1) == 0, "an aligned register pair");
+    asm volatile("s_mov_b64 s[%c1:%c2], 1\n\ts_atomic_add_x2 s[%c1:%c2], %0, 0x0 glc" :: "s"((G)p), "n"(R), "n"(R + 1) : "memory", C2A_SREG_CLOBBERS);
+}
+template <int R> __device__ __forceinline__ void sreg_inc32(SRegs&, u32* p) {
+    typedef __attribute__((address_space(1))) u32* G;
+    asm volatile("s_mov_b32 s%c1, 1\n\ts_atomic_add s%c1, %0, 0x0 glc" :: "s"((G)p), "n"(R) : "memory", C2A_SREG_CLOBBERS);
 }
 template <int R> __device__ __forceinline__ void sreg_set(SRegs&, u32 v) { asm volatile("s_mov_b32 s%c1, %0" :: "s"(v), "n"(R) : C2A_SREG_CLOBBERS); }
 template <int R> __device__ __forceinline__ u32 sreg_get(const SRegs&) { u32 v; asm volatile("s_mov_b32 %0, s%c1" : "=s"(v) : "n"(R)); return v; }
@@ -1027,9 +1051,11 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             u32 nxt = C2A_NONE, nxt_label = 0;
             u32 push_t = 0, push_c = 0, push_f = 0;
             if (C2A_LIKELY(rmask != 0)) {
-                const u32 j0 = (rmask & 1u) ? 0u : 1u;
+                const u32 j0 = (rmask & 1u) ^ 1u;
                 nxt = j0 ? g_dep1 : g_dep0; nxt_label = j0;
-                const u32 gsel = j0 ? row_shl8(cur.gw) : cur.gw;         // lanes 0..7: the static records of nxt
+                // lanes 0..7: the static records of nxt — the row shift always, then ONE select by a scalar mask (as a branch
+                // around the shift this was eleven instructions of flags)
+                const u32 gsel = select_uniform(j0, row_shl8(cur.gw), cur.gw);
                 gi = make_uint4(rdlane(gsel, 0), rdlane(gsel, 1), rdlane(gsel, 2), rdlane(gsel, 3));
                 gi2 = make_uint4(rdlane(gsel, 4), rdlane(gsel, 5), rdlane(gsel, 6), rdlane(gsel, 7));
                 if (rmask == 3u) {
@@ -1038,8 +1064,8 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                     // before anybody can see it
                     push_f = (push_rr++) & (A.n_fifos - 1u);
 #if C2A_SPUSH
-                    sreg_add64<kSregPush>(sr, &A.q_pc[(u64)push_f * kPcStride], 1ull);
-                    sreg_add32<kSregBegin>(sr, &A.ctl[CTL_BEGIN + (me & (kAcctShards - 1u)) * kAcctStride], 1u);
+                    sreg_inc64<kSregPush>(sr, &A.q_pc[(u64)push_f * kPcStride]);
+                    sreg_inc32<kSregBegin>(sr, &A.ctl[CTL_BEGIN + (me & (kAcctShards - 1u)) * kAcctStride]);
 #else
                     if (lane == 0) { const ull pc = atomicAdd(reinterpret_cast<ull*>(&A.q_pc[(u64)push_f * kPcStride]), 1ull); push_t = (u32)pc; push_c = (u32)(pc >> 32); }
                     if (lane == 1) push_t = atomicAdd(&A.ctl[CTL_BEGIN + (me & (kAcctShards - 1u)) * kAcctStride], 1u);
