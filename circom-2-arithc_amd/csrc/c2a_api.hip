@@ -55,7 +55,7 @@ struct c2a_ctx {
     Stage stage = ST_EMPTY;
     int n_cu = 256;
     u32 bool_chunk = 256;          // arithmetic gates per k_boolify workgroup: 128, 256 (measured best) or 512
-    u32 peel_seed_chunk = 8;       // dataflow launch: seeds a wave takes at a time (1: the one counter they all hit costs 1.4 ms; 8 and 32 are equal)
+    u32 peel_seed_chunk = 4;       // dataflow launch: seeds a wave takes at a time (1: the one counter they all hit cost 1.4 ms with 175 000 seeds; with the 33 000 the shallow passes leave: 2 / 4 / 8 / 16 = 7.72 / 7.70 / 7.78 / 7.85 ms)
     u32 peel_shallow = 4;          // levels behind the sinks done a whole level at once before the dataflow launch (>= 1, <= 48)
     u32 peel_sinks_blocks = 4096;  // grid cap of the sinks pass (latency-bound per thread: two dependent round trips per sink)
     u32 peel_waves = 8;            // dataflow launch: single-wave workgroups per CU (clamped by the occupancy query)
