@@ -29,9 +29,13 @@
 // yet).  A single-consumer producer needs no ticket at all.  The chain loop is SOFTWARE-PIPELINED: the loads and tickets
 // of the next step are issued as soon as this step's tickets say where the chain goes on, before this step's own
 // tournament and stores.
-// A step is ~380 instructions of one wave, most of them scalar and dependent on the one before; the memory round trip of
-// the tickets and loads issued at its top (0.4 us unloaded) hides behind them: a graph one gate wide peels at 1.0 us per
-// level, 16 wide at 1.45 us.
+// A step is ~300 instructions of one wave, most of them scalar and dependent on the one before; the memory round trip of
+// the tickets and loads issued at its top hides behind them.  What the step is written in — scalar-memory atomics for the
+// tickets and scalar stores for the tree entries, with results in registers reserved from the compiler; branch weights
+// that keep the hot path falling through; lane reads / writes and DPP instead of shuffles — is in c2a_wave.h, each
+// primitive next to its twin for the host emulation.  Up to eight candidate records are loaded one step ahead.
+// The first few levels behind the sinks are far wider than the body of a circuit and are done a whole level at once by
+// k_peel_shallow (a lane per gate) before the launch; what the last of those passes claims seeds it.
 // HAND-OFF.  A second producer completed by the same gate goes to one of F first-in-first-out arrays with tickets on
 // BOTH sides: a wave without work takes a consumer ticket c on one of them and watches slot c alone; the pusher takes a
 // producer ticket p (the round trip overlaps its tournament) and stores the entry into slot p — there is no claim step
