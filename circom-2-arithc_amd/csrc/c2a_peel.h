@@ -450,10 +450,6 @@ __global__ void k_set_cold(PeelCold* dst, PeelCold v) { *dst = v; }
 // everything issued for one gate at the top of its step; two of these swap roles (nothing is ever copied: a register
 // copy of a value still in flight is a use, and its wait would drain the step that was just issued)
 struct StepIO {
-#if !C2A_SFILL
-    u32 kfill;                 // lane l < 2: ticket taken on producer l
-    u32 dcnt;                  // lane l < 2: consumers of producer l (0: no such producer)
-#endif
     u32 cnt0, cnt1;            // consumers of producer 0 / 1 (0: no such producer); the tickets taken on them are in the
                                // fixed scalar registers of this set (SCALAR TICKETS above)
     u32 gw;                    // lane 8 l + j (l < 2, j < 8): word j of the two gstat records of producer l
@@ -562,16 +558,10 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             }
             if (C2A_LIKELY(!held)) {
                 const u32 f = (pop_rr++) & (A.n_fifos - 1u);
-#if C2A_SPUSH
                 // (a scalar ticket here too — nothing else is in flight in those registers while a wave has no work)
                 sreg_add64<kSregPush>(sr, &A.q_pc[(u64)f * kPcStride], 1ull << 32);
                 sreg_wait();
                 held_slot = (u64)f * A.q_cap + sreg_get<kSregPush + 1>(sr);
-#else
-                u64 pc = 0;
-                if (lane == 0) pc = atomicAdd(reinterpret_cast<ull*>(&A.q_pc[(u64)f * kPcStride]), 1ull << 32); wave_join();
-                held_slot = (u64)f * A.q_cap + rdlane((u32)(pc >> 32), 0);
-#endif
                 held = 1;
             }
             u64 slot_i = held_slot;          // the slot this wave watches: its own, or (see below) one that is served already
@@ -660,39 +650,16 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             S.cnt0 = cnt0; S.cnt1 = cnt1;                                // (0 where there is no producer: gstat holds 0 then)
             // a ticket is needed where there is a producer with other consumers (else the register says 0: with cnt 1 that
             // reads as "the last ticket", with cnt 0 as "nothing claimed")
-#if C2A_SFILL == 2
             sfill_take<R0>(sr, A.fill, dep0, cnt0, dummy_idx);
             sfill_take<R1>(sr, A.fill, dep1, cnt1, dummy_idx);
-#elif C2A_SFILL
-            if (cnt0 > 1u) sreg_add32<R0>(sr, &A.fill[dep0], 1u); else sreg_set<R0>(sr, 0u);
-            if (cnt1 > 1u) sreg_add32<R1>(sr, &A.fill[dep1], 1u); else sreg_set<R1>(sr, 0u);
-#else
-            {
-                const u32 dl = wrlane_c<1>(dep1, wrlane_c<0>(dep0, C2A_NONE));
-                const u32 dcnt = wrlane_c<1>(cnt1, wrlane_c<0>(cnt0, 0u));
-                S.kfill = 0; S.dcnt = dcnt;
-                if (dcnt > 1u) S.kfill = atomicAdd(&A.fill[dl], 1u);
-            }
-#endif
             // static data of both producers, one word per lane, BRANCH-FREE (clamped index, result discarded where there
             // is nothing to load)
             {
-#if C2A_ISSUE_MASKS
-                u32 ln = lane; C2A_OPAQUE(ln);                          // (lane masks made on the spot: see the hand-off entry)
-                const u32 dw = (ln & 8u) ? dep1 : dep0;
-                S.gw = reinterpret_cast<const u32*>(A.gstat)[8 * (u64)(dw != C2A_NONE ? dw : 0u) + (ln & 7u)];
-#else
                 const u32 dw = (lane & 8u) ? dep1 : dep0;
                 S.gw = reinterpret_cast<const u32*>(A.gstat)[8 * (u64)(dw != C2A_NONE ? dw : 0u) + (lane & 7u)];
-#endif
             }
             {
-#if C2A_ISSUE_MASKS
-                u32 ln = lane; C2A_OPAQUE(ln);
-                const u32 half = ln >> 5, i = ln & 31u;
-#else
                 const u32 half = lane >> 5, i = lane & 31u;
-#endif
                 const u32 poff = half ? off1 : off0;
                 S.clp = A.clist[poff + i];                               // (clist is padded by 64 entries: lanes beyond the list read
                                                                          // somebody else's entries, which nobody looks at)
@@ -759,14 +726,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             wave_priority(3);
             // ---- everything of THIS step (issued one step ago) is needed now, and is pinned HERE: a register of `cur` that
             // the compiler still counts as in flight further down would put its wait behind the issue of the next step
-#if C2A_SFILL == 2
             const u32 rmask = sfill_claims<RC0, RC1>(sr, cur.cnt0, cur.cnt1);
-#elif C2A_SFILL
-            sreg_wait();
-            const u32 k0 = sreg_get<RC0>(sr), k1 = sreg_get<RC1>(sr);
-#else
-            C2A_PIN(cur.kfill);
-#endif
             const ull ph0a = STATS ? c2a_now() : 0;
             C2A_PIN(cur.gw);
             C2A_PIN(cur.clp);
@@ -777,12 +737,6 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             const u32 gc = g, g_dep0 = gi.x, g_dep1 = gi.y, g_off = gi.z, g_cnt = gi.w;
             // producer l is claimed when its ticket was the last of cnt (no ticket was taken for a single-consumer producer:
             // 0 of 1; no producer: cnt 0 — the one comparison covers all three)
-#if C2A_SFILL == 2
-#elif C2A_SFILL
-            const u32 rmask = (k0 + 1u == cur.cnt0 ? 1u : 0u) | (k1 + 1u == cur.cnt1 ? 2u : 0u);
-#else
-            const u32 rmask = (u32)__ballot(cur.kfill + 1u == cur.dcnt) & 3u;
-#endif
             const ull ph1 = STATS ? c2a_now() : 0;
             // ---- go on with the first claimed producer: issue its step now; a second one goes to whoever has no work: its
             // producer ticket is taken here and its entry stored after the tournament (the ticket is back by then)
@@ -801,14 +755,8 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                     // one of the hand-off arrays: the ticket now, the entry after the tournament; BEGIN counts the entry
                     // before anybody can see it
                     push_f = (push_rr++) & (A.n_fifos - 1u);
-#if C2A_SPUSH
                     sreg_inc64<kSregPush>(sr, &A.q_pc[(u64)push_f * kPcStride]);
                     sreg_inc32<kSregBegin>(sr, &A.ctl[CTL_BEGIN + (me & (kAcctShards - 1u)) * kAcctStride]);
-#else
-                    if (lane == 0) { const ull pc = atomicAdd(reinterpret_cast<ull*>(&A.q_pc[(u64)push_f * kPcStride]), 1ull); push_t = (u32)pc; push_c = (u32)(pc >> 32); }
-                    if (lane == 1) push_t = atomicAdd(&A.ctl[CTL_BEGIN + (me & (kAcctShards - 1u)) * kAcctStride], 1u);
-                    wave_join();
-#endif
                 }
                 // the consumers of nxt are already here (lanes 32 j0 ... of the prefetched lists) unless it has more than 32
                 issue(nx_set, nx, gi.x, gi.y, gi.w, gi2.x, gi2.y, gi2.z, gi2.w, cur.clp, 32u * j0, 32u, true, gc);
@@ -914,13 +862,8 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             const ull ph2a = STATS ? c2a_now() : 0;
             if (rmask == 3u) {
                 // the entry: lanes 8..15 hold the pushed gate's static records, lanes 32..38 its first consumers
-#if C2A_SPUSH
                 sreg_wait();                                        // (both atomics are back: the unit is in BEGIN before the entry can be seen)
                 push_t = sreg_get<kSregPush>(sr); push_c = sreg_get<kSregPush + 1>(sr);
-#else
-                C2A_PIN(push_t);                                    // (both atomics are back)
-                push_t = rdlane(push_t, 0); push_c = rdlane(push_c, 0);
-#endif
                 if (STATS) ph_pwait += c2a_now() - ph2a;
                 const u32 t = push_f * A.q_cap + push_t;            // (all slots together stay below 2^32: the host checks)
                 // nobody was in line for this entry: tell the reserve (reserve_min is 0 when the launch has none)

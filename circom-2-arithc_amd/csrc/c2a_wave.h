@@ -122,9 +122,6 @@ __device__ __forceinline__ u32 own_sgpr(u32 v) {
 // Branch weights for the block layout: a TAKEN branch costs a wave its instruction buffer (~16+ clocks against 4 for one
 // that falls through), and a chain step runs some fifty branches — the hot path should fall through, the cold code
 // (re-reads, deep trees, the cold list loop, giving up) sit out of line.
-#ifndef C2A_ISSUE_MASKS
-#define C2A_ISSUE_MASKS 0
-#endif
 #ifndef C2A_HINTS
 #define C2A_HINTS 1
 #endif
@@ -159,28 +156,12 @@ __device__ __forceinline__ u32 own_sgpr(u32 v) {
 //   s[98:99]     hand-off: tickets taken so far on the array, producer side | consumer side (the pre-op value)
 //   s97          hand-off: BEGIN unit counted (value unused: the wait is what matters)
 // Under emulation the "registers" are a small array per lane and the atomics go through lane 0.
-// (C2A_SFILL: 0 vector fill[] tickets, 1 scalar through C++ helpers, 2 scalar, hand-written; C2A_SPUSH: the hand-off's two
-// atomics scalar.  Same-box A/B, peel stage: 0/0 10.42 ms, 1/1 10.61 (the helpers' branches and spills cost more than the
-// shorter round trip brings), 2/1 10.28; with the branch weights below 0/0 9.97, 2/1 9.70 — the default)
-#ifndef C2A_SPUSH
-#define C2A_SPUSH 1
-#endif
-#ifndef C2A_SFILL
-#define C2A_SFILL 2
-#endif
-#if C2A_SPUSH && C2A_SFILL
+// (Same-box A/B of the peel stage while this went in: one-lane vector atomics 10.42 ms; scalar ones through C++ helpers 10.61 —
+// the helpers' branches and the spills of a smaller register budget cost more than the shorter round trip brings —; the
+// hand-written sequences below 10.28; with the branch weights 9.97 / 9.70.)
 constexpr int kSregBase = 97, kSregBegin = 97, kSregPush = 98, kSregFill0 = 100, kSregFill1 = 101;
 #define C2A_SREG_BUDGET 103      /* 6 of the budget are VCC, FLAT_SCRATCH, XNACK_MASK: s0..s96 for the compiler */
 #define C2A_SREG_CLOBBERS "s97", "s98", "s99", "s100", "s101"
-#elif C2A_SPUSH
-constexpr int kSregBase = 99, kSregBegin = 99, kSregPush = 100, kSregFill0 = 100, kSregFill1 = 101;
-#define C2A_SREG_BUDGET 105
-#define C2A_SREG_CLOBBERS "s99", "s100", "s101"
-#else
-constexpr int kSregBase = 100, kSregFill0 = 100, kSregFill1 = 101;
-#define C2A_SREG_BUDGET 106
-#define C2A_SREG_CLOBBERS "s100", "s101"
-#endif
 // SCALAR STORES for one-lane stores of wave-uniform data (s_store_dword[x4]: gfx9 family, still there on gfx950).  They go
 // through the scalar data cache, which is WRITE-BACK: nothing is visible to anybody else until s_dcache_wb — fine for data
 // that only later launches read, provided every wave writes the cache back before it ends (tools/ubench/sstore.hip: 0 of
