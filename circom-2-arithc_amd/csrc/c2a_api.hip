@@ -67,14 +67,7 @@ struct c2a_ctx {
     bool io_clash = false;         // a node is both an input and an output (compiler.rs:363-383), found at load time
     bool peel_meta_valid = false;  // meta[] / stats.levels describe the circuit now loaded (c2a_verify_boolify schedules by them)
     bool node_clear = true;        // node records must be zeroed before the next run (new graph, or a run that failed)
-    u32 peel_mode = 0;             // 0: the one-wave dataflow launch (c2a_peel.h); 1: the decoupled launch (c2a_peel2.h: claim waves +
-                                   // tournament waves — measured slower; C2A_PEEL_MODE=split), which falls back to 0 when it gives up
-    u32 peel2_claim = 64;          // decoupled launch: claim waves (a tournament wave per claim lane comes on top)
-    u32 peel2_lanes = 64;          // ... lanes of a claim wave that take part
-    u32 peel2_mbcap = 4096;        // ... entries of a mailbox ring (a power of two)
-    u32 mb_seq_cur = 0;            // which of the two mailbox sequence arrays holds the current numbers
     bool peel_gave_up = false;     // the last dataflow launch ended by its watchdog (do_peel retries once on clean buffers)
-    bool mb_dirty = true;          // mailboxes / sequence numbers must be zeroed (fresh buffers, or a run that failed)
 
     // problem
     u32 n = 0, n_nodes = 0, n_in = 0, n_out = 0;
@@ -93,7 +86,7 @@ struct c2a_ctx {
     u32* hrb_dev = nullptr;        // ... as the device sees it.  Words 0-7: peel, 8-15: order, 16-23: wires, 24-31: boolify
     u32 rb_edges = 0, rb_dup = 0, rb_nmid = 0, rb_err = 0;  // read-back slots (edge count, duplicate-writer flag, wires handed out, in/out clash)
     bool has_dup = false;          // two gates write one node (compiler.rs:403-406 keeps the last): the general numbering path
-    DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof, peel_trace, mb, mb_seq, mb_rd;
+    DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof, peel_trace;
     DevBuf tsz, asz, goff, aoff, tmpl, tables, b_in0, b_in1, b_out, b_op;
     DevBuf fmt_len, fmt_off, fmt_text, fmt_table, shard_cut, shard_qcut;
     u64 fmt_chunk_first = 0, fmt_chunk_cnt = 0;      // boolean gates held by the chunk buffers (c2a_boolify_chunk)
@@ -110,7 +103,7 @@ struct c2a_ctx {
         all = {&lh, &rh, &out, &op, &gate4, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &aq_items, &aq_pc, &aq_seeds, &aq_seeds1, &aq_seed_flat, &aq_seed_cnt, &fill,
                &gstat, &clist, &pctl, &pcold, &meta, &node, &child, &rflag, &ridx, &rlist, &next,
                &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
-               &node_wire, &e_in0, &e_in1, &e_out, &e_op, &gs, &wcnt, &wfo, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &peel_trace, &mb, &mb_seq, &mb_rd, &tsz, &asz, &goff,
+               &node_wire, &e_in0, &e_in1, &e_out, &e_op, &gs, &wcnt, &wfo, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &peel_trace, &tsz, &asz, &goff,
                &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &fmt_len, &fmt_off, &fmt_text, &fmt_table, &shard_cut, &shard_qcut, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &ev_lcount, &ev_lbase, &ev_lorder, &ev_bar, &ev_io, &g_in0, &g_in1, &g_out, &g_op, &pr_rep, &pr_need, &pr_tin0, &pr_tin1, &pr_top, &pr_live, &pr_goff, &pr_counts, &p_in0, &p_in1, &p_out, &p_op, &cb_in0, &cb_in1, &cb_out, &cb_op};
     }
 };
@@ -268,7 +261,6 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
     A.run = ++c->peel_run;
     A.n_primary = n_primary;
     A.reserve_min = 4;
-    if (const char* e = std::getenv("C2A_PEEL_RESERVE_MIN")) A.reserve_min = std::max<u32>(1u, (u32)std::strtoul(e, nullptr, 10));
     if (waves <= n_primary) A.reserve_min = 0;       // no reserve waves: pushers need not count the entries nobody was in line for
     ENSURE(c->aq_pc, (size_t)A.n_fifos * kPcStride * 8);
     ENSURE(c->pctl, (size_t)CTL_WORDS * 4);
@@ -384,128 +376,7 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
     return C2A_OK;
 }
 
-// The decoupled peel (c2a_peel2.h): the sinks pass, then ONE launch of claim waves (tickets only, a lane per chain) and
-// tournament waves (one per claim lane, fed through its mailbox).  *gave_up: the launch ended by its watchdog.
-int do_peel2(c2a_ctx* c, u32* peeled_out, bool* gave_up) {
-    const u32 n = c->n;
-    hipStream_t s = c->stream;
-    *gave_up = false;
-    if (c->node_clear) {
-        HIP_TRY(hipMemsetAsync(c->node.p, 0, (size_t)n * kNodeWords * 8, s));
-        c->peel_epoch = 0;
-    }
-    c->peel_epoch ^= 1u;
-    c->node_clear = true;                            // until this run has finished cleanly
-    // the grid: every tournament wave owns a mailbox, so all of them must be resident
-    u32 n_claim = c->peel2_claim, n_lanes = c->peel2_lanes;
-#ifndef C2A_EMULATE
-    {
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_peel2, 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-        const u32 resident = (u32)per_cu * (u32)c->n_cu;
-        while (n_claim > 1 && n_claim * (n_lanes + 1) > resident) --n_claim;
-        while (n_lanes > 1 && n_claim * (n_lanes + 1) > resident) --n_lanes;
-    }
-#endif
-    if (n_lanes > kPoolRoom) n_lanes = kPoolRoom;      // (a turn may add an entry per lane to the pool)
-    const u32 mails = n_claim * n_lanes;
-    u32 mb_lg = 0;
-    while ((1u << mb_lg) < c->peel2_mbcap) ++mb_lg;
-    const size_t mb_bytes = (size_t)mails * c->peel2_mbcap * 16;
-    if (c->mb.cap < mb_bytes || c->mb_seq.cap < (size_t)mails * 16 || c->mb_rd.cap < (size_t)mails * 128) c->mb_dirty = true;
-    ENSURE(c->mb, mb_bytes); ENSURE(c->mb_seq, (size_t)mails * 16); ENSURE(c->mb_rd, (size_t)mails * 128);
-    if (c->mb_dirty) {
-        HIP_TRY(hipMemsetAsync(c->mb.p, 0, c->mb.cap, s));
-        HIP_TRY(hipMemsetAsync(c->mb_seq.p, 0, c->mb_seq.cap, s));
-        HIP_TRY(hipMemsetAsync(c->mb_rd.p, 0, c->mb_rd.cap, s));
-        c->mb_seq_cur = 0;
-    }
-    c->mb_dirty = true;                              // until this run has finished cleanly
-    // global hand-off entries: used once per run, never cleared (every word carries the number of the run)
-    const size_t slots = (size_t)n + 64;
-    if (c->aq_items.cap < slots * kHqWords2 * 8 || c->peel_run == 0xFFFFFFFFu) {
-        ENSURE(c->aq_items, slots * kHqWords2 * 8);
-        HIP_TRY(hipMemsetAsync(c->aq_items.p, 0, c->aq_items.cap, s));
-        c->peel_run = 0;
-    }
-    ENSURE(c->pctl, (size_t)CTL_WORDS * 4);
-    HIP_TRY(hipMemsetAsync(c->pctl.p, 0, (size_t)CTL_WORDS * 4, s));
-    // seed regions: one per workgroup of the sinks pass
-    const u32 sink_blocks = grid_for(n, c->peel_sinks_blocks);
-    const u64 gates_per_block = ((u64)n + (u64)sink_blocks * kThreads - 1) / ((u64)sink_blocks * kThreads) * kThreads;
-    const u32 region_cap = (u32)(2 * gates_per_block);
-    ENSURE(c->aq_seeds, (size_t)sink_blocks * region_cap * 4); ENSURE(c->aq_seed_cnt, (size_t)sink_blocks * 4);
-    HIP_TRY(hipMemsetAsync(c->aq_seed_cnt.p, 0, (size_t)sink_blocks * 4, s));
-    PeelArgs S;
-    std::memset(&S, 0, sizeof(S));
-    S.epoch = c->peel_epoch; S.n = n; S.gstat = c->gstat.as<uint4>(); S.node = c->node.as<u64>(); S.fill = c->fill.as<u32>();
-    S.meta = c->meta.as<uint4>(); S.ctl = c->pctl.as<u32>();
-    S.seeds_w = c->aq_seeds.as<u32>(); S.seed_cnt_w = c->aq_seed_cnt.as<u32>(); S.region_cap = region_cap; S.proc_word = P2_PROCESSED; S.proc_mask = 0;
-    Peel2Args A;
-    A.epoch = c->peel_epoch; A.n = n; A.gstat = c->gstat.as<uint4>(); A.clist = c->clist.as<u32>(); A.node = c->node.as<u64>();
-    A.fill = c->fill.as<u32>(); A.meta = c->meta.as<uint4>(); A.child = c->child.as<u32>();
-    A.n_claim = n_claim; A.n_lanes = n_lanes; A.mb = c->mb.as<u64>(); A.mb_cap = c->peel2_mbcap; A.mb_lg = mb_lg;
-    A.mb_seq_in = c->mb_seq.as<u64>() + (size_t)c->mb_seq_cur * mails; A.mb_seq_out = c->mb_seq.as<u64>() + (size_t)(c->mb_seq_cur ^ 1u) * mails;
-    A.mb_rd = c->mb_rd.as<u64>(); A.hq = c->aq_items.as<u64>(); A.hq_cap = (u32)slots; A.run = ++c->peel_run;
-    A.seeds = c->aq_seeds.as<u32>(); A.seed_cnt = c->aq_seed_cnt.as<u32>(); A.n_regions = sink_blocks; A.region_cap = region_cap;
-    A.ctl = c->pctl.as<u32>();
-    A.dbg = 0;
-    if (const char* e = std::getenv("C2A_PEEL2_DBG")) A.dbg = (u32)std::strtoul(e, nullptr, 10);
-    C2A_LAUNCH(k_peel_sinks, sink_blocks, kThreads, s, S);
-    C2A_LAUNCH(k_seed_total, 1, 256, s, sink_blocks, (const u32*)c->aq_seed_cnt.as<u32>(), c->pctl.as<u32>() + P2_ACCT);
-    const u32 grid = n_claim + mails;
-    const bool want_stats = std::getenv("C2A_PEEL_STATS") != nullptr;
-    hipEvent_t e0{}, e1{};
-    if (want_stats) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventRecord(e0, s)); }
-    C2A_LAUNCH_CONCURRENT(k_peel2, grid, 64, s, A);
-    if (want_stats) HIP_TRY(hipEventRecord(e1, s));
-    u32 t[24] = {0};
-    HIP_TRY(hipMemcpyAsync(t, c->pctl.p, sizeof(t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&c->rb_edges, c->cons_off.as<u32>() + n, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&c->rb_dup, c->scalars.as<u32>() + SC_DUP, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    if (want_stats) {
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-        std::fprintf(stderr, "[c2a peel2] k_peel2 %.3f ms\n", ms);
-        if (A.dbg & 2u) {
-            const ull* t64 = reinterpret_cast<const ull*>(t + 10);
-            std::fprintf(stderr, "[c2a peel2] claim waves: %u turns with work (of %u); per such turn: %.0f ns waiting for the round trip, %.0f ns elsewhere, %.1f lanes with a gate\n",
-                         t[9], t[P2_TURNS], t64[0] * 10.0 / std::max(1u, t[9]), t64[1] * 10.0 / std::max(1u, t[9]), (double)t64[2] / std::max(1u, t[9]));
-        }
-    }
-    if (A.dbg & 4u) {
-        const ull* t64 = reinterpret_cast<const ull*>(t + 16);
-        std::fprintf(stderr, "[c2a peel2] tournament waves, per wave: alive %.2f ms, waiting for an entry %.2f ms, waiting for candidate records %.2f ms\n",
-                     t64[2] / 1e5 / mails, t64[0] / 1e5 / mails, t64[1] / 1e5 / mails);
-    }
-    if (A.dbg & 3u) return fail(c, C2A_ERR_STATE, "C2A_PEEL2_DBG: a measurement run, no results");
-    if (want_stats)
-        std::fprintf(stderr, "[c2a peel2] %u claim waves x %u lanes, %u tournament waves | processed %u, claimed %u, pushed %u, popped %u, claim turns %u (%.1f per wave), ring-full waits %u, record re-reads %u, aborts %u\n",
-                     n_claim, n_lanes, mails, t[P2_PROCESSED], t[P2_CLAIMED], t[P2_PUSHED], t[P2_POPPED], t[P2_TURNS], (double)t[P2_TURNS] / n_claim, t[P2_STALLS], t[P2_REREADS], t[P2_ABORT]);
-    if (t[P2_ABORT]) { *gave_up = true; return C2A_OK; }
-    c->node_clear = false;
-    c->mb_dirty = false;
-    c->mb_seq_cur ^= 1u;
-    *peeled_out = t[P2_PROCESSED];
-    c->stats.levels = t[P2_PROCESSED] ? t[P2_MAXLEVEL] + 1 : 0;
-    c->stats.level_launches = 2;
-    c->stats.peel_waves = grid;
-    c->stats.peel_rereads = t[P2_REREADS];
-    return C2A_OK;
-}
-
 int do_peel(c2a_ctx* c, u32* peeled_out) {
-    if (c->peel_mode == 1) {
-        bool gave_up = false;
-        int r = do_peel2(c, peeled_out, &gave_up);
-        if (r || !gave_up) return r;
-        // the decoupled launch gave up (its watchdog): run the one-wave launch on clean buffers instead of failing
-        std::fprintf(stderr, "[c2a] the decoupled peel gave up; falling back to the one-wave dataflow launch\n");
-        HIP_TRY(hipMemsetAsync(c->fill.p, 0, (size_t)c->n * 4, c->stream));
-        HIP_TRY(hipMemsetAsync(c->child.p, 0xFF, (size_t)c->n * 8, c->stream));
-    }
     int r = do_peel_classic(c, peeled_out);
     if (r == C2A_ERR_HIP && c->peel_gave_up) {
         // the launch's watchdog tripped (a wave waited too long for a record or for global progress): once more on clean
@@ -748,20 +619,9 @@ int c2a_create(int n_devices, const int* device_ids, c2a_ctx** out) {
     if (const char* e = std::getenv("C2A_BOOL_CHUNK")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 128 || v == 256 || v == 512) c->bool_chunk = v; }
     if (const char* e = std::getenv("C2A_PEEL_SEED_CHUNK")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 4096) c->peel_seed_chunk = v; }
     if (const char* e = std::getenv("C2A_PEEL_SHALLOW")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 48) c->peel_shallow = v; }
-    if (const char* e = std::getenv("C2A_PEEL_SINKS_BLOCKS")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 16) c->peel_sinks_blocks = v; }
     if (const char* e = std::getenv("C2A_PEEL_WAVES")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 32) c->peel_waves = v; }
     if (const char* e = std::getenv("C2A_PEEL_RESERVE")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v <= 32) c->peel_reserve = v; }
-    if (const char* e = std::getenv("C2A_PEEL_MODE")) c->peel_mode = (std::strcmp(e, "split") == 0 || std::strcmp(e, "1") == 0) ? 1u : 0u;
-    if (const char* e = std::getenv("C2A_PEEL2_CLAIM")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 1024) c->peel2_claim = v; }
-    if (const char* e = std::getenv("C2A_PEEL2_LANES")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 64) c->peel2_lanes = v; }
-    if (const char* e = std::getenv("C2A_PEEL2_MBCAP")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 32 && v <= (1u << 20) && (v & (v - 1)) == 0) c->peel2_mbcap = v; }
     if (const char* e = std::getenv("C2A_PEEL_FIFOS")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->peel_fifos = v; }
-#ifdef C2A_EMULATE
-    // (the emulation runs every fiber of the launch on one host thread: a small grid, short rings that wrap and fill)
-    if (!std::getenv("C2A_PEEL2_CLAIM")) c->peel2_claim = 2;
-    if (!std::getenv("C2A_PEEL2_LANES")) c->peel2_lanes = 5;
-    if (!std::getenv("C2A_PEEL2_MBCAP")) c->peel2_mbcap = 32;
-#endif
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return C2A_ERR_HIP; }
     if (hipStreamCreate(&c->aux) != hipSuccess) { c->aux = hipStream_t{}; c2a_destroy(c); return C2A_ERR_HIP; }
     {

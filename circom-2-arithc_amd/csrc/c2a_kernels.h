@@ -28,7 +28,6 @@ __device__ __forceinline__ u64 gstride() { return (u64)gridDim.x * blockDim.x; }
 }  // namespace c2a
 
 #include "c2a_peel.h"       // (also the agent-scope access helpers the scan below uses)
-#include "c2a_peel2.h"
 
 namespace c2a {
 

@@ -47,7 +47,7 @@ def orc():
 @pytest.fixture(scope="session")
 def emul_lib():
     srcs = [os.path.join(ROOT, "circom-2-arithc_amd", "csrc", f) for f in
-            ("c2a_api.hip", "c2a_kernels.h", "c2a_peel.h", "c2a_peel2.h", "c2a_templates.h", "c2a_platform.h")] + [
+            ("c2a_api.hip", "c2a_kernels.h", "c2a_peel.h", "c2a_wave.h", "c2a_templates.h", "c2a_platform.h")] + [
         os.path.join(EMUL_DIR, "hip_emul.h"), os.path.join(ROOT, "include", "c2a.h")]
     if (not os.path.exists(EMUL_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(EMUL_LIB) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", EMUL_DIR])
@@ -120,20 +120,16 @@ def backend_wave(request, c2a):
     be.close()
 
 
-# (library build, peel kernel: "classic" = the one-wave dataflow launch, "split" = the decoupled launch of c2a_peel2.h; under
-# emulation every wave of either launch is alive at once and C2A_EMUL_SEED shuffles the schedule per pass)
-PEEL_BACKENDS = [_variant("emul", "classic-s1"), _variant("emul", "classic-s2"), _variant("emul", "classic-s3"),
-                 _variant("emul", "split-s0"), _variant("emul", "split-s1"), _variant("emul", "split-s2"), _variant("hip", "split-s0")]
+# (the dataflow launch under emulation: every wave is alive at once and C2A_EMUL_SEED shuffles the schedule per pass)
+PEEL_BACKENDS = [_variant("emul", "s1"), _variant("emul", "s2"), _variant("emul", "s3"), _variant("emul", "s4"), _variant("emul", "s5")]
 
 
 @pytest.fixture(params=PEEL_BACKENDS)
 def backend_peel(request, c2a):
-    """Either peel kernel under a seeded random interleaving of its waves (emulation), and the decoupled launch on the GPU."""
+    """The dataflow peel under a seeded random interleaving of its waves (emulation)."""
     kind, mode = request.param
-    peel, seed = mode.split("-s")
-    env = {"C2A_PEEL_MODE": peel}
-    with _Env(**env):
-        be = c2a.Backend(0, lib_path=request.getfixturevalue("emul_lib")) if kind == "emul" else c2a.Backend(0)
+    seed = mode[1:]
+    be = c2a.Backend(0, lib_path=request.getfixturevalue("emul_lib")) if kind == "emul" else c2a.Backend(0)
     old = os.environ.get("C2A_EMUL_SEED")
     if int(seed):
         os.environ["C2A_EMUL_SEED"] = seed

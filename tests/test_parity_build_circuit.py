@@ -116,9 +116,9 @@ def test_layered_dags(backend, orc, c2a, layers, width, window):
 
 
 def test_peel_protocols_under_random_schedules(backend_peel, orc, c2a):
-    """The ticket / hand-off / termination protocol of the dataflow launch, and the claim-wave / mailbox protocol of the
-    decoupled launch, with every wave of the launch alive at once and taking turns in a shuffled order (the emulator's
-    concurrent launch, C2A_EMUL_SEED): the results do not depend on the interleaving.  Also cyclic inputs and duplicate writers."""
+    """The ticket / hand-off / termination protocol of the dataflow launch with every wave of the launch alive at once and
+    taking turns in a shuffled order (the emulator's concurrent launch, C2A_EMUL_SEED): the results do not depend on the
+    interleaving.  Also cyclic inputs and duplicate writers."""
     be = backend_peel
     rng = np.random.default_rng(31337)
     seen = {"ok": 0, "cyclic": 0, "inconsistent": 0, "cyclic-and-inconsistent": 0}
@@ -131,7 +131,7 @@ def test_peel_protocols_under_random_schedules(backend_peel, orc, c2a):
         fg = c2a.synth.layered_dag(layers, width, n_in=16, n_const=3, window=window, mix=c2a.synth.MIX_ALL, seed=seed)
         p = dict(lh=fg.lh, rh=fg.rh, out=fg.out, op=fg.op, n_nodes=fg.n_nodes, input_nodes=fg.input_nodes, output_nodes=fg.output_nodes)
         assert _compare(be, orc, p, check_serial=False) == "ok"
-        assert _compare(be, orc, p, check_serial=False) == "ok"       # the same buffers again (run tags, mailbox sequence numbers)
+        assert _compare(be, orc, p, check_serial=False) == "ok"       # the same buffers again (run tags)
 
 
 def test_deep_chain_exercises_path_string_chunks(backend, orc):
