@@ -67,7 +67,12 @@ struct c2a_ctx {
     bool io_clash = false;         // a node is both an input and an output (compiler.rs:363-383), found at load time
     bool peel_meta_valid = false;  // meta[] / stats.levels describe the circuit now loaded (c2a_verify_boolify schedules by them)
     bool node_clear = true;        // node records must be zeroed before the next run (new graph, or a run that failed)
-    bool peel_gave_up = false;     // the last dataflow launch ended by its watchdog (do_peel retries once on clean buffers)
+    bool peel_gave_up = false;     // the last dataflow launch ended by its watchdog (do_peel retries once on clean buffers, then do_topo_sort sorts serially)
+    bool serial_fallback = false;  // ... and that happened for the circuit now loaded (logged once per context)
+    bool fallback_logged = false;
+#ifdef C2A_EMULATE
+    u32 emul_peel_abort = 0;       // tests only (C2A_EMUL_PEEL_ABORT): this many dataflow launches are treated as given up
+#endif
 
     // problem
     u32 n = 0, n_nodes = 0, n_in = 0, n_out = 0;
@@ -78,9 +83,9 @@ struct c2a_ctx {
     u32 bool_width = 0;
 
     // device buffers
-    DevBuf lh, rh, out, op, gate4, in_nodes, out_nodes;
+    DevBuf lh, rh, out, op, gate4, nrec, orig, in_nodes, out_nodes;
     DevBuf prod1, dep0, dep1, cons_cnt, cons_off, eslot, aq_items, aq_pc, aq_seeds, aq_seeds1, aq_seed_flat, aq_seed_cnt, fill, meta, node, child, gstat, clist, pctl, pcold;
-    DevBuf rflag, ridx, rlist, next, owner, local, slist, snext, ssum, jnxt, jval, sorted;
+    DevBuf rbits, rpre, ridx, rlist, next, owner, local, slist, snext, ssum, jnxt, jval, sorted, sorted_r;
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op, gs, wcnt, wfo;
     u32* hrb = nullptr;            // 256 words of host memory the device writes the end-of-stage numbers to (k_post_*) ...
     u32* hrb_dev = nullptr;        // ... as the device sees it.  Words 0-7: peel, 8-15: order, 16-23: wires, 24-31: boolify
@@ -100,9 +105,9 @@ struct c2a_ctx {
     std::vector<DevBuf*> all;
 
     c2a_ctx() {
-        all = {&lh, &rh, &out, &op, &gate4, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &aq_items, &aq_pc, &aq_seeds, &aq_seeds1, &aq_seed_flat, &aq_seed_cnt, &fill,
-               &gstat, &clist, &pctl, &pcold, &meta, &node, &child, &rflag, &ridx, &rlist, &next,
-               &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &first, &nflag, &wflag, &widx, &node_wire1,
+        all = {&lh, &rh, &out, &op, &gate4, &nrec, &orig, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &aq_items, &aq_pc, &aq_seeds, &aq_seeds1, &aq_seed_flat, &aq_seed_cnt, &fill,
+               &gstat, &clist, &pctl, &pcold, &meta, &node, &child, &rbits, &rpre, &ridx, &rlist, &next,
+               &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &sorted_r, &first, &nflag, &wflag, &widx, &node_wire1,
                &node_wire, &e_in0, &e_in1, &e_out, &e_op, &gs, &wcnt, &wfo, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &peel_trace, &tsz, &asz, &goff,
                &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &fmt_len, &fmt_off, &fmt_text, &fmt_table, &shard_cut, &shard_qcut, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &ev_lcount, &ev_lbase, &ev_lorder, &ev_bar, &ev_io, &g_in0, &g_in1, &g_out, &g_op, &pr_rep, &pr_need, &pr_tin0, &pr_tin1, &pr_top, &pr_live, &pr_goff, &pr_counts, &p_in0, &p_in1, &p_out, &p_op, &cb_in0, &cb_in1, &cb_out, &cb_op};
     }
@@ -184,20 +189,33 @@ int read_scalars(c2a_ctx* c, u32* host, int first, int count) {
     return C2A_OK;
 }
 
-int do_prep(c2a_ctx* c) {
+// producer map (compiler.rs:401-406), relabelling by out-node order (c2a_kernels.h RELABELLING), deps closure
+// (compiler.rs:408-421), consumer lists and the static records of the dataflow launch — everything behind k_relabel in rank space
+int do_prep(c2a_ctx* c, bool for_peel = true) {
     const u32 n = c->n;
     hipStream_t s = c->stream;
     const u32 G = grid_for(n, 4096);
     HIP_TRY(hipMemsetAsync(c->prod1.p, 0, (size_t)c->n_nodes * 4, s));
     HIP_TRY(hipMemsetAsync(c->scalars.p, 0, SC_WORDS * 4, s));
-    C2A_LAUNCH_NOSYNC(k_producer, G, kThreads, s, n, c->out.as<u32>(), c->prod1.as<u32>(), c->scalars.as<u32>() + SC_DUP,
-                      c->cons_cnt.as<u32>(), c->fill.as<u32>(), c->child.as<uint2>());
-    C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->out.as<u32>(), c->op.as<u8>(), c->prod1.as<u32>(),
-                      c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>(), c->gate4.as<uint4>());
-    int r = scan_exclusive<u32>(c, c->cons_cnt.as<u32>(), c->cons_off.as<u32>(), n);
+    const u32* dup = c->scalars.as<u32>() + SC_DUP;
+    C2A_LAUNCH_NOSYNC(k_producer, G, kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->out.as<u32>(), c->op.as<u8>(), c->prod1.as<u32>(), c->nrec.as<uint4>(),
+                      c->scalars.as<u32>() + SC_DUP, c->cons_cnt.as<u32>(), for_peel ? c->fill.as<u32>() : (u32*)nullptr, for_peel ? c->child.as<uint2>() : (uint2*)nullptr);
+    {
+        const u64 tiles = ((u64)c->n_nodes + kRelTile - 1) / kRelTile;
+        const size_t bytes = 64 + (size_t)tiles * 8;
+        ENSURE(c->scan_tmp, bytes);
+        HIP_TRY(hipMemsetAsync(c->scan_tmp.p, 0, bytes, s));
+        C2A_LAUNCH(k_relabel, (u32)tiles, kRelThreads, s, c->n_nodes, c->prod1.as<u32>(), (const uint4*)c->nrec.as<uint4>(), dup, c->orig.as<u32>(),
+                          c->gate4.as<uint4>(), c->scan_tmp.as<u64>() + 8, c->scan_tmp.as<u32>());
+    }
+    int r;
+    C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->out.as<u32>(), c->op.as<u8>(), dup, c->prod1.as<u32>(), c->orig.as<u32>(),
+                      c->gate4.as<uint4>(), c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>());
+    if (!for_peel) return C2A_OK;
+    r = scan_exclusive<u32>(c, c->cons_cnt.as<u32>(), c->cons_off.as<u32>(), n);
     if (r) return r;
     C2A_LAUNCH_NOSYNC(k_gstat, G, kThreads, s, n, c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_off.as<u32>(),
-                      c->eslot.as<u32>(), c->gstat.as<uint4>(), c->clist.as<u32>());
+                      c->eslot.as<u32>(), c->orig.as<u32>(), c->gstat.as<uint4>(), c->clist.as<u32>());
     return C2A_OK;
 }
 
@@ -296,6 +314,7 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
     // workgroup first, then moved to ONE list the waves of the launch take seed_chunk at a time; its length stays on the
     // device: the word behind the region counts)
     ENSURE(c->aq_seeds1, (size_t)sink_blocks * l1_cap * 4); ENSURE(c->aq_seed_flat, ((size_t)n + 64) * 4);
+    cold.cons_off = c->cons_off.as<u32>();
     cold.seeds = c->aq_seed_flat.as<u32>(); cold.seed_total = c->aq_seed_cnt.as<u32>() + (size_t)(shallow + 1) * sink_blocks; cold.seed_chunk = c->peel_seed_chunk;
     // what only the edges of the launch touch travels as one small block in HBM (keeps the kernel's scalar registers free)
     // (written by a one-thread launch that takes it by value: a copy from this stack object would need a host round trip)
@@ -308,7 +327,7 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
         u32* cnts = c->aq_seed_cnt.as<u32>();
         const u32* in = (lvl & 1u) ? c->aq_seeds.as<u32>() : c->aq_seeds1.as<u32>();
         u32* out = (lvl & 1u) ? c->aq_seeds1.as<u32>() : c->aq_seeds.as<u32>();
-        C2A_LAUNCH(k_peel_shallow, sink_blocks, kThreads, s, A, lvl, lvl == shallow ? 1u : 0u, in, (const u32*)(cnts + (size_t)(lvl - 1) * sink_blocks), lvl == 1 ? sink_cap : l1_cap,
+        C2A_LAUNCH(k_peel_shallow, sink_blocks, kThreads, s, A, (const u32*)c->cons_off.as<u32>(), lvl, lvl == shallow ? 1u : 0u, in, (const u32*)(cnts + (size_t)(lvl - 1) * sink_blocks), lvl == 1 ? sink_cap : l1_cap,
                    out, cnts + (size_t)lvl * sink_blocks, l1_cap, c->aq_seed_flat.as<u32>(), cnts + (size_t)(shallow + 1) * sink_blocks);
     }
     // (every wave of the launch is alive at once under emulation too, interleaved at the back-offs — in a shuffled order per
@@ -318,7 +337,10 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
     static_assert(CTL_PROCESSED == 0 && CTL_MAXLEVEL == 1 && CTL_ABORT == 2 && CTL_REREADS == 3, "the order k_post_peel writes them in");
     C2A_LAUNCH(k_post_peel, 1, 64, s, c->hrb_dev, (const u32*)c->pctl.as<u32>(), (const u32*)(c->cons_off.as<u32>() + n), (const u32*)(c->scalars.as<u32>() + SC_DUP));
     HIP_TRY(hipStreamSynchronize(s));
-    const u32 t4[4] = {c->hrb[0], c->hrb[1], c->hrb[2], c->hrb[3]};
+    u32 t4[4] = {c->hrb[0], c->hrb[1], c->hrb[2], c->hrb[3]};
+#ifdef C2A_EMULATE
+    if (c->emul_peel_abort) { --c->emul_peel_abort; t4[CTL_ABORT] = 1; }      // (tests: a launch that "gave up", to exercise the retry and the serial fall-back)
+#endif
     c->rb_edges = c->hrb[4]; c->rb_dup = c->hrb[5];      // (ride along: one round trip)
     if (want_stats) {
         ull st[32];
@@ -393,17 +415,23 @@ int do_order(c2a_ctx* c) {
     const u32 n = c->n;
     hipStream_t s = c->stream;
     const u32 G = grid_for(n, 4096);
-    // DFS roots (tree nodes without a parent) in ascending gate id: flags, their scan and the root list in one launch
-    int r = scan_1pass<1>(c, s, c->scan_tmp, n, ScanRootFlag{c->meta.as<uint4>()}, c->ridx.as<u32>(), (u32*)nullptr, ScanRootList{c->rlist.as<u32>()});
+    // DFS roots (tree nodes without a parent) in ascending ORIGINAL gate id: a bit per id, a scan over the bitmap's words, the list
+    const u32 W = (n + 31u) / 32u;
+    HIP_TRY(hipMemsetAsync(c->rbits.p, 0, (size_t)W * 4, s));
+    C2A_LAUNCH_NOSYNC(k_root_bits, G, kThreads, s, n, (const uint4*)c->meta.as<uint4>(), (const u32*)c->orig.as<u32>(), c->rbits.as<u32>());
+    int r = scan_1pass<1>(c, s, c->scan_tmp, W, ScanPopc{c->rbits.as<u32>()}, c->rpre.as<u32>(), (u32*)nullptr, ScanNoEpilogue{});
     if (r) return r;
+    const u32* n_roots_p = c->rpre.as<u32>() + W;
+    C2A_LAUNCH_NOSYNC(k_root_list, G, kThreads, s, n, (const uint4*)c->meta.as<uint4>(), (const u32*)c->orig.as<u32>(), (const u32*)c->rbits.as<u32>(),
+                      (const u32*)c->rpre.as<u32>(), c->ridx.as<u32>(), c->rlist.as<u32>());
     C2A_LAUNCH(k_euler_next, G, kThreads, s, n, c->meta.as<uint4>(), c->child.as<u32>(),
-               c->ridx.as<u32>(), c->rlist.as<u32>(), (const u32*)(c->ridx.as<u32>() + n), c->next.as<u32>(), c->scalars.as<u32>() + SC_MAXDEPTH);
+               c->ridx.as<u32>(), c->rlist.as<u32>(), n_roots_p, c->next.as<u32>(), c->scalars.as<u32>() + SC_MAXDEPTH);
     const u32 m = 2 * n;
     u32* scount = c->scalars.as<u32>() + SC_SCOUNT;
     C2A_LAUNCH(k_rank_mark, std::max<u32>(1u, std::min<u32>(2048u, (m + kThreads * 8 - 1) / (kThreads * 8))), kThreads, s, m, c->rlist.as<u32>(), scount, c->slist.as<u32>(),
                       c->owner.as<u32>());
     static_assert(SC_SCOUNT == SC_MAXDEPTH + 1, "read as a pair");
-    C2A_LAUNCH_NOSYNC(k_post_words, 1, 64, s, c->hrb_dev + 8, (const u32*)(c->scalars.as<u32>() + SC_MAXDEPTH), 2u, (const u32*)(c->ridx.as<u32>() + n), 1u, (const u32*)nullptr, 0u);
+    C2A_LAUNCH_NOSYNC(k_post_words, 1, 64, s, c->hrb_dev + 8, (const u32*)(c->scalars.as<u32>() + SC_MAXDEPTH), 2u, n_roots_p, 1u, (const u32*)nullptr, 0u);
     HIP_TRY(hipStreamSynchronize(s));
     const u32 sc[3] = {c->hrb[8], c->hrb[9], c->hrb[10]};      // depth of the DFS forest, splitters, roots
     const u32 S = sc[1];
@@ -422,23 +450,47 @@ int do_order(c2a_ctx* c) {
         std::swap(nx_a, nx_b);
         std::swap(vl_a, vl_b);
     }
-    C2A_LAUNCH_NOSYNC(k_rank_final, G, kThreads, s, n, (const u64*)c->local.as<u64>(), (const u32*)vl_a, c->sorted.as<u32>());
+    // (the tour's next[] has been consumed by the walk: its buffer takes the packed {rank, original id} pairs)
+    C2A_LAUNCH_NOSYNC(k_rank_final, G, kThreads, s, n, (const u64*)c->local.as<u64>(), (const u32*)vl_a, (const u32*)c->orig.as<u32>(), c->next.as<uint2>());
+    C2A_LAUNCH_NOSYNC(k_sorted_split, G, kThreads, s, n, (const uint2*)c->next.as<uint2>(), c->sorted_r.as<u32>(), c->sorted.as<u32>());
     return C2A_OK;
 }
 
+// the reference's own DFS on one lane (original gate ids; needs prod1 / orig of do_prep): sorted[] or the cycle's gate
 int run_serial_dfs(c2a_ctx* c, u32* status, u64* cycle_at) {
     const u32 n = c->n;
     hipStream_t s = c->stream;
     ENSURE(c->dfs_state, (size_t)n);
     ENSURE(c->dfs_stack, (size_t)n * 4);
     HIP_TRY(hipMemsetAsync(c->dfs_state.p, 0, (size_t)n, s));
-    C2A_LAUNCH_NOSYNC(k_serial_dfs, 1, 64, s, n, c->dep0.as<u32>(), c->dep1.as<u32>(), c->dfs_state.as<u8>(),
+    C2A_LAUNCH_NOSYNC(k_serial_dfs, 1, 64, s, n, c->lh.as<u32>(), c->rh.as<u32>(), (const u32*)c->prod1.as<u32>(), (const u32*)c->orig.as<u32>(), c->dfs_state.as<u8>(),
                       c->dfs_stack.as<u32>(), c->sorted.as<u32>(), c->scalars.as<u32>() + SC_DFS);
     u32 res[3] = {0, 0, 0};
     int r = read_scalars(c, res, SC_DFS, 3);
     if (r) return r;
     *status = res[0];
     *cycle_at = res[1];
+    return C2A_OK;
+}
+
+// behind a serial sort: the order in rank space (what the numbering kernels walk) and — with_levels — the reverse Kahn levels
+// the level-parallel evaluators schedule by (the dataflow launch leaves them in meta[]; here one more serial walk)
+int after_serial_sort(c2a_ctx* c, bool with_levels) {
+    const u32 n = c->n;
+    hipStream_t s = c->stream;
+    const u32 G = grid_for(n, 4096);
+    u32* inv = c->next.as<u32>();                  // (scratch of the order stage, idle on this path)
+    C2A_LAUNCH_NOSYNC(k_invert, G, kThreads, s, n, (const u32*)c->orig.as<u32>(), inv);
+    C2A_LAUNCH_NOSYNC(k_sorted_to_rank, G, kThreads, s, n, (const u32*)c->sorted.as<u32>(), (const u32*)inv, c->sorted_r.as<u32>());
+    if (!with_levels) return C2A_OK;
+    u32* lvl = c->owner.as<u32>();
+    HIP_TRY(hipMemsetAsync(lvl, 0, (size_t)n * 4, s));
+    C2A_LAUNCH_NOSYNC(k_serial_levels, 1, 64, s, n, (const u32*)c->sorted_r.as<u32>(), (const u32*)c->dep0.as<u32>(), (const u32*)c->dep1.as<u32>(), lvl,
+                      c->meta.as<uint4>(), c->scalars.as<u32>() + SC_LEVELS);
+    u32 mx = 0;
+    int r = read_scalars(c, &mx, SC_LEVELS, 1);
+    if (r) return r;
+    c->stats.levels = mx + 1;
     return C2A_OK;
 }
 
@@ -458,11 +510,32 @@ int do_topo_sort(c2a_ctx* c, u64* cycle_at) {
     if (r) return r;
     rec(c, EV_PREP1);
     u32 peeled = 0;
+    c->serial_fallback = false;
     r = do_peel(c, &peeled);
-    if (r) return r;
+    if (r == C2A_ERR_HIP && c->peel_gave_up) {
+        // The dataflow launch gave up twice (its watchdog: a wave waited too long).  The reference's sort cannot fail on an
+        // acyclic graph (topological_sort.rs:3-21), and neither may this one: the same DFS on one lane (exact, always
+        // terminates, slow), the order in rank space and the reverse Kahn levels for what comes behind.
+        if (!c->fallback_logged) { std::fprintf(stderr, "[c2a] the dataflow peel gave up twice (%s): sorting with the serial DFS instead\n", c->err.c_str()); c->fallback_logged = true; }
+        c->serial_fallback = true;
+        c->err.clear();
+    } else if (r) return r;
     rec(c, EV_PEEL1);
     c->stats.n_edges = c->rb_edges;                  // (read back with the launch's own counters)
     c->has_dup = c->rb_dup != 0;
+    if (c->serial_fallback) {
+        u32 status = 0;
+        u64 at = 0;
+        r = run_serial_dfs(c, &status, &at);
+        if (r) return r;
+        if (cycle_at) *cycle_at = at;
+        if (status == 1) return fail(c, C2A_ERR_CYCLIC, "Cyclic dependency: detected at i=" + std::to_string(at));
+        if ((r = after_serial_sort(c, true))) return r;
+        rec(c, EV_ORDER1);
+        c->stage = ST_SORTED;
+        c->peel_meta_valid = true;
+        return C2A_OK;
+    }
     if (peeled != n) {
         // leftover gates sit on or above a dependency cycle: replay the reference's DFS for its message
         u32 status = 0;
@@ -510,7 +583,7 @@ int do_assign_wires(c2a_ctx* c, bool defer_readback = false) {
     int r;
     if (fast) {
         if (n) {
-            C2A_LAUNCH_NOSYNC(k_walk, G, kThreads, s, n, c->sorted.as<u32>(), (const uint4*)c->gate4.as<uint4>(),
+            C2A_LAUNCH_NOSYNC(k_walk, G, kThreads, s, n, c->sorted_r.as<u32>(), (const uint4*)c->gate4.as<uint4>(),
                               (const u8*)c->nflag.as<u8>(), c->gs.as<uint4>(), c->wcnt.as<u32>(), c->wfo.as<u8>(), c->first.as<u32>());
             C2A_LAUNCH_NOSYNC(k_walk_nodes, GN, kThreads, s, c->n_nodes, (const u32*)c->prod1.as<u32>(), (const u8*)c->nflag.as<u8>(),
                               (const u32*)c->first.as<u32>(), c->wcnt.as<u32>());
@@ -526,16 +599,16 @@ int do_assign_wires(c2a_ctx* c, bool defer_readback = false) {
         }
     } else {
         if (n) {
-            C2A_LAUNCH_NOSYNC(k_first_seen, G, kThreads, s, n, c->sorted.as<u32>(), (const uint4*)c->gate4.as<uint4>(),
+            C2A_LAUNCH_NOSYNC(k_first_seen, G, kThreads, s, n, c->sorted_r.as<u32>(), (const uint4*)c->gate4.as<uint4>(),
                               (const u32*)c->prod1.as<u32>(), (const u32*)(c->scalars.as<u32>() + SC_DUP), c->first.as<u32>());
-            C2A_LAUNCH_NOSYNC(k_new_wire_flags, G, kThreads, s, n, c->sorted.as<u32>(), (const uint4*)c->gate4.as<uint4>(),
+            C2A_LAUNCH_NOSYNC(k_new_wire_flags, G, kThreads, s, n, c->sorted_r.as<u32>(), (const uint4*)c->gate4.as<uint4>(),
                               c->first.as<u32>(), c->nflag.as<u8>(), (const u32*)c->prod1.as<u32>(),
                               (const u32*)(c->scalars.as<u32>() + SC_DUP), c->wflag.as<u32>());
         }
         r = scan_exclusive<u32>(c, c->wflag.as<u32>(), c->widx.as<u32>(), m);
         if (r) return r;
         if (n) {
-            C2A_LAUNCH_NOSYNC(k_assign_wires, G, kThreads, s, n, c->sorted.as<u32>(),
+            C2A_LAUNCH_NOSYNC(k_assign_wires, G, kThreads, s, n, c->sorted_r.as<u32>(),
                               (const uint4*)c->gate4.as<uint4>(), c->wflag.as<u32>(), c->widx.as<u32>(), c->n_in,
                               c->node_wire1.as<u32>());
         }
@@ -559,7 +632,7 @@ int do_emit(c2a_ctx* c) {
                           (const u32*)c->wcnt.as<u32>(), (const u8*)c->wfo.as<u8>(), (const u32*)c->widx.as<u32>(), c->n_in,
                           (const u32*)c->node_wire1.as<u32>(), c->e_in0.as<u32>(), c->e_in1.as<u32>(), c->e_out.as<u32>(), c->e_op.as<u8>());
     else if (c->n)
-        C2A_LAUNCH_NOSYNC(k_emit, grid_for(c->n, 4096), kThreads, c->stream, c->n, c->sorted.as<u32>(),
+        C2A_LAUNCH_NOSYNC(k_emit, grid_for(c->n, 4096), kThreads, c->stream, c->n, c->sorted_r.as<u32>(),
                           (const uint4*)c->gate4.as<uint4>(), c->node_wire1.as<u32>(), c->e_in0.as<u32>(), c->e_in1.as<u32>(),
                           c->e_out.as<u32>(), c->e_op.as<u8>());
     rec(c, EV_EMIT1);
@@ -622,6 +695,9 @@ int c2a_create(int n_devices, const int* device_ids, c2a_ctx** out) {
     if (const char* e = std::getenv("C2A_PEEL_WAVES")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 32) c->peel_waves = v; }
     if (const char* e = std::getenv("C2A_PEEL_RESERVE")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v <= 32) c->peel_reserve = v; }
     if (const char* e = std::getenv("C2A_PEEL_FIFOS")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->peel_fifos = v; }
+#ifdef C2A_EMULATE
+    if (const char* e = std::getenv("C2A_EMUL_PEEL_ABORT")) c->emul_peel_abort = (u32)std::strtoul(e, nullptr, 10);
+#endif
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return C2A_ERR_HIP; }
     if (hipStreamCreate(&c->aux) != hipSuccess) { c->aux = hipStream_t{}; c2a_destroy(c); return C2A_ERR_HIP; }
     {
@@ -702,6 +778,7 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     }
     const size_t n4 = (size_t)n * 4, nn4 = (size_t)n_nodes * 4;
     ENSURE(c->lh, n4); ENSURE(c->rh, n4); ENSURE(c->out, n4); ENSURE(c->op, n); ENSURE(c->gate4, (size_t)n * 16);
+    ENSURE(c->nrec, (size_t)n_nodes * 16); ENSURE(c->orig, n4);
     ENSURE(c->in_nodes, (size_t)n_in * 4); ENSURE(c->out_nodes, (size_t)n_out * 4);
     ENSURE(c->prod1, nn4); ENSURE(c->dep0, n4); ENSURE(c->dep1, n4); ENSURE(c->cons_cnt, n4);
     ENSURE(c->cons_off, n4 + 4); ENSURE(c->eslot, 2 * n4); ENSURE(c->fill, n4 + (size_t)kFillDummyStride * kFillDummyWaves * 4);
@@ -713,10 +790,10 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     c->node_clear = true;
     bool cleared = false;
     if (n && hipMemsetAsync(c->node.p, 0, (size_t)n * kNodeWords * 8, c->aux) == hipSuccess) cleared = true;
-    ENSURE(c->rflag, n4); ENSURE(c->ridx, n4 + 4); ENSURE(c->rlist, n4);
+    ENSURE(c->rbits, n4 / 32 + 8); ENSURE(c->rpre, n4 / 32 + 16); ENSURE(c->ridx, n4); ENSURE(c->rlist, n4);
     ENSURE(c->next, 2 * n4); ENSURE(c->owner, 2 * n4); ENSURE(c->local, 2 * n4); ENSURE(c->slist, 2 * n4);
     ENSURE(c->snext, 2 * n4); ENSURE(c->ssum, 2 * n4); ENSURE(c->jnxt, 2 * n4); ENSURE(c->jval, 2 * n4);
-    ENSURE(c->sorted, n4);
+    ENSURE(c->sorted, n4); ENSURE(c->sorted_r, n4);
     ENSURE(c->first, nn4); ENSURE(c->nflag, n_nodes); ENSURE(c->wflag, 3 * n4); ENSURE(c->widx, 3 * n4 + 4);
     ENSURE(c->node_wire1, nn4); ENSURE(c->node_wire, nn4);
     ENSURE(c->gs, (size_t)n * 16); ENSURE(c->wcnt, n4 + 4); ENSURE(c->wfo, n);
@@ -757,17 +834,12 @@ int c2a_topo_sort_serial(c2a_ctx* c, uint32_t* sorted, uint64_t* cycle_at) {
     c->stats = c2a_stats{}; c->stats.n_gates = c->n;
     if (cycle_at) *cycle_at = 0;
     if (c->n == 0) { c->stage = ST_SORTED; return C2A_OK; }
-    // the deps closure only (no peel)
-    HIP_TRY(hipMemsetAsync(c->prod1.p, 0, (size_t)c->n_nodes * 4, c->stream));
-    HIP_TRY(hipMemsetAsync(c->scalars.p, 0, SC_WORDS * 4, c->stream));
-    const u32 G = grid_for(c->n, 4096);
-    C2A_LAUNCH_NOSYNC(k_producer, G, kThreads, c->stream, c->n, c->out.as<u32>(), c->prod1.as<u32>(), c->scalars.as<u32>() + SC_DUP,
-                      c->cons_cnt.as<u32>(), (u32*)nullptr, (uint2*)nullptr);
-    C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, c->stream, c->n, c->lh.as<u32>(), c->rh.as<u32>(), c->out.as<u32>(), c->op.as<u8>(), c->prod1.as<u32>(),
-                      c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>(), c->gate4.as<uint4>());
+    // the producer map, the relabelling and the deps closure only (no peel)
+    int r = do_prep(c, false);
+    if (r) return r;
     u32 status = 0;
     u64 at = 0;
-    int r = run_serial_dfs(c, &status, &at);
+    r = run_serial_dfs(c, &status, &at);
     if (r) return r;
     {
         u32 dup = 0;
@@ -779,6 +851,7 @@ int c2a_topo_sort_serial(c2a_ctx* c, uint32_t* sorted, uint64_t* cycle_at) {
         if (cycle_at) *cycle_at = at;
         return fail(c, C2A_ERR_CYCLIC, "Cyclic dependency: detected at i=" + std::to_string(at));
     }
+    if ((r = after_serial_sort(c, false))) return r;
     r = copy_out(c, sorted, c->sorted.p, (size_t)c->n * 4);
     if (r) return r;
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1201,7 +1274,7 @@ static int eval_levels(c2a_ctx* c) {
     ENSURE(c->ev_spos, (size_t)n * 4);
     ENSURE(c->ev_lcount, ((size_t)L + 1) * 4); ENSURE(c->ev_lbase, ((size_t)L + 2) * 4); ENSURE(c->ev_lorder, (size_t)n * 4);
     if (!n) return C2A_OK;
-    C2A_LAUNCH_NOSYNC(k_eval_inverse, grid_for(n, 4096), kThreads, s, n, c->sorted.as<u32>(), c->ev_spos.as<u32>());
+    C2A_LAUNCH_NOSYNC(k_eval_inverse, grid_for(n, 4096), kThreads, s, n, c->sorted_r.as<u32>(), c->ev_spos.as<u32>());
     HIP_TRY(hipMemsetAsync(c->ev_lcount.p, 0, ((size_t)L + 1) * 4, s));
     C2A_LAUNCH_NOSYNC(k_level_hist, grid_for(n, 4096), kThreads, s, n, (const uint4*)c->meta.as<uint4>(), c->ev_lcount.as<u32>());
     int r = scan_exclusive<u32>(c, c->ev_lcount.as<u32>(), c->ev_lbase.as<u32>(), L);

@@ -40,8 +40,14 @@ namespace c2a {
 // of a three-kernel scan is never written —, and an epilogue sees every element with its exclusive prefix (the root list is
 // written there).  out[c][n] = the total.
 // ------------------------------------------------------------------------------------------------
-constexpr int kScanItems = 16;
-constexpr int kScanThreads = 1024;          // fat tiles: the look-back is a chain over tiles (64 per round trip), 611 of them for 10 M elements
+#ifndef C2A_SCAN_ITEMS
+#define C2A_SCAN_ITEMS 16
+#endif
+#ifndef C2A_SCAN_THREADS
+#define C2A_SCAN_THREADS 1024
+#endif
+constexpr int kScanItems = C2A_SCAN_ITEMS;
+constexpr int kScanThreads = C2A_SCAN_THREADS;          // fat tiles: the look-back is a chain over tiles (64 per round trip), 611 of them for 10 M elements
 constexpr int kScanTile = kScanThreads * kScanItems;
 constexpr u64 kScanAgg = 1ull << 62, kScanPre = 2ull << 62, kScanVal = (1ull << 62) - 1ull;
 
@@ -137,14 +143,14 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_1pass(u64 n, F f, TOut* o
     for (int i = 0; i < kScanItems; ++i) {
         const u64 idx = base + i;
         if (idx < n) {
-            out0[idx] = (TOut)run[0];
+            if (out0) out0[idx] = (TOut)run[0];
             if (NC > 1) out1[idx] = (TOut)run[NC - 1];
             epi(idx, v[i], run);
         }
 #pragma unroll
         for (int c = 0; c < NC; ++c) run[c] += v[i][c];
     }
-    if ((u64)(tile + 1) * kScanTile >= n && tid == kScanThreads - 1) {      // the last tile: the totals
+    if ((u64)(tile + 1) * kScanTile >= n && tid == kScanThreads - 1 && out0) {      // the last tile: the totals
         out0[n] = (TOut)(s_excl[0] + tile_total[0]);
         if (NC > 1) out1[n] = (TOut)(s_excl[NC - 1] + tile_total[NC - 1]);
     }
@@ -158,49 +164,150 @@ struct ScanFromU32 { const u32* in; __device__ __forceinline__ void operator()(u
 // ------------------------------------------------------------------------------------------------
 // producer[node] = last gate writing it (compiler.rs:403-406: later insert overwrites) -> max gate id.
 // prod1 holds gate id + 1 (0 = no producer); must be zeroed.
-// *dup is raised when two gates write one node (the reference keeps the last writer, compiler.rs:403-406): the wire
-// numbering then takes its general path (first-seen by atomicMin over every reference)
-// (also resets what the rest of the sort keeps per gate — consumer count, claim tickets, tree children —: three coalesced
-// stores here instead of three clears of their own)
-__global__ void k_producer(u32 n, const u32* __restrict__ out, u32* prod1, u32* dup, u32* cons_cnt, u32* fill, uint2* child) {
+// *dup is raised when two gates write one node (the reference keeps the last writer, compiler.rs:403-406): the relabelling
+// below is then the identity and the wire numbering takes its general path (first-seen by atomicMin over every reference).
+// The gate's payload goes WITH it to its out node — one random 16-byte store here instead of three random reads later
+// (k_relabel picks the records up in node order, i.e. streaming) — and what the rest of the sort keeps per gate (consumer
+// count, claim tickets, tree children) is reset on the way: three coalesced stores instead of three clears of their own.
+__global__ void k_producer(u32 n, const u32* __restrict__ lh, const u32* __restrict__ rh, const u32* __restrict__ out, const u8* __restrict__ op,
+                           u32* prod1, uint4* nrec, u32* dup, u32* cons_cnt, u32* fill, uint2* child) {
     for (u64 g = gtid(); g < n; g += gstride()) {
         cons_cnt[g] = 0u;
         if (fill) { fill[g] = 0u; child[g] = make_uint2(C2A_NONE, C2A_NONE); }
-        if (atomicMax(&prod1[out[g]], (u32)g + 1) != 0) *dup = 1u;
+        const u32 o = out[g];
+        if (atomicMax(&prod1[o], (u32)g + 1) != 0) *dup = 1u;
+        nrec[o] = make_uint4(lh[g], rh[g], (u32)g, (u32)op[g]);      // (two writers of one node race here: *dup is up then, and nobody reads it)
     }
 }
 
-// deps closure (compiler.rs:408-421) + consumer counts.  dep1 is dropped when equal to dep0: a second
+// RELABELLING.  Gate ids arrive in no particular order (the headline input permutes them), but NODE ids are handed out by a
+// counter as the circuit is built (compiler.rs:497-500): the position of a gate's out node among the produced nodes — its
+// RANK — follows the creation order, producers sit a bounded distance before their consumers, and everything the sort does
+// per edge (deps, consumer lists, node records, the tour, the wire numbering) becomes local in rank space instead of paying a
+// memory sector per 4-byte access.  One scan over the node table: rank = number of produced nodes before this one;
+// orig[rank] = the gate, gate4[rank] = its payload {lh node, rh node, out node, op}, prod1[node] = rank + 1.  From here to
+// k_rank_final every "gate id" is a rank; the DFS roots are compared by orig[] (topological_sort.rs:11-13 walks gate ids).
+// With duplicate writers (*dup) nothing is moved: rank = gate id (k_deps copies the payload as it lies).
+// One launch (decoupled look-back over tiles of 4 096 nodes, like k_scan_1pass) in a STRIPED arrangement — lane l of a round
+// looks at node base + l — so that the flags are a ballot, a node's rank inside the wave a population count, and every access
+// streams: the node table and the records are read as whole lines, orig[] / gate4[] are written as whole lines (consecutive
+// produced nodes have consecutive ranks).
+constexpr int kRelThreads = 256, kRelRounds = 16, kRelTile = kRelThreads * kRelRounds;
+// (wave 0 of a workgroup: publish this tile's sum, find the sum of all tiles before it — one sum, descriptors as in k_scan_1pass)
+__device__ __forceinline__ u64 tile_lookback(u64* desc, u32 tile, u64 tile_total, u32 lane) {
+    u64 excl = 0;
+    if (tile == 0) { if (lane == 0) st_nw(&desc[tile], kScanPre | tile_total); return 0; }
+    if (lane == 0) st_nw(&desc[tile], kScanAgg | tile_total);
+    i64 look = (i64)tile - 1;               // lane l looks at tile look - l
+    for (;;) {
+        const i64 t = look - (i64)lane;
+        const u64 d = t >= 0 ? ld_nw(&desc[t]) : kScanPre;
+        const u64 pre = __ballot((d >> 62) == 2u);
+        const u64 notready = __ballot((d >> 62) == 0u);
+        const u32 upto = pre ? (u32)__builtin_ctzll(pre) : 63u;              // lanes 0..upto are summed
+        const u64 need = upto == 63u ? ~0ull : ((2ull << upto) - 1ull);
+        if (notready & need) continue;                     // (looked at again at once: the tiles before this one are running)
+        u64 x = lane <= upto ? (d & kScanVal) : 0ull;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+        excl += x;
+        if (pre) break;
+        look -= 64;
+    }
+    if (lane == 0) st_nw(&desc[tile], kScanPre | ((excl + tile_total) & kScanVal));
+    return excl;
+}
+__global__ void __launch_bounds__(kRelThreads) k_relabel(u32 n_nodes, u32* prod1, const uint4* __restrict__ nrec, const u32* __restrict__ dup,
+                                                         u32* orig, uint4* gate4, u64* desc, u32* counter) {
+    __shared__ u32 s_tile, s_wave[kRelThreads / 64];
+    __shared__ u64 s_excl;
+    if (*dup != 0u) return;                        // (wave-uniform, grid-uniform: nobody takes a tile)
+    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    if (tid == 0) s_tile = atomicAdd(counter, 1u);
+    __syncthreads();
+    const u32 tile = s_tile;
+    const u64 base = (u64)tile * kRelTile + (u64)wv * (64 * kRelRounds) + lane;
+    const u64 lt_mask = (1ull << lane) - 1ull;
+    u32 p[kRelRounds], pre[kRelRounds];
+#pragma unroll
+    for (int i = 0; i < kRelRounds; ++i) { const u64 v = base + (u64)i * 64; p[i] = v < n_nodes ? prod1[v] : 0u; }
+    u32 cnt = 0;
+    uint4 rec[kRelRounds];
+#pragma unroll
+    for (int i = 0; i < kRelRounds; ++i) {
+        const u64 bal = __ballot(p[i] != 0u);
+        pre[i] = cnt + (u32)__popcll(bal & lt_mask);
+        cnt += (u32)__popcll(bal);
+        if (p[i] != 0u) rec[i] = nrec[base + (u64)i * 64];      // (on its way while the tile finds its place)
+    }
+    if (lane == 0) s_wave[wv] = cnt;
+    __syncthreads();
+    u32 wave_base = 0, tile_total = 0;
+#pragma unroll
+    for (u32 w = 0; w < kRelThreads / 64; ++w) { const u32 v = s_wave[w]; wave_base += w < wv ? v : 0u; tile_total += v; }
+    if (wv == 0) {
+        const u64 e = tile_lookback(desc, tile, tile_total, lane);
+        if (lane == 0) s_excl = e;
+    }
+    __syncthreads();
+    const u32 first = (u32)s_excl + wave_base;
+#pragma unroll
+    for (int i = 0; i < kRelRounds; ++i) {
+        if (p[i] == 0u) continue;
+        const u64 v = base + (u64)i * 64;
+        const u32 rank = first + pre[i];
+        orig[rank] = p[i] - 1u;                    // (one writer per node here: the record's gate is the producer)
+        gate4[rank] = make_uint4(rec[i].x, rec[i].y, (u32)v, rec[i].w);
+        prod1[v] = rank + 1u;
+    }
+}
+
+// deps closure (compiler.rs:408-421) + consumer counts, in rank space.  dep1 is dropped when equal to dep0: a second
 // visit of the same gate is a no-op in the DFS (topological_sort.rs:30-32).
-// Also packs the payload as 16-byte records {lh, rh, out, op | lh node un-produced << 8 | rh node un-produced << 9}: the
-// numbering kernels visit gates in SORTED order, i.e. at random gate ids — one line per gate instead of four, and what they
-// want to know about the two input nodes (does any gate produce them?) comes along instead of costing two more random reads.
+// The payload record gets two flags {lh node un-produced << 8 | rh node un-produced << 9}: what the numbering kernels want to
+// know about the two input nodes (does any gate produce them?) comes along instead of costing two more reads.
 __global__ void k_deps(u32 n, const u32* __restrict__ lh, const u32* __restrict__ rh, const u32* __restrict__ out, const u8* __restrict__ op,
-                       const u32* __restrict__ prod1, u32* dep0, u32* dep1, u32* cons_cnt, u32* eslot, uint4* gate4) {
+                       const u32* __restrict__ dup, const u32* __restrict__ prod1, u32* orig, uint4* gate4, u32* dep0, u32* dep1,
+                       u32* cons_cnt, u32* eslot) {
+    const bool ident = *dup != 0u;
     for (u64 g = gtid(); g < n; g += gstride()) {
-        const u32 a = lh[g], b = rh[g];
-        const u32 p0 = prod1[a], p1 = prod1[b];
-        gate4[g] = make_uint4(a, b, out[g], (u32)op[g] | (p0 ? 0u : 0x100u) | (p1 ? 0u : 0x200u));
+        uint4 r;
+        if (ident) { r = make_uint4(lh[g], rh[g], out[g], (u32)op[g]); orig[g] = (u32)g; }
+        else r = gate4[g];
+        const u32 p0 = prod1[r.x], p1 = prod1[r.y];
+        gate4[g] = make_uint4(r.x, r.y, r.z, (r.w & 0xFFu) | (p0 ? 0u : 0x100u) | (p1 ? 0u : 0x200u));
         const u32 d0 = p0 ? p0 - 1 : C2A_NONE;
         u32 d1 = p1 ? p1 - 1 : C2A_NONE;
         if (d1 == d0) d1 = C2A_NONE;
         dep0[g] = d0;
         dep1[g] = d1;
-        // eslot[2g + l] = index of the edge (g, l) in its producer's consumer list: a static home for the candidate record
+        // eslot[2g + l] = index of the edge (g, l) in its producer's consumer list
         eslot[2 * g] = d0 != C2A_NONE ? atomicAdd(&cons_cnt[d0], 1u) : 0u;
         eslot[2 * g + 1] = d1 != C2A_NONE ? atomicAdd(&cons_cnt[d1], 1u) : 0u;
     }
 }
 
-
-
 // ------------------------------------------------------------------------------------------------
 // post-order numbering: Euler tour of the DFS tree + list ranking (random splitters)
 // ------------------------------------------------------------------------------------------------
-// DFS roots = tree nodes without a parent, in ascending gate id (topological_sort.rs:11-13): the flag is computed where the
-// scan reads it, the root list is written where the scan knows a root's index
-struct ScanRootFlag { const uint4* meta; __device__ __forceinline__ void operator()(u64 g, u64* x) const { x[0] = meta[g].x == C2A_NONE ? 1u : 0u; } };
-struct ScanRootList { u32* rlist; __device__ __forceinline__ void operator()(u64 g, const u64* v, const u64* excl) const { if (v[0]) rlist[excl[0]] = (u32)g; } };
+// DFS roots = tree nodes without a parent, in ascending ORIGINAL gate id (topological_sort.rs:11-13) — the tree lives in
+// rank space, so: a bit per original id (1.25 MB for 10 M gates: the scattered atomics stay on chip), a scan over the bitmap's
+// words, and every root finds its index by a look-up in the two small arrays.
+__global__ void k_root_bits(u32 n, const uint4* __restrict__ meta, const u32* __restrict__ orig, u32* rbits) {
+    for (u64 r = gtid(); r < n; r += gstride())
+        if (meta[r].x == C2A_NONE) { const u32 o = orig[r]; atomicOr(&rbits[o >> 5], 1u << (o & 31u)); }
+}
+struct ScanPopc { const u32* w; __device__ __forceinline__ void operator()(u64 i, u64* x) const { x[0] = (u64)__popc(w[i]); } };
+__global__ void k_root_list(u32 n, const uint4* __restrict__ meta, const u32* __restrict__ orig, const u32* __restrict__ rbits,
+                            const u32* __restrict__ rpre, u32* ridx, u32* rlist) {
+    for (u64 r = gtid(); r < n; r += gstride()) {
+        if (meta[r].x != C2A_NONE) continue;
+        const u32 o = orig[r];
+        const u32 k = rpre[o >> 5] + (u32)__popc(rbits[o >> 5] & ((1u << (o & 31u)) - 1u));
+        ridx[r] = k;
+        rlist[k] = (u32)r;
+    }
+}
 
 // element 2x = enter(x), 2x+1 = exit(x); the tour visits label-0 child, label-1 child, then exits.
 // child[2p + l] was written by the peel when the child picked (p, l) as its parent (NONE otherwise).
@@ -339,23 +446,30 @@ __global__ void k_rank_jump(const u32* __restrict__ scount, const u32* __restric
     }
 }
 
-// sorted[post-order index of x] = gate(x)   (== sorted.push(i), topological_sort.rs:46)
-__global__ void k_rank_final(u32 n, const u64* __restrict__ ol, const u32* __restrict__ suffix, u32* sorted) {
+// sorted[post-order index of x] = gate(x)   (== sorted.push(i), topological_sort.rs:46): the rank for the numbering kernels
+// behind this one, the original gate id for the caller
+__global__ void k_rank_final(u32 n, const u64* __restrict__ ol, const u32* __restrict__ suffix, const u32* __restrict__ orig,
+                             uint2* sorted2) {
     for (u64 x = gtid(); x < n; x += gstride()) {
         const u64 r = ol[x];
         const u32 post = (n - suffix[(u32)(r >> 32)]) + (u32)r;
-        sorted[post] = (u32)x;
+        sorted2[post] = make_uint2((u32)x, orig[x]);      // (ONE scattered 8-byte store; k_sorted_split makes the two arrays of it, streaming)
     }
+}
+__global__ void k_sorted_split(u32 n, const uint2* __restrict__ sorted2, u32* sorted_r, u32* sorted) {
+    for (u64 i = gtid(); i < n; i += gstride()) { const uint2 v = sorted2[i]; sorted_r[i] = v.x; sorted[i] = v.y; }
 }
 
 // ------------------------------------------------------------------------------------------------
-// serial DFS on one lane: literal topological_sort.rs with an explicit stack.  Only used to produce the
-// reference's cycle diagnostic ("detected at i={}", topological_sort.rs:34-38) once the parallel peel
-// has found leftover gates, and as an in-library cross-check (c2a_topo_sort_serial).
+// serial DFS on one lane: literal topological_sort.rs with an explicit stack, in ORIGINAL gate ids (the deps of a gate are
+// looked up as the reference does, compiler.rs:408-421: producer of lh, producer of rh — prod1 holds ranks, orig[] leads back).
+// Produces the reference's cycle diagnostic ("detected at i={}", topological_sort.rs:34-38) once the parallel peel has found
+// leftover gates; it is also the sort that cannot fail (the fall-back when the dataflow launch gives up) and an in-library
+// cross-check (c2a_topo_sort_serial).
 // state[g]: bit0 visiting, bit1 visited, bits 2..3 next dep index.  result = {status, cycle_at, count}
 // ------------------------------------------------------------------------------------------------
-__global__ void k_serial_dfs(u32 n, const u32* __restrict__ dep0, const u32* __restrict__ dep1, u8* state, u32* stack,
-                             u32* sorted, u32* result) {
+__global__ void k_serial_dfs(u32 n, const u32* __restrict__ lh, const u32* __restrict__ rh, const u32* __restrict__ prod1,
+                             const u32* __restrict__ orig, u8* state, u32* stack, u32* sorted, u32* result) {
     if (gtid() != 0) return;
     u32 ns = 0;
     for (u32 root = 0; root < n; ++root) {
@@ -369,8 +483,9 @@ __global__ void k_serial_dfs(u32 n, const u32* __restrict__ dep0, const u32* __r
             const u32 k = st >> 2;
             if (k < 2) {
                 state[i] = (u8)((st & 3u) | ((k + 1) << 2));
-                const u32 j = k == 0 ? dep0[i] : dep1[i];
-                if (j == C2A_NONE) continue;
+                const u32 p = prod1[k == 0 ? lh[i] : rh[i]];
+                if (p == 0u) continue;
+                const u32 j = orig[p - 1u];
                 const u32 sj = state[j];
                 if (sj & 2u) continue;
                 if (sj & 1u) { result[0] = 1; result[1] = j; result[2] = ns; return; }
@@ -384,6 +499,30 @@ __global__ void k_serial_dfs(u32 n, const u32* __restrict__ dep0, const u32* __r
         }
     }
     result[0] = 0; result[1] = 0; result[2] = ns;
+}
+// what the kernels behind a serial sort want besides sorted[]: the order in rank space ...
+__global__ void k_invert(u32 n, const u32* __restrict__ orig, u32* inv) {
+    for (u64 r = gtid(); r < n; r += gstride()) inv[orig[r]] = (u32)r;
+}
+__global__ void k_sorted_to_rank(u32 n, const u32* __restrict__ sorted, const u32* __restrict__ inv, u32* sorted_r) {
+    for (u64 i = gtid(); i < n; i += gstride()) sorted_r[i] = inv[sorted[i]];
+}
+// ... and — for the level-parallel evaluators — the reverse Kahn level of every gate, which the dataflow launch would have
+// left in meta[]: consumers come after their producers in sorted[], so one walk from the back sees every consumer of a gate
+// before the gate.  One lane; this only ever runs behind a launch that gave up twice.
+__global__ void k_serial_levels(u32 n, const u32* __restrict__ sorted_r, const u32* __restrict__ dep0, const u32* __restrict__ dep1,
+                                u32* lvl, uint4* meta, u32* max_level) {
+    if (gtid() != 0) return;
+    u32 mx = 0;
+    for (u32 i = n; i-- > 0;) {
+        const u32 r = sorted_r[i], L = lvl[r];
+        meta[r] = make_uint4(C2A_NONE, 0u, 0u, L << 1);
+        mx = L > mx ? L : mx;
+        const u32 d0 = dep0[r], d1 = dep1[r];
+        if (d0 != C2A_NONE && lvl[d0] < L + 1u) lvl[d0] = L + 1u;
+        if (d1 != C2A_NONE && lvl[d1] < L + 1u) lvl[d1] = L + 1u;
+    }
+    *max_level = mx;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -98,6 +98,7 @@ constexpr u32 kFillDummyWaves = 8192;       // ... of at most this many waves (2
 
 // what only the edges of the launch touch (kept out of the kernel's scalar registers)
 struct PeelCold {
+    const u32* cons_off;       // [n + 1] where a gate's own consumer list starts in clist (chain starts and the cold list loop only)
     const u32* seeds;          // [*seed_total] the gates the launch starts chains from (claimed by the last k_peel_shallow pass), one flat list
     const u32* seed_total;     // how many (device side: the host never learns it)
     u32 seed_chunk;            // a wave takes this many at a time
@@ -110,7 +111,7 @@ struct PeelCold {
 struct PeelArgs {
     u32 epoch;                 // tag (0/1) of this run's node words
     u32 n;
-    const uint4* gstat;        // [2n] {dep0, dep1, cons_off, cons_cnt} {cons_off[dep0], cons_cnt[dep0], cons_off[dep1], cons_cnt[dep1]}
+    const uint4* gstat;        // [2n] {dep0, dep1, original gate id, cons_cnt} {cons_off[dep0], cons_cnt[dep0], cons_off[dep1], cons_cnt[dep1]}
     const u32* clist;          // [edges + 64] consumer | edge label << 31, grouped by producer
     u64* node;                 // [n][64] node records
     u32* fill;                 // [n] claim tickets taken so far (zeroed per run)
@@ -247,14 +248,15 @@ __device__ __attribute__((noinline)) bool deep_less(const u64* node_base, u32 ep
 // gstat and the consumer lists (eslot[2g + l] = index of edge (g, l) in its producer's list, from k_deps)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_gstat(u32 n, const u32* __restrict__ dep0, const u32* __restrict__ dep1, const u32* __restrict__ cons_off,
-                        const u32* __restrict__ eslot, uint4* gstat, u32* clist) {
+                        const u32* __restrict__ eslot, const u32* __restrict__ orig, uint4* gstat, u32* clist) {
     // (the consumer count of a gate is the difference of two neighbouring offsets — cons_off has n + 1 entries —: ONE
-    // random 8-byte access per producer instead of two 4-byte ones in two arrays; gate ids are in no particular order,
-    // so every such access is an HBM sector of its own)
+    // 8-byte access per producer instead of two 4-byte ones in two arrays.  Word 2 of a gate's first record is its ORIGINAL
+    // id — what the DFS roots are compared by, topological_sort.rs:11-13; the launch works in rank space, c2a_kernels.h
+    // RELABELLING —; the offset of its own consumer list is only wanted off the hot path and is read from cons_off there)
     for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (u64)gridDim.x * blockDim.x) {
         const u32 d0 = dep0[g], d1 = dep1[g];
         const u32 o = cons_off[g];
-        gstat[2 * g] = make_uint4(d0, d1, o, cons_off[g + 1] - o);
+        gstat[2 * g] = make_uint4(d0, d1, orig[g], cons_off[g + 1] - o);
         uint4 g2 = make_uint4(0, 0, 0, 0);
         if (d0 != C2A_NONE) { g2.x = cons_off[d0]; g2.y = cons_off[(u64)d0 + 1] - g2.x; clist[g2.x + eslot[2 * g]] = (u32)g; }
         if (d1 != C2A_NONE) { g2.z = cons_off[d1]; g2.w = cons_off[(u64)d1 + 1] - g2.z; clist[g2.z + eslot[2 * g + 1]] = (u32)g | 0x80000000u; }
@@ -282,8 +284,8 @@ __global__ void __launch_bounds__(256) k_peel_sinks(PeelArgs A) {
             const uint4 gi = A.gstat[2 * g];
             if (gi.w == 0) {
                 ++done;
-                A.meta[g] = make_uint4(C2A_NONE, 0u, (u32)g, 0u);
-                A.node[g * kNodeWords] = tag | hdr0_word((u32)g, 0u);
+                A.meta[g] = make_uint4(C2A_NONE, 0u, gi.z, 0u);
+                A.node[g * kNodeWords] = tag | hdr0_word(gi.z, 0u);
                 A.node[g * kNodeWords + 1] = tag | hdr1_word(0u, C2A_NONE);
                 A.node[g * kNodeWords + 2] = tag;
                 const uint4 g2 = A.gstat[2 * g + 1];
@@ -339,7 +341,7 @@ __device__ __forceinline__ u64 c2a_brev64(u64 x) {
     return __brevll(x);
 #endif
 }
-__global__ void __launch_bounds__(256) k_peel_shallow(PeelArgs A, u32 lvl, u32 last, const u32* __restrict__ in, const u32* __restrict__ in_cnt, u32 in_cap,
+__global__ void __launch_bounds__(256) k_peel_shallow(PeelArgs A, const u32* __restrict__ cons_off, u32 lvl, u32 last, const u32* __restrict__ in, const u32* __restrict__ in_cnt, u32 in_cap,
                                                       u32* out, u32* out_cnt, u32 out_cap, u32* flat, u32* flat_total) {
     // what a lane decided about its gate, for the wave that writes the records
     __shared__ u32 s_g[256], s_root[256], s_depth[256];       // gate (C2A_NONE: none), DFS root, depth
@@ -360,6 +362,7 @@ __global__ void __launch_bounds__(256) k_peel_shallow(PeelArgs A, u32 lvl, u32 l
         if (i < cnt) {
             g = src[i];
             const uint4 gi = A.gstat[2 * (u64)g], gi2 = A.gstat[2 * (u64)g + 1];
+            const u32 g_off = cons_off[g], g_orig = gi.z;
             u32 b_root = C2A_NONE, b_c = C2A_NONE, b_el = 0, b_depth = 0;
             u64 b_rev = 0, b_x = 0;
             // (records of the passes before: plain loads; a sink's record has header words only — its string is empty.  The
@@ -376,7 +379,7 @@ __global__ void __launch_bounds__(256) k_peel_shallow(PeelArgs A, u32 lvl, u32 l
             constexpr u32 kTogether = 8;
             u32 ee[kTogether]; u64 hh[kTogether], ss[kTogether];
 #pragma unroll
-            for (u32 k = 0; k < kTogether; ++k) ee[k] = k < gi.w ? A.clist[gi.z + k] : 0u;
+            for (u32 k = 0; k < kTogether; ++k) ee[k] = k < gi.w ? A.clist[g_off + k] : 0u;
 #pragma unroll
             for (u32 k = 0; k < kTogether; ++k) hh[k] = k < gi.w ? A.node[(u64)(ee[k] & kIdMask) * kNodeWords] : 0ull;
 #pragma unroll
@@ -384,11 +387,11 @@ __global__ void __launch_bounds__(256) k_peel_shallow(PeelArgs A, u32 lvl, u32 l
 #pragma unroll
             for (u32 k = 0; k < kTogether; ++k) if (k < gi.w) meet(ee[k], hh[k], ss[k]);
             for (u32 e_i = kTogether; e_i < gi.w; ++e_i) {
-                const u32 e = A.clist[gi.z + e_i];
+                const u32 e = A.clist[g_off + e_i];
                 meet(e, A.node[(u64)(e & kIdMask) * kNodeWords], A.node[(u64)(e & kIdMask) * kNodeWords + kHdrWords]);
             }
-            const bool has = b_root < g;             // (else every consumer belongs to a later DFS root: [g] itself)
-            const u32 ch = has ? b_c : C2A_NONE, depth = has ? b_depth + 1u : 0u, root = has ? b_root : g, label = has ? b_el : 0u;
+            const bool has = b_root < g_orig;        // (else every consumer belongs to a later DFS root: [g] itself)
+            const u32 ch = has ? b_c : C2A_NONE, depth = has ? b_depth + 1u : 0u, root = has ? b_root : g_orig, label = has ? b_el : 0u;
             A.meta[g] = make_uint4(ch, depth, root, label | (lvl << 1));
             if (has) A.child[2 * (u64)ch + label] = g;
             s_root[threadIdx.x] = root; s_depth[threadIdx.x] = depth; s_str[threadIdx.x] = has ? b_x : 0ull;
@@ -525,9 +528,10 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             // static data of a seed (a chain step gets all of this prefetched by the step before; a popped gate brings it
             // along); consumed HERE, in scalar registers where wave-uniform: a load still pending at the loop header would
             // cost every chain step a wait
+            const u32 g_off = uniform(A.cold->cons_off[g]);
             gi = uniform4(A.gstat[2 * (u64)g]);
             gi2 = uniform4(A.gstat[2 * (u64)g + 1]);
-            cl0 = A.clist[gi.z + lane];                                      // clist is padded by 64 entries
+            cl0 = A.clist[g_off + lane];                                     // clist is padded by 64 entries
             C2A_PIN(cl0);
         } else {
             wave_priority(0);
@@ -734,7 +738,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             C2A_PIN(cur.w0); C2A_PIN(cur.w1); C2A_PIN(cur.w2); C2A_PIN(cur.w3); C2A_PIN(cur.w4); C2A_PIN(cur.w5); C2A_PIN(cur.w6); C2A_PIN(cur.w7);
             if (STATS) { const ull ph0c = c2a_now(); ph_w1 += ph0a - ph0; ph_w2 += ph0b - ph0a; ph_w3 += ph0c - ph0b; }
             // (the next gate's static records are written over gi / gi2 below: what the rest of this step needs of its own)
-            const u32 gc = g, g_dep0 = gi.x, g_dep1 = gi.y, g_off = gi.z, g_cnt = gi.w;
+            const u32 gc = g, g_dep0 = gi.x, g_dep1 = gi.y, g_orig = gi.z, g_cnt = gi.w;
             // producer l is claimed when its ticket was the last of cnt (no ticket was taken for a single-consumer producer:
             // 0 of 1; no producer: cnt 0 — the one comparison covers all three)
             const ull ph1 = STATS ? c2a_now() : 0;
@@ -765,7 +769,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             const ull ph2 = STATS ? c2a_now() : 0;
             // ---- tournament of THIS gate
             u32 level = own_level + 1u;
-            if (!(ch_root < gc)) { ch = C2A_NONE; ch_el = 0; ch_root = gc; ch_depth = 0; ch_pos = 0; ch_w = 0; ch_x = 0; }
+            if (!(ch_root < g_orig)) { ch = C2A_NONE; ch_el = 0; ch_root = g_orig; ch_depth = 0; ch_pos = 0; ch_w = 0; ch_x = 0; }
             // one candidate: its record must be all there (else read it again: out of line), then it meets the champion
             auto candidate = [&](u64& w, u32 e) {             // (w by reference: the cold path mends it in place, no copy)
                 const u32 c = e & kIdMask, el = e >> 31;
@@ -842,6 +846,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             }
             // ... then — cold — the consumer list itself, one record at a time, when it holds more than that
             if (C2A_UNLIKELY(cur.more != 0)) {
+                const u32 g_off = uniform(A.cold->cons_off[gc]);
                 for (u32 eb = 0; eb < g_cnt; eb += 64) {
                     u32 blk = A.clist[g_off + eb + lane];
                     C2A_PIN(blk);                                // (consumed here, like w below)
