@@ -62,6 +62,7 @@ struct c2a_ctx {
     u32 peel_fifos = 64;           // dataflow launch: hand-off arrays (a power of two <= 64)
     u32 peel_reserve = 0;          // dataflow launch: reserve waves per CU (join the hand-off lines on demand only).  Measured with 8:
                                    // 2 000 gates per level 14.0 -> 14.5 ms, 4 000: 12.0 -> 9.3, 8 000: 12.8 -> 7.8, 50 000: 10.9 -> 7.3
+    u32 build_no = 0;              // number of the last producer map on this context (tag of its node-table records: k_producer)
     u32 peel_run = 0;              // number of the last dataflow run on this context (tag of its hand-off entries)
     u32 peel_epoch = 0;            // tag of the node words written by the last run (alternates; restarts after a clear)
     bool io_clash = false;         // a node is both an input and an output (compiler.rs:363-383), found at load time
@@ -160,32 +161,43 @@ void rec(c2a_ctx* c, Ev e) {
     if (hipEventRecord(c->ev[e], c->stream) == hipSuccess) c->ev_valid[e] = true;
 }
 
-// one-launch exclusive scans (k_scan_1pass): NC sums of the functor's element values into out0 (/ out1), n + 1 entries each
-// (out[n] = the total); `epi` sees every element with its exclusive prefix.  Descriptors + tile counter live in scan_tmp.
-template <int NC, class F, typename TOut, class Epi>
-int scan_1pass(c2a_ctx* c, hipStream_t s, DevBuf& tmp, u64 n, F f, TOut* out0, TOut* out1, Epi epi) {
+// one-launch exclusive scans (k_scan_stream): NC sums of the functor's element values into out0 (/ out1), n + 1 entries each
+// (out[n] = the total).  Descriptors + the ticket counter live in scan_tmp.
+template <int NC, class F, typename TOut>
+int scan_1pass(c2a_ctx* c, hipStream_t s, DevBuf& tmp, u64 n, F f, TOut* out0, TOut* out1) {
     if (n == 0) {
         HIP_TRY(hipMemsetAsync(out0, 0, sizeof(TOut), s));
         if (NC > 1) HIP_TRY(hipMemsetAsync(out1, 0, sizeof(TOut), s));
         return C2A_OK;
     }
-    const u64 tiles = (n + kScanTile - 1) / kScanTile;
+    const u64 tiles = (n + kScanTile - 1) / kScanTile, groups = (tiles + ScanGeom<NC>::kGroup - 1) / ScanGeom<NC>::kGroup;
     const size_t bytes = 64 + (size_t)tiles * NC * 8;
     ENSURE(tmp, bytes);
     HIP_TRY(hipMemsetAsync(tmp.p, 0, bytes, s));
-    C2A_LAUNCH((k_scan_1pass<NC, F, TOut, Epi>), (u32)tiles, kScanThreads, s, n, f, out0, out1, tmp.as<u64>() + 8, tmp.as<u32>(), epi);
+    C2A_LAUNCH((k_scan_stream<NC, F, TOut>), (u32)groups, ScanGeom<NC>::kThreads, s, n, f, out0, out1, tmp.as<u64>() + 8, tmp.as<u32>());
     return C2A_OK;
 }
 
 // exclusive scan of `in` (n entries, u32) into `out` (n+1 entries; out[n] = total).
 template <typename TOut>
 int scan_exclusive(c2a_ctx* c, const u32* in, TOut* out, u64 n) {
-    return scan_1pass<1>(c, c->stream, c->scan_tmp, n, ScanFromU32{in}, out, (TOut*)nullptr, ScanNoEpilogue{});
+    return scan_1pass<1>(c, c->stream, c->scan_tmp, n, ScanFromU32{in}, out, (TOut*)nullptr);
 }
 
 int read_scalars(c2a_ctx* c, u32* host, int first, int count) {
     HIP_TRY(hipMemcpyAsync(host, c->scalars.as<u32>() + first, sizeof(u32) * count, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return C2A_OK;
+}
+
+// the scalars block cleared and the IO flags of the nodes set (compiler.rs:363-395: a node that is both raises SC_ERR) — in
+// front of k_deps, which folds "the out node is an IO node" into the payload records
+int mark_io(c2a_ctx* c) {
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemsetAsync(c->scalars.p, 0, SC_WORDS * 4, s));
+    HIP_TRY(hipMemsetAsync(c->nflag.p, 0, (size_t)c->n_nodes, s));
+    if (c->n_in) C2A_LAUNCH_NOSYNC(k_mark_inputs, grid_for(c->n_in, 1024), kThreads, s, c->n_in, c->in_nodes.as<u32>(), c->nflag.as<u8>());
+    if (c->n_out) C2A_LAUNCH_NOSYNC(k_mark_outputs, grid_for(c->n_out, 1024), kThreads, s, c->n_out, c->out_nodes.as<u32>(), c->nflag.as<u8>(), c->scalars.as<u32>() + SC_ERR);
     return C2A_OK;
 }
 
@@ -195,21 +207,26 @@ int do_prep(c2a_ctx* c, bool for_peel = true) {
     const u32 n = c->n;
     hipStream_t s = c->stream;
     const u32 G = grid_for(n, 4096);
-    HIP_TRY(hipMemsetAsync(c->prod1.p, 0, (size_t)c->n_nodes * 4, s));
-    HIP_TRY(hipMemsetAsync(c->scalars.p, 0, SC_WORDS * 4, s));
-    const u32* dup = c->scalars.as<u32>() + SC_DUP;
-    C2A_LAUNCH_NOSYNC(k_producer, G, kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->out.as<u32>(), c->op.as<u8>(), c->prod1.as<u32>(), c->nrec.as<uint4>(),
-                      c->scalars.as<u32>() + SC_DUP, c->cons_cnt.as<u32>(), for_peel ? c->fill.as<u32>() : (u32*)nullptr, for_peel ? c->child.as<uint2>() : (uint2*)nullptr);
+    int r0 = mark_io(c);
+    if (r0) return r0;
+    u32* dup = c->scalars.as<u32>() + SC_DUP;
+    // (the node records carry the number of the build that wrote them — 24 bits — and are only ever cleared when that wraps)
+    if (++c->build_no >= (1u << 24)) { HIP_TRY(hipMemsetAsync(c->nrec.p, 0, (size_t)c->n_nodes * 16, s)); c->build_no = 1; }
+    C2A_LAUNCH_NOSYNC(k_producer, G, kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->out.as<u32>(), c->op.as<u8>(), c->nrec.as<uint4>(), c->build_no,
+                      c->cons_cnt.as<u32>(), for_peel ? c->fill.as<u32>() : (u32*)nullptr, for_peel ? c->child.as<uint2>() : (uint2*)nullptr);
     {
         const u64 tiles = ((u64)c->n_nodes + kRelTile - 1) / kRelTile;
         const size_t bytes = 64 + (size_t)tiles * 8;
         ENSURE(c->scan_tmp, bytes);
         HIP_TRY(hipMemsetAsync(c->scan_tmp.p, 0, bytes, s));
-        C2A_LAUNCH(k_relabel, (u32)tiles, kRelThreads, s, c->n_nodes, c->prod1.as<u32>(), (const uint4*)c->nrec.as<uint4>(), dup, c->orig.as<u32>(),
-                          c->gate4.as<uint4>(), c->scan_tmp.as<u64>() + 8, c->scan_tmp.as<u32>());
+        C2A_LAUNCH(k_relabel, (u32)tiles, kRelThreads, s, c->n_nodes, n, c->build_no, c->prod1.as<u32>(), (const uint4*)c->nrec.as<uint4>(), dup, c->orig.as<u32>(),
+                   c->gate4.as<uint4>(), c->scan_tmp.as<u64>() + 8, c->scan_tmp.as<u32>());
     }
+    // (two gates wrote one node — never, for a circuit the reference's front-end built: these two leave at once)
+    C2A_LAUNCH_NOSYNC(k_dup_clear, 512, kThreads, s, c->n_nodes, (const u32*)dup, c->prod1.as<u32>());
+    C2A_LAUNCH_NOSYNC(k_dup_producer, 512, kThreads, s, n, (const u32*)dup, (const u32*)c->out.as<u32>(), c->prod1.as<u32>());
     int r;
-    C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->out.as<u32>(), c->op.as<u8>(), dup, c->prod1.as<u32>(), c->orig.as<u32>(),
+    C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->out.as<u32>(), c->op.as<u8>(), dup, c->prod1.as<u32>(), (const u8*)c->nflag.as<u8>(), c->orig.as<u32>(),
                       c->gate4.as<uint4>(), c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>());
     if (!for_peel) return C2A_OK;
     r = scan_exclusive<u32>(c, c->cons_cnt.as<u32>(), c->cons_off.as<u32>(), n);
@@ -419,7 +436,7 @@ int do_order(c2a_ctx* c) {
     const u32 W = (n + 31u) / 32u;
     HIP_TRY(hipMemsetAsync(c->rbits.p, 0, (size_t)W * 4, s));
     C2A_LAUNCH_NOSYNC(k_root_bits, G, kThreads, s, n, (const uint4*)c->meta.as<uint4>(), (const u32*)c->orig.as<u32>(), c->rbits.as<u32>());
-    int r = scan_1pass<1>(c, s, c->scan_tmp, W, ScanPopc{c->rbits.as<u32>()}, c->rpre.as<u32>(), (u32*)nullptr, ScanNoEpilogue{});
+    int r = scan_1pass<1>(c, s, c->scan_tmp, W, ScanPopc{c->rbits.as<u32>()}, c->rpre.as<u32>(), (u32*)nullptr);
     if (r) return r;
     const u32* n_roots_p = c->rpre.as<u32>() + W;
     C2A_LAUNCH_NOSYNC(k_root_list, G, kThreads, s, n, (const uint4*)c->meta.as<uint4>(), (const u32*)c->orig.as<u32>(), (const u32*)c->rbits.as<u32>(),
@@ -504,7 +521,12 @@ int do_topo_sort(c2a_ctx* c, u64* cycle_at) {
     c->stats = c2a_stats{};
     c->stats.n_gates = n;
     if (cycle_at) *cycle_at = 0;
-    if (n == 0) { c->stage = ST_SORTED; c->peel_meta_valid = true; return C2A_OK; }      // (no gates: no levels, and that is valid level data)
+    if (n == 0) {                                    // (no gates: no levels, and that is valid level data)
+        int r0 = mark_io(c);
+        if (r0) return r0;
+        c->stage = ST_SORTED; c->peel_meta_valid = true;
+        return C2A_OK;
+    }
     rec(c, EV_PREP0);
     int r = do_prep(c);
     if (r) return r;
@@ -569,14 +591,9 @@ int do_assign_wires(c2a_ctx* c, bool defer_readback = false) {
     hipStream_t s = c->stream;
     const u64 m = (u64)n * 3;
     rec(c, EV_WIRES0);
-    C2A_LAUNCH_NOSYNC(k_node_init, grid_for(std::max<u32>(1u, c->n_nodes), 4096), kThreads, s, c->n_nodes, c->node_wire1.as<u32>(), c->nflag.as<u8>(),
-                      c->first.as<u32>(), c->scalars.as<u32>() + SC_ERR);
-    if (c->n_in)
-        C2A_LAUNCH_NOSYNC(k_mark_inputs, grid_for(c->n_in, 1024), kThreads, s, c->n_in, c->in_nodes.as<u32>(),
-                          c->node_wire1.as<u32>(), c->nflag.as<u8>());
-    if (c->n_out)
-        C2A_LAUNCH_NOSYNC(k_mark_outputs, grid_for(c->n_out, 1024), kThreads, s, c->n_out, c->out_nodes.as<u32>(),
-                          c->nflag.as<u8>(), c->scalars.as<u32>() + SC_ERR);
+    // (the IO flags of the nodes and the in / out clash word are do_prep's: they do not change between the sort and here)
+    C2A_LAUNCH_NOSYNC(k_node_init, grid_for(std::max<u32>(1u, c->n_nodes), 4096), kThreads, s, c->n_nodes, c->node_wire1.as<u32>(), c->first.as<u32>());
+    if (c->n_in) C2A_LAUNCH_NOSYNC(k_input_wires, grid_for(c->n_in, 1024), kThreads, s, c->n_in, c->in_nodes.as<u32>(), c->node_wire1.as<u32>());
     const bool fast = !c->has_dup;
     const u64 n_scan = fast ? (u64)n : m;          // entries of the scanned flag array; widx[n_scan] = wires handed out
     const u32 G = grid_for(n, 4096), GN = grid_for(c->n_nodes, 4096);
@@ -584,7 +601,7 @@ int do_assign_wires(c2a_ctx* c, bool defer_readback = false) {
     if (fast) {
         if (n) {
             C2A_LAUNCH_NOSYNC(k_walk, G, kThreads, s, n, c->sorted_r.as<u32>(), (const uint4*)c->gate4.as<uint4>(),
-                              (const u8*)c->nflag.as<u8>(), c->gs.as<uint4>(), c->wcnt.as<u32>(), c->wfo.as<u8>(), c->first.as<u32>());
+                              c->gs.as<uint4>(), c->wcnt.as<u32>(), c->wfo.as<u8>(), c->first.as<u32>());
             C2A_LAUNCH_NOSYNC(k_walk_nodes, GN, kThreads, s, c->n_nodes, (const u32*)c->prod1.as<u32>(), (const u8*)c->nflag.as<u8>(),
                               (const u32*)c->first.as<u32>(), c->wcnt.as<u32>());
         }
@@ -790,6 +807,7 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     c->node_clear = true;
     bool cleared = false;
     if (n && hipMemsetAsync(c->node.p, 0, (size_t)n * kNodeWords * 8, c->aux) == hipSuccess) cleared = true;
+    if (n_nodes) { HIP_TRY(hipMemsetAsync(c->nrec.p, 0, (size_t)n_nodes * 16, c->aux)); c->build_no = 0; }      // (no record of any build)
     ENSURE(c->rbits, n4 / 32 + 8); ENSURE(c->rpre, n4 / 32 + 16); ENSURE(c->ridx, n4); ENSURE(c->rlist, n4);
     ENSURE(c->next, 2 * n4); ENSURE(c->owner, 2 * n4); ENSURE(c->local, 2 * n4); ENSURE(c->slist, 2 * n4);
     ENSURE(c->snext, 2 * n4); ENSURE(c->ssum, 2 * n4); ENSURE(c->jnxt, 2 * n4); ENSURE(c->jval, 2 * n4);
@@ -809,7 +827,8 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     if (n_in) HIP_TRY(hipMemcpyAsync(c->in_nodes.p, input_nodes, (size_t)n_in * 4, hipMemcpyHostToDevice, s));
     if (n_out) HIP_TRY(hipMemcpyAsync(c->out_nodes.p, output_nodes, (size_t)n_out * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
-    if (cleared) { HIP_TRY(hipStreamSynchronize(c->aux)); c->node_clear = false; c->peel_epoch = 0; }
+    HIP_TRY(hipStreamSynchronize(c->aux));
+    if (cleared) { c->node_clear = false; c->peel_epoch = 0; }
     c->stage = ST_LOADED;
     return C2A_OK;
 }
@@ -833,7 +852,7 @@ int c2a_topo_sort_serial(c2a_ctx* c, uint32_t* sorted, uint64_t* cycle_at) {
     c->bool_planned = false; c->fmt_chunk_valid = false; c->pruned = false; c->gathered = false; c->peel_meta_valid = false;
     c->stats = c2a_stats{}; c->stats.n_gates = c->n;
     if (cycle_at) *cycle_at = 0;
-    if (c->n == 0) { c->stage = ST_SORTED; return C2A_OK; }
+    if (c->n == 0) { int r0 = mark_io(c); if (r0) return r0; c->stage = ST_SORTED; return C2A_OK; }
     // the producer map, the relabelling and the deps closure only (no peel)
     int r = do_prep(c, false);
     if (r) return r;
@@ -949,7 +968,7 @@ int bool_plan(c2a_ctx* c, uint32_t width) {
     rec(c, EV_BPREP0);
     ENSURE(c->goff, ((size_t)n + 1) * 8); ENSURE(c->aoff, ((size_t)n + 1) * 8);
     // template sizes and aux-wire counts straight from the op bytes, both scanned in one launch
-    int r = scan_1pass<2>(c, s, c->scan_tmp, n, ScanBoolSizes{c->e_op.as<u8>(), c->tables.as<BoolTables>()}, c->goff.as<u64>(), c->aoff.as<u64>(), ScanNoEpilogue{});
+    int r = scan_1pass<2>(c, s, c->scan_tmp, n, ScanBoolSizes{c->e_op.as<u8>(), c->tables.as<BoolTables>()}, c->goff.as<u64>(), c->aoff.as<u64>());
     if (r) return r;
     C2A_LAUNCH_NOSYNC(k_post_words, 1, 64, s, c->hrb_dev + 24, reinterpret_cast<const u32*>(c->goff.as<u64>() + n), 2u, reinterpret_cast<const u32*>(c->aoff.as<u64>() + n), 2u, (const u32*)nullptr, 0u);
     HIP_TRY(hipStreamSynchronize(s));

@@ -25,183 +25,45 @@ constexpr int kThreads = 256;
 __device__ __forceinline__ u64 gtid() { return (u64)blockIdx.x * blockDim.x + threadIdx.x; }
 __device__ __forceinline__ u64 gstride() { return (u64)gridDim.x * blockDim.x; }
 
+// XCD-AWARE grid-stride.  Workgroup b runs on XCD b % 8 (observed on gfx950, not promised: this is for speed only), and every
+// XCD has an L2 of its own.  A kernel that walks the gates in rank order and looks a bounded distance back (a gate's producers,
+// their consumer lists) has a moving window of nearby data; with the plain grid-stride all eight XCDs sweep the SAME span at
+// once and each L2 has to hold the whole span's window (6 MB for a sweep of 4 096 workgroups: it does not fit).  Here every
+// XCD takes one contiguous eighth of the range and sweeps it with its own workgroups: the window an L2 sees is an eighth as wide.
+#ifndef C2A_XCD_AWARE
+#define C2A_XCD_AWARE 1
+#endif
+struct XcdSweep { u64 i, end, step; };
+__device__ __forceinline__ XcdSweep xcd_sweep(u64 n) {
+#if C2A_XCD_AWARE
+    if ((gridDim.x & 7u) == 0u && n >= 8ull * 4096ull) {
+        const u64 xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, wgs = gridDim.x >> 3;
+        const u64 share = (((n + 7) / 8) + blockDim.x - 1) / blockDim.x * blockDim.x;
+        const u64 lo = xcd * share, hi = lo + share < n ? lo + share : n;
+        return XcdSweep{lo + j * blockDim.x + threadIdx.x, hi, wgs * blockDim.x};
+    }
+#endif
+    return XcdSweep{gtid(), n, gstride()};
+}
+
 }  // namespace c2a
 
 #include "c2a_peel.h"       // (also the agent-scope access helpers the scan below uses)
 
 namespace c2a {
 
-// ------------------------------------------------------------------------------------------------
-// exclusive scan in ONE launch (decoupled look-back): a workgroup takes the next tile of 1024 x 16 elements, publishes the
-// tile's sum as soon as it has it, and finds its exclusive prefix by looking back over the descriptors of the tiles before
-// it (a sum that is already inclusive ends the walk).  NC sums are carried at once (the boolify plan scans the template
-// sizes and the aux-wire counts of the same gates together).  The element values come from a functor — a plain array, or
-// something computed on the fly (root flags from the tree records, template sizes from the op bytes) so that the flag array
-// of a three-kernel scan is never written —, and an epilogue sees every element with its exclusive prefix (the root list is
-// written there).  out[c][n] = the total.
-// ------------------------------------------------------------------------------------------------
-#ifndef C2A_SCAN_ITEMS
-#define C2A_SCAN_ITEMS 16
-#endif
-#ifndef C2A_SCAN_THREADS
-#define C2A_SCAN_THREADS 1024
-#endif
-constexpr int kScanItems = C2A_SCAN_ITEMS;
-constexpr int kScanThreads = C2A_SCAN_THREADS;          // fat tiles: the look-back is a chain over tiles (64 per round trip), 611 of them for 10 M elements
-constexpr int kScanTile = kScanThreads * kScanItems;
 constexpr u64 kScanAgg = 1ull << 62, kScanPre = 2ull << 62, kScanVal = (1ull << 62) - 1ull;
-
-struct ScanNoEpilogue { __device__ __forceinline__ void operator()(u64, const u64*, const u64*) const {} };
-
-template <int NC, class F, typename TOut, class Epi>
-__global__ void __launch_bounds__(kScanThreads) k_scan_1pass(u64 n, F f, TOut* out0, TOut* out1, u64* desc, u32* counter, Epi epi) {
-    __shared__ u32 s_tile;
-    __shared__ u64 s_wave[NC][kScanThreads / 64];
-    __shared__ u64 s_excl[NC];
-    const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    if (tid == 0) s_tile = atomicAdd(counter, 1u);
-    __syncthreads();
-    const u32 tile = s_tile;
-    const u64 base = (u64)tile * kScanTile + (u64)tid * kScanItems;
-    u64 v[kScanItems][NC];
-    u64 sum[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) sum[c] = 0;
-#pragma unroll
-    for (int i = 0; i < kScanItems; ++i) {
-        u64 x[NC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) x[c] = 0;
-        if (base + i < n) f(base + i, x);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) { v[i][c] = x[c]; sum[c] += x[c]; }
-    }
-    // inclusive scan of the per-thread sums inside the wave, then across the four waves
-    u64 inc[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        u64 t = sum[c];
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const u64 o = __shfl_up(t, off, 64);
-            if (lane >= (u32)off) t += o;
-        }
-        inc[c] = t;
-        if (lane == 63) s_wave[c][wv] = t;
-    }
-    __syncthreads();
-    u64 tile_total[NC], wave_base[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        u64 run = 0;
-        wave_base[c] = 0;
-#pragma unroll
-        for (int w = 0; w < kScanThreads / 64; ++w) { if ((u32)w == wv) wave_base[c] = run; run += s_wave[c][w]; }
-        tile_total[c] = run;
-    }
-    // ---- the tile's exclusive prefix: wave 0 publishes the sum and looks back
-    if (wv == 0) {
-        u64 excl[NC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) excl[c] = 0;
-        if (tile == 0) {
-            if (lane == 0) for (int c = 0; c < NC; ++c) st_nw(&desc[(u64)tile * NC + c], kScanPre | tile_total[c]);
-        } else {
-            if (lane == 0) for (int c = 0; c < NC; ++c) st_nw(&desc[(u64)tile * NC + c], kScanAgg | tile_total[c]);
-            i64 look = (i64)tile - 1;               // lane l looks at tile look - l
-            for (;;) {
-                const i64 t = look - (i64)lane;
-                u64 d[NC];
-                bool ready = true;
-#pragma unroll
-                for (int c = 0; c < NC; ++c) { d[c] = t >= 0 ? ld_nw(&desc[(u64)t * NC + c]) : kScanPre; ready = ready && (d[c] >> 62) != 0 && (d[c] >> 62) == (d[0] >> 62); }
-                // the window up to the first tile whose sum is inclusive must be all there; else look again
-                const u64 pre = __ballot(ready && (d[0] >> 62) == 2u);
-                const u64 notready = __ballot(!ready);
-                const u32 upto = pre ? (u32)__builtin_ctzll(pre) : 63u;              // lanes 0..upto are summed
-                const u64 need = upto == 63u ? ~0ull : ((2ull << upto) - 1ull);
-                if (notready & need) continue;                     // (looked at again at once: the tiles before this one are running)
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    u64 x = lane <= upto ? (d[c] & kScanVal) : 0ull;
-#pragma unroll
-                    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
-                    excl[c] += x;
-                }
-                if (pre) break;
-                look -= 64;
-            }
-            if (lane == 0) for (int c = 0; c < NC; ++c) st_nw(&desc[(u64)tile * NC + c], kScanPre | ((excl[c] + tile_total[c]) & kScanVal));
-        }
-        if (lane == 0) for (int c = 0; c < NC; ++c) s_excl[c] = excl[c];
-    }
-    __syncthreads();
-    u64 run[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) run[c] = s_excl[c] + wave_base[c] + inc[c] - sum[c];
-#pragma unroll
-    for (int i = 0; i < kScanItems; ++i) {
-        const u64 idx = base + i;
-        if (idx < n) {
-            if (out0) out0[idx] = (TOut)run[0];
-            if (NC > 1) out1[idx] = (TOut)run[NC - 1];
-            epi(idx, v[i], run);
-        }
-#pragma unroll
-        for (int c = 0; c < NC; ++c) run[c] += v[i][c];
-    }
-    if ((u64)(tile + 1) * kScanTile >= n && tid == kScanThreads - 1 && out0) {      // the last tile: the totals
-        out0[n] = (TOut)(s_excl[0] + tile_total[0]);
-        if (NC > 1) out1[n] = (TOut)(s_excl[NC - 1] + tile_total[NC - 1]);
-    }
-}
-
-// element functors
-struct ScanFromU32 { const u32* in; __device__ __forceinline__ void operator()(u64 i, u64* x) const { x[0] = in[i]; } };
-
-// ------------------------------------------------------------------------------------------------
-// graph prep
-// ------------------------------------------------------------------------------------------------
-// producer[node] = last gate writing it (compiler.rs:403-406: later insert overwrites) -> max gate id.
-// prod1 holds gate id + 1 (0 = no producer); must be zeroed.
-// *dup is raised when two gates write one node (the reference keeps the last writer, compiler.rs:403-406): the relabelling
-// below is then the identity and the wire numbering takes its general path (first-seen by atomicMin over every reference).
-// The gate's payload goes WITH it to its out node — one random 16-byte store here instead of three random reads later
-// (k_relabel picks the records up in node order, i.e. streaming) — and what the rest of the sort keeps per gate (consumer
-// count, claim tickets, tree children) is reset on the way: three coalesced stores instead of three clears of their own.
-__global__ void k_producer(u32 n, const u32* __restrict__ lh, const u32* __restrict__ rh, const u32* __restrict__ out, const u8* __restrict__ op,
-                           u32* prod1, uint4* nrec, u32* dup, u32* cons_cnt, u32* fill, uint2* child) {
-    for (u64 g = gtid(); g < n; g += gstride()) {
-        cons_cnt[g] = 0u;
-        if (fill) { fill[g] = 0u; child[g] = make_uint2(C2A_NONE, C2A_NONE); }
-        const u32 o = out[g];
-        if (atomicMax(&prod1[o], (u32)g + 1) != 0) *dup = 1u;
-        nrec[o] = make_uint4(lh[g], rh[g], (u32)g, (u32)op[g]);      // (two writers of one node race here: *dup is up then, and nobody reads it)
-    }
-}
-
-// RELABELLING.  Gate ids arrive in no particular order (the headline input permutes them), but NODE ids are handed out by a
-// counter as the circuit is built (compiler.rs:497-500): the position of a gate's out node among the produced nodes — its
-// RANK — follows the creation order, producers sit a bounded distance before their consumers, and everything the sort does
-// per edge (deps, consumer lists, node records, the tour, the wire numbering) becomes local in rank space instead of paying a
-// memory sector per 4-byte access.  One scan over the node table: rank = number of produced nodes before this one;
-// orig[rank] = the gate, gate4[rank] = its payload {lh node, rh node, out node, op}, prod1[node] = rank + 1.  From here to
-// k_rank_final every "gate id" is a rank; the DFS roots are compared by orig[] (topological_sort.rs:11-13 walks gate ids).
-// With duplicate writers (*dup) nothing is moved: rank = gate id (k_deps copies the payload as it lies).
-// One launch (decoupled look-back over tiles of 4 096 nodes, like k_scan_1pass) in a STRIPED arrangement — lane l of a round
-// looks at node base + l — so that the flags are a ballot, a node's rank inside the wave a population count, and every access
-// streams: the node table and the records are read as whole lines, orig[] / gate4[] are written as whole lines (consecutive
-// produced nodes have consecutive ranks).
-constexpr int kRelThreads = 256, kRelRounds = 16, kRelTile = kRelThreads * kRelRounds;
-// (wave 0 of a workgroup: publish this tile's sum, find the sum of all tiles before it — one sum, descriptors as in k_scan_1pass)
-__device__ __forceinline__ u64 tile_lookback(u64* desc, u32 tile, u64 tile_total, u32 lane) {
+// (wave 0 of a workgroup: publish this tile's sum, find the sum of all tiles before it.  Descriptors: value | state << 62 —
+// 1: the tile's own sum, 2: the sum up to and including the tile —, `stride` words apart; lane l looks at tile look - l, the
+// window up to the first tile whose sum is inclusive must be all there, else it is looked at again)
+__device__ __forceinline__ u64 tile_lookback(u64* desc, u32 stride, u32 tile, u64 tile_total, u32 lane) {
     u64 excl = 0;
-    if (tile == 0) { if (lane == 0) st_nw(&desc[tile], kScanPre | tile_total); return 0; }
-    if (lane == 0) st_nw(&desc[tile], kScanAgg | tile_total);
-    i64 look = (i64)tile - 1;               // lane l looks at tile look - l
+    if (tile == 0) { if (lane == 0) st_nw(&desc[0], kScanPre | tile_total); return 0; }
+    if (lane == 0) st_nw(&desc[(u64)tile * stride], kScanAgg | tile_total);
+    i64 look = (i64)tile - 1;
     for (;;) {
         const i64 t = look - (i64)lane;
-        const u64 d = t >= 0 ? ld_nw(&desc[t]) : kScanPre;
+        const u64 d = t >= 0 ? ld_nw(&desc[(u64)t * stride]) : kScanPre;
         const u64 pre = __ballot((d >> 62) == 2u);
         const u64 notready = __ballot((d >> 62) == 0u);
         const u32 upto = pre ? (u32)__builtin_ctzll(pre) : 63u;              // lanes 0..upto are summed
@@ -214,31 +76,180 @@ __device__ __forceinline__ u64 tile_lookback(u64* desc, u32 tile, u64 tile_total
         if (pre) break;
         look -= 64;
     }
-    if (lane == 0) st_nw(&desc[tile], kScanPre | ((excl + tile_total) & kScanVal));
+    if (lane == 0) st_nw(&desc[(u64)tile * stride], kScanPre | ((excl + tile_total) & kScanVal));
     return excl;
 }
-__global__ void __launch_bounds__(kRelThreads) k_relabel(u32 n_nodes, u32* prod1, const uint4* __restrict__ nrec, const u32* __restrict__ dup,
+
+// ------------------------------------------------------------------------------------------------
+// exclusive scan in ONE launch (decoupled look-back), STREAMING: a tile is 256 threads x 4 rounds x 4 consecutive elements,
+// so that a lane's accesses are 16-byte vectors next to its neighbours' (the first version gave every thread 16 consecutive
+// elements: 4-byte accesses 64 bytes apart, one cache line per lane per instruction — the texture path, not HBM, set its pace);
+// a workgroup is four such tiles side by side — one ticket for the four (the tickets come from one word, ~11 ns apiece: a
+// ticket per 2 048-element tile was 55 us of a 95 us scan), each quarter publishes its own sum and looks back on its own (tiles
+// worked off one after the other by one workgroup would chain the look-backs: every tile would wait for the whole tile before).  NC sums are carried at once (the boolify plan
+// scans the template sizes and the aux-wire counts of the same gates together); the element values come from a functor (a plain
+// array, template sizes from op bytes, bit counts of a bitmap's words: the array a three-kernel scan would read is never
+// written).  out[c][n] = the total.
+// ------------------------------------------------------------------------------------------------
+constexpr int kScanQuarter = 256, kScanRounds = 4, kScanVec = 4;
+constexpr int kScanTile = kScanQuarter * kScanRounds * kScanVec;      // 4 096 elements
+// tiles per ticket = 256-thread parts of a workgroup: four for one sum, two for two (the two-sum scan needs more than the 128
+// registers a 1 024-thread workgroup leaves a thread: it spilled 300 bytes per lane)
+template <int NC> struct ScanGeom { static constexpr int kGroup = NC == 1 ? 4 : 2; static constexpr int kThreads = kScanQuarter * kGroup; };
+
+template <int NC, class F, typename TOut>
+__global__ void __launch_bounds__(ScanGeom<NC>::kThreads) k_scan_stream(u64 n, F f, TOut* out0, TOut* out1, u64* desc, u32* counter) {
+    constexpr int kScanGroup = ScanGeom<NC>::kGroup;
+    __shared__ u32 s_group;
+    __shared__ u64 s_part[kScanGroup][NC][kScanRounds][kScanQuarter / 64];
+    __shared__ u64 s_excl[kScanGroup][NC];
+    const u32 q = threadIdx.x / kScanQuarter, tid = threadIdx.x % kScanQuarter, lane = tid & 63u, wv = tid >> 6;
+    if (threadIdx.x == 0) s_group = atomicAdd(counter, 1u);
+    __syncthreads();
+    const u64 n_tiles = (n + kScanTile - 1) / kScanTile;
+    const u64 tile = (u64)s_group * kScanGroup + q;         // (a tile beyond the end: its lanes see no element and publish nothing)
+    const bool live = tile < n_tiles;
+    const u64 tbase = tile * kScanTile;
+    u32 v[kScanRounds][kScanVec][NC];                      // (element values are 32-bit, sums 64-bit: with 64-bit values the two-sum scan spilled)
+    u64 rs[kScanRounds][NC];
+#pragma unroll
+    for (int j = 0; j < kScanRounds; ++j) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) rs[j][c] = 0;
+#pragma unroll
+        for (int e = 0; e < kScanVec; ++e) {
+            const u64 idx = tbase + (u64)j * (kScanQuarter * kScanVec) + (u64)tid * kScanVec + e;
+            u32 x[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) x[c] = 0;
+            if (live && idx < n) f(idx, x);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { v[j][e][c] = x[c]; rs[j][c] += x[c]; }
+        }
+    }
+    // inclusive scan of the per-thread sums of every round inside the wave; the waves' totals meet in LDS
+    u64 inc[kScanRounds][NC];
+#pragma unroll
+    for (int j = 0; j < kScanRounds; ++j)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            u64 t = rs[j][c];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const u64 o = __shfl_up(t, off, 64);
+                if (lane >= (u32)off) t += o;
+            }
+            inc[j][c] = t;
+            if (lane == 63) s_part[q][c][j][wv] = t;
+        }
+    __syncthreads();
+    // element order inside a tile: round, then wave, then lane
+    u64 before[kScanRounds][NC], tile_total[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        u64 run = 0;
+#pragma unroll
+        for (int j = 0; j < kScanRounds; ++j)
+#pragma unroll
+            for (int w = 0; w < kScanQuarter / 64; ++w) { if ((u32)w == wv) before[j][c] = run; run += s_part[q][c][j][w]; }
+        tile_total[c] = run;
+    }
+    if (live && wv == 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const u64 e = tile_lookback(desc + c, (u32)NC, (u32)tile, tile_total[c], lane);
+            if (lane == 0) s_excl[q][c] = e;
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+#pragma unroll
+    for (int j = 0; j < kScanRounds; ++j) {
+        u64 run[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) run[c] = s_excl[q][c] + before[j][c] + inc[j][c] - rs[j][c];
+#pragma unroll
+        for (int e = 0; e < kScanVec; ++e) {
+            const u64 idx = tbase + (u64)j * (kScanQuarter * kScanVec) + (u64)tid * kScanVec + e;
+            if (idx < n) {
+                out0[idx] = (TOut)run[0];
+                if (NC > 1) out1[idx] = (TOut)run[NC - 1];
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) run[c] += v[j][e][c];
+        }
+    }
+    if (tile + 1 == n_tiles && tid == 0) {           // the last tile: the totals
+        out0[n] = (TOut)(s_excl[q][0] + tile_total[0]);
+        if (NC > 1) out1[n] = (TOut)(s_excl[q][NC - 1] + tile_total[NC - 1]);
+    }
+}
+
+// element functors
+struct ScanFromU32 { const u32* in; __device__ __forceinline__ void operator()(u64 i, u32* x) const { x[0] = in[i]; } };
+
+// ------------------------------------------------------------------------------------------------
+// graph prep
+// ------------------------------------------------------------------------------------------------
+// producer[node] = last gate writing it (compiler.rs:401-406: a later insert overwrites an earlier one).
+// NO ATOMICS on the way in: every gate stores its payload into its OUT NODE's record — one scattered 16-byte store, tagged with
+// the number of this build (the records are never cleared between builds) — and k_relabel, which walks the node table anyway,
+// counts the tagged records: as many as gates <=> every node has one writer, which is what the reference's front-end produces.
+// Fewer <=> two gates wrote one node (*dup, raised by k_relabel): the two kernels behind it then redo the producer map with
+// atomicMax (the last writer = the largest gate id), the relabelling is the identity and the wire numbering takes its general
+// path.  (Round 3: 10 M scattered atomicMax, 0.40 ms, for a case that does not occur.)
+// What the rest of the sort keeps per gate (consumer count, claim tickets, tree children) is reset on the way: three coalesced
+// stores instead of three clears of their own.
+__global__ void k_producer(u32 n, const u32* __restrict__ lh, const u32* __restrict__ rh, const u32* __restrict__ out, const u8* __restrict__ op,
+                           uint4* nrec, u32 build, u32* cons_cnt, u32* fill, uint2* child) {
+    for (u64 g = gtid(); g < n; g += gstride()) {
+        cons_cnt[g] = 0u;
+        if (fill) { fill[g] = 0u; child[g] = make_uint2(C2A_NONE, C2A_NONE); }
+        nrec[out[g]] = make_uint4(lh[g], rh[g], (u32)g, (u32)op[g] | (build << 8));
+    }
+}
+__global__ void k_dup_clear(u32 n_nodes, const u32* __restrict__ dup, u32* prod1) {
+    if (*dup == 0u) return;
+    for (u64 v = gtid(); v < n_nodes; v += gstride()) prod1[v] = 0u;
+}
+__global__ void k_dup_producer(u32 n, const u32* __restrict__ dup, const u32* __restrict__ out, u32* prod1) {
+    if (*dup == 0u) return;
+    for (u64 g = gtid(); g < n; g += gstride()) atomicMax(&prod1[out[g]], (u32)g + 1u);
+}
+
+// RELABELLING.  Gate ids arrive in no particular order (the headline input permutes them), but NODE ids are handed out by a
+// counter as the circuit is built (compiler.rs:497-500): the position of a gate's out node among the produced nodes — its
+// RANK — follows the creation order, producers sit a bounded distance before their consumers, and what the sort does per edge
+// (deps, consumer lists, node records) becomes local in rank space.  One pass over the node table: rank = number of produced
+// nodes before this one; orig[rank] = the gate, gate4[rank] = its payload {lh node, rh node, out node, op}, prod1[node] =
+// rank + 1 (0: nobody produces it).  From here to k_rank_final every "gate id" is a rank; the DFS roots are compared by orig[]
+// (topological_sort.rs:11-13 walks gate ids).  With duplicate writers nothing is moved: rank = gate id (k_deps copies the
+// payload as it lies).
+// One launch (decoupled look-back over tiles of 4 096 nodes, like k_scan_1pass) in a STRIPED arrangement — lane l of a round
+// looks at node base + l — so that the flags are a ballot, a node's rank inside the wave a population count, and every access
+// streams: the node table and the records are read as whole lines, orig[] / gate4[] are written as whole lines (consecutive
+// produced nodes have consecutive ranks).
+constexpr int kRelThreads = 256, kRelRounds = 16, kRelTile = kRelThreads * kRelRounds;
+__global__ void __launch_bounds__(kRelThreads) k_relabel(u32 n_nodes, u32 n, u32 build, u32* prod1, const uint4* __restrict__ nrec, u32* dup,
                                                          u32* orig, uint4* gate4, u64* desc, u32* counter) {
     __shared__ u32 s_tile, s_wave[kRelThreads / 64];
     __shared__ u64 s_excl;
-    if (*dup != 0u) return;                        // (wave-uniform, grid-uniform: nobody takes a tile)
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     if (tid == 0) s_tile = atomicAdd(counter, 1u);
     __syncthreads();
     const u32 tile = s_tile;
     const u64 base = (u64)tile * kRelTile + (u64)wv * (64 * kRelRounds) + lane;
     const u64 lt_mask = (1ull << lane) - 1ull;
-    u32 p[kRelRounds], pre[kRelRounds];
-#pragma unroll
-    for (int i = 0; i < kRelRounds; ++i) { const u64 v = base + (u64)i * 64; p[i] = v < n_nodes ? prod1[v] : 0u; }
-    u32 cnt = 0;
+    u32 pre[kRelRounds];
     uint4 rec[kRelRounds];
 #pragma unroll
+    for (int i = 0; i < kRelRounds; ++i) { const u64 v = base + (u64)i * 64; rec[i] = v < n_nodes ? nrec[v] : make_uint4(0u, 0u, 0u, ~build << 8); }
+    u32 cnt = 0;
+#pragma unroll
     for (int i = 0; i < kRelRounds; ++i) {
-        const u64 bal = __ballot(p[i] != 0u);
+        const u64 bal = __ballot((rec[i].w >> 8) == build);      // a record of THIS build: the node is produced
         pre[i] = cnt + (u32)__popcll(bal & lt_mask);
         cnt += (u32)__popcll(bal);
-        if (p[i] != 0u) rec[i] = nrec[base + (u64)i * 64];      // (on its way while the tile finds its place)
     }
     if (lane == 0) s_wave[wv] = cnt;
     __syncthreads();
@@ -246,36 +257,42 @@ __global__ void __launch_bounds__(kRelThreads) k_relabel(u32 n_nodes, u32* prod1
 #pragma unroll
     for (u32 w = 0; w < kRelThreads / 64; ++w) { const u32 v = s_wave[w]; wave_base += w < wv ? v : 0u; tile_total += v; }
     if (wv == 0) {
-        const u64 e = tile_lookback(desc, tile, tile_total, lane);
+        const u64 e = tile_lookback(desc, 1u, tile, tile_total, lane);
         if (lane == 0) s_excl = e;
     }
     __syncthreads();
     const u32 first = (u32)s_excl + wave_base;
+    // (the tile that ends the table knows how many nodes are produced: fewer than gates = a node with two writers)
+    if (tid == 0 && (u64)(tile + 1) * kRelTile >= n_nodes && (u32)s_excl + tile_total != n) *dup = 1u;
 #pragma unroll
     for (int i = 0; i < kRelRounds; ++i) {
-        if (p[i] == 0u) continue;
         const u64 v = base + (u64)i * 64;
+        if (v >= n_nodes) continue;
+        if ((rec[i].w >> 8) != build) { prod1[v] = 0u; continue; }
         const u32 rank = first + pre[i];
-        orig[rank] = p[i] - 1u;                    // (one writer per node here: the record's gate is the producer)
-        gate4[rank] = make_uint4(rec[i].x, rec[i].y, (u32)v, rec[i].w);
+        if (rank < n) {                            // (always, unless two gates wrote one node: then all of this is redone)
+            orig[rank] = rec[i].z;
+            gate4[rank] = make_uint4(rec[i].x, rec[i].y, (u32)v, rec[i].w & 0xFFu);
+        }
         prod1[v] = rank + 1u;
     }
 }
 
 // deps closure (compiler.rs:408-421) + consumer counts, in rank space.  dep1 is dropped when equal to dep0: a second
 // visit of the same gate is a no-op in the DFS (topological_sort.rs:30-32).
-// The payload record gets two flags {lh node un-produced << 8 | rh node un-produced << 9}: what the numbering kernels want to
-// know about the two input nodes (does any gate produce them?) comes along instead of costing two more reads.
+// The payload record gets three flags {lh node un-produced << 8 | rh node un-produced << 9 | out node is an IO node << 10}:
+// what the numbering kernels want to know about a gate's nodes comes along instead of costing three more scattered reads.
 __global__ void k_deps(u32 n, const u32* __restrict__ lh, const u32* __restrict__ rh, const u32* __restrict__ out, const u8* __restrict__ op,
-                       const u32* __restrict__ dup, const u32* __restrict__ prod1, u32* orig, uint4* gate4, u32* dep0, u32* dep1,
-                       u32* cons_cnt, u32* eslot) {
+                       const u32* __restrict__ dup, const u32* __restrict__ prod1, const u8* __restrict__ nflag, u32* orig, uint4* gate4,
+                       u32* dep0, u32* dep1, u32* cons_cnt, u32* eslot) {
     const bool ident = *dup != 0u;
-    for (u64 g = gtid(); g < n; g += gstride()) {
+    const XcdSweep R = xcd_sweep(n);
+    for (u64 g = R.i; g < R.end; g += R.step) {
         uint4 r;
         if (ident) { r = make_uint4(lh[g], rh[g], out[g], (u32)op[g]); orig[g] = (u32)g; }
         else r = gate4[g];
         const u32 p0 = prod1[r.x], p1 = prod1[r.y];
-        gate4[g] = make_uint4(r.x, r.y, r.z, (r.w & 0xFFu) | (p0 ? 0u : 0x100u) | (p1 ? 0u : 0x200u));
+        gate4[g] = make_uint4(r.x, r.y, r.z, (r.w & 0xFFu) | (p0 ? 0u : 0x100u) | (p1 ? 0u : 0x200u) | (nflag[r.z] ? 0x400u : 0u));
         const u32 d0 = p0 ? p0 - 1 : C2A_NONE;
         u32 d1 = p1 ? p1 - 1 : C2A_NONE;
         if (d1 == d0) d1 = C2A_NONE;
@@ -297,7 +314,7 @@ __global__ void k_root_bits(u32 n, const uint4* __restrict__ meta, const u32* __
     for (u64 r = gtid(); r < n; r += gstride())
         if (meta[r].x == C2A_NONE) { const u32 o = orig[r]; atomicOr(&rbits[o >> 5], 1u << (o & 31u)); }
 }
-struct ScanPopc { const u32* w; __device__ __forceinline__ void operator()(u64 i, u64* x) const { x[0] = (u64)__popc(w[i]); } };
+struct ScanPopc { const u32* w; __device__ __forceinline__ void operator()(u64 i, u32* x) const { x[0] = (u32)__popc(w[i]); } };
 __global__ void k_root_list(u32 n, const uint4* __restrict__ meta, const u32* __restrict__ orig, const u32* __restrict__ rbits,
                             const u32* __restrict__ rpre, u32* ridx, u32* rlist) {
     for (u64 r = gtid(); r < n; r += gstride()) {
@@ -529,17 +546,18 @@ __global__ void k_serial_levels(u32 n, const u32* __restrict__ sorted_r, const u
 // wire numbering (compiler.rs:388-449) and gate emission (compiler.rs:451-464)
 // node_wire1[node] = wire id + 1 (0 = none); nflag bit0 = input node, bit1 = output node.
 // ------------------------------------------------------------------------------------------------
-// the per-node state of the wire numbering in one launch (was three clears): no wire, no IO flag, not seen yet
-__global__ void k_node_init(u32 n_nodes, u32* node_wire1, u8* nflag, u32* first, u32* err) {
-    if (gtid() == 0) *err = 0u;
-    for (u64 v = gtid(); v < n_nodes; v += gstride()) { node_wire1[v] = 0u; nflag[v] = 0; first[v] = 0xFFFFFFFFu; }
+// The IO flags of the nodes are set up in front of the sort (do_prep: nflag cleared, inputs marked, then outputs): k_deps
+// folds "the out node is an IO node" into the gate's payload record, where the out nodes lie in rank order, and the walk in
+// sorted order (k_walk) no longer pays a scattered read per gate for it.
+__global__ void k_mark_inputs(u32 n_in, const u32* __restrict__ in_nodes, u8* nflag) {
+    for (u64 i = gtid(); i < n_in; i += gstride()) nflag[in_nodes[i]] = 1;      // (all writers store the same byte)
 }
-__global__ void k_mark_inputs(u32 n_in, const u32* __restrict__ in_nodes, u32* node_wire1, u8* nflag) {
-    for (u64 i = gtid(); i < n_in; i += gstride()) {
-        const u32 node = in_nodes[i];
-        atomicMax(&node_wire1[node], (u32)i + 1);   // duplicate node: the later insert wins (:392-395)
-        nflag[node] = 1;                            // (all writers store the same byte)
-    }
+// the per-node state of the wire numbering in one launch: no wire, not seen yet; then the input wires (compiler.rs:388-395)
+__global__ void k_node_init(u32 n_nodes, u32* node_wire1, u32* first) {
+    for (u64 v = gtid(); v < n_nodes; v += gstride()) { node_wire1[v] = 0u; first[v] = 0xFFFFFFFFu; }
+}
+__global__ void k_input_wires(u32 n_in, const u32* __restrict__ in_nodes, u32* node_wire1) {
+    for (u64 i = gtid(); i < n_in; i += gstride()) atomicMax(&node_wire1[in_nodes[i]], (u32)i + 1);   // duplicate node: the later insert wins (:392-395)
 }
 
 // outputs are marked in a second launch so that "input and output" is seen whatever the order
@@ -635,14 +653,14 @@ __global__ void k_emit(u32 n, const u32* __restrict__ sorted, const uint4* __res
 //   k_assign_nodes  the un-produced nodes' wires (lh before rh inside one gate, compiler.rs:430)
 //   k_emit_fast     in0 / in1 by gather, out by formula, op from the record
 __global__ void k_walk(u32 n, const u32* __restrict__ sorted, const uint4* __restrict__ gate4,
-                       const u8* __restrict__ nflag, uint4* gs, u32* cnt, u8* fo, u32* first) {
+                       uint4* gs, u32* cnt, u8* fo, u32* first) {
     for (u64 pos = gtid(); pos < n; pos += gstride()) {
         const uint4 g = gate4[sorted[pos]];
         gs[pos] = g;
         const u32 i = 3u * (u32)pos;
         if (g.w & 0x100u) atomicMin(&first[g.x], i);                              // (un-produced input nodes: flags packed by k_deps)
         if (g.w & 0x200u) atomicMin(&first[g.y], i + 1);
-        const u32 f = nflag[g.z] == 0 ? 1u : 0u;                                 // :431-438 for the out node
+        const u32 f = (g.w & 0x400u) ? 0u : 1u;                                  // :431-438 for the out node (IO flag packed by k_deps)
         cnt[pos] = f;
         fo[pos] = (u8)f;
     }
@@ -702,7 +720,7 @@ struct BoolTables {
 // T(op, w) and AUX(op, w) of the gate at sorted position p, for the scan that places its boolean gates and aux wires
 struct ScanBoolSizes {
     const u8* e_op; const BoolTables* T;
-    __device__ __forceinline__ void operator()(u64 p, u64* x) const { const u32 o = e_op[p]; x[0] = T->tsize[o]; x[1] = T->taux[o]; }
+    __device__ __forceinline__ void operator()(u64 p, u32* x) const { const u32 o = e_op[p]; x[0] = T->tsize[o]; x[1] = T->taux[o]; }
 };
 
 // cut[k] = first sorted position p with goff[p] >= G k / N (k = 0..N; cut[N] = n), qcut[k] = goff[cut[k]]: N ranges of

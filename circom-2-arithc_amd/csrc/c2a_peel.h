@@ -253,7 +253,8 @@ __global__ void k_gstat(u32 n, const u32* __restrict__ dep0, const u32* __restri
     // 8-byte access per producer instead of two 4-byte ones in two arrays.  Word 2 of a gate's first record is its ORIGINAL
     // id — what the DFS roots are compared by, topological_sort.rs:11-13; the launch works in rank space, c2a_kernels.h
     // RELABELLING —; the offset of its own consumer list is only wanted off the hot path and is read from cons_off there)
-    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (u64)gridDim.x * blockDim.x) {
+    const XcdSweep R = xcd_sweep(n);
+    for (u64 g = R.i; g < R.end; g += R.step) {
         const u32 d0 = dep0[g], d1 = dep1[g];
         const u32 o = cons_off[g];
         gstat[2 * g] = make_uint4(d0, d1, orig[g], cons_off[g + 1] - o);
