@@ -114,17 +114,6 @@ class BristolCircuit:               # compiler.rs:478-493
         head = self.header().encode()
         w.write(head)
         nbytes = len(head)
-        if which == 1 and len(getattr(backend, "devices", [0])) > 1:
-            # the boolean circuit is spread over the devices of the context: stream it chunk by chunk through the primary
-            # device instead (c2a_boolify_chunk + which = 2) — same gates, same text
-            backend.boolify_plan(self.io_widths[0][0] if self.io_widths[0] else self.io_widths[1][0])
-            step = max(1, chunk_gates // 64)
-            for first in range(0, backend.n, step):
-                _, cnt = backend.boolify_chunk(first, min(step, backend.n - first), fetch=False)
-                part = backend.format_bristol(2, 0, cnt) if cnt else b""
-                w.write(part)
-                nbytes += len(part)
-            return nbytes
         for first in range(0, total, chunk_gates):
             part = backend.format_bristol(which, first, min(chunk_gates, total - first))
             w.write(part)

@@ -39,6 +39,7 @@ struct PeerDev {
     u64 q_lo = 0, q_hi = 0;        // boolean gates [q_lo, q_hi) of the whole circuit
     u64 q_bias = 0;                // boolean gate q is stored at index q - q_bias
     DevBuf e_in0, e_in1, e_out, e_op, goff, aoff, tmpl, tables, b_in0, b_in1, b_out, b_op, acc;
+    DevBuf fmt_len, fmt_off, fmt_text, fmt_table, scan_tmp;      // c2a_format_bristol prints a device's own gates on that device
     u32 tmpl_width = 0;
 };
 
@@ -743,7 +744,8 @@ void c2a_destroy(c2a_ctx* c) {
     for (PeerDev& P : c->peers) {
         (void)hipSetDevice(P.device);
         if (P.stream) { (void)hipStreamSynchronize(P.stream); }
-        for (DevBuf* b : {&P.e_in0, &P.e_in1, &P.e_out, &P.e_op, &P.goff, &P.aoff, &P.tmpl, &P.tables, &P.b_in0, &P.b_in1, &P.b_out, &P.b_op, &P.acc})
+        for (DevBuf* b : {&P.e_in0, &P.e_in1, &P.e_out, &P.e_op, &P.goff, &P.aoff, &P.tmpl, &P.tables, &P.b_in0, &P.b_in1, &P.b_out, &P.b_op, &P.acc,
+                          &P.fmt_len, &P.fmt_off, &P.fmt_text, &P.fmt_table, &P.scan_tmp})
             if (b->p) (void)hipFree(b->p);
         if (P.stream) (void)hipStreamDestroy(P.stream);
     }
@@ -917,11 +919,15 @@ int c2a_build_circuit(c2a_ctx* c, uint64_t* cycle_at, uint32_t* wire_count) {
     int r = do_topo_sort(c, cycle_at);
     if (r) return r;
     c->ev_valid[EV_BUILD0] = true;
-    if ((r = do_assign_wires(c, true))) return r;    // (its read-back is picked up below: one host round trip for numbering + emission)
+    // (the numbering's read-back is picked up below — one host round trip for numbering + emission —: until it has been, the
+    // stage must not stay at WIRED / EMITTED with the wire count of the graph before)
+    struct StageGuard { c2a_ctx* c; bool armed; ~StageGuard() { if (armed && c->stage > ST_SORTED) c->stage = ST_SORTED; } } guard{c, true};
+    if ((r = do_assign_wires(c, true))) return r;
     if ((r = do_emit(c))) return r;
     rec(c, EV_BUILD1);
     HIP_TRY(hipStreamSynchronize(c->stream));
     if ((r = finish_wires(c))) return r;
+    guard.armed = false;
     if (wire_count) *wire_count = c->wire_count;
     return C2A_OK;
 }
@@ -1175,7 +1181,7 @@ int c2a_boolify_shard_range(c2a_ctx* c, uint32_t k, uint32_t n_shards, uint64_t*
 int c2a_bool_read(c2a_ctx* c, uint64_t first, uint64_t count, uint32_t* in0, uint32_t* in1, uint32_t* out, uint8_t* op) {
     if (!c) return C2A_ERR_ARG;
     if (c->stage < ST_BOOLIFIED) return fail(c, C2A_ERR_STATE, "c2a_bool_read: call c2a_boolify first");
-    if (first + count > c->binfo.n_gates) return fail(c, C2A_ERR_ARG, "c2a_bool_read: range out of bounds");
+    if (first > c->binfo.n_gates || count > c->binfo.n_gates - first) return fail(c, C2A_ERR_ARG, "c2a_bool_read: range out of bounds");
     // the boolean circuit may be spread over the devices of the context: copy each owner's part of [first, first + count)
     const u64 last = first + count;
     const u64 own_hi = c->peers.empty() ? c->binfo.n_gates : c->shard0_qhi;
@@ -1304,6 +1310,14 @@ static int eval_levels(c2a_ctx* c) {
     return C2A_OK;
 }
 
+// a level-parallel launch whose grid barrier gave up (kBarrierPolls: some workgroup was never resident) reports it here
+static int barrier_gave_up(c2a_ctx* c, const char* who) {
+    u32 ab = 0;
+    HIP_TRY(hipMemcpy(&ab, c->ev_bar.as<u32>() + kBarAbort, 4, hipMemcpyDeviceToHost));
+    if (ab) return fail(c, C2A_ERR_HIP, std::string(who) + ": the grid barrier of the level-parallel launch gave up (not every workgroup of the grid was resident)");
+    return C2A_OK;
+}
+
 static int eval_run(c2a_ctx* c, u32 mode, u32 width) {
     hipStream_t s = c->stream;
     if (!c->n) return C2A_OK;
@@ -1315,8 +1329,8 @@ static int eval_run(c2a_ctx* c, u32 mode, u32 width) {
     if (mode & 2u) { int rv = full_bool(c, &bv); if (rv) return rv; }
     R.goff = c->goff.as<u64>(); R.b_in0 = bv.in0; R.b_in1 = bv.in1; R.b_out = bv.out; R.b_op = bv.op;
     R.aval = c->ev_aval.as<u64>(); R.bval = c->ev_bval.as<u64>();
-    ENSURE(c->ev_bar, 64);
-    HIP_TRY(hipMemsetAsync(c->ev_bar.p, 0, 64, s));
+    ENSURE(c->ev_bar, 256);
+    HIP_TRY(hipMemsetAsync(c->ev_bar.p, 0, 256, s));
     R.bar = c->ev_bar.as<u32>();
     // every workgroup waits for every other at the end of a level: the grid must be resident as a whole
     u32 grid = 8;
@@ -1335,6 +1349,7 @@ int c2a_verify_boolify(c2a_ctx* c, uint64_t seed, uint64_t* n_checked, uint64_t*
     if (!c) return C2A_ERR_ARG;
     if (c->stage < ST_BOOLIFIED) return fail(c, C2A_ERR_STATE, "c2a_verify_boolify: call c2a_boolify first");
     if (!c->peel_meta_valid) return fail(c, C2A_ERR_STATE, "c2a_verify_boolify: needs the level data of c2a_topo_sort (not of c2a_topo_sort_serial)");
+    if (c->has_dup) return fail(c, C2A_ERR_STATE, "c2a_verify_boolify: two gates write one node (compiler.rs:403-406 keeps the last): the level-parallel passes do not order the writers of one wire — evaluate the emitted gate list sequentially instead");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const u32 n = c->n, wc = c->wire_count, width = c->binfo.width, M = c->binfo.m_wires;
@@ -1358,6 +1373,7 @@ int c2a_verify_boolify(c2a_ctx* c, uint64_t seed, uint64_t* n_checked, uint64_t*
     u64 bad = 0;
     HIP_TRY(hipMemcpyAsync(&bad, acc, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (n && (r = barrier_gave_up(c, "c2a_verify_boolify"))) return r;
     if (n_checked) *n_checked = (u64)wc * 64;
     if (n_mismatch) *n_mismatch = bad;
     return C2A_OK;
@@ -1368,6 +1384,7 @@ int c2a_boolify_prune(c2a_ctx* c, c2a_prune_info* info) {
     c->pruned = false;
     if (c->stage < ST_BOOLIFIED) return fail(c, C2A_ERR_STATE, "c2a_boolify_prune: call c2a_boolify first");
     if (!c->peel_meta_valid) return fail(c, C2A_ERR_STATE, "c2a_boolify_prune: needs the level data of c2a_topo_sort (not of c2a_topo_sort_serial)");
+    if (c->has_dup) return fail(c, C2A_ERR_STATE, "c2a_boolify_prune: two gates write one node (compiler.rs:403-406 keeps the last): the level-parallel passes do not order the writers of one wire — evaluate the emitted gate list sequentially instead");
     if (c->binfo.wire_count + 2 >= 0xFFFFFFFFull) return fail(c, C2A_ERR_OVERFLOW, "c2a_boolify_prune: no room for the two constant wires in u32");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
@@ -1375,7 +1392,7 @@ int c2a_boolify_prune(c2a_ctx* c, c2a_prune_info* info) {
     const u64 G = c->binfo.n_gates, wires = c->binfo.wire_count;
     ENSURE(c->pr_rep, (wires + 2) * 4); ENSURE(c->pr_need, (wires + 2) * 4);
     ENSURE(c->pr_tin0, G * 4 + 16); ENSURE(c->pr_tin1, G * 4 + 16); ENSURE(c->pr_top, G + 16);
-    ENSURE(c->pr_live, (size_t)n * 4 + 16); ENSURE(c->pr_goff, ((size_t)n + 1) * 4); ENSURE(c->pr_counts, 64); ENSURE(c->ev_bar, 64);
+    ENSURE(c->pr_live, (size_t)n * 4 + 16); ENSURE(c->pr_goff, ((size_t)n + 1) * 4); ENSURE(c->pr_counts, 64); ENSURE(c->ev_bar, 256);
     HIP_TRY(hipMemsetAsync(c->pr_counts.p, 0, 64, s));
     C2A_LAUNCH_NOSYNC(k_prune_init, grid_for(wires + 2, 8192), kThreads, s, wires + 2, c->pr_rep.as<u32>(), c->pr_need.as<u32>());
     int r = eval_levels(c);
@@ -1400,9 +1417,9 @@ int c2a_boolify_prune(c2a_ctx* c, c2a_prune_info* info) {
     }
 #endif
     if (n) {
-        HIP_TRY(hipMemsetAsync(c->ev_bar.p, 0, 64, s));
+        HIP_TRY(hipMemsetAsync(c->ev_bar.p, 0, 256, s));
         C2A_LAUNCH_CONCURRENT(k_prune_fold, grid, kThreads, s, R);
-        HIP_TRY(hipMemsetAsync(c->ev_bar.p, 0, 64, s));
+        HIP_TRY(hipMemsetAsync(c->ev_bar.p, 0, 4, s));      // (the arrival count only: a give-up of the first pass must stay visible)
         C2A_LAUNCH_CONCURRENT(k_prune_live, grid, kThreads, s, R);
     }
     r = scan_exclusive<u32>(c, c->pr_live.as<u32>(), c->pr_goff.as<u32>(), n);
@@ -1412,6 +1429,7 @@ int c2a_boolify_prune(c2a_ctx* c, c2a_prune_info* info) {
     HIP_TRY(hipMemcpyAsync(&kept, c->pr_goff.as<u32>() + n, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(cnts, c->pr_counts.p, 16, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (n && (r = barrier_gave_up(c, "c2a_boolify_prune"))) return r;
     const u64 PG = (u64)kept + 2;
     ENSURE(c->p_in0, PG * 4); ENSURE(c->p_in1, PG * 4); ENSURE(c->p_out, PG * 4); ENSURE(c->p_op, PG);
     C2A_LAUNCH_NOSYNC(k_prune_consts, 1, 64, s, R.zero_wire, R.one_wire, c->p_in0.as<u32>(), c->p_in1.as<u32>(), c->p_out.as<u32>(), c->p_op.as<u8>());
@@ -1430,7 +1448,7 @@ int c2a_boolify_prune(c2a_ctx* c, c2a_prune_info* info) {
 int c2a_pruned_read(c2a_ctx* c, uint64_t first, uint64_t count, uint32_t* in0, uint32_t* in1, uint32_t* out, uint8_t* op) {
     if (!c) return C2A_ERR_ARG;
     if (!c->pruned || c->stage < ST_BOOLIFIED) return fail(c, C2A_ERR_STATE, "c2a_pruned_read: call c2a_boolify_prune first");
-    if (first + count > c->pinfo.n_gates) return fail(c, C2A_ERR_ARG, "c2a_pruned_read: range out of bounds");
+    if (first > c->pinfo.n_gates || count > c->pinfo.n_gates - first) return fail(c, C2A_ERR_ARG, "c2a_pruned_read: range out of bounds");
     HIP_TRY(hipSetDevice(c->device));
     int r;
     if ((r = copy_out(c, in0, c->p_in0.as<u32>() + first, count * 4)) || (r = copy_out(c, in1, c->p_in1.as<u32>() + first, count * 4)) ||
@@ -1448,6 +1466,7 @@ int c2a_eval(c2a_ctx* c, int which, uint32_t width, uint32_t n_vectors, const ui
     if (n_vectors == 0 || n_vectors > 64) return fail(c, C2A_ERR_ARG, "c2a_eval: 1..64 vectors per call");
     if (c->stage < (which ? ST_BOOLIFIED : ST_EMITTED)) return fail(c, C2A_ERR_STATE, which ? "c2a_eval: call c2a_boolify first" : "c2a_eval: call c2a_emit_gates / c2a_build_circuit first");
     if (!c->peel_meta_valid) return fail(c, C2A_ERR_STATE, "c2a_eval: needs the level data of c2a_topo_sort (not of c2a_topo_sort_serial)");
+    if (c->has_dup) return fail(c, C2A_ERR_STATE, "c2a_eval: two gates write one node (compiler.rs:403-406 keeps the last): the level-parallel passes do not order the writers of one wire — evaluate the emitted gate list sequentially instead");
     if (which) width = c->binfo.width;
     if (width == 0 || width > 64) return fail(c, C2A_ERR_ARG, "c2a_eval: width must be in 1..64");
     if ((c->n_in && !inputs) || (c->n_out && !outputs) || (n_const && (!const_wires || !const_values))) return fail(c, C2A_ERR_ARG, "c2a_eval: null value arrays");
@@ -1493,8 +1512,8 @@ int c2a_eval(c2a_ctx* c, int which, uint32_t width, uint32_t n_vectors, const ui
             R.e_in0 = c->e_in0.as<u32>(); R.e_in1 = c->e_in1.as<u32>(); R.e_out = c->e_out.as<u32>(); R.e_op = c->e_op.as<u8>();
             R.goff = c->goff.as<u64>(); R.b_in0 = c->p_in0.as<u32>(); R.b_in1 = c->p_in1.as<u32>(); R.b_out = c->p_out.as<u32>(); R.b_op = c->p_op.as<u8>();
             R.aval = c->ev_aval.as<u64>(); R.bval = c->ev_bval.as<u64>();
-            ENSURE(c->ev_bar, 64);
-            HIP_TRY(hipMemsetAsync(c->ev_bar.p, 0, 64, s));
+            ENSURE(c->ev_bar, 256);
+            HIP_TRY(hipMemsetAsync(c->ev_bar.p, 0, 256, s));
             R.bar = c->ev_bar.as<u32>();
             u32 grid = 8;
 #ifndef C2A_EMULATE
@@ -1512,6 +1531,34 @@ int c2a_eval(c2a_ctx* c, int which, uint32_t width, uint32_t n_vectors, const ui
                           (const u64*)c->ev_aval.as<u64>(), (const u64*)c->ev_bval.as<u64>(), d_out);
         HIP_TRY(hipMemcpyAsync(outputs, d_out, out_words * 8, hipMemcpyDeviceToHost, s));
     }
+    HIP_TRY(hipStreamSynchronize(s));
+    if (c->n && (r = barrier_gave_up(c, "c2a_eval"))) return r;
+    return C2A_OK;
+}
+
+// the gate lines of `count` gates (SoA pointers already at the first of them) on the CURRENT device: lengths, offsets, print,
+// copy out.  text == nullptr: the size only.
+struct FmtBufs { DevBuf* len; DevBuf* off; DevBuf* text; DevBuf* table; DevBuf* scan_tmp; };
+static int fmt_range(c2a_ctx* c, hipStream_t s, const FmtBufs& B, const FmtTable& T, const u32* in0, const u32* in1, const u32* out, const u8* op,
+                     u64 count, char* text, u64 capacity, u64* bytes_out) {
+    *bytes_out = 0;
+    if (count == 0) return C2A_OK;
+    ENSURE(*B.table, sizeof(FmtTable)); ENSURE(*B.len, count * 4); ENSURE(*B.off, (count + 1) * 8);
+    HIP_TRY(hipMemcpyAsync(B.table->p, &T, sizeof(T), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const FmtTable* dT = B.table->as<FmtTable>();
+    C2A_LAUNCH_NOSYNC(k_fmt_len, grid_for(count, 4096), kThreads, s, count, in0, in1, out, op, dT, B.len->as<u32>());
+    int r = scan_1pass<1>(c, s, *B.scan_tmp, count, ScanFromU32{B.len->as<u32>()}, B.off->as<u64>(), (u64*)nullptr);
+    if (r) return r;
+    u64 bytes = 0;
+    HIP_TRY(hipMemcpyAsync(&bytes, B.off->as<u64>() + count, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *bytes_out = bytes;
+    if (!text) return C2A_OK;                        // size query
+    if (bytes > capacity) return fail(c, C2A_ERR_ARG, "c2a_format_bristol: buffer too small (" + std::to_string(bytes) + " more bytes needed here)");
+    ENSURE(*B.text, bytes);
+    C2A_LAUNCH_NOSYNC(k_fmt_write, grid_for(count, 4096), kThreads, s, count, in0, in1, out, op, dT, (const u64*)B.off->as<u64>(), B.text->as<char>());
+    HIP_TRY(hipMemcpyAsync(text, B.text->p, bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return C2A_OK;
 }
@@ -1531,13 +1578,7 @@ int c2a_format_bristol(c2a_ctx* c, int which, uint64_t first, uint64_t count, ch
         in0 = c->e_in0.as<u32>(); in1 = c->e_in1.as<u32>(); out = c->e_out.as<u32>(); op = c->e_op.as<u8>(); total = c->n; break;
     case 1:
         if (c->stage < ST_BOOLIFIED) return fail(c, C2A_ERR_STATE, "c2a_format_bristol: call c2a_boolify first");
-        {   // (a multi-device context gathers the circuit on the primary device once per c2a_boolify)
-            BoolView bv;
-            int rv = full_bool(c, &bv);
-            if (rv) return rv;
-            in0 = bv.in0; in1 = bv.in1; out = bv.out; op = bv.op; total = c->binfo.n_gates;
-        }
-        break;
+        in0 = c->b_in0.as<u32>(); in1 = c->b_in1.as<u32>(); out = c->b_out.as<u32>(); op = c->b_op.as<u8>(); total = c->binfo.n_gates; break;
     case 2: {
         if (!c->bool_planned || !c->fmt_chunk_valid) return fail(c, C2A_ERR_STATE, "c2a_format_bristol: call c2a_boolify_chunk first");
         const u64 lead = c->fmt_chunk_first - (c->fmt_chunk_first & ~3ull);
@@ -1561,24 +1602,40 @@ int c2a_format_bristol(c2a_ctx* c, int which, uint64_t first, uint64_t count, ch
                               "AShiftL", "AShiftR", "ABoolOr", "ABoolAnd", "ABitOr", "ABitAnd"};
         for (int i = 0; i < 20; ++i) { T.len[i] = (u8)std::strlen(nm[i]); std::memcpy(T.name[i], nm[i], T.len[i]); }
     }
-    ENSURE(c->fmt_table, sizeof(FmtTable)); ENSURE(c->fmt_len, count * 4); ENSURE(c->fmt_off, (count + 1) * 8);
-    HIP_TRY(hipMemcpyAsync(c->fmt_table.p, &T, sizeof(T), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    const FmtTable* dT = c->fmt_table.as<FmtTable>();
-    C2A_LAUNCH_NOSYNC(k_fmt_len, grid_for(count, 4096), kThreads, s, count, in0 + first, in1 + first, out + first, op + first, dT, c->fmt_len.as<u32>());
-    int r = scan_exclusive<u64>(c, c->fmt_len.as<u32>(), c->fmt_off.as<u64>(), count);
-    if (r) return r;
-    u64 bytes = 0;
-    HIP_TRY(hipMemcpyAsync(&bytes, c->fmt_off.as<u64>() + count, 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    *written = bytes;
-    if (!text) return C2A_OK;                        // size query
-    if (bytes > capacity) return fail(c, C2A_ERR_ARG, "c2a_format_bristol: buffer too small (" + std::to_string(bytes) + " bytes needed)");
-    ENSURE(c->fmt_text, bytes);
-    C2A_LAUNCH_NOSYNC(k_fmt_write, grid_for(count, 4096), kThreads, s, count, in0 + first, in1 + first, out + first, op + first, dT,
-                      (const u64*)c->fmt_off.as<u64>(), c->fmt_text.as<char>());
-    HIP_TRY(hipMemcpyAsync(text, c->fmt_text.p, bytes, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    const FmtBufs own{&c->fmt_len, &c->fmt_off, &c->fmt_text, &c->fmt_table, &c->scan_tmp};
+    if (which != 1 || c->peers.empty()) {
+        u64 bytes = 0;
+        int r = fmt_range(c, s, own, T, in0 + first, in1 + first, out + first, op + first, count, text, capacity, &bytes);
+        *written = bytes;
+        return r;
+    }
+    // the boolean circuit of a multi-device context: every device prints the gates it holds (no gather on the primary device),
+    // the pieces land in the caller's buffer one behind the other
+    DeviceGuard guard(c->device);
+    const u64 last = first + count;
+    u64 total_bytes = 0;
+    {
+        const u64 hi = std::min(last, c->shard0_qhi);
+        if (first < hi) {
+            u64 bytes = 0;
+            int r = fmt_range(c, s, own, T, in0 + first, in1 + first, out + first, op + first, hi - first, text, capacity, &bytes);
+            if (r) { *written = total_bytes + bytes; return r; }
+            total_bytes += bytes;
+        }
+    }
+    for (PeerDev& P : c->peers) {
+        const u64 lo = std::max<u64>(first, P.q_lo), hi = std::min<u64>(last, P.q_hi);
+        if (lo >= hi) continue;
+        HIP_TRY(hipSetDevice(P.device));
+        const u64 src = lo - P.q_bias;
+        const FmtBufs pb{&P.fmt_len, &P.fmt_off, &P.fmt_text, &P.fmt_table, &P.scan_tmp};
+        u64 bytes = 0;
+        int r = fmt_range(c, P.stream, pb, T, P.b_in0.as<u32>() + src, P.b_in1.as<u32>() + src, P.b_out.as<u32>() + src, P.b_op.as<u8>() + src, hi - lo,
+                          text ? text + total_bytes : nullptr, text ? capacity - std::min<u64>(capacity, total_bytes) : 0, &bytes);
+        if (r) { *written = total_bytes + bytes; return r; }
+        total_bytes += bytes;
+    }
+    *written = total_bytes;
     return C2A_OK;
 }
 

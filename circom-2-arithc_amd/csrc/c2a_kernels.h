@@ -1029,6 +1029,47 @@ __device__ __forceinline__ void chunk_fence() {
     (void)__ballot(1);
 #endif
 }
+
+// ---- the grid-wide barrier of the level-parallel passes: every workgroup has finished a level before any starts the next.
+// bar[0] counts arrivals (it only grows: the k-th barrier is over at k x gridDim.x), bar[32] is raised by a workgroup that
+// has waited kBarrierPolls polls (~2 s) — some workgroup of the grid is not resident (CU masking, another process holding CUs:
+// the launch sizes the grid by the occupancy query, which is a promise about THIS kernel only) — and then every workgroup
+// leaves; the host reports it as an error instead of hanging the stream.  One lane per workgroup makes the arrival a release
+// and the departure an acquire at agent scope on top of the agent-scope accesses the values travel by (a fence per workgroup
+// and level is ~3 us; per WAVE it was what a level cost, see store_fence).  false: the launch is being given up.
+#ifdef C2A_EMULATE
+constexpr u32 kBarrierPolls = 1u << 22;
+#else
+constexpr u32 kBarrierPolls = 1u << 23;
+#endif
+constexpr u32 kBarAbort = 32;
+__device__ __forceinline__ bool grid_barrier(u32* bar, u32& target) {
+    __shared__ u32 s_ok;
+    store_fence();
+    __syncthreads();
+    target += gridDim.x;
+    if (threadIdx.x == 0) {
+        u32 ok = 1;
+#ifndef C2A_EMULATE
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+        atomicAdd(bar, 1u);
+        u32 polls = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if ((++polls & 255u) == 0 && __hip_atomic_load(bar + kBarAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+            if (polls > kBarrierPolls) { atomicAdd(bar + kBarAbort, 1u); ok = 0; break; }
+            peel_sleep(2);
+        }
+#ifndef C2A_EMULATE
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+        s_ok = ok;
+    }
+    __syncthreads();
+    store_fence();
+    return s_ok != 0;
+}
+
 struct ChunkDeps { int d0, d1; };
 // which earlier lane of the chunk (nv lanes hold gates) drives this lane's inputs; -1: nobody here (out wires are unique)
 __device__ __forceinline__ ChunkDeps chunk_deps(u32 in0, u32 in1, u32 out, u32 nv, u32 lane) {
@@ -1086,16 +1127,7 @@ __global__ void __launch_bounds__(kThreads) k_eval_run(EvalRun R) {
                 eval_template_wave(R.goff[p], R.goff[p + 1], R.b_in0, R.b_in1, R.b_out, R.b_op, R.bval, lane);
             }
         if (lv == 0) break;
-        // ---- every workgroup has finished the level before any starts the next
-        store_fence();
-        __syncthreads();
-        target += gridDim.x;
-        if (threadIdx.x == 0) {
-            atomicAdd(R.bar, 1u);
-            while (__hip_atomic_load(R.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) peel_sleep(2);
-        }
-        __syncthreads();
-        store_fence();
+        if (!grid_barrier(R.bar, target)) return;
     }
 }
 
@@ -1126,17 +1158,6 @@ struct PruneRun {
 };
 __device__ __forceinline__ u32 ev_ld32(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ev_st32(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void grid_barrier(u32* bar, u32& target) {
-    store_fence();
-    __syncthreads();
-    target += gridDim.x;
-    if (threadIdx.x == 0) {
-        atomicAdd(bar, 1u);
-        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) peel_sleep(2);
-    }
-    __syncthreads();
-    store_fence();
-}
 // (both passes: a wave per arithmetic gate, its template 64 gates at a time like eval_template_wave)
 __global__ void __launch_bounds__(kThreads) k_prune_fold(PruneRun R) {
     const u32 lane = threadIdx.x & 63u;
@@ -1198,7 +1219,7 @@ __global__ void __launch_bounds__(kThreads) k_prune_fold(PruneRun R) {
             }
         }
         if (lv == 0) break;
-        grid_barrier(R.bar, target);
+        if (!grid_barrier(R.bar, target)) return;
     }
     if (folded) atomicAdd(&R.counts[0], (ull)folded);
 }
@@ -1249,7 +1270,7 @@ __global__ void __launch_bounds__(kThreads) k_prune_live(PruneRun R) {
             if (lane == 0) R.live_cnt[p] = live_total;
         }
         if (lv + 1 == R.levels) break;
-        grid_barrier(R.bar, target);
+        if (!grid_barrier(R.bar, target)) return;
     }
     if (dead) atomicAdd(&R.counts[1], (ull)dead);
 }
@@ -1288,7 +1309,7 @@ __global__ void __launch_bounds__(kThreads) k_eval_pruned(EvalRun R, const u32* 
             eval_template_wave(2ull + pgoff[p], 2ull + pgoff[p + 1], R.b_in0, R.b_in1, R.b_out, R.b_op, R.bval, lane);
         }
         if (lv == 0) break;
-        grid_barrier(R.bar, target);
+        if (!grid_barrier(R.bar, target)) return;
     }
 }
 

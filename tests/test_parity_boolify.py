@@ -353,3 +353,19 @@ def test_verifier_refuses_stale_level_data(backend, c2a):
         backend.load_gates(fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes)
         backend.build_circuit()
         backend.boolify_chunk(0, 4)
+
+
+def test_level_parallel_passes_refuse_duplicate_writers(backend, c2a):
+    """Two gates writing one node (the reference keeps the last, compiler.rs:403-406): the non-producer writer carries no
+    dependency edge, so the level-parallel passes would race it against the wire's readers.  c2a_eval, c2a_verify_boolify and
+    c2a_boolify_prune say so instead of returning a schedule-dependent result; sort, numbering, emission and boolify still work."""
+    # g0: n2 = n0 + n1, g1: n2 = n0 * n1 (the producer: last writer), g2: n3 = n2 + n0
+    lh = np.array([10, 10, 12], np.uint32); rh = np.array([11, 11, 10], np.uint32); out = np.array([12, 12, 13], np.uint32)
+    backend.load_gates(lh, rh, out, np.array([0, 7, 0], np.uint8), 14, np.array([10, 11], np.uint32), np.array([13], np.uint32))
+    backend.build_circuit()
+    backend.boolify(8)
+    for call in (lambda: backend.eval(np.array([5, 7], np.uint64), {}, width=8), lambda: backend.eval(np.array([5, 7], np.uint64), {}, boolean=True),
+                 lambda: backend.verify_boolify(seed=1), lambda: backend.boolify_prune()):
+        with pytest.raises(c2a.BackendError) as ei:
+            call()
+        assert "two gates write one node" in str(ei.value)

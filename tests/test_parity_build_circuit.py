@@ -394,3 +394,57 @@ def test_connection_with_an_unknown_signal_merges_with_the_placeholder_node(c2a,
     lit.add_connection(1, 77)
     assert [(x.lh_in, x.rh_in, x.out) for x in lit.gates] == [(a, b, c) for _, a, b, c in host.gates] == [(1, 4, 3)]
     assert sorted(lit.nodes) == sorted(host.nodes) == [1, 3, 4]
+
+
+def test_serial_fallback_when_the_dataflow_launch_gives_up(orc, c2a, emul_lib):
+    """A sort that cannot give up (topological_sort.rs:3-21 always terminates on an acyclic graph): when the dataflow launch and
+    its retry both end by their watchdog — simulated here by the emulated build's C2A_EMUL_PEEL_ABORT hook — c2a_topo_sort sorts
+    with the serial DFS instead of failing, the numbering and the emission are the oracle's, and the reverse Kahn levels it
+    derives let the level-parallel evaluator run."""
+    import os
+    from conftest import _Env
+    fg = c2a.synth.layered_dag(25, 12, n_in=8, n_const=3, window=4, mix=tuple(m for m in c2a.synth.MIX_ALL if m[0] != "APow"), seed=77)
+    p = dict(lh=fg.lh, rh=fg.rh, out=fg.out, op=fg.op, n_nodes=fg.n_nodes, input_nodes=fg.input_nodes, output_nodes=fg.output_nodes)
+    with _Env(C2A_EMUL_PEEL_ABORT=2):
+        be = c2a.Backend(0, lib_path=emul_lib)
+    try:
+        assert _compare(be, orc, p, check_serial=False) == "ok"          # first build: both launches "gave up" -> serial DFS
+        st = be.stats()
+        assert st["levels"] >= 25
+        # the evaluator schedules by the levels of the fall-back
+        nw, wc = be.assign_wires()
+        in0, in1, out, op = be.emit_gates()
+        rng = np.random.default_rng(3)
+        ins = rng.integers(0, 2 ** 32, (len(fg.input_nodes), 8), dtype=np.uint64)
+        consts = {int(nw[nd]): 5 + k for k, nd in enumerate(fg.const_nodes) if nw[nd] != 0xFFFFFFFF}
+        vals = np.zeros((wc, 8), np.uint64)
+        vals[:len(fg.input_nodes)] = ins
+        for w, v in consts.items():
+            vals[w] = v
+        circ = orc.ArithCircuit(sorted=np.empty(0, np.uint32), in0=in0, in1=in1, out=out, op=op, node_wire=np.empty(0, np.uint32),
+                                wire_count=wc, n_in=len(fg.input_nodes), n_out=len(fg.output_nodes))
+        orc.eval_arith(circ, 32, vals)
+        np.testing.assert_array_equal(be.eval(ins, consts, width=32), vals[wc - len(fg.output_nodes):])
+        # the hook is spent: the next build takes the dataflow launch again, same results
+        assert _compare(be, orc, p, check_serial=False) == "ok"
+        # a cyclic graph through the fall-back still reports the reference's message
+        be.close()
+        with _Env(C2A_EMUL_PEEL_ABORT=2):
+            be = c2a.Backend(0, lib_path=emul_lib)
+        cyc = dict(lh=np.array([5, 6, 7], np.uint32), rh=np.array([1, 1, 5], np.uint32), out=np.array([6, 5, 8], np.uint32),
+                   op=np.zeros(3, np.uint8), n_nodes=9, input_nodes=np.array([1], np.uint32), output_nodes=np.array([8], np.uint32))
+        assert _compare(be, orc, cyc, check_serial=False) == "cyclic"
+    finally:
+        be.close()
+
+
+def test_node_ids_without_creation_order(backend, orc, c2a):
+    """The relabelling by out-node order finds locality where node ids follow the creation order (compiler.rs:497-500); it must
+    stay exact where they carry none: the same layered graphs with the NODE ids permuted as well as the gate ids."""
+    for layers, width, seed in ((40, 25, 11), (120, 9, 12)):
+        fg = c2a.synth.layered_dag(layers, width, n_in=16, n_const=3, window=8, mix=c2a.synth.MIX_ALL, seed=seed)
+        rng = np.random.default_rng(seed)
+        perm = rng.permutation(fg.n_nodes).astype(np.uint32)
+        p = dict(lh=perm[fg.lh], rh=perm[fg.rh], out=perm[fg.out], op=fg.op, n_nodes=fg.n_nodes, input_nodes=perm[fg.input_nodes],
+                 output_nodes=perm[fg.output_nodes])
+        assert _compare(backend, orc, p) == "ok"
