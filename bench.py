@@ -21,9 +21,9 @@ One JSON line on stdout (rank 0):
     peel, the boolify map) with its own algorithmic bytes, its launch time from HIP events on the library's stream,
     and its HBM traffic from the rocprofv3 PMC passes committed under profiles/;
   * `cpu_baseline`: the CPU oracle ("port": the reference is Rust and cannot be built here), 1 core, on the SAME
-    10 M-gate input: flat-array build_circuit on the whole graph + the bit-blast timed on a bounded slice of the
-    sorted circuit and scaled (the full 9.6 GB boolean output takes about a minute of host time); the
-    structure-faithful variant (hash maps, per-visit Vec) is timed on a 2 M-gate sample in `faithful_sample`;
+    10 M-gate input, nothing scaled: the structure-faithful build_circuit (hash maps, per-visit Vec — what BASELINE.md §2
+    defines as THE baseline) on the whole graph + the bit-blast of ALL sorted gates (in chunks, so that the 9.6 GB boolean
+    output never sits in host memory at once); `flat_array` is the second row of BASELINE.md §2 (dense ids, no hashing);
   * `width64`: the same step at --boolify-width 64 (SURVEY §8(d) "widths 32 and 64").
 """
 import argparse
@@ -40,7 +40,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (~6.3 TB/s achievable)
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc_hbm_bytes.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r04_pmc_hbm_bytes.json")
 
 
 def timed_region(warm_step, step, steps, warmup, dist=None, torch=None, device=None):
@@ -140,35 +140,31 @@ def check_against_oracle(be, backend_mod, circ, width, shard=None, slice_gates=2
     return msg
 
 
-def cpu_baseline(synth, fg, width, bool_slice_gates, faithful_layers, layer_width, circ, handle, t_build):
-    """CPU oracle on the host cores of this box, 1 thread."""
+def cpu_baseline(fg, width, chunk_gates, circ, handle, t_flat):
+    """CPU oracle on the host cores of this box, 1 thread, the whole benchmark input: the structure-faithful
+    build_circuit (hash maps, per-visit Vec: THE baseline) and the flat-array one (second row), and the bit-blast of every sorted
+    gate — chunk by chunk, each chunk's boolean gates freed before the next (the whole output is 9.6 GB)."""
     from oracle import oracle as orc
-    cnt = min(bool_slice_gates, fg.n)
     t0 = time.perf_counter()
-    bslice, _ = orc.boolify_range(circ, width, 0, cnt)
-    t_slice = time.perf_counter() - t0
-    ng_slice = len(bslice.in0)
-    del bslice
-    t_bool_scaled = t_slice * fg.n / max(1, cnt)
-    out = {"value": fg.n / (t_build + t_bool_scaled), "unit": "gates/s", "cores": 1, "kind": "port",
-           "sample": f"the SAME {fg.n}-gate input as the GPU run: flat-array build_circuit on the whole graph {t_build:.2f}s; "
-                     f"bit-blast timed on the first {cnt} sorted gates ({ng_slice} boolean gates, {t_slice:.2f}s) and scaled "
-                     f"x{fg.n / max(1, cnt):.1f} = {t_bool_scaled:.2f}s",
-           "host_cores_available": os.cpu_count()}
-    if faithful_layers > 0:
-        sfg = synth.layered_dag(faithful_layers, layer_width, seed=synth.SEED)
+    c2, h2 = orc.build_circuit(fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes, mode=0, keep_handle=True)
+    t_faithful = time.perf_counter() - t0
+    same = bool(np.array_equal(c2.sorted, circ.sorted) and np.array_equal(c2.in0, circ.in0) and np.array_equal(c2.out, circ.out))
+    orc.free_circuit(h2)
+    del c2
+    t_bool, n_bool = 0.0, 0
+    for first in range(0, fg.n, chunk_gates):
+        cnt = min(chunk_gates, fg.n - first)
         t0 = time.perf_counter()
-        c2, h2 = orc.build_circuit(sfg.lh, sfg.rh, sfg.out, sfg.op, sfg.n_nodes, sfg.input_nodes, sfg.output_nodes,
-                                   mode=0, keep_handle=True)
-        t1 = time.perf_counter()
-        b2, bh = orc.boolify_handle(h2, width, copy=False)
-        t2 = time.perf_counter()
-        orc.lib().orc_free_bool(bh)
-        orc.free_circuit(h2)
-        out["faithful_sample"] = {"value": sfg.n / (t2 - t0), "unit": "gates/s",
-                                  "sample": f"structure-faithful build_circuit (hash maps, per-visit Vec) {t1 - t0:.2f}s + bit-blast "
-                                            f"{t2 - t1:.2f}s on the first {faithful_layers} layers = {sfg.n} gates of the same generator"}
-    return out
+        bslice, _ = orc.boolify_range(circ, width, first, cnt)
+        t_bool += time.perf_counter() - t0
+        n_bool += len(bslice.in0)
+        del bslice
+    return {"value": fg.n / (t_faithful + t_bool), "unit": "gates/s", "cores": 1, "kind": "port",
+            "sample": f"the SAME {fg.n}-gate input as the GPU run, nothing scaled: structure-faithful build_circuit (hash maps, per-visit Vec) "
+                      f"{t_faithful:.2f}s + bit-blast of all {fg.n} sorted gates ({n_bool} boolean gates, in chunks of {chunk_gates}) {t_bool:.2f}s",
+            "flat_array": {"value": fg.n / (t_flat + t_bool), "unit": "gates/s",
+                           "sample": f"flat-array build_circuit (dense ids, no hashing) {t_flat:.2f}s + the same bit-blast {t_bool:.2f}s"},
+            "variants_agree": same, "boolean_gates": n_bool, "host_cores_available": os.cpu_count()}
 
 
 def main():
@@ -179,9 +175,10 @@ def main():
     ap.add_argument("--width", type=int, default=32, help="--boolify-width")
     ap.add_argument("--layers", type=int, default=5000)
     ap.add_argument("--layer-width", type=int, default=2000)
-    ap.add_argument("--cpu-sample-layers", type=int, default=1000,
-                    help="layers of the structure-faithful CPU sample; 0 = skip the whole CPU baseline")
-    ap.add_argument("--cpu-bool-slice", type=int, default=2_000_000, help="sorted gates the CPU bit-blast is timed on")
+    ap.add_argument("--cpu-sample-layers", type=int, default=1,
+                    help="0 = skip the CPU baseline (name kept from the rounds when the faithful variant ran on a sample of the layers)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline (same as --cpu-sample-layers 0)")
+    ap.add_argument("--cpu-bool-chunk", type=int, default=1_000_000, help="sorted gates per chunk of the CPU bit-blast (all gates are timed)")
     ap.add_argument("--no-width64", action="store_true", help="skip the extra --boolify-width 64 step")
     ap.add_argument("--no-artefacts", action="store_true", help="skip the circuit.txt formatting measurement")
     ap.add_argument("--check", action="store_true", help="verify the GPU result against the oracle even when the CPU baseline is skipped")
@@ -191,6 +188,8 @@ def main():
                     help="N>1: 'shard' (default) = ONE graph, sort replicated on every rank, boolify sharded by sorted-position "
                          "range (strong scaling, BASELINE's metric); 'replicas' = N independent graphs, one per GPU (throughput, weak)")
     args = ap.parse_args()
+    if args.no_cpu_baseline:
+        args.cpu_sample_layers = 0
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -322,16 +321,36 @@ def main():
                     e[extra] = k[extra]
         return e
 
-    kernels = [kernel_entry("k_peel (dataflow launch: DFS-tree parents of all gates)", "c2a::k_peel", sort_bytes, stages.get("peel", 0.0)),
+    # what each entry's kernel_ms is: the k_peel launch ALONE (its own event pair); every launch of the step that is neither
+    # k_peel nor k_boolify ("around the peel": producer map, relabelling, deps, consumer lists, sinks + whole-level passes,
+    # Euler tour + list ranking, wire numbering, emission, the boolify plan) as stage time minus those two; k_boolify alone.
+    # Algorithmic bytes: the sort stage's 30 B/gate are booked on the launches around the peel, where the
+    # payload is read and sorted ids / emitted gates are written — k_peel itself moves node records only (its algorithmic
+    # share is the 8 B/gate of deps it consumes: reported, structurally ~0 of the roofline).
+    k_peel_ms = stages.get("k_peel", 0.0)
+    around_ms = (stages.get("prep", 0.0) + (stages.get("peel", 0.0) - k_peel_ms) + stages.get("order", 0.0) + stages.get("wires", 0.0) +
+                 stages.get("emit", 0.0) + stages.get("bool_prep", 0.0))
+    kernels = [kernel_entry("k_peel (the dataflow launch alone: DFS-tree parents of the gates the whole-level passes leave)", "c2a::k_peel", 8.0 * n, k_peel_ms),
                kernel_entry("k_boolify (bit-blast map)", "c2a::k_boolify", bool_bytes, stages.get("bool_map", 0.0))]
+    around = {"kernel": "around the peel: every other launch of the step (producer map, relabelling, deps, consumer lists, sinks and whole-level "
+                        "passes, Euler tour + list ranking, wire numbering, emission, boolify plan)",
+              "algorithmic_bytes_per_step": sort_bytes, "kernel_ms": around_ms,
+              "achieved": (sort_bytes / (around_ms * 1e-3) / 1e9) if around_ms > 0 else 0.0, "unit": "GB/s"}
+    around["frac"] = around["achieved"] / HBM_PEAK_GBS
+    if pmc:
+        t = sum(k["hbm_bytes_per_launch"] * k.get("launches_per_step", 1) for name, k in pmc.items() if name not in ("c2a::k_peel", "c2a::k_boolify"))
+        around["traffic"] = t
+        around["traffic_over_algorithmic"] = t / sort_bytes
+    else:
+        around["traffic"] = None
+    kernels.append(around)
     total_traffic = None
     if pmc:
         total_traffic = sum(k["hbm_bytes_per_launch"] * k.get("launches_per_step", 1) for k in pmc.values())
 
     cpu = None
     if args.cpu_sample_layers > 0 and not replicas:
-        cpu = cpu_baseline(synth, fg, args.width, args.cpu_bool_slice, min(args.cpu_sample_layers, args.layers), args.layer_width,
-                           circ, handle, t_oracle_build)
+        cpu = cpu_baseline(fg, args.width, args.cpu_bool_chunk, circ, handle, t_oracle_build)
     if handle is not None:
         from oracle import oracle as orc
         orc.free_circuit(handle)
@@ -417,7 +436,7 @@ def main():
         "roofline": {"bound": "hbm", "scope": "whole timed step (sort + numbering + emission + boolify)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_step": step_bytes, "traffic": total_traffic,
-                     "traffic_source": "profiles/r03_pmc_hbm_bytes.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 per the gfx950 note)" if pmc else None,
+                     "traffic_source": "profiles/r04_pmc_hbm_bytes.json — a QUOTED figure from the committed rocprofv3 --pmc passes of this command (TCC_EA0_RDREQ x 128 B + WRITE_SIZE), not counters of this run" if pmc else None,
                      "kernels": kernels,
                      "note": "the step is bound by the dependent-step latency of the exact DFS order (k_peel), not by bytes: its algorithmic traffic is 0.3 GB"},
         "cpu_baseline": cpu,

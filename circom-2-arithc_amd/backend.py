@@ -63,7 +63,7 @@ class _PruneInfo(ctypes.Structure):
 
 class _Timings(ctypes.Structure):
     _fields_ = [(k, ctypes.c_float) for k in ("prep", "peel", "order", "wires", "emit", "bool_prep", "bool_map",
-                                              "build_total", "boolify_total")]
+                                              "build_total", "boolify_total", "k_peel")]
 
 
 class _Stats(ctypes.Structure):
@@ -90,7 +90,7 @@ class BoolInfo:
         return np.where(W < M, W * w + bit, M * w + self.aux_total + (W - M) * w + bit)
 
 
-ABI_VERSION = 4          # == C2A_ABI_VERSION of include/c2a.h this binding was written against
+ABI_VERSION = 5          # == C2A_ABI_VERSION of include/c2a.h this binding was written against
 
 _EXPORTS = ["c2a_abi_version", "c2a_visible_devices", "c2a_create", "c2a_device_count", "c2a_format_bristol", "c2a_destroy", "c2a_last_error", "c2a_version", "c2a_load_gates", "c2a_topo_sort",
             "c2a_topo_sort_serial", "c2a_assign_wires", "c2a_emit_gates", "c2a_build_circuit", "c2a_boolify",

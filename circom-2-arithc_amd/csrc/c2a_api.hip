@@ -27,7 +27,7 @@ struct DevBuf {
 enum Stage { ST_EMPTY = 0, ST_LOADED, ST_SORTED, ST_WIRED, ST_EMITTED, ST_BOOLIFIED };
 
 enum Ev { EV_PREP0, EV_PREP1, EV_PEEL1, EV_ORDER1, EV_WIRES0, EV_WIRES1, EV_EMIT0, EV_EMIT1, EV_BPREP0, EV_BPREP1,
-          EV_BMAP1, EV_BUILD0, EV_BUILD1, EV_COUNT };
+          EV_BMAP1, EV_BUILD0, EV_BUILD1, EV_KPEEL0, EV_KPEEL1, EV_COUNT };
 
 }  // namespace
 
@@ -350,8 +350,10 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
     }
     // (every wave of the launch is alive at once under emulation too, interleaved at the back-offs — in a shuffled order per
     // C2A_EMUL_SEED: the ticket / hand-off / termination protocol is exercised without a GPU)
+    rec(c, EV_KPEEL0);
     if (want_stats) C2A_LAUNCH_CONCURRENT((k_peel<true>), waves, 64, s, A);
     else C2A_LAUNCH_CONCURRENT((k_peel<false>), waves, 64, s, A);
+    rec(c, EV_KPEEL1);
     static_assert(CTL_PROCESSED == 0 && CTL_MAXLEVEL == 1 && CTL_ABORT == 2 && CTL_REREADS == 3, "the order k_post_peel writes them in");
     C2A_LAUNCH(k_post_peel, 1, 64, s, c->hrb_dev, (const u32*)c->pctl.as<u32>(), (const u32*)(c->cons_off.as<u32>() + n), (const u32*)(c->scalars.as<u32>() + SC_DUP));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1659,6 +1661,7 @@ int c2a_get_timings(c2a_ctx* c, c2a_timings* t) {
     t->bool_map = elapsed(c, EV_BPREP1, EV_BMAP1);
     t->build_total = elapsed(c, EV_BUILD0, EV_BUILD1);
     t->boolify_total = elapsed(c, EV_BPREP0, EV_BMAP1);
+    t->k_peel = c->serial_fallback ? 0.f : elapsed(c, EV_KPEEL0, EV_KPEEL1);
     return C2A_OK;
 }
 

@@ -68,6 +68,8 @@ typedef struct c2a_timings {     /* milliseconds, HIP events on the context's st
     float bool_map;              /* the boolify map kernel alone (dominant kernel; roofline) */
     float build_total;           /* c2a_build_circuit wall (events) */
     float boolify_total;         /* c2a_boolify wall (events) */
+    float k_peel;                /* the dataflow launch alone (an event pair around k_peel: `peel` also holds the sinks pass and the
+                                    whole-level passes in front of it); 0 when the serial fall-back sorted */
 } c2a_timings;
 
 typedef struct c2a_stats {
@@ -99,7 +101,7 @@ const char* c2a_last_error(const c2a_ctx* ctx);
 const char* c2a_version(void);
 /* Bumped whenever a signature or a struct layout of this header changes (round 2 changed c2a_create and c2a_stats without
  * a signal): a binding built against another header must refuse to go on.  c2a_abi_version() == C2A_ABI_VERSION. */
-#define C2A_ABI_VERSION 4
+#define C2A_ABI_VERSION 5
 int c2a_abi_version(void);
 
 /*
