@@ -3,7 +3,12 @@ script its unroller makes (tests/golden/ml/*.json, derived from the .circom text
 mirror -> the C ABI -> circuit, checked against the literal oracle (sorted order, wire numbering, emitted gates, name maps),
 the IO vectors through the GPU evaluator (c2a_eval) for the arithmetic circuit and its --boolify-width 32 image, and the
 bit-blast verified wire by wire (c2a_verify_boolify).  ml/_unsupported.json lists every other file of that tree and why it
-is not here (no main / main commented out upstream / a construct outside the front-end's subset)."""
+is not here (no main / main commented out upstream / a construct outside the front-end's subset).
+
+All three of those sort to the identity.  tests/golden/nonidentity/*.json are three more circuits from Circom text —
+this repo's mains (tests/golden/circuits/) over LIBRARY templates the reference ships (Switcher, Mux3 / MultiMux3, matMul), with
+the components instantiated before their inputs are wired, so that the DFS order differs from the list order in nearly every
+position (make_nonidentity_fixtures.py; the IO vectors are also asserted there against what each circuit is for)."""
 import glob
 import importlib
 import json
@@ -13,7 +18,10 @@ import numpy as np
 import pytest
 
 ML = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ml")
+NONID = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nonidentity")
 NAMES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(ML, "*.json")) if not os.path.basename(p).startswith("_"))
+NONID_NAMES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(NONID, "*.json")))
+CASES = [(ML, n) for n in NAMES] + [(NONID, n) for n in NONID_NAMES]
 
 
 def test_every_file_of_the_tree_is_accounted_for():
@@ -22,10 +30,20 @@ def test_every_file_of_the_tree_is_accounted_for():
     assert all(("main" in why) or why.startswith("front-end:") for why in uns.values())
 
 
-@pytest.mark.parametrize("name", NAMES)
-def test_reference_ml_circuit(name, backend, orc):
+def test_the_non_identity_fixtures_are_what_they_claim():
+    assert NONID_NAMES == ["matMulChain", "mux3Select", "switcherNet"]
+    for n in NONID_NAMES:
+        fx = json.load(open(os.path.join(NONID, f"{n}.json")))
+        srt = fx["expect"]["sorted"]
+        assert sorted(srt) == list(range(len(srt))) and sum(1 for i, g in enumerate(srt) if i != g) > len(srt) * 0.9
+    for n in NAMES:
+        assert json.load(open(os.path.join(ML, f"{n}.json")))["expect"]["sorted_is_identity"]
+
+
+@pytest.mark.parametrize("where,name", CASES, ids=[n for _, n in CASES])
+def test_reference_ml_circuit(where, name, backend, orc):
     comp_mod = importlib.import_module("circom-2-arithc_amd.compiler")
-    fx = json.load(open(os.path.join(ML, f"{name}.json")))
+    fx = json.load(open(os.path.join(where, f"{name}.json")))
     C = comp_mod.Compiler(backend)
     lit = orc.CompilerModel()
     for st in fx["script"]:

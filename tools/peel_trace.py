@@ -24,6 +24,10 @@ be.load_gates(fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output
 be.topo_sort(fetch=False)
 be.topo_sort(fetch=False)                    # (the second run is the warm one; its trace overwrites the first)
 n = fg.n
+# (the launch works in RANK space — gates relabelled by out-node order, c2a_kernels.h RELABELLING — and so do its trace arrays:
+# bring the graph into the same numbering)
+order = np.argsort(fg.out, kind="stable")
+fg.lh, fg.rh, fg.out = fg.lh[order], fg.rh[order], fg.out[order]
 tr = np.fromfile(os.path.join(d, "peel_trace.bin"), dtype=np.uint64).reshape(n, 3)
 meta = np.fromfile(os.path.join(d, "peel_meta.bin"), dtype=np.uint32).reshape(n, 4)
 t_start = (tr[:, 0] >> np.uint64(2)).astype(np.int64)
