@@ -59,7 +59,7 @@ typedef struct c2a_bool_info {
 } c2a_bool_info;
 
 typedef struct c2a_timings {     /* milliseconds, HIP events on the context's stream, last run */
-    float prep;                  /* producer map, deps, consumer lists */
+    float prep;                  /* producer map, relabelling by out-node order, deps, consumer lists */
     float peel;                  /* reverse Kahn peel + DFS-tree parent selection (dataflow launch, or all levels) */
     float order;                 /* Euler tour + list ranking -> sorted_gate_ids */
     float wires;                 /* first-seen wire numbering */
@@ -122,7 +122,9 @@ int c2a_load_gates(c2a_ctx* ctx, uint64_t n, const uint32_t* lh, const uint32_t*
  */
 int c2a_topo_sort(c2a_ctx* ctx, uint32_t* sorted_gate_ids, uint64_t* cycle_at);
 
-/* Same contract, executed as the literal DFS on one GPU lane (diagnostics / cross-check; slow). */
+/* Same contract, executed as the literal DFS on one GPU lane (diagnostics / cross-check; slow).  c2a_topo_sort falls back to
+ * it by itself when its dataflow launch gives up twice (a watchdog, never seen on hardware): like the reference's sort
+ * (src/topological_sort.rs:3-21) it cannot fail on an acyclic graph. */
 int c2a_topo_sort_serial(c2a_ctx* ctx, uint32_t* sorted_gate_ids, uint64_t* cycle_at);
 
 /*
@@ -171,8 +173,8 @@ int c2a_boolify_shard_range(c2a_ctx* ctx, uint32_t k, uint32_t n_shards, uint64_
 /*
  * == the gate lines of BristolCircuit::write_bristol (src/main.rs:34-35; crate absent: Bristol-fashion text per SURVEY C.2),
  * printed on the GPU: "2 1 <in0> <in1> <out> <OP>\n", "1 1 <in0> <out> INV\n" for the one-input op.  Gates
- * [first, first + count) of  which = 0: the arithmetic circuit (c2a_emit_gates);  1: the boolean circuit (c2a_boolify; a
- * multi-device context gathers it on the primary device first, once);  2: the chunk of the last c2a_boolify_chunk.  text == NULL only queries *written (bytes).
+ * [first, first + count) of  which = 0: the arithmetic circuit (c2a_emit_gates);  1: the boolean circuit (c2a_boolify; on a
+ * multi-device context every device prints the gates it holds, nothing is gathered);  2: the chunk of the last c2a_boolify_chunk.  text == NULL only queries *written (bytes).
  * The header lines (gate / wire counts, io widths) are the host's: it knows the name tables.
  */
 int c2a_format_bristol(c2a_ctx* ctx, int which, uint64_t first, uint64_t count, char* text, uint64_t capacity, uint64_t* written);
@@ -221,6 +223,9 @@ int c2a_pruned_read(c2a_ctx* ctx, uint64_t first, uint64_t count, uint32_t* in0,
  * inputs[i * n_vectors + t]: value of input wire i (wires 0 .. n_in-1 in the order of c2a_load_gates' input list) in vector
  * t;  n_const constants given as (ARITHMETIC wire id, value) — the host knows them from its name tables (ConstantInfo);
  * outputs[j * n_vectors + t]: value of output j (the last n_out wires).  1 <= n_vectors <= 64.  Wires nothing drives are 0.
+ * C2A_ERR_STATE for a circuit in which two gates write one node (the reference keeps the last, src/compiler.rs:403-406): a
+ * writer that is not the producer carries no dependency edge, the level-parallel passes (this one, c2a_verify_boolify,
+ * c2a_boolify_prune) would race it against the wire's readers — evaluate the emitted gate list sequentially instead.
  */
 int c2a_eval(c2a_ctx* ctx, int which, uint32_t width, uint32_t n_vectors, const uint64_t* inputs, uint32_t n_const,
              const uint32_t* const_wires, const uint64_t* const_values, uint64_t* outputs);

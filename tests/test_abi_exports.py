@@ -36,6 +36,16 @@ def test_product_library_exports_every_symbol(c2a):
     assert (g.value, a.value) == (32, 0)
 
 
+def test_integration_md_names_every_entry_point():
+    """INTEGRATION.md §2 is the Rust binding a maintainer would add: its extern "C" block has a line for every symbol of the
+    header (round 3's review found ten missing)."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = text[text.index('extern "C" {'):]
+    block = block[:block.index("```")]
+    bound = set(re.findall(r"pub fn (c2a_[a-z_]+)\(", block))
+    assert bound == set(_declared()), (sorted(set(_declared()) - bound), sorted(bound - set(_declared())))
+
+
 def test_abi_version_is_one_number_everywhere(c2a):
     """include/c2a.h, the built library and the ctypes binding agree on C2A_ABI_VERSION (a signature change must
     be a loud load-time error, not undefined behaviour), and the device query works without a GPU."""
