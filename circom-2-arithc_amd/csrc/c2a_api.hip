@@ -40,6 +40,7 @@ struct PeerDev {
     u64 q_bias = 0;                // boolean gate q is stored at index q - q_bias
     DevBuf e_in0, e_in1, e_out, e_op, goff, aoff, tmpl, tables, b_in0, b_in1, b_out, b_op, acc;
     DevBuf fmt_len, fmt_off, fmt_text, fmt_table, scan_tmp;      // c2a_format_bristol prints a device's own gates on that device
+    DevBuf vscratch;                                             // c2a_verify_boolify checks a device's own gates on that device
     u32 tmpl_width = 0;
 };
 
@@ -83,6 +84,7 @@ struct c2a_ctx {
     c2a_stats stats{};
     c2a_bool_info binfo{};
     u32 bool_width = 0;
+    u32 bool_max_aux = 0;          // most aux wires any template of that width has (scratch of the local verifier)
 
     // device buffers
     DevBuf lh, rh, out, op, gate4, nrec, orig, in_nodes, out_nodes;
@@ -747,7 +749,7 @@ void c2a_destroy(c2a_ctx* c) {
         (void)hipSetDevice(P.device);
         if (P.stream) { (void)hipStreamSynchronize(P.stream); }
         for (DevBuf* b : {&P.e_in0, &P.e_in1, &P.e_out, &P.e_op, &P.goff, &P.aoff, &P.tmpl, &P.tables, &P.b_in0, &P.b_in1, &P.b_out, &P.b_op, &P.acc,
-                          &P.fmt_len, &P.fmt_off, &P.fmt_text, &P.fmt_table, &P.scan_tmp})
+                          &P.fmt_len, &P.fmt_off, &P.fmt_text, &P.fmt_table, &P.scan_tmp, &P.vscratch})
             if (b->p) (void)hipFree(b->p);
         if (P.stream) (void)hipStreamDestroy(P.stream);
     }
@@ -958,12 +960,14 @@ int bool_plan(c2a_ctx* c, uint32_t width) {
     if (c->bool_width != width) {
         std::vector<TemplateEntry> all;
         BoolTables T;
+        u32 max_aux = 0;
         for (u32 op = 0; op < 20; ++op) {
             TemplateBuilder tb(width);
             tb.build(op);
             T.toff[op] = (u32)all.size();
             T.tsize[op] = (u32)tb.gates.size();
             T.taux[op] = tb.aux;
+            max_aux = std::max<u32>(max_aux, tb.aux);
             all.insert(all.end(), tb.gates.begin(), tb.gates.end());
         }
         ENSURE(c->tmpl, all.size() * sizeof(TemplateEntry));
@@ -972,6 +976,7 @@ int bool_plan(c2a_ctx* c, uint32_t width) {
         HIP_TRY(hipMemcpyAsync(c->tables.p, &T, sizeof(T), hipMemcpyHostToDevice, s));
         HIP_TRY(hipStreamSynchronize(s));
         c->bool_width = width;
+        c->bool_max_aux = max_aux;
     }
     rec(c, EV_BPREP0);
     ENSURE(c->goff, ((size_t)n + 1) * 8); ENSURE(c->aoff, ((size_t)n + 1) * 8);
@@ -1347,9 +1352,62 @@ static int eval_run(c2a_ctx* c, u32 mode, u32 width) {
     return C2A_OK;
 }
 
+// the verifier of a multi-device context: every device checks the gates it holds (k_verify_local), nothing is gathered
+static int verify_local(c2a_ctx* c, u64 seed, u64* n_checked, u64* n_mismatch) {
+    DeviceGuard guard(c->device);
+    const u32 width = c->binfo.width, M = c->binfo.m_wires;
+    const u32 words = 3u * width + c->bool_max_aux + 1u;
+    auto launch = [&](hipStream_t s, DevBuf& scratch, ull* bad, VerifyLocal V) -> int {
+        if (V.p_hi <= V.p_lo) return C2A_OK;
+        u32 blocks = std::min<u32>((u32)c->n_cu * 8u, (V.p_hi - V.p_lo + 3u) / 4u);
+        while (blocks > 1 && (size_t)blocks * 4 * words * 8 > (256u << 20)) blocks /= 2;      // (a wave per gate, 4 waves per workgroup)
+        ENSURE(scratch, (size_t)blocks * 4 * words * 8);
+        HIP_TRY(hipMemsetAsync(bad, 0, 8, s));
+        V.scratch = scratch.as<u64>(); V.scratch_words = words; V.bad = bad;
+        V.width = width; V.M = M; V.aux_base = (u64)M * width; V.out_base = (u64)M * width + c->binfo.aux_total; V.seed = seed;
+        C2A_LAUNCH(k_verify_local, blocks, kThreads, s, V);
+        return C2A_OK;
+    };
+    HIP_TRY(hipSetDevice(c->device));
+    ull* acc0 = reinterpret_cast<ull*>(c->scalars.as<u32>() + SC_TOTAL64);
+    {
+        VerifyLocal V{};
+        V.p_lo = 0; V.p_hi = c->shard0_hi; V.p_base = 0; V.q_bias = 0;
+        V.e_in0 = c->e_in0.as<u32>(); V.e_in1 = c->e_in1.as<u32>(); V.e_out = c->e_out.as<u32>(); V.e_op = c->e_op.as<u8>();
+        V.goff = c->goff.as<u64>(); V.aoff = c->aoff.as<u64>();
+        V.b_in0 = c->b_in0.as<u32>(); V.b_in1 = c->b_in1.as<u32>(); V.b_out = c->b_out.as<u32>(); V.b_op = c->b_op.as<u8>();
+        int r = launch(c->stream, c->ev_bval, acc0, V);
+        if (r) return r;
+    }
+    for (PeerDev& P : c->peers) {
+        HIP_TRY(hipSetDevice(P.device));
+        VerifyLocal V{};
+        V.p_lo = P.p_lo; V.p_hi = P.p_hi; V.p_base = P.p_lo; V.q_bias = P.q_bias;
+        V.e_in0 = P.e_in0.as<u32>(); V.e_in1 = P.e_in1.as<u32>(); V.e_out = P.e_out.as<u32>(); V.e_op = P.e_op.as<u8>();
+        V.goff = P.goff.as<u64>(); V.aoff = P.aoff.as<u64>();
+        V.b_in0 = P.b_in0.as<u32>(); V.b_in1 = P.b_in1.as<u32>(); V.b_out = P.b_out.as<u32>(); V.b_op = P.b_op.as<u8>();
+        int r = launch(P.stream, P.vscratch, P.acc.as<ull>(), V);
+        if (r) return r;
+    }
+    u64 bad = 0, part = 0;
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->shard0_hi) { HIP_TRY(hipMemcpyAsync(&part, acc0, 8, hipMemcpyDeviceToHost, c->stream)); HIP_TRY(hipStreamSynchronize(c->stream)); bad += part; }
+    for (PeerDev& P : c->peers) {
+        if (P.p_hi <= P.p_lo) continue;
+        HIP_TRY(hipSetDevice(P.device));
+        HIP_TRY(hipMemcpyAsync(&part, P.acc.p, 8, hipMemcpyDeviceToHost, P.stream));
+        HIP_TRY(hipStreamSynchronize(P.stream));
+        bad += part;
+    }
+    if (n_checked) *n_checked = (u64)c->n * 64;
+    if (n_mismatch) *n_mismatch = bad;
+    return C2A_OK;
+}
+
 int c2a_verify_boolify(c2a_ctx* c, uint64_t seed, uint64_t* n_checked, uint64_t* n_mismatch) {
     if (!c) return C2A_ERR_ARG;
     if (c->stage < ST_BOOLIFIED) return fail(c, C2A_ERR_STATE, "c2a_verify_boolify: call c2a_boolify first");
+    if (!c->peers.empty()) return verify_local(c, seed, n_checked, n_mismatch);
     if (!c->peel_meta_valid) return fail(c, C2A_ERR_STATE, "c2a_verify_boolify: needs the level data of c2a_topo_sort (not of c2a_topo_sort_serial)");
     if (c->has_dup) return fail(c, C2A_ERR_STATE, "c2a_verify_boolify: two gates write one node (compiler.rs:403-406 keeps the last): the level-parallel passes do not order the writers of one wire — evaluate the emitted gate list sequentially instead");
     HIP_TRY(hipSetDevice(c->device));
@@ -1643,9 +1701,21 @@ int c2a_format_bristol(c2a_ctx* c, int which, uint64_t first, uint64_t count, ch
 
 int c2a_debug_patch_bool_op(c2a_ctx* c, uint64_t index, uint8_t new_op) {
     if (!c) return C2A_ERR_ARG;
-    if (c->stage < ST_BOOLIFIED || index >= c->binfo.n_gates || new_op > C2A_INV || !c->peers.empty()) return fail(c, C2A_ERR_ARG, "c2a_debug_patch_bool_op: bad index / op");
-    HIP_TRY(hipMemcpyAsync(c->b_op.as<u8>() + index, &new_op, 1, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->stage < ST_BOOLIFIED || index >= c->binfo.n_gates || new_op > C2A_INV) return fail(c, C2A_ERR_ARG, "c2a_debug_patch_bool_op: bad index / op");
+    c->gathered = false;
+    if (c->peers.empty() || index < c->shard0_qhi) {
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipMemcpyAsync(c->b_op.as<u8>() + index, &new_op, 1, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return C2A_OK;
+    }
+    DeviceGuard guard(c->device);
+    for (PeerDev& P : c->peers) {
+        if (index < P.q_lo || index >= P.q_hi) continue;
+        HIP_TRY(hipSetDevice(P.device));
+        HIP_TRY(hipMemcpyAsync(P.b_op.as<u8>() + (index - P.q_bias), &new_op, 1, hipMemcpyHostToDevice, P.stream));
+        HIP_TRY(hipStreamSynchronize(P.stream));
+    }
     return C2A_OK;
 }
 

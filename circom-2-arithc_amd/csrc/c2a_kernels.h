@@ -1081,13 +1081,15 @@ __device__ __forceinline__ ChunkDeps chunk_deps(u32 in0, u32 in1, u32 out, u32 n
     return d;
 }
 // gates [k0, k1) on wire values (64 vectors per wire, one bit each)
+struct WireIdentity { __device__ __forceinline__ u32 operator()(u32 w) const { return w; } };
+template <class Map = WireIdentity>
 __device__ __forceinline__ void eval_template_wave(u64 k0, u64 k1, const u32* __restrict__ g_in0, const u32* __restrict__ g_in1,
-                                                   const u32* __restrict__ g_out, const u8* __restrict__ g_op, u64* bval, u32 lane) {
+                                                   const u32* __restrict__ g_out, const u8* __restrict__ g_op, u64* bval, u32 lane, Map map = Map()) {
     for (u64 base = k0; base < k1; base += 64) {
         const u32 nv = k1 - base < 64 ? (u32)(k1 - base) : 64u;
         const bool valid = lane < nv;
         u32 i0 = 0xFFFFFFFFu, i1 = 0xFFFFFFFFu, o = 0xFFFFFFFEu, op = 2;
-        if (valid) { i0 = g_in0[base + lane]; i1 = g_in1[base + lane]; o = g_out[base + lane]; op = g_op[base + lane]; }
+        if (valid) { i0 = map(g_in0[base + lane]); i1 = map(g_in1[base + lane]); o = map(g_out[base + lane]); op = g_op[base + lane]; }
         ChunkDeps d = chunk_deps(i0, i1, o, nv, lane);
         if (op == 2u) d.d1 = -1;
         const u64 a_mem = valid && d.d0 < 0 ? ev_ld(&bval[i0]) : 0ull;
@@ -1129,6 +1131,74 @@ __global__ void __launch_bounds__(kThreads) k_eval_run(EvalRun R) {
         if (lv == 0) break;
         if (!grid_barrier(R.bar, target)) return;
     }
+}
+
+// ---- the verifier of a MULTI-DEVICE context: every device checks the boolean gates it holds, where they lie.  The whole-circuit
+// simulation above needs every boolean gate in one place (round 3 gathered 9.6 GB on the primary device for it); what a
+// bit-blast can get wrong, though, is local to an arithmetic gate — its template, and which wires the template's gates name —
+// so: a wave per arithmetic gate of the device's range draws 64 input vectors (a function of the input WIRE, so that a gate
+// whose two inputs are one wire sees equal values), bit-slices them onto the boolean wires the gate's inputs MUST occupy
+// (DESIGN.md 5.1), runs the gate's boolean gates out of a private scratch (every wire they name must be one of the gate's own:
+// an A, B or O bit or one of its aux wires — anything else is a mismatch), and compares the O bits with the arithmetic op.
+struct VerifyLocal {
+    u32 p_lo, p_hi, p_base;            // arithmetic gates (sorted positions) [p_lo, p_hi); e_* / goff / aoff are indexed by p - p_base
+    u32 width, M;
+    u64 aux_base, out_base, q_bias, seed;
+    const u32* e_in0; const u32* e_in1; const u32* e_out; const u8* e_op; const u64* goff; const u64* aoff;
+    const u32* b_in0; const u32* b_in1; const u32* b_out; const u8* b_op;      // boolean gate q at index q - q_bias
+    u64* scratch; u32 scratch_words;   // per wave: A bits, B bits, O bits, aux wires, one word nobody reads
+    ull* bad;
+};
+struct LocalWires {
+    u32 A, B, O, X, w, n_aux, junk; u32* stray;
+    __device__ __forceinline__ u32 operator()(u32 wire) const {
+        if (wire - A < w) return wire - A;
+        if (wire - B < w) return w + (wire - B);
+        if (wire - O < w) return 2u * w + (wire - O);
+        if (wire - X < n_aux) return 3u * w + (wire - X);
+        *stray = 1u;                                   // (a wire of some other gate: the template is wired wrongly)
+        return junk;
+    }
+};
+__device__ __forceinline__ u64 verify_value(u64 seed, u32 W, u32 t, u32 width, u64 mk) {
+    u64 v = mix64(seed ^ ((u64)W << 8) ^ t) & mk;
+    if (t == 0) v = 0; else if (t == 1) v = mk; else if (t == 2) v = 1 & mk; else if (t == 3) v = (1ull << (width - 1)) & mk;
+    return v;
+}
+__global__ void __launch_bounds__(kThreads) k_verify_local(VerifyLocal V) {
+    const u32 lane = threadIdx.x & 63u;
+    const u64 wave = gtid() >> 6, n_waves = gstride() >> 6;
+    const u32 w = V.width;
+    const u64 mk = w >= 64 ? ~0ull : ((1ull << w) - 1ull);
+    u64* sc = V.scratch + wave * V.scratch_words;
+    ull bad = 0;
+    for (u64 p = V.p_lo + wave; p < V.p_hi; p += n_waves) {
+        const u64 i = p - V.p_base;
+        const u32 W0 = V.e_in0[i], W1 = V.e_in1[i], Wo = V.e_out[i], op = V.e_op[i];
+        const u64 a = verify_value(V.seed, W0, lane, w, mk), b = verify_value(V.seed, W1, lane, w, mk);
+        // bit-slice: word k of the A bits = bit k of the 64 vectors
+        u64 wa = 0, wb = 0;
+        for (u32 k = 0; k < w; ++k) {
+            const u64 ma = __ballot((a >> k) & 1ull), mb = __ballot((b >> k) & 1ull);
+            if (lane == k) { wa = ma; wb = mb; }
+        }
+        if (lane < w) { ev_st(&sc[lane], wa); ev_st(&sc[w + lane], wb); }
+        chunk_fence();
+        u32 stray = 0;
+        const u64 x0 = V.aoff[i], x1 = V.aoff[i + 1];
+        LocalWires L{bool_wire(W0, 0, w, V.M, V.out_base), bool_wire(W1, 0, w, V.M, V.out_base), bool_wire(Wo, 0, w, V.M, V.out_base),
+                     (u32)(V.aux_base + x0), w, (u32)(x1 - x0), V.scratch_words - 1u, &stray};
+        eval_template_wave(V.goff[i] - V.q_bias, V.goff[i + 1] - V.q_bias, V.b_in0, V.b_in1, V.b_out, V.b_op, sc, lane, L);
+        chunk_fence();
+        // lane t reads vector t of the O bits back and compares it with the arithmetic result
+        u64 got = 0;
+        for (u32 k = 0; k < w; ++k) got |= ((ev_ld(&sc[2u * w + k]) >> lane) & 1ull) << k;
+        const u64 want = eval_arith_op(op, a, b, w, mk);
+        const u64 wrong = __ballot(got != want) | (__ballot(stray != 0u) ? ~0ull : 0ull);
+        bad += (ull)__popcll(wrong);
+        chunk_fence();                                 // (the scratch is free for the next gate)
+    }
+    if (lane == 0 && bad) atomicAdd(V.bad, bad);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -193,6 +193,10 @@ int c2a_checksum(c2a_ctx* ctx, int which, uint64_t* value);
  * pseudo-random input vectors and compares EVERY arithmetic wire with its `width` boolean wires.
  * *n_checked = wire_count * 64 (wire, vector) pairs, *n_mismatch = how many differ (0 when the bit-blast is right).
  * Needs ~8 B per (arithmetic wire x 64) + 8 B per boolean wire of scratch HBM; requires c2a_boolify.
+ * On a MULTI-DEVICE context nothing is gathered: every device checks the gates it holds, gate by gate — 64 vectors (a function
+ * of the input wire) bit-sliced onto the boolean wires the gate's inputs must occupy, its boolean gates run out of a private
+ * scratch (every wire they name must be the gate's own A / B / O bit or aux wire), the O bits compared with the arithmetic
+ * op.  *n_checked = n_gates * 64 (gate, vector) pairs there.
  */
 int c2a_verify_boolify(c2a_ctx* ctx, uint64_t seed, uint64_t* n_checked, uint64_t* n_mismatch);
 /*

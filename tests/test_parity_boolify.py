@@ -313,10 +313,28 @@ def test_multi_device_boolify_equals_the_single_device_result(multi_backend, orc
         backend_mod = __import__("importlib").import_module("circom-2-arithc_amd.backend")
         for name, arr in (("bool_in0", exp.in0), ("bool_in1", exp.in1), ("bool_out", exp.out), ("bool_op", exp.op)):
             assert be.checksum(name) == backend_mod.checksum_host(arr), name
-    # what needs the whole circuit in one place — the verifier, the evaluator, the prune pass, the text of a gate range —
-    # gathers it on the primary device once (peer copies) and gives the single-device answers
+    # the verifier of a multi-device context: every device checks the gates it holds (a wave per arithmetic gate: 64 vectors
+    # through its boolean gates out of a private scratch, every wire they name must be the gate's own) — nothing is gathered;
+    # a flipped op anywhere — first gate, a gate of every shard, last gate — is caught where it lies
     checked, bad = be.verify_boolify(1)
-    assert bad == 0 and checked > 0
+    assert bad == 0 and checked == fg.n * 64
+    if width <= 8 or multi_backend.version.find("emulation") < 0:      # (the emulator takes seconds per pass at width 32: once is enough there)
+        ops = be.bool_read()[3]
+        rng = np.random.default_rng(width)
+        caught = tried = 0
+        for k in sorted(set(rng.integers(0, n, size=8).tolist()) | {0, n - 1}):       # (gates of every shard)
+            if ops[k] == 2:
+                continue                                      # (INV -> anything changes the arity: not a fair fault)
+            be.debug_patch_bool_op(k, 1 - int(ops[k]))
+            caught += be.verify_boolify(1)[1] > 0
+            tried += 1
+            be.debug_patch_bool_op(k, int(ops[k]))
+        # (a flip inside a multiplier / divider template, or in zero-filled logic, is often masked for all 64 vectors: cf.
+        # test_gpu_verifier_agrees_and_detects_faults, which uses the linear-size templates for its detection rate)
+        assert tried >= 4 and caught >= 1, (caught, tried)
+        assert be.verify_boolify(1)[1] == 0
+    # the evaluator of the boolean image and the prune pass simulate the circuit level by level across all its gates: they
+    # gather it on the primary device once (peer copies) and give the single-device answers
     pi = be.boolify_prune()
     want, wcnt = orc.prune_bool(exp, int(info.wire(_oracle(orc, fg).wire_count - len(fg.output_nodes))))
     assert {k: pi[k] for k in wcnt} == wcnt
