@@ -75,6 +75,7 @@ struct c2a_ctx {
     bool fallback_logged = false;
 #ifdef C2A_EMULATE
     u32 emul_peel_abort = 0;       // tests only (C2A_EMUL_PEEL_ABORT): this many dataflow launches are treated as given up
+    u32 emul_build_no = 0;         // tests only (C2A_EMUL_BUILD_NO): the build number a freshly loaded graph starts from
 #endif
 
     // problem
@@ -156,6 +157,7 @@ int ensure(c2a_ctx* c, DevBuf& b, size_t bytes) {
 inline u32 grid_for(u64 items, u32 cap_blocks) {
     u64 b = (items + kThreads - 1) / kThreads;
     if (b < 1) b = 1;
+    if (b > 8) b = (b + 7) & ~7ull;              // (whole multiples of the eight XCDs: xcd_sweep gives each an eighth of the range)
     if (b > cap_blocks) b = cap_blocks;
     return (u32)b;
 }
@@ -719,6 +721,7 @@ int c2a_create(int n_devices, const int* device_ids, c2a_ctx** out) {
     if (const char* e = std::getenv("C2A_PEEL_FIFOS")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->peel_fifos = v; }
 #ifdef C2A_EMULATE
     if (const char* e = std::getenv("C2A_EMUL_PEEL_ABORT")) c->emul_peel_abort = (u32)std::strtoul(e, nullptr, 10);
+    if (const char* e = std::getenv("C2A_EMUL_BUILD_NO")) c->emul_build_no = (u32)std::strtoul(e, nullptr, 10);      // tests: start the build numbers near their wrap
 #endif
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return C2A_ERR_HIP; }
     if (hipStreamCreate(&c->aux) != hipSuccess) { c->aux = hipStream_t{}; c2a_destroy(c); return C2A_ERR_HIP; }
@@ -814,6 +817,9 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     bool cleared = false;
     if (n && hipMemsetAsync(c->node.p, 0, (size_t)n * kNodeWords * 8, c->aux) == hipSuccess) cleared = true;
     if (n_nodes) { HIP_TRY(hipMemsetAsync(c->nrec.p, 0, (size_t)n_nodes * 16, c->aux)); c->build_no = 0; }      // (no record of any build)
+#ifdef C2A_EMULATE
+    c->build_no = c->emul_build_no;
+#endif
     ENSURE(c->rbits, n4 / 32 + 8); ENSURE(c->rpre, n4 / 32 + 16); ENSURE(c->ridx, n4); ENSURE(c->rlist, n4);
     ENSURE(c->next, 2 * n4); ENSURE(c->owner, 2 * n4); ENSURE(c->local, 2 * n4); ENSURE(c->slist, 2 * n4);
     ENSURE(c->snext, 2 * n4); ENSURE(c->ssum, 2 * n4); ENSURE(c->jnxt, 2 * n4); ENSURE(c->jval, 2 * n4);

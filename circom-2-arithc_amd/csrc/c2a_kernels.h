@@ -36,7 +36,12 @@ __device__ __forceinline__ u64 gstride() { return (u64)gridDim.x * blockDim.x; }
 struct XcdSweep { u64 i, end, step; };
 __device__ __forceinline__ XcdSweep xcd_sweep(u64 n) {
 #if C2A_XCD_AWARE
-    if ((gridDim.x & 7u) == 0u && n >= 8ull * 4096ull) {
+#ifdef C2A_EMULATE
+    constexpr u64 kXcdMin = 1024;                  // (so that the CPU suite walks this mapping too)
+#else
+    constexpr u64 kXcdMin = 8ull * 4096ull;
+#endif
+    if ((gridDim.x & 7u) == 0u && n >= kXcdMin) {
         const u64 xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, wgs = gridDim.x >> 3;
         const u64 share = (((n + 7) / 8) + blockDim.x - 1) / blockDim.x * blockDim.x;
         const u64 lo = xcd * share, hi = lo + share < n ? lo + share : n;

@@ -448,3 +448,22 @@ def test_node_ids_without_creation_order(backend, orc, c2a):
         p = dict(lh=perm[fg.lh], rh=perm[fg.rh], out=perm[fg.out], op=fg.op, n_nodes=fg.n_nodes, input_nodes=perm[fg.input_nodes],
                  output_nodes=perm[fg.output_nodes])
         assert _compare(backend, orc, p) == "ok"
+
+
+def test_build_numbers_wrap(orc, c2a, emul_lib):
+    """The node-table records are tagged with the number of the build that wrote them (24 bits) instead of being cleared per
+    build; when the number wraps the table is cleared once.  Builds across the wrap give the same results (emulator hook:
+    the numbering starts two short of the wrap)."""
+    from conftest import _Env
+    fg = c2a.synth.layered_dag(30, 40, n_in=16, n_const=3, window=6, mix=c2a.synth.MIX_BITWISE, seed=5)       # (1 200 gates: the XCD-aware sweeps too)
+    p = dict(lh=fg.lh, rh=fg.rh, out=fg.out, op=fg.op, n_nodes=fg.n_nodes, input_nodes=fg.input_nodes, output_nodes=fg.output_nodes)
+    with _Env(C2A_EMUL_BUILD_NO=(1 << 24) - 3):
+        be = c2a.Backend(0, lib_path=emul_lib)
+    try:
+        assert _compare(be, orc, p, check_serial=False) == "ok"
+        be.load_gates(p["lh"], p["rh"], p["out"], p["op"], p["n_nodes"], p["input_nodes"], p["output_nodes"])
+        exp = orc.build_circuit(p["lh"], p["rh"], p["out"], p["op"], p["n_nodes"], p["input_nodes"], p["output_nodes"], mode=1)
+        for _ in range(5):                                   # ... - 2, - 1, wrap -> 1, 2, 3
+            np.testing.assert_array_equal(be.topo_sort(), exp.sorted)
+    finally:
+        be.close()
