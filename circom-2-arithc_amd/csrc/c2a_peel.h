@@ -6,6 +6,10 @@
 // (topological_sort.rs:11-13) and whose other edges carry label 0 (lh producer) / 1 (rh producer)
 // (compiler.rs:408-421, topological_sort.rs:42-44); the DFS post-order is the post-order of that tree.  A gate can pick
 // its parent once every consumer has picked its own (reverse Kahn order from the sinks).
+// GATE IDS IN THIS FILE ARE RANKS (c2a_kernels.h RELABELLING: the position of a gate's out node among the produced nodes, i.e.
+// the creation order) — records, tickets, consumer lists and tree entries of gates that are claimed together lie together —,
+// except where the DFS roots are compared: word 2 of a gate's first static record is its ORIGINAL id, the "root" fields of
+// records and tree entries hold original ids, and a gate is its own root when no consumer's root has a smaller original id.
 //
 // NODE RECORDS.  Every gate owns one 512-byte record of 64 self-validating 8-byte words: bit 63 of a word is the tag of
 // the run that wrote it (a word is written by ONE agent-scope store, so it is never torn; a reader that sees the wrong
