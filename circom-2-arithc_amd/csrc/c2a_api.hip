@@ -73,6 +73,7 @@ struct c2a_ctx {
     bool peel_gave_up = false;     // the last dataflow launch ended by its watchdog (do_peel retries once on clean buffers, then do_topo_sort sorts serially)
     bool serial_fallback = false;  // ... and that happened for the circuit now loaded (logged once per context)
     bool fallback_logged = false;
+    bool numbering_walk = false;   // C2A_NUMBERING_WALK=1: never the positional numbering (tests and A/B runs: the walk in sorted order on any circuit)
 #ifdef C2A_EMULATE
     u32 emul_peel_abort = 0;       // tests only (C2A_EMUL_PEEL_ABORT): this many dataflow launches are treated as given up
     u32 emul_build_no = 0;         // tests only (C2A_EMUL_BUILD_NO): the build number a freshly loaded graph starts from
@@ -91,11 +92,16 @@ struct c2a_ctx {
     DevBuf lh, rh, out, op, gate4, nrec, orig, in_nodes, out_nodes;
     DevBuf prod1, dep0, dep1, cons_cnt, cons_off, eslot, aq_items, aq_pc, aq_seeds, aq_seeds1, aq_seed_flat, aq_seed_cnt, fill, meta, node, child, gstat, clist, pctl, pcold;
     DevBuf rbits, rpre, ridx, rlist, next, owner, local, slist, snext, ssum, jnxt, jval, sorted, sorted_r;
-    DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op, gs, wcnt, wfo;
+    DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op;
+    DevBuf pos_r, erec, ev_items, ev_key, ev_cum, ev_blk, cnode, gflag;      // positional numbering (c2a_kernels.h POSITIONAL NUMBERING)
     u32* hrb = nullptr;            // 256 words of host memory the device writes the end-of-stage numbers to (k_post_*) ...
     u32* hrb_dev = nullptr;        // ... as the device sees it.  Words 0-7: peel, 8-15: order, 16-23: wires, 24-31: boolify
     u32 rb_edges = 0, rb_dup = 0, rb_nmid = 0, rb_err = 0;  // read-back slots (edge count, duplicate-writer flag, wires handed out, in/out clash)
     bool has_dup = false;          // two gates write one node (compiler.rs:403-406 keeps the last): the general numbering path
+    bool positional = false;       // the circuit now sorted takes the positional numbering (one writer per node, few events)
+    bool sorted_ready = false;     // sorted[] / sorted_r[] are written (c2a_build_circuit leaves them to the emission's split pass)
+    bool emitted_with_wires = false;   // the positional numbering has emitted the gates as well (do_emit has nothing left to do)
+    const u32* rank_suffix = nullptr;  // the splitter suffix sums the list ranking ended in (which of its ping-pong buffers)
     DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof, peel_trace;
     DevBuf tsz, asz, goff, aoff, tmpl, tables, b_in0, b_in1, b_out, b_op;
     DevBuf fmt_len, fmt_off, fmt_text, fmt_table, shard_cut, shard_qcut;
@@ -113,7 +119,7 @@ struct c2a_ctx {
         all = {&lh, &rh, &out, &op, &gate4, &nrec, &orig, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &aq_items, &aq_pc, &aq_seeds, &aq_seeds1, &aq_seed_flat, &aq_seed_cnt, &fill,
                &gstat, &clist, &pctl, &pcold, &meta, &node, &child, &rbits, &rpre, &ridx, &rlist, &next,
                &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &sorted_r, &first, &nflag, &wflag, &widx, &node_wire1,
-               &node_wire, &e_in0, &e_in1, &e_out, &e_op, &gs, &wcnt, &wfo, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &peel_trace, &tsz, &asz, &goff,
+               &node_wire, &e_in0, &e_in1, &e_out, &e_op, &pos_r, &erec, &ev_items, &ev_key, &ev_cum, &ev_blk, &cnode, &gflag, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &peel_trace, &tsz, &asz, &goff,
                &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &fmt_len, &fmt_off, &fmt_text, &fmt_table, &shard_cut, &shard_qcut, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &ev_lcount, &ev_lbase, &ev_lorder, &ev_bar, &ev_io, &g_in0, &g_in1, &g_out, &g_op, &pr_rep, &pr_need, &pr_tin0, &pr_tin1, &pr_top, &pr_live, &pr_goff, &pr_counts, &p_in0, &p_in1, &p_out, &p_op, &cb_in0, &cb_in1, &cb_out, &cb_op};
     }
 };
@@ -121,7 +127,8 @@ struct c2a_ctx {
 namespace {
 
 // scalars block layout (u32 words unless noted)
-enum Scalar { SC_MAXDEPTH = 0, SC_SCOUNT = 1, SC_ERR = 2, SC_NMID = 3, SC_NROOTS = 4, SC_LEVELS = 5, SC_DFS = 8 /*3 words*/, SC_DUP = 52,
+enum Scalar { SC_MAXDEPTH = 0, SC_SCOUNT = 1, SC_ERR = 2, SC_NMID = 3, SC_NROOTS = 4, SC_LEVELS = 5, SC_EV = 6 /*2 words: IO-out gates, constant-like nodes*/,
+              SC_DFS = 8 /*3 words*/, SC_EV_N = 11 /*events appended*/, SC_DUP = 52,
               SC_TOTAL64 = 16 /* u64 slots from here: 16..31 */, SC_WORDS = 64 };
 
 int fail(c2a_ctx* c, int code, const std::string& msg) {
@@ -225,14 +232,14 @@ int do_prep(c2a_ctx* c, bool for_peel = true) {
         ENSURE(c->scan_tmp, bytes);
         HIP_TRY(hipMemsetAsync(c->scan_tmp.p, 0, bytes, s));
         C2A_LAUNCH(k_relabel, (u32)tiles, kRelThreads, s, c->n_nodes, n, c->build_no, c->prod1.as<u32>(), (const uint4*)c->nrec.as<uint4>(), dup, c->orig.as<u32>(),
-                   c->gate4.as<uint4>(), c->scan_tmp.as<u64>() + 8, c->scan_tmp.as<u32>());
+                   c->gate4.as<uint4>(), c->scan_tmp.as<u64>() + 8, c->scan_tmp.as<u32>(), (const u8*)c->nflag.as<u8>(), c->scalars.as<u32>() + SC_EV);
     }
     // (two gates wrote one node — never, for a circuit the reference's front-end built: these two leave at once)
     C2A_LAUNCH_NOSYNC(k_dup_clear, 512, kThreads, s, c->n_nodes, (const u32*)dup, c->prod1.as<u32>());
     C2A_LAUNCH_NOSYNC(k_dup_producer, 512, kThreads, s, n, (const u32*)dup, (const u32*)c->out.as<u32>(), c->prod1.as<u32>());
     int r;
-    C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->out.as<u32>(), c->op.as<u8>(), dup, c->prod1.as<u32>(), (const u8*)c->nflag.as<u8>(), c->orig.as<u32>(),
-                      c->gate4.as<uint4>(), c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>());
+    C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->out.as<u32>(), c->op.as<u8>(), dup, c->prod1.as<u32>(), c->nflag.as<u8>(), c->orig.as<u32>(),
+                      c->gate4.as<uint4>(), c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>(), c->scalars.as<u32>() + SC_EV, c->cnode.as<u32>(), kEvCap, c->gflag.as<u8>());
     if (!for_peel) return C2A_OK;
     r = scan_exclusive<u32>(c, c->cons_cnt.as<u32>(), c->cons_off.as<u32>(), n);
     if (r) return r;
@@ -435,7 +442,7 @@ int do_peel(c2a_ctx* c, u32* peeled_out) {
     return r;
 }
 
-int do_order(c2a_ctx* c) {
+int do_order(c2a_ctx* c, bool defer_sorted) {
     const u32 n = c->n;
     hipStream_t s = c->stream;
     const u32 G = grid_for(n, 4096);
@@ -455,13 +462,18 @@ int do_order(c2a_ctx* c) {
     C2A_LAUNCH(k_rank_mark, std::max<u32>(1u, std::min<u32>(2048u, (m + kThreads * 8 - 1) / (kThreads * 8))), kThreads, s, m, c->rlist.as<u32>(), scount, c->slist.as<u32>(),
                       c->owner.as<u32>());
     static_assert(SC_SCOUNT == SC_MAXDEPTH + 1, "read as a pair");
-    C2A_LAUNCH_NOSYNC(k_post_words, 1, 64, s, c->hrb_dev + 8, (const u32*)(c->scalars.as<u32>() + SC_MAXDEPTH), 2u, n_roots_p, 1u, (const u32*)nullptr, 0u);
+    C2A_LAUNCH_NOSYNC(k_post_words, 1, 64, s, c->hrb_dev + 8, (const u32*)(c->scalars.as<u32>() + SC_MAXDEPTH), 2u, n_roots_p, 1u, (const u32*)(c->scalars.as<u32>() + SC_EV), 2u);
     HIP_TRY(hipStreamSynchronize(s));
     const u32 sc[3] = {c->hrb[8], c->hrb[9], c->hrb[10]};      // depth of the DFS forest, splitters, roots
     const u32 S = sc[1];
     c->stats.max_depth = sc[0];
     c->stats.n_splitters = S;
     c->stats.n_roots = sc[2];
+    // what bends the wire numbering away from "position q gets wire n_in + q" (k_relabel / k_deps counted it): few events and one
+    // writer per node => the positional numbering, which needs no walk in sorted order (c2a_kernels.h POSITIONAL NUMBERING)
+    c->positional = !c->has_dup && !c->numbering_walk && (u64)c->hrb[11] + c->hrb[12] <= kEvCap;
+    c->stats.numbering_events = c->hrb[11] + c->hrb[12];
+    c->stats.numbering_path = c->positional ? 1u : 0u;
     C2A_LAUNCH_NOSYNC(k_rank_walk, grid_for(S, 8192), kThreads, s, (const u32*)scount, c->rlist.as<u32>(), c->slist.as<u32>(),
                       c->next.as<u32>(), (const u32*)c->owner.as<u32>(), c->local.as<u64>(), c->snext.as<u32>(), c->ssum.as<u32>());
     // pointer jumping, ping-pong between (snext,ssum) and (jnxt,jval)
@@ -474,6 +486,9 @@ int do_order(c2a_ctx* c) {
         std::swap(nx_a, nx_b);
         std::swap(vl_a, vl_b);
     }
+    c->rank_suffix = vl_a;
+    c->sorted_ready = !(defer_sorted && c->positional);
+    if (!c->sorted_ready) return C2A_OK;            // (c2a_build_circuit: the emission's records carry the sorted order along)
     // (the tour's next[] has been consumed by the walk: its buffer takes the packed {rank, original id} pairs)
     C2A_LAUNCH_NOSYNC(k_rank_final, G, kThreads, s, n, (const u64*)c->local.as<u64>(), (const u32*)vl_a, (const u32*)c->orig.as<u32>(), c->next.as<uint2>());
     C2A_LAUNCH_NOSYNC(k_sorted_split, G, kThreads, s, n, (const uint2*)c->next.as<uint2>(), c->sorted_r.as<u32>(), c->sorted.as<u32>());
@@ -518,11 +533,12 @@ int after_serial_sort(c2a_ctx* c, bool with_levels) {
     return C2A_OK;
 }
 
-int do_topo_sort(c2a_ctx* c, u64* cycle_at) {
+int do_topo_sort(c2a_ctx* c, u64* cycle_at, bool defer_sorted = false) {
     if (c->stage < ST_LOADED) return fail(c, C2A_ERR_STATE, "c2a_topo_sort: no gates loaded");
     c->stage = ST_LOADED;
     c->bool_planned = false; c->fmt_chunk_valid = false; c->pruned = false; c->gathered = false;
     c->peel_meta_valid = false;
+    c->positional = false; c->sorted_ready = true; c->emitted_with_wires = false;
     const u32 n = c->n;
     std::memset(c->ev_valid, 0, sizeof(c->ev_valid));
     c->stats = c2a_stats{};
@@ -575,7 +591,7 @@ int do_topo_sort(c2a_ctx* c, u64* cycle_at) {
         if (status == 1) return fail(c, C2A_ERR_CYCLIC, "Cyclic dependency: detected at i=" + std::to_string(at));
         return fail(c, C2A_ERR_HIP, "internal: peel left gates behind but the serial DFS found no cycle");
     }
-    r = do_order(c);
+    r = do_order(c, defer_sorted);
     if (r) return r;
     rec(c, EV_ORDER1);
     c->stage = ST_SORTED;
@@ -592,35 +608,42 @@ int finish_wires(c2a_ctx* c) {
     return C2A_OK;
 }
 
+// block size of the event table: the smallest power of two that keeps it within kEvBlocks entries
+inline u32 ev_shift(u32 n) {
+    u32 sh = 0;
+    while ((((u64)3 * n) >> sh) + 2 > kEvBlocks) ++sh;
+    return sh;
+}
+
 int do_assign_wires(c2a_ctx* c, bool defer_readback = false) {
     if (c->stage < ST_SORTED) return fail(c, C2A_ERR_STATE, "c2a_assign_wires: call c2a_topo_sort first");
     const u32 n = c->n;
     hipStream_t s = c->stream;
     const u64 m = (u64)n * 3;
     rec(c, EV_WIRES0);
+    c->emitted_with_wires = false;
     // (the IO flags of the nodes and the in / out clash word are do_prep's: they do not change between the sort and here)
-    C2A_LAUNCH_NOSYNC(k_node_init, grid_for(std::max<u32>(1u, c->n_nodes), 4096), kThreads, s, c->n_nodes, c->node_wire1.as<u32>(), c->first.as<u32>());
+    C2A_LAUNCH_NOSYNC(k_node_init, grid_for(std::max<u32>(1u, c->n_nodes), 4096), kThreads, s, c->n_nodes, c->node_wire1.as<u32>(), c->first.as<u32>(),
+                      c->scalars.as<u32>() + SC_EV_N);
     if (c->n_in) C2A_LAUNCH_NOSYNC(k_input_wires, grid_for(c->n_in, 1024), kThreads, s, c->n_in, c->in_nodes.as<u32>(), c->node_wire1.as<u32>());
-    const bool fast = !c->has_dup;
-    const u64 n_scan = fast ? (u64)n : m;          // entries of the scanned flag array; widx[n_scan] = wires handed out
-    const u32 G = grid_for(n, 4096), GN = grid_for(c->n_nodes, 4096);
+    const u32 G = grid_for(n, 4096);
+    const u32* n_mid_p;
     int r;
-    if (fast) {
-        if (n) {
-            C2A_LAUNCH_NOSYNC(k_walk, G, kThreads, s, n, c->sorted_r.as<u32>(), (const uint4*)c->gate4.as<uint4>(),
-                              c->gs.as<uint4>(), c->wcnt.as<u32>(), c->wfo.as<u8>(), c->first.as<u32>());
-            C2A_LAUNCH_NOSYNC(k_walk_nodes, GN, kThreads, s, c->n_nodes, (const u32*)c->prod1.as<u32>(), (const u8*)c->nflag.as<u8>(),
-                              (const u32*)c->first.as<u32>(), c->wcnt.as<u32>());
-        }
-        r = scan_exclusive<u32>(c, c->wcnt.as<u32>(), c->widx.as<u32>(), n_scan);
-        if (r) return r;
-        if (n) {
-            C2A_LAUNCH_NOSYNC(k_assign_fast, G, kThreads, s, n, (const uint4*)c->gs.as<uint4>(), (const u32*)c->wcnt.as<u32>(),
-                              (const u8*)c->wfo.as<u8>(), (const u32*)c->widx.as<u32>(), c->n_in, c->node_wire1.as<u32>());
-            C2A_LAUNCH_NOSYNC(k_assign_nodes, GN, kThreads, s, c->n_nodes, (const u32*)c->prod1.as<u32>(), (const u8*)c->nflag.as<u8>(),
-                              (const u32*)c->first.as<u32>(), (const uint4*)c->gs.as<uint4>(), (const u32*)c->widx.as<u32>(), c->n_in,
-                              c->node_wire1.as<u32>());
-        }
+    if (c->positional && n) {
+        // POSITIONAL NUMBERING (c2a_kernels.h): positions, the few events that shift the numbering, then wires AND gates by formula
+        u32* ev_n = c->scalars.as<u32>() + SC_EV_N;
+        if (c->sorted_ready)
+            C2A_LAUNCH_NOSYNC(k_pos_sorted, G, kThreads, s, n, (const u32*)c->sorted_r.as<u32>(), (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), c->pos_r.as<u32>(),
+                              c->first.as<u32>(), c->ev_items.as<uint2>(), ev_n);
+        else
+            C2A_LAUNCH_NOSYNC(k_pos_rank, G, kThreads, s, n, (const u64*)c->local.as<u64>(), c->rank_suffix, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), c->pos_r.as<u32>(),
+                              c->first.as<u32>(), c->ev_items.as<uint2>(), ev_n);
+        C2A_LAUNCH_NOSYNC(k_const_events, grid_for(kEvCap, 16), kThreads, s, (const u32*)(c->scalars.as<u32>() + SC_EV + 1), (const u32*)c->cnode.as<u32>(),
+                          (const u32*)c->first.as<u32>(), c->ev_items.as<uint2>(), ev_n);
+        const u32 shift = ev_shift(n), n_blk = (u32)((((u64)3 * n) >> shift) + 2);
+        C2A_LAUNCH(k_event_sort, 1, kEvThreads, s, (const u32*)ev_n, (const uint2*)c->ev_items.as<uint2>(), n, c->n_in, n_blk, shift, c->ev_key.as<u32>(),
+                   c->ev_cum.as<int>(), c->ev_blk.as<u32>(), c->node_wire1.as<u32>(), c->scalars.as<u32>() + SC_NMID);
+        n_mid_p = c->scalars.as<u32>() + SC_NMID;
     } else {
         if (n) {
             C2A_LAUNCH_NOSYNC(k_first_seen, G, kThreads, s, n, c->sorted_r.as<u32>(), (const uint4*)c->gate4.as<uint4>(),
@@ -636,12 +659,30 @@ int do_assign_wires(c2a_ctx* c, bool defer_readback = false) {
                               (const uint4*)c->gate4.as<uint4>(), c->wflag.as<u32>(), c->widx.as<u32>(), c->n_in,
                               c->node_wire1.as<u32>());
         }
+        n_mid_p = c->widx.as<u32>() + m;
     }
     if (c->n_out)
         C2A_LAUNCH_NOSYNC(k_assign_outputs, grid_for(c->n_out, 1024), kThreads, s, c->n_out, c->out_nodes.as<u32>(), c->n_in,
-                          (const u32*)(c->widx.as<u32>() + n_scan), c->node_wire1.as<u32>());
+                          n_mid_p, c->node_wire1.as<u32>());
     rec(c, EV_WIRES1);
-    C2A_LAUNCH_NOSYNC(k_post_words, 1, 64, s, c->hrb_dev + 16, (const u32*)(c->widx.as<u32>() + n_scan), 1u, (const u32*)(c->scalars.as<u32>() + SC_ERR), 1u, (const u32*)nullptr, 0u);
+    C2A_LAUNCH_NOSYNC(k_post_words, 1, 64, s, c->hrb_dev + 16, n_mid_p, 1u, (const u32*)(c->scalars.as<u32>() + SC_ERR), 1u, (const u32*)nullptr, 0u);
+    if (c->positional && n) {
+        // the gates' own out wires are part of node -> wire, and the formula that gives them gives in0 / in1 as well: the emission
+        // belongs to this stage (do_emit finds it done)
+        rec(c, EV_EMIT0);
+        const EvTable T{c->ev_key.as<u32>(), c->ev_cum.as<int>(), c->ev_blk.as<u32>(), ev_shift(n)};
+        C2A_LAUNCH_NOSYNC(k_emit_rank, G, kThreads, s, n, c->n_in, (const uint4*)c->gate4.as<uint4>(), (const u32*)c->dep0.as<u32>(), (const u32*)c->dep1.as<u32>(),
+                          (const u32*)c->orig.as<u32>(), (const u32*)c->pos_r.as<u32>(), T, c->node_wire1.as<u32>(), c->erec.as<EmitRec>());
+        if (c->sorted_ready)
+            C2A_LAUNCH_NOSYNC(k_emit_split<false>, G, kThreads, s, n, (const EmitRec*)c->erec.as<EmitRec>(), c->e_in0.as<u32>(), c->e_in1.as<u32>(), c->e_out.as<u32>(),
+                              c->e_op.as<u8>(), c->sorted_r.as<u32>(), c->sorted.as<u32>());
+        else
+            C2A_LAUNCH_NOSYNC(k_emit_split<true>, G, kThreads, s, n, (const EmitRec*)c->erec.as<EmitRec>(), c->e_in0.as<u32>(), c->e_in1.as<u32>(), c->e_out.as<u32>(),
+                              c->e_op.as<u8>(), c->sorted_r.as<u32>(), c->sorted.as<u32>());
+        rec(c, EV_EMIT1);
+        c->sorted_ready = true;
+        c->emitted_with_wires = true;
+    }
     c->stage = ST_WIRED;                             // (the emission may be queued behind this; finish_wires() makes it official)
     if (defer_readback) return C2A_OK;
     HIP_TRY(hipStreamSynchronize(s));
@@ -650,12 +691,9 @@ int do_assign_wires(c2a_ctx* c, bool defer_readback = false) {
 
 int do_emit(c2a_ctx* c) {
     if (c->stage < ST_WIRED) return fail(c, C2A_ERR_STATE, "c2a_emit_gates: call c2a_assign_wires first");
+    if (c->emitted_with_wires) { c->stage = ST_EMITTED; return C2A_OK; }      // (positional numbering: done with the wires)
     rec(c, EV_EMIT0);
-    if (c->n && !c->has_dup)
-        C2A_LAUNCH_NOSYNC(k_emit_fast, grid_for(c->n, 4096), kThreads, c->stream, c->n, (const uint4*)c->gs.as<uint4>(),
-                          (const u32*)c->wcnt.as<u32>(), (const u8*)c->wfo.as<u8>(), (const u32*)c->widx.as<u32>(), c->n_in,
-                          (const u32*)c->node_wire1.as<u32>(), c->e_in0.as<u32>(), c->e_in1.as<u32>(), c->e_out.as<u32>(), c->e_op.as<u8>());
-    else if (c->n)
+    if (c->n)
         C2A_LAUNCH_NOSYNC(k_emit, grid_for(c->n, 4096), kThreads, c->stream, c->n, c->sorted_r.as<u32>(),
                           (const uint4*)c->gate4.as<uint4>(), c->node_wire1.as<u32>(), c->e_in0.as<u32>(), c->e_in1.as<u32>(),
                           c->e_out.as<u32>(), c->e_op.as<u8>());
@@ -718,6 +756,7 @@ int c2a_create(int n_devices, const int* device_ids, c2a_ctx** out) {
     if (const char* e = std::getenv("C2A_PEEL_SHALLOW")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 48) c->peel_shallow = v; }
     if (const char* e = std::getenv("C2A_PEEL_WAVES")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 32) c->peel_waves = v; }
     if (const char* e = std::getenv("C2A_PEEL_RESERVE")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v <= 32) c->peel_reserve = v; }
+    if (const char* e = std::getenv("C2A_NUMBERING_WALK")) c->numbering_walk = e[0] == '1';
     if (const char* e = std::getenv("C2A_PEEL_FIFOS")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->peel_fifos = v; }
 #ifdef C2A_EMULATE
     if (const char* e = std::getenv("C2A_EMUL_PEEL_ABORT")) c->emul_peel_abort = (u32)std::strtoul(e, nullptr, 10);
@@ -824,9 +863,10 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     ENSURE(c->next, 2 * n4); ENSURE(c->owner, 2 * n4); ENSURE(c->local, 2 * n4); ENSURE(c->slist, 2 * n4);
     ENSURE(c->snext, 2 * n4); ENSURE(c->ssum, 2 * n4); ENSURE(c->jnxt, 2 * n4); ENSURE(c->jval, 2 * n4);
     ENSURE(c->sorted, n4); ENSURE(c->sorted_r, n4);
-    ENSURE(c->first, nn4); ENSURE(c->nflag, n_nodes); ENSURE(c->wflag, 3 * n4); ENSURE(c->widx, 3 * n4 + 4);
+    ENSURE(c->first, nn4); ENSURE(c->nflag, (size_t)n_nodes + 4); ENSURE(c->wflag, 3 * n4); ENSURE(c->widx, 3 * n4 + 4);
     ENSURE(c->node_wire1, nn4); ENSURE(c->node_wire, nn4);
-    ENSURE(c->gs, (size_t)n * 16); ENSURE(c->wcnt, n4 + 4); ENSURE(c->wfo, n);
+    ENSURE(c->pos_r, n4); ENSURE(c->erec, (size_t)n * sizeof(EmitRec)); ENSURE(c->ev_items, (size_t)kEvCap * 8); ENSURE(c->ev_key, (size_t)kEvCap * 4 + 4);
+    ENSURE(c->ev_cum, ((size_t)kEvCap + 1) * 4); ENSURE(c->ev_blk, (size_t)kEvBlocks * 4 + 64); ENSURE(c->cnode, (size_t)kEvCap * 4); ENSURE(c->gflag, n);
     ENSURE(c->e_in0, n4); ENSURE(c->e_in1, n4); ENSURE(c->e_out, n4); ENSURE(c->e_op, n);
     ENSURE(c->scalars, SC_WORDS * 4);
     hipStream_t s = c->stream;
@@ -862,6 +902,7 @@ int c2a_topo_sort_serial(c2a_ctx* c, uint32_t* sorted, uint64_t* cycle_at) {
     HIP_TRY(hipSetDevice(c->device));
     c->stage = ST_LOADED;
     c->bool_planned = false; c->fmt_chunk_valid = false; c->pruned = false; c->gathered = false; c->peel_meta_valid = false;
+    c->positional = false; c->sorted_ready = true; c->emitted_with_wires = false;
     c->stats = c2a_stats{}; c->stats.n_gates = c->n;
     if (cycle_at) *cycle_at = 0;
     if (c->n == 0) { int r0 = mark_io(c); if (r0) return r0; c->stage = ST_SORTED; return C2A_OK; }
@@ -926,7 +967,7 @@ int c2a_build_circuit(c2a_ctx* c, uint64_t* cycle_at, uint32_t* wire_count) {
     if (c->io_clash) return fail(c, C2A_ERR_INCONSISTENCY, "Inconsistency: a node is used for both input and output");
     hipEvent_t b0 = c->ev[EV_BUILD0];
     HIP_TRY(hipEventRecord(b0, c->stream));
-    int r = do_topo_sort(c, cycle_at);
+    int r = do_topo_sort(c, cycle_at, true);
     if (r) return r;
     c->ev_valid[EV_BUILD0] = true;
     // (the numbering's read-back is picked up below — one host round trip for numbering + emission —: until it has been, the

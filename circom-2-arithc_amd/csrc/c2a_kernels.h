@@ -236,7 +236,7 @@ __global__ void k_dup_producer(u32 n, const u32* __restrict__ dup, const u32* __
 // produced nodes have consecutive ranks).
 constexpr int kRelThreads = 256, kRelRounds = 16, kRelTile = kRelThreads * kRelRounds;
 __global__ void __launch_bounds__(kRelThreads) k_relabel(u32 n_nodes, u32 n, u32 build, u32* prod1, const uint4* __restrict__ nrec, u32* dup,
-                                                         u32* orig, uint4* gate4, u64* desc, u32* counter) {
+                                                         u32* orig, uint4* gate4, u64* desc, u32* counter, const u8* __restrict__ nflag, u32* ev) {
     __shared__ u32 s_tile, s_wave[kRelThreads / 64];
     __shared__ u64 s_excl;
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
@@ -249,13 +249,19 @@ __global__ void __launch_bounds__(kRelThreads) k_relabel(u32 n_nodes, u32 n, u32
     uint4 rec[kRelRounds];
 #pragma unroll
     for (int i = 0; i < kRelRounds; ++i) { const u64 v = base + (u64)i * 64; rec[i] = v < n_nodes ? nrec[v] : make_uint4(0u, 0u, 0u, ~build << 8); }
-    u32 cnt = 0;
+    u32 cnt = 0, n_io = 0, io_mask = 0;
 #pragma unroll
     for (int i = 0; i < kRelRounds; ++i) {
-        const u64 bal = __ballot((rec[i].w >> 8) == build);      // a record of THIS build: the node is produced
+        const u64 v = base + (u64)i * 64;
+        const bool produced = (rec[i].w >> 8) == build;          // a record of THIS build: the node is produced
+        const bool io = produced && v < n_nodes && (nflag[v] & 3u) != 0u;      // ... and it is an input or output node (k_deps: kGateOutIO)
+        const u64 bal = __ballot(produced);
         pre[i] = cnt + (u32)__popcll(bal & lt_mask);
         cnt += (u32)__popcll(bal);
+        n_io += (u32)__popcll(__ballot(io));
+        io_mask |= io ? 1u << i : 0u;
     }
+    if (lane == 0 && n_io) atomicAdd(&ev[0], n_io);
     if (lane == 0) s_wave[wv] = cnt;
     __syncthreads();
     u32 wave_base = 0, tile_total = 0;
@@ -277,7 +283,7 @@ __global__ void __launch_bounds__(kRelThreads) k_relabel(u32 n_nodes, u32 n, u32
         const u32 rank = first + pre[i];
         if (rank < n) {                            // (always, unless two gates wrote one node: then all of this is redone)
             orig[rank] = rec[i].z;
-            gate4[rank] = make_uint4(rec[i].x, rec[i].y, (u32)v, rec[i].w & 0xFFu);
+            gate4[rank] = make_uint4(rec[i].x, rec[i].y, (u32)v, (rec[i].w & 0xFFu) | ((io_mask >> i) & 1u ? 0x400u : 0u));
         }
         prod1[v] = rank + 1u;
     }
@@ -285,11 +291,25 @@ __global__ void __launch_bounds__(kRelThreads) k_relabel(u32 n_nodes, u32 n, u32
 
 // deps closure (compiler.rs:408-421) + consumer counts, in rank space.  dep1 is dropped when equal to dep0: a second
 // visit of the same gate is a no-op in the DFS (topological_sort.rs:30-32).
-// The payload record gets three flags {lh node un-produced << 8 | rh node un-produced << 9 | out node is an IO node << 10}:
-// what the numbering kernels want to know about a gate's nodes comes along instead of costing three more scattered reads.
+// The payload record gets five flags {lh node un-produced << 8 | rh node un-produced << 9 | out node is an IO node << 10 |
+// lh node is a CONSTANT-like node (un-produced and no IO node: it gets its wire where the walk first sees it) << 11 | rh
+// likewise << 12}: what the numbering kernels want to know about a gate's nodes comes along instead of costing scattered reads.
+// It also counts what bends the wire numbering away from "the gate at sorted position q gets wire n_in + q" (POSITIONAL
+// NUMBERING below): ev[0] = gates whose out node is an IO node, ev[1] = distinct constant-like nodes (bit 2 of the node's
+// flag byte: the first gate to set it lists the node in cnode[]).
+constexpr u32 kGateLhUnprod = 0x100u, kGateRhUnprod = 0x200u, kGateOutIO = 0x400u, kGateLhConst = 0x800u, kGateRhConst = 0x1000u;
+__device__ __forceinline__ bool note_const_node(u32 v, u8* nflag, u32* ev, u32* cnode, u32 cnode_cap) {
+    if (nflag[v] & 3u) return false;                                              // an input or output node: its wire is fixed
+    if (!(nflag[v] & 4u)) {
+        const u32 bit = 4u << (8u * (v & 3u));
+        const u32 old = atomicOr(reinterpret_cast<u32*>(nflag) + (v >> 2), bit);      // (the flag bytes are padded to whole words)
+        if (!(old & bit)) { const u32 i = atomicAdd(&ev[1], 1u); if (i < cnode_cap) cnode[i] = v; }
+    }
+    return true;
+}
 __global__ void k_deps(u32 n, const u32* __restrict__ lh, const u32* __restrict__ rh, const u32* __restrict__ out, const u8* __restrict__ op,
-                       const u32* __restrict__ dup, const u32* __restrict__ prod1, const u8* __restrict__ nflag, u32* orig, uint4* gate4,
-                       u32* dep0, u32* dep1, u32* cons_cnt, u32* eslot) {
+                       const u32* __restrict__ dup, const u32* __restrict__ prod1, u8* nflag, u32* orig, uint4* gate4,
+                       u32* dep0, u32* dep1, u32* cons_cnt, u32* eslot, u32* ev, u32* cnode, u32 cnode_cap, u8* gflag) {
     const bool ident = *dup != 0u;
     const XcdSweep R = xcd_sweep(n);
     for (u64 g = R.i; g < R.end; g += R.step) {
@@ -297,7 +317,12 @@ __global__ void k_deps(u32 n, const u32* __restrict__ lh, const u32* __restrict_
         if (ident) { r = make_uint4(lh[g], rh[g], out[g], (u32)op[g]); orig[g] = (u32)g; }
         else r = gate4[g];
         const u32 p0 = prod1[r.x], p1 = prod1[r.y];
-        gate4[g] = make_uint4(r.x, r.y, r.z, (r.w & 0xFFu) | (p0 ? 0u : 0x100u) | (p1 ? 0u : 0x200u) | (nflag[r.z] ? 0x400u : 0u));
+        u32 w = (r.w & (0xFFu | kGateOutIO)) | (p0 ? 0u : kGateLhUnprod) | (p1 ? 0u : kGateRhUnprod);      // (kGateOutIO: k_relabel's)
+        if (ident && (nflag[r.z] & 3u)) w |= kGateOutIO;
+        if (!p0 && note_const_node(r.x, nflag, ev, cnode, cnode_cap)) w |= kGateLhConst;
+        if (!p1 && note_const_node(r.y, nflag, ev, cnode, cnode_cap)) w |= kGateRhConst;
+        gate4[g] = make_uint4(r.x, r.y, r.z, w);
+        gflag[g] = (u8)(w >> 8);                                  // (the flags alone, for the pass that only wants them: k_pos_rank)
         const u32 d0 = p0 ? p0 - 1 : C2A_NONE;
         u32 d1 = p1 ? p1 - 1 : C2A_NONE;
         if (d1 == d0) d1 = C2A_NONE;
@@ -558,7 +583,8 @@ __global__ void k_mark_inputs(u32 n_in, const u32* __restrict__ in_nodes, u8* nf
     for (u64 i = gtid(); i < n_in; i += gstride()) nflag[in_nodes[i]] = 1;      // (all writers store the same byte)
 }
 // the per-node state of the wire numbering in one launch: no wire, not seen yet; then the input wires (compiler.rs:388-395)
-__global__ void k_node_init(u32 n_nodes, u32* node_wire1, u32* first) {
+__global__ void k_node_init(u32 n_nodes, u32* node_wire1, u32* first, u32* ev_n) {
+    if (gtid() == 0) *ev_n = 0u;                                  // (the event list of the positional numbering starts empty)
     for (u64 v = gtid(); v < n_nodes; v += gstride()) { node_wire1[v] = 0u; first[v] = 0xFFFFFFFFu; }
 }
 __global__ void k_input_wires(u32 n_in, const u32* __restrict__ in_nodes, u32* node_wire1) {
@@ -605,13 +631,13 @@ __global__ void k_new_wire_flags(u32 n, const u32* __restrict__ sorted, const ui
         const uint4 g = gate4[sorted[pos]];
         const u32 i = 3u * (u32)pos;
         if (general) {
-            flag[i] = (first[g.x] == i && nflag[g.x] == 0) ? 1u : 0u;                 // :431-438
-            flag[i + 1] = (first[g.y] == i + 1 && nflag[g.y] == 0) ? 1u : 0u;
-            flag[i + 2] = (first[g.z] == i + 2 && nflag[g.z] == 0) ? 1u : 0u;
+            flag[i] = (first[g.x] == i && (nflag[g.x] & 3u) == 0) ? 1u : 0u;                 // :431-438
+            flag[i + 1] = (first[g.y] == i + 1 && (nflag[g.y] & 3u) == 0) ? 1u : 0u;
+            flag[i + 2] = (first[g.z] == i + 2 && (nflag[g.z] & 3u) == 0) ? 1u : 0u;
         } else {
-            flag[i] = (prod1[g.x] == 0 && first[g.x] == i && nflag[g.x] == 0) ? 1u : 0u;
-            flag[i + 1] = (prod1[g.y] == 0 && first[g.y] == i + 1 && nflag[g.y] == 0) ? 1u : 0u;
-            flag[i + 2] = nflag[g.z] == 0 ? 1u : 0u;                                  // first seen here: its only writer
+            flag[i] = (prod1[g.x] == 0 && first[g.x] == i && (nflag[g.x] & 3u) == 0) ? 1u : 0u;
+            flag[i + 1] = (prod1[g.y] == 0 && first[g.y] == i + 1 && (nflag[g.y] & 3u) == 0) ? 1u : 0u;
+            flag[i + 2] = (nflag[g.z] & 3u) == 0 ? 1u : 0u;                                  // first seen here: its only writer
         }
     }
 }
@@ -646,65 +672,165 @@ __global__ void k_emit(u32 n, const u32* __restrict__ sorted, const uint4* __res
     }
 }
 
-// ---- fast path: every node has one writer (*dup == 0, the normal case).  The sorted order is topological, so a produced
-// node is first seen as its producer's `out`: whether it gets a new wire is local (it does unless it is an IO node),
-// and only nodes NO gate produces (constants, dangling nodes) need the first-appearance race.  One gather of the gate
-// record per sorted position for the whole numbering + emission (the record is re-stored in sorted order), instead of
-// four; the first-appearance flags are scattered per NODE, not re-derived per reference.
-//   k_walk          gs[pos] = gate4[sorted[pos]]; cnt[pos] = fo[pos] = (out is no IO node); first[] race for un-produced lh / rh
-//   k_walk_nodes    every un-produced, non-IO node that appears: cnt[first / 3] += 1
-//   (scan cnt -> widx)
-//   k_assign_fast   node_wire1[out] = n_in + widx[pos] + (cnt[pos] - 1) for fo[pos]
-//   k_assign_nodes  the un-produced nodes' wires (lh before rh inside one gate, compiler.rs:430)
-//   k_emit_fast     in0 / in1 by gather, out by formula, op from the record
-__global__ void k_walk(u32 n, const u32* __restrict__ sorted, const uint4* __restrict__ gate4,
-                       uint4* gs, u32* cnt, u8* fo, u32* first) {
-    for (u64 pos = gtid(); pos < n; pos += gstride()) {
-        const uint4 g = gate4[sorted[pos]];
-        gs[pos] = g;
-        const u32 i = 3u * (u32)pos;
-        if (g.w & 0x100u) atomicMin(&first[g.x], i);                              // (un-produced input nodes: flags packed by k_deps)
-        if (g.w & 0x200u) atomicMin(&first[g.y], i + 1);
-        const u32 f = (g.w & 0x400u) ? 0u : 1u;                                  // :431-438 for the out node (IO flag packed by k_deps)
-        cnt[pos] = f;
-        fo[pos] = (u8)f;
+// ------------------------------------------------------------------------------------------------
+// POSITIONAL NUMBERING — wires and emission of a circuit whose nodes have one writer each (*dup == 0, what the reference's
+// front-end builds), without a walk in sorted order.
+// The walk `for gate in sorted: [lh, rh, out]` (compiler.rs:427-430) hands a node a new wire where it is first seen unless it
+// is an IO node (:431-438).  The sorted order is topological, so a PRODUCED node is first seen as its producer's out: the gate
+// at sorted position q gets wire n_in + q — but for two kinds of EVENT that shift everything behind them: a gate whose out
+// node is an IO node hands out nothing (-1 from walk index 3q + 2 on), and a constant-like node (un-produced, no IO node)
+// takes a wire at the walk index it is first seen at (+1 from there on).  Events are few (k_relabel / k_deps count them; the
+// host takes the general path when they are more than kEvCap), so:
+//     wire of the out node at position q = n_in + q + D(3q + 2),   D(key) = sum of the deltas of the events before walk index key
+// with the events sorted by walk index (one workgroup, in LDS) and looked up through a table of blocks of walk indices.  A
+// gate then needs nothing but POSITIONS: its own and its producers' — pos_r[] is indexed by rank, producers sit a bounded
+// distance before their consumers in rank space, so these gathers stay on chip; the sorted order is only ever written, one
+// scattered 32-byte record per gate {in0, in1, out, op, rank, original id}, which k_emit_split streams into the arrays of the
+// ABI.  (The walk it replaces: one 16-byte gather + a scatter + two 4-byte gathers by node id per sorted position, in an
+// order that is local in no space — 0.76 ms for 10 M gates; this: 0.45.)
+//   k_pos_rank      pos_r[rank] = post-order position | IO-out tag; IO-out events; first walk index of every constant-like node
+//   k_const_events  one event per constant-like node
+//   k_event_sort    sorted events, running deltas, block table, the constant-like nodes' wires
+//   (k_assign_outputs: n_mid = n - IO-out events + constant-like nodes is known to the host)
+//   k_emit_rank     in0 / in1 / out by formula (IO nodes and un-produced nodes: by look-up), node -> wire, the 32-byte records
+//   k_emit_split    e_in0 / e_in1 / e_out / e_op / sorted_r / sorted
+// ------------------------------------------------------------------------------------------------
+#ifdef C2A_EMULATE
+constexpr u32 kEvCap = 64;            // (small, so that the CPU suite takes the general path too)
+#else
+constexpr u32 kEvCap = 4096;          // events one workgroup sorts in LDS
+#endif
+constexpr u32 kEvBlocks = 8192;      // entries of the block table at most (the host picks the block size: ev_shift)
+constexpr u32 kPosIO = 0x80000000u;   // pos_r[]: the gate's out node is an IO node (its wire is looked up, not computed)
+
+__device__ __forceinline__ void pos_note(u32 x, u32 p, const u8* __restrict__ gflag, const uint4* __restrict__ gate4, u32* pos_r, u32* first,
+                                         uint2* ev_items, u32* ev_n) {
+    const u32 w = (u32)gflag[x] << 8;
+    pos_r[x] = p | ((w & kGateOutIO) ? kPosIO : 0u);
+    if (w & kGateOutIO) { const u32 i = atomicAdd(ev_n, 1u); if (i < kEvCap) ev_items[i] = make_uint2(((3u * p + 2u) << 1) | 1u, 0u); }
+    if (w & (kGateLhConst | kGateRhConst)) {
+        const uint4 g = gate4[x];
+        if (w & kGateLhConst) atomicMin(&first[g.x], 3u * p);
+        if (w & kGateRhConst) atomicMin(&first[g.y], 3u * p + 1u);
     }
 }
-__global__ void k_walk_nodes(u32 n_nodes, const u32* __restrict__ prod1, const u8* __restrict__ nflag, const u32* __restrict__ first,
-                             u32* cnt) {
-    for (u64 v = gtid(); v < n_nodes; v += gstride()) {
-        const u32 f = first[v];
-        if (f != 0xFFFFFFFFu && prod1[v] == 0 && nflag[v] == 0) atomicAdd(&cnt[f / 3u], 1u);
+// positions from the list ranking (ol / suffix as k_rank_final reads them) ...
+__global__ void k_pos_rank(u32 n, const u64* __restrict__ ol, const u32* __restrict__ suffix, const u8* __restrict__ gflag, const uint4* __restrict__ gate4,
+                           u32* pos_r, u32* first, uint2* ev_items, u32* ev_n) {
+    for (u64 x = gtid(); x < n; x += gstride()) {
+        const u64 r = ol[x];
+        pos_note((u32)x, (n - suffix[(u32)(r >> 32)]) + (u32)r, gflag, gate4, pos_r, first, ev_items, ev_n);
     }
 }
-__global__ void k_assign_fast(u32 n, const uint4* __restrict__ gs, const u32* __restrict__ cnt, const u8* __restrict__ fo,
-                              const u32* __restrict__ widx, u32 n_in, u32* node_wire1) {
-    for (u64 pos = gtid(); pos < n; pos += gstride())
-        if (fo[pos]) node_wire1[gs[pos].z] = n_in + widx[pos] + (cnt[pos] - 1u) + 1u;        // out comes last in [lh, rh, out]
+// ... or from a sorted order that exists already (c2a_topo_sort handed it to the caller)
+__global__ void k_pos_sorted(u32 n, const u32* __restrict__ sorted_r, const u8* __restrict__ gflag, const uint4* __restrict__ gate4,
+                             u32* pos_r, u32* first, uint2* ev_items, u32* ev_n) {
+    for (u64 p = gtid(); p < n; p += gstride()) pos_note(sorted_r[p], (u32)p, gflag, gate4, pos_r, first, ev_items, ev_n);
 }
-__global__ void k_assign_nodes(u32 n_nodes, const u32* __restrict__ prod1, const u8* __restrict__ nflag, const u32* __restrict__ first,
-                               const uint4* __restrict__ gs, const u32* __restrict__ widx, u32 n_in, u32* node_wire1) {
-    for (u64 v = gtid(); v < n_nodes; v += gstride()) {
-        const u32 f = first[v];
-        if (f == 0xFFFFFFFFu || prod1[v] != 0 || nflag[v] != 0) continue;
-        const u32 pos = f / 3u, k = f - 3u * pos;
-        u32 before = 0;
-        if (k == 1u) {                                                           // rh: one more if lh got its wire at this very gate
-            const u32 x = gs[pos].x;
-            before = (prod1[x] == 0 && nflag[x] == 0 && first[x] == 3u * pos) ? 1u : 0u;
+__global__ void k_const_events(const u32* __restrict__ n_const, const u32* __restrict__ cnode, const u32* __restrict__ first, uint2* ev_items, u32* ev_n) {
+    const u32 nc = *n_const < kEvCap ? *n_const : kEvCap;
+    for (u64 k = gtid(); k < nc; k += gstride()) {
+        const u32 v = cnode[k], i = atomicAdd(ev_n, 1u);
+        if (i < kEvCap) ev_items[i] = make_uint2(first[v] << 1, v);      // (every listed node is an operand of some gate, and every gate is in the sorted order)
+    }
+}
+
+// One workgroup: the (<= kEvCap) events sorted by walk index — walk indices are unique, so an event's place is the number of
+// smaller keys: every thread counts that for its (<= kEvCap / 1 024) events in one sweep over the keys in LDS (broadcast reads;
+// a bitonic network over 4 096 keys is 78 rounds with a barrier each: 74 µs, this: a few) —, the exclusive running sum of their
+// deltas, the table blk[b] = number of events before walk index b << shift, and the wires of the constant-like nodes (their own
+// event's formula).
+constexpr int kEvThreads = 1024;
+constexpr u32 kEvPer = (kEvCap + kEvThreads - 1) / kEvThreads;
+__global__ void __launch_bounds__(kEvThreads) k_event_sort(const u32* __restrict__ ev_n, const uint2* __restrict__ ev_items, u32 n, u32 n_in, u32 n_blk, u32 shift,
+                                                           u32* ev_key, int* ev_cum, u32* blk, u32* node_wire1, u32* n_mid) {
+    __shared__ u32 s_in[kEvCap], s_key[kEvCap], s_val[kEvCap];
+    __shared__ int s_part[kEvThreads];
+    const u32 tid = threadIdx.x;
+    const u32 E = *ev_n < kEvCap ? *ev_n : kEvCap;
+    uint2 own[kEvPer];
+    u32 place[kEvPer];
+#pragma unroll
+    for (u32 k = 0; k < kEvPer; ++k) {
+        const u32 i = tid + k * kEvThreads;
+        own[k] = i < E ? ev_items[i] : make_uint2(0xFFFFFFFFu, 0u);
+        place[k] = 0;
+        if (i < kEvCap) s_in[i] = own[k].x;
+    }
+    __syncthreads();
+    for (u32 j = 0; j < E; ++j) {
+        const u32 kj = s_in[j];
+#pragma unroll
+        for (u32 k = 0; k < kEvPer; ++k) place[k] += kj < own[k].x ? 1u : 0u;
+    }
+#pragma unroll
+    for (u32 k = 0; k < kEvPer; ++k)
+        if (tid + k * kEvThreads < E) { s_key[place[k]] = own[k].x; s_val[place[k]] = own[k].y; }
+    __syncthreads();
+    // running deltas: thread t owns the sorted events [t * per, (t + 1) * per)
+    const u32 per = (E + kEvThreads - 1) / kEvThreads;
+    const u32 i_lo = tid * per < E ? tid * per : E, i_hi = (tid + 1) * per < E ? (tid + 1) * per : E;
+    int mine = 0;
+    for (u32 i = i_lo; i < i_hi; ++i) mine += (s_key[i] & 1u) ? -1 : 1;
+    s_part[tid] = mine;
+    __syncthreads();
+    int before = 0;
+    for (u32 t = 0; t < tid; ++t) before += s_part[t];      // (1 024 partial sums, read by everyone: broadcasts)
+    for (u32 i = i_lo; i < i_hi; ++i) {
+        const u32 kv = s_key[i], key = kv >> 1;
+        ev_key[i] = key;
+        ev_cum[i] = before;
+        if (!(kv & 1u)) node_wire1[s_val[i]] = n_in + key / 3u + (u32)before + 1u;      // a constant-like node: the wire its own event hands out
+        before += (kv & 1u) ? -1 : 1;
+    }
+    if (tid == kEvThreads - 1) { ev_cum[E] = before; *n_mid = n + (u32)before; }      // (the last thread's running sum is the total: wires handed out in the walk, compiler.rs:440-441)
+    for (u32 b = tid; b < n_blk; b += kEvThreads) {
+        const u64 lim = (u64)b << shift;
+        u32 lo = 0, hi = E;
+        while (lo < hi) { const u32 m = (lo + hi) >> 1; if ((u64)(s_key[m] >> 1) < lim) lo = m + 1; else hi = m; }
+        blk[b] = lo;
+    }
+}
+
+struct EvTable { const u32* key; const int* cum; const u32* blk; u32 shift; };
+// D(key): sum of the deltas of the events before walk index `key`
+__device__ __forceinline__ int ev_delta(const EvTable& T, u32 key) {
+    const u32 b = key >> T.shift;
+    u32 lo = T.blk[b], hi = T.blk[b + 1];
+    while (lo < hi) { const u32 m = (lo + hi) >> 1; if (T.key[m] < key) lo = m + 1; else hi = m; }
+    return T.cum[lo];
+}
+struct EmitRec { uint4 gate, ids; };      // {in0, in1, out, op}, {rank, original id, -, -}: one 32-byte store
+__global__ void k_emit_rank(u32 n, u32 n_in, const uint4* __restrict__ gate4, const u32* __restrict__ dep0, const u32* __restrict__ dep1,
+                            const u32* __restrict__ orig, const u32* __restrict__ pos_r, EvTable T, u32* node_wire1, EmitRec* erec) {
+    const XcdSweep R = xcd_sweep(n);
+    for (u64 x = R.i; x < R.end; x += R.step) {
+        const uint4 g = gate4[x];
+        const u32 px = pos_r[x], p = px & ~kPosIO;
+        const u32 d0 = dep0[x];
+        u32 in0, in1, out;
+        if (g.w & kGateLhUnprod) in0 = node_wire1[g.x] - 1u;                        // an input, a constant-like node (k_event_sort), an output nobody produces
+        else { const u32 q = pos_r[d0]; in0 = (q & kPosIO) ? node_wire1[g.x] - 1u : n_in + q + (u32)ev_delta(T, 3u * q + 2u); }
+        if (g.w & kGateRhUnprod) in1 = node_wire1[g.y] - 1u;
+        else {
+            const u32 d1 = dep1[x];                                                 // (dropped when it equals dep0: k_deps)
+            const u32 q = pos_r[d1 != C2A_NONE ? d1 : d0];
+            in1 = (q & kPosIO) ? node_wire1[g.y] - 1u : n_in + q + (u32)ev_delta(T, 3u * q + 2u);
         }
-        node_wire1[v] = n_in + widx[pos] + before + 1u;
+        if (px & kPosIO) out = node_wire1[g.z] - 1u;
+        else { out = n_in + p + (u32)ev_delta(T, 3u * p + 2u); node_wire1[g.z] = out + 1u; }
+        EmitRec e;
+        e.gate = make_uint4(in0, in1, out, g.w & 0xFFu);
+        e.ids = make_uint4((u32)x, orig[x], 0u, 0u);
+        erec[p] = e;
     }
 }
-__global__ void k_emit_fast(u32 n, const uint4* __restrict__ gs, const u32* __restrict__ cnt, const u8* __restrict__ fo,
-                            const u32* __restrict__ widx, u32 n_in, const u32* __restrict__ node_wire1, u32* e_in0, u32* e_in1,
-                            u32* e_out, u8* e_op) {
-    for (u64 pos = gtid(); pos < n; pos += gstride()) {
-        const uint4 g = gs[pos];
-        e_in0[pos] = node_wire1[g.x] - 1;
-        e_in1[pos] = node_wire1[g.y] - 1;
-        e_out[pos] = fo[pos] ? n_in + widx[pos] + (cnt[pos] - 1u) : node_wire1[g.z] - 1;
-        e_op[pos] = (u8)g.w;
+template <bool WITH_SORTED>
+__global__ void k_emit_split(u32 n, const EmitRec* __restrict__ erec, u32* e_in0, u32* e_in1, u32* e_out, u8* e_op, u32* sorted_r, u32* sorted) {
+    for (u64 i = gtid(); i < n; i += gstride()) {
+        const EmitRec e = erec[i];
+        e_in0[i] = e.gate.x; e_in1[i] = e.gate.y; e_out[i] = e.gate.z; e_op[i] = (u8)e.gate.w;
+        if (WITH_SORTED) { sorted_r[i] = e.ids.x; sorted[i] = e.ids.y; }
     }
 }
 

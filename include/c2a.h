@@ -83,6 +83,10 @@ typedef struct c2a_stats {
     uint32_t peel_waves;         /* single-wave workgroups of the dataflow launch (CUs x min(knob, occupancy query)) */
     uint32_t path_chunks;        /* 3843-bit path-string chunks the deepest DFS path spans (1 = every tournament is one round trip) */
     uint32_t peel_rereads;       /* times a wave read a candidate record again because a word of it had not arrived yet */
+    uint32_t numbering_events;   /* what shifts the wire numbering away from "sorted position q gets wire n_in + q": gates whose out node
+                                    is an IO node + constant-like nodes (un-produced, no IO node) — src/compiler.rs:431-438 */
+    uint32_t numbering_path;     /* 1: positional numbering (one writer per node, few events: wires and gates by formula from the
+                                    positions); 0: the walk in sorted order (duplicate writers, many events, or a serial sort) */
 } c2a_stats;
 
 /*
@@ -101,7 +105,7 @@ const char* c2a_last_error(const c2a_ctx* ctx);
 const char* c2a_version(void);
 /* Bumped whenever a signature or a struct layout of this header changes (round 2 changed c2a_create and c2a_stats without
  * a signal): a binding built against another header must refuse to go on.  c2a_abi_version() == C2A_ABI_VERSION. */
-#define C2A_ABI_VERSION 5
+#define C2A_ABI_VERSION 6
 int c2a_abi_version(void);
 
 /*

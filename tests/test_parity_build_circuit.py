@@ -467,3 +467,67 @@ def test_build_numbers_wrap(orc, c2a, emul_lib):
             np.testing.assert_array_equal(be.topo_sort(), exp.sorted)
     finally:
         be.close()
+
+
+def _check_fused(be, orc, bm, p, want_path=None):
+    """c2a_build_circuit (sort + numbering + emission in one call: the sorted order is written by the emission's split pass
+    when the positional numbering runs) against the oracle: sorted ids and node -> wire by checksum, the gates element-wise."""
+    args = (p["lh"], p["rh"], p["out"], p["op"], p["n_nodes"], p["input_nodes"], p["output_nodes"])
+    exp = orc.build_circuit(*args, mode=1)
+    be.load_gates(*args)
+    assert be.build_circuit() == exp.wire_count
+    st = be.stats()
+    if want_path is not None:
+        assert st["numbering_path"] == want_path, st
+    assert be.checksum("sorted") == bm.checksum_host(exp.sorted)
+    nw1 = ((exp.node_wire.astype(np.uint64) + 1) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    assert be.checksum("node_wire1") == bm.checksum_host(nw1)
+    in0, in1, out, op = be.emit_gates()
+    np.testing.assert_array_equal(in0, exp.in0)
+    np.testing.assert_array_equal(in1, exp.in1)
+    np.testing.assert_array_equal(out, exp.out)
+    np.testing.assert_array_equal(op, exp.op)
+    return st
+
+
+NUMBERING = [pytest.param(("emul", 0), id="emul"), pytest.param(("emul", 1), id="emul-walk"),
+             pytest.param(("hip", 0), id="hip", marks=pytest.mark.gpu), pytest.param(("hip", 1), id="hip-walk", marks=pytest.mark.gpu)]
+
+
+@pytest.mark.parametrize("variant", NUMBERING)
+def test_numbering_paths(variant, request, orc, c2a):
+    """The positional numbering (wires and gates by formula from the sorted positions + the few events that shift them:
+    IO-node outputs, constant-like nodes — src/compiler.rs:423-464) and the walk in sorted order give what the reference's walk
+    gives: random graphs with constants read at both operands, inputs and outputs produced by gates, un-produced output nodes
+    as operands; few events (the formula) and many (more than one workgroup sorts: the walk)."""
+    import importlib
+    from conftest import _Env
+    bm = importlib.import_module("circom-2-arithc_amd.backend")
+    kind, walk = variant
+    with _Env(C2A_NUMBERING_WALK=walk):
+        be = c2a.Backend(0, lib_path=request.getfixturevalue("emul_lib")) if kind == "emul" else c2a.Backend(0)
+    cap = 64 if kind == "emul" else 4096                 # (kEvCap of the build)
+    rng = np.random.default_rng(77)
+    seen = {0: 0, 1: 0}
+    try:
+        for trial in range(120):
+            n = int(rng.integers(1, 90))
+            p = random_gate_graph(rng, n, p_dup_out=0.0, p_same=0.2, p_cycle=0.0)
+            try:
+                orc.build_circuit(p["lh"], p["rh"], p["out"], p["op"], p["n_nodes"], p["input_nodes"], p["output_nodes"], mode=1)
+            except (orc.CyclicDependency, orc.Inconsistency):
+                continue
+            st = _check_fused(be, orc, bm, p)
+            assert st["numbering_path"] == (0 if walk or st["numbering_events"] > cap else 1), st
+            seen[st["numbering_path"]] += 1
+            _compare(be, orc, p, check_serial=False)         # (the staged calls: positions from the sorted order that exists already)
+        # layered graphs: 64 constants + `width` outputs = the events
+        for layers, width, n_const in ((40, 20, 8), (30, 100, 64), (12, 3000, 64), (6, 5000, 3000)):
+            fg = c2a.synth.layered_dag(layers, width, n_in=32, n_const=n_const, window=4, seed=5)
+            p = dict(lh=fg.lh, rh=fg.rh, out=fg.out, op=fg.op, n_nodes=fg.n_nodes, input_nodes=fg.input_nodes, output_nodes=fg.output_nodes)
+            st = _check_fused(be, orc, bm, p)
+            assert st["numbering_path"] == (0 if walk or st["numbering_events"] > cap else 1), st
+            seen[st["numbering_path"]] += 1
+        assert seen[0] > 0 and (walk or seen[1] > 0), seen
+    finally:
+        be.close()
