@@ -91,9 +91,9 @@ struct c2a_ctx {
     // device buffers
     DevBuf lh, rh, out, op, gate4, nrec, orig, in_nodes, out_nodes;
     DevBuf prod1, dep0, dep1, cons_cnt, cons_off, eslot, aq_items, aq_pc, aq_seeds, aq_seeds1, aq_seed_flat, aq_seed_cnt, fill, meta, node, child, gstat, clist, pctl, pcold;
-    DevBuf rbits, rpre, ridx, rlist, next, owner, local, slist, snext, ssum, jnxt, jval, sorted, sorted_r;
+    DevBuf rbits, rpre, ridx, rlist, next, owner, local, slist, sjump, sjump2, sorted, sorted_r;
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op;
-    DevBuf pos_r, erec, ev_items, ev_key, ev_cum, ev_blk, cnode, gflag;      // positional numbering (c2a_kernels.h POSITIONAL NUMBERING)
+    DevBuf pos_r, wire_r, erec, io_rank, ev_items, ev_sorted, ev_key, ev_cum, ev_blk, cnode, gflag;      // positional numbering (c2a_kernels.h POSITIONAL NUMBERING)
     u32* hrb = nullptr;            // 256 words of host memory the device writes the end-of-stage numbers to (k_post_*) ...
     u32* hrb_dev = nullptr;        // ... as the device sees it.  Words 0-7: peel, 8-15: order, 16-23: wires, 24-31: boolify
     u32 rb_edges = 0, rb_dup = 0, rb_nmid = 0, rb_err = 0;  // read-back slots (edge count, duplicate-writer flag, wires handed out, in/out clash)
@@ -101,7 +101,8 @@ struct c2a_ctx {
     bool positional = false;       // the circuit now sorted takes the positional numbering (one writer per node, few events)
     bool sorted_ready = false;     // sorted[] / sorted_r[] are written (c2a_build_circuit leaves them to the emission's split pass)
     bool emitted_with_wires = false;   // the positional numbering has emitted the gates as well (do_emit has nothing left to do)
-    const u32* rank_suffix = nullptr;  // the splitter suffix sums the list ranking ended in (which of its ping-pong buffers)
+    const uint2* rank_suffix = nullptr;    // the splitter suffix sums the list ranking ended in (which of its ping-pong buffers)
+    u32 n_ev_io = 0, n_ev_const = 0;   // gates whose out node is an IO node / constant-like nodes of the circuit now sorted
     DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof, peel_trace;
     DevBuf tsz, asz, goff, aoff, tmpl, tables, b_in0, b_in1, b_out, b_op;
     DevBuf fmt_len, fmt_off, fmt_text, fmt_table, shard_cut, shard_qcut;
@@ -118,8 +119,8 @@ struct c2a_ctx {
     c2a_ctx() {
         all = {&lh, &rh, &out, &op, &gate4, &nrec, &orig, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &aq_items, &aq_pc, &aq_seeds, &aq_seeds1, &aq_seed_flat, &aq_seed_cnt, &fill,
                &gstat, &clist, &pctl, &pcold, &meta, &node, &child, &rbits, &rpre, &ridx, &rlist, &next,
-               &owner, &local, &slist, &snext, &ssum, &jnxt, &jval, &sorted, &sorted_r, &first, &nflag, &wflag, &widx, &node_wire1,
-               &node_wire, &e_in0, &e_in1, &e_out, &e_op, &pos_r, &erec, &ev_items, &ev_key, &ev_cum, &ev_blk, &cnode, &gflag, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &peel_trace, &tsz, &asz, &goff,
+               &owner, &local, &slist, &sjump, &sjump2, &sorted, &sorted_r, &first, &nflag, &wflag, &widx, &node_wire1,
+               &node_wire, &e_in0, &e_in1, &e_out, &e_op, &pos_r, &wire_r, &erec, &io_rank, &ev_items, &ev_sorted, &ev_key, &ev_cum, &ev_blk, &cnode, &gflag, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &peel_trace, &tsz, &asz, &goff,
                &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &fmt_len, &fmt_off, &fmt_text, &fmt_table, &shard_cut, &shard_qcut, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &ev_lcount, &ev_lbase, &ev_lorder, &ev_bar, &ev_io, &g_in0, &g_in1, &g_out, &g_op, &pr_rep, &pr_need, &pr_tin0, &pr_tin1, &pr_top, &pr_live, &pr_goff, &pr_counts, &p_in0, &p_in1, &p_out, &p_op, &cb_in0, &cb_in1, &cb_out, &cb_op};
     }
 };
@@ -128,7 +129,7 @@ namespace {
 
 // scalars block layout (u32 words unless noted)
 enum Scalar { SC_MAXDEPTH = 0, SC_SCOUNT = 1, SC_ERR = 2, SC_NMID = 3, SC_NROOTS = 4, SC_LEVELS = 5, SC_EV = 6 /*2 words: IO-out gates, constant-like nodes*/,
-              SC_DFS = 8 /*3 words*/, SC_EV_N = 11 /*events appended*/, SC_DUP = 52,
+              SC_DFS = 8 /*3 words*/, SC_DUP = 52,
               SC_TOTAL64 = 16 /* u64 slots from here: 16..31 */, SC_WORDS = 64 };
 
 int fail(c2a_ctx* c, int code, const std::string& msg) {
@@ -232,11 +233,14 @@ int do_prep(c2a_ctx* c, bool for_peel = true) {
         ENSURE(c->scan_tmp, bytes);
         HIP_TRY(hipMemsetAsync(c->scan_tmp.p, 0, bytes, s));
         C2A_LAUNCH(k_relabel, (u32)tiles, kRelThreads, s, c->n_nodes, n, c->build_no, c->prod1.as<u32>(), (const uint4*)c->nrec.as<uint4>(), dup, c->orig.as<u32>(),
-                   c->gate4.as<uint4>(), c->scan_tmp.as<u64>() + 8, c->scan_tmp.as<u32>(), (const u8*)c->nflag.as<u8>(), c->scalars.as<u32>() + SC_EV);
+                   c->gate4.as<uint4>(), c->scan_tmp.as<u64>() + 8, c->scan_tmp.as<u32>());
     }
     // (two gates wrote one node — never, for a circuit the reference's front-end built: these two leave at once)
     C2A_LAUNCH_NOSYNC(k_dup_clear, 512, kThreads, s, c->n_nodes, (const u32*)dup, c->prod1.as<u32>());
     C2A_LAUNCH_NOSYNC(k_dup_producer, 512, kThreads, s, n, (const u32*)dup, (const u32*)c->out.as<u32>(), c->prod1.as<u32>());
+    if (c->n_in + c->n_out)
+        C2A_LAUNCH(k_io_gates, grid_for((u64)c->n_in + c->n_out, 256), kThreads, s, c->n_in, (const u32*)c->in_nodes.as<u32>(), c->n_out, (const u32*)c->out_nodes.as<u32>(),
+                   (const u32*)c->prod1.as<u32>(), c->nflag.as<u8>(), c->scalars.as<u32>() + SC_EV, c->io_rank.as<u32>(), kEvCap);
     int r;
     C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->out.as<u32>(), c->op.as<u8>(), dup, c->prod1.as<u32>(), c->nflag.as<u8>(), c->orig.as<u32>(),
                       c->gate4.as<uint4>(), c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>(), c->scalars.as<u32>() + SC_EV, c->cnode.as<u32>(), kEvCap, c->gflag.as<u8>());
@@ -469,28 +473,28 @@ int do_order(c2a_ctx* c, bool defer_sorted) {
     c->stats.max_depth = sc[0];
     c->stats.n_splitters = S;
     c->stats.n_roots = sc[2];
-    // what bends the wire numbering away from "position q gets wire n_in + q" (k_relabel / k_deps counted it): few events and one
+    // what bends the wire numbering away from "position q gets wire n_in + q" (k_io_gates / k_deps counted it): few events and one
     // writer per node => the positional numbering, which needs no walk in sorted order (c2a_kernels.h POSITIONAL NUMBERING)
     c->positional = !c->has_dup && !c->numbering_walk && (u64)c->hrb[11] + c->hrb[12] <= kEvCap;
+    c->n_ev_io = c->hrb[11]; c->n_ev_const = c->hrb[12];
     c->stats.numbering_events = c->hrb[11] + c->hrb[12];
     c->stats.numbering_path = c->positional ? 1u : 0u;
     C2A_LAUNCH_NOSYNC(k_rank_walk, grid_for(S, 8192), kThreads, s, (const u32*)scount, c->rlist.as<u32>(), c->slist.as<u32>(),
-                      c->next.as<u32>(), (const u32*)c->owner.as<u32>(), c->local.as<u64>(), c->snext.as<u32>(), c->ssum.as<u32>());
-    // pointer jumping, ping-pong between (snext,ssum) and (jnxt,jval)
+                      c->next.as<u32>(), (const u32*)c->owner.as<u32>(), c->local.as<u64>(), c->sjump.as<uint2>());
+    // pointer jumping, ping-pong between the two {next, sum} arrays
     u32 rounds = 0;
-    while ((1ull << rounds) < S) ++rounds;
-    u32 *nx_a = c->snext.as<u32>(), *vl_a = c->ssum.as<u32>(), *nx_b = c->jnxt.as<u32>(), *vl_b = c->jval.as<u32>();
+    for (u64 reach = 1; reach < S; reach *= kJumpSpan) ++rounds;
+    uint2 *ja = c->sjump.as<uint2>(), *jb = c->sjump2.as<uint2>();
     for (u32 k = 0; k < rounds; ++k) {
-        C2A_LAUNCH_NOSYNC(k_rank_jump, grid_for(S, 4096), kThreads, s, (const u32*)scount, (const u32*)nx_a, (const u32*)vl_a,
-                          nx_b, vl_b);
-        std::swap(nx_a, nx_b);
-        std::swap(vl_a, vl_b);
+        C2A_LAUNCH_NOSYNC(k_rank_jump, grid_for(S, 4096), kThreads, s, (const u32*)scount, (const uint2*)ja, jb);
+        std::swap(ja, jb);
     }
+    const uint2* vl_a = ja;
     c->rank_suffix = vl_a;
     c->sorted_ready = !(defer_sorted && c->positional);
     if (!c->sorted_ready) return C2A_OK;            // (c2a_build_circuit: the emission's records carry the sorted order along)
     // (the tour's next[] has been consumed by the walk: its buffer takes the packed {rank, original id} pairs)
-    C2A_LAUNCH_NOSYNC(k_rank_final, G, kThreads, s, n, (const u64*)c->local.as<u64>(), (const u32*)vl_a, (const u32*)c->orig.as<u32>(), c->next.as<uint2>());
+    C2A_LAUNCH_NOSYNC(k_rank_final, G, kThreads, s, n, (const u64*)c->local.as<u64>(), vl_a, (const u32*)c->orig.as<u32>(), c->next.as<uint2>());
     C2A_LAUNCH_NOSYNC(k_sorted_split, G, kThreads, s, n, (const uint2*)c->next.as<uint2>(), c->sorted_r.as<u32>(), c->sorted.as<u32>());
     return C2A_OK;
 }
@@ -611,7 +615,7 @@ int finish_wires(c2a_ctx* c) {
 // block size of the event table: the smallest power of two that keeps it within kEvBlocks entries
 inline u32 ev_shift(u32 n) {
     u32 sh = 0;
-    while ((((u64)3 * n) >> sh) + 2 > kEvBlocks) ++sh;
+    while ((((u64)3 * n) >> sh) + 1 > kEvBlocks) ++sh;
     return sh;
 }
 
@@ -623,26 +627,31 @@ int do_assign_wires(c2a_ctx* c, bool defer_readback = false) {
     rec(c, EV_WIRES0);
     c->emitted_with_wires = false;
     // (the IO flags of the nodes and the in / out clash word are do_prep's: they do not change between the sort and here)
-    C2A_LAUNCH_NOSYNC(k_node_init, grid_for(std::max<u32>(1u, c->n_nodes), 4096), kThreads, s, c->n_nodes, c->node_wire1.as<u32>(), c->first.as<u32>(),
-                      c->scalars.as<u32>() + SC_EV_N);
+    C2A_LAUNCH_NOSYNC(k_node_init, grid_for(std::max<u32>(1u, c->n_nodes), 4096), kThreads, s, c->n_nodes, c->node_wire1.as<u32>(), c->first.as<u32>());
     if (c->n_in) C2A_LAUNCH_NOSYNC(k_input_wires, grid_for(c->n_in, 1024), kThreads, s, c->n_in, c->in_nodes.as<u32>(), c->node_wire1.as<u32>());
     const u32 G = grid_for(n, 4096);
     const u32* n_mid_p;
     int r;
     if (c->positional && n) {
         // POSITIONAL NUMBERING (c2a_kernels.h): positions, the few events that shift the numbering, then wires AND gates by formula
-        u32* ev_n = c->scalars.as<u32>() + SC_EV_N;
-        if (c->sorted_ready)
-            C2A_LAUNCH_NOSYNC(k_pos_sorted, G, kThreads, s, n, (const u32*)c->sorted_r.as<u32>(), (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), c->pos_r.as<u32>(),
-                              c->first.as<u32>(), c->ev_items.as<uint2>(), ev_n);
-        else
-            C2A_LAUNCH_NOSYNC(k_pos_rank, G, kThreads, s, n, (const u64*)c->local.as<u64>(), c->rank_suffix, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), c->pos_r.as<u32>(),
-                              c->first.as<u32>(), c->ev_items.as<uint2>(), ev_n);
-        C2A_LAUNCH_NOSYNC(k_const_events, grid_for(kEvCap, 16), kThreads, s, (const u32*)(c->scalars.as<u32>() + SC_EV + 1), (const u32*)c->cnode.as<u32>(),
-                          (const u32*)c->first.as<u32>(), c->ev_items.as<uint2>(), ev_n);
-        const u32 shift = ev_shift(n), n_blk = (u32)((((u64)3 * n) >> shift) + 2);
-        C2A_LAUNCH(k_event_sort, 1, kEvThreads, s, (const u32*)ev_n, (const uint2*)c->ev_items.as<uint2>(), n, c->n_in, n_blk, shift, c->ev_key.as<u32>(),
-                   c->ev_cum.as<int>(), c->ev_blk.as<u32>(), c->node_wire1.as<u32>(), c->scalars.as<u32>() + SC_NMID);
+        const u32 E1 = c->n_ev_io, E2 = c->n_ev_const;     // (k_io_gates / k_deps counted and listed them; do_order read the counts back)
+        const PosSrc S{n, c->local.as<u64>(), c->rank_suffix, c->pos_r.as<u32>()};
+        if (c->sorted_ready) {                          // (the staged calls: positions = the inverse of the order the caller has been given)
+            C2A_LAUNCH_NOSYNC(k_eval_inverse, G, kThreads, s, n, c->sorted_r.as<u32>(), c->pos_r.as<u32>());
+            if (E1) C2A_LAUNCH_NOSYNC(k_io_events<true>, grid_for(E1, 64), kThreads, s, S, E1, (const u32*)c->io_rank.as<u32>(), c->ev_items.as<uint2>());
+            if (E2) C2A_LAUNCH_NOSYNC(k_const_first<true>, grid_for(((u64)n + 15) / 16, 4096), kThreads, s, S, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), c->first.as<u32>());
+        } else {
+            if (E1) C2A_LAUNCH_NOSYNC(k_io_events<false>, grid_for(E1, 64), kThreads, s, S, E1, (const u32*)c->io_rank.as<u32>(), c->ev_items.as<uint2>());
+            if (E2) C2A_LAUNCH_NOSYNC(k_const_first<false>, grid_for(((u64)n + 15) / 16, 4096), kThreads, s, S, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), c->first.as<u32>());
+        }
+        if (E2) C2A_LAUNCH_NOSYNC(k_const_events, grid_for(E2, 64), kThreads, s, E1, E2, (const u32*)c->cnode.as<u32>(), (const u32*)c->first.as<u32>(), c->ev_items.as<uint2>());
+        const u32 shift = ev_shift(n), n_blk = (u32)((((u64)3 * n) >> shift) + 1);
+        const u32 E = E1 + E2;
+        if (E) C2A_LAUNCH(k_event_rank, std::min<u32>((E + 3u) / 4u, 2048u), kThreads, s, E, (const uint2*)c->ev_items.as<uint2>(), c->ev_sorted.as<uint2>());
+        C2A_LAUNCH(k_event_finish, 1, kEvThreads, s, E, (const uint2*)c->ev_sorted.as<uint2>(), n, c->n_in, c->ev_key.as<u32>(),
+                   c->ev_cum.as<int>(), c->node_wire1.as<u32>(), c->scalars.as<u32>() + SC_NMID);
+        C2A_LAUNCH_NOSYNC(k_event_table, grid_for(n_blk, 256), kThreads, s, E, n_blk, shift, (const u32*)c->ev_key.as<u32>(), (const int*)c->ev_cum.as<int>(),
+                          c->ev_blk.as<uint2>());
         n_mid_p = c->scalars.as<u32>() + SC_NMID;
     } else {
         if (n) {
@@ -670,14 +679,21 @@ int do_assign_wires(c2a_ctx* c, bool defer_readback = false) {
         // the gates' own out wires are part of node -> wire, and the formula that gives them gives in0 / in1 as well: the emission
         // belongs to this stage (do_emit finds it done)
         rec(c, EV_EMIT0);
-        const EvTable T{c->ev_key.as<u32>(), c->ev_cum.as<int>(), c->ev_blk.as<u32>(), ev_shift(n)};
-        C2A_LAUNCH_NOSYNC(k_emit_rank, G, kThreads, s, n, c->n_in, (const uint4*)c->gate4.as<uint4>(), (const u32*)c->dep0.as<u32>(), (const u32*)c->dep1.as<u32>(),
-                          (const u32*)c->orig.as<u32>(), (const u32*)c->pos_r.as<u32>(), T, c->node_wire1.as<u32>(), c->erec.as<EmitRec>());
+        const EvTable T{c->ev_key.as<u32>(), c->ev_cum.as<int>(), c->ev_blk.as<uint2>(), ev_shift(n)};
+        const PosSrc S{n, c->local.as<u64>(), c->rank_suffix, c->pos_r.as<u32>()};
         if (c->sorted_ready)
-            C2A_LAUNCH_NOSYNC(k_emit_split<false>, G, kThreads, s, n, (const EmitRec*)c->erec.as<EmitRec>(), c->e_in0.as<u32>(), c->e_in1.as<u32>(), c->e_out.as<u32>(),
+            C2A_LAUNCH_NOSYNC(k_pos_rank<true>, G, kThreads, s, S, c->n_in, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), (const u32*)c->node_wire1.as<u32>(), T,
+                              c->pos_r.as<u32>(), c->wire_r.as<u32>());
+        else
+            C2A_LAUNCH_NOSYNC(k_pos_rank<false>, G, kThreads, s, S, c->n_in, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), (const u32*)c->node_wire1.as<u32>(), T,
+                              c->pos_r.as<u32>(), c->wire_r.as<u32>());
+        C2A_LAUNCH_NOSYNC(k_emit_rank, G, kThreads, s, n, (const uint4*)c->gate4.as<uint4>(), (const u32*)c->dep0.as<u32>(), (const u32*)c->dep1.as<u32>(),
+                          (const u32*)c->orig.as<u32>(), (const u32*)c->pos_r.as<u32>(), (const u32*)c->wire_r.as<u32>(), c->node_wire1.as<u32>(), c->erec.as<EmitRec>());
+        if (c->sorted_ready)
+            C2A_LAUNCH_NOSYNC(k_emit_split<false>, G, kThreads, s, n, c->n_in, (const EmitRec*)c->erec.as<EmitRec>(), (const uint4*)c->gate4.as<uint4>(), (const u32*)c->node_wire1.as<u32>(), T, c->e_in0.as<u32>(), c->e_in1.as<u32>(), c->e_out.as<u32>(),
                               c->e_op.as<u8>(), c->sorted_r.as<u32>(), c->sorted.as<u32>());
         else
-            C2A_LAUNCH_NOSYNC(k_emit_split<true>, G, kThreads, s, n, (const EmitRec*)c->erec.as<EmitRec>(), c->e_in0.as<u32>(), c->e_in1.as<u32>(), c->e_out.as<u32>(),
+            C2A_LAUNCH_NOSYNC(k_emit_split<true>, G, kThreads, s, n, c->n_in, (const EmitRec*)c->erec.as<EmitRec>(), (const uint4*)c->gate4.as<uint4>(), (const u32*)c->node_wire1.as<u32>(), T, c->e_in0.as<u32>(), c->e_in1.as<u32>(), c->e_out.as<u32>(),
                               c->e_op.as<u8>(), c->sorted_r.as<u32>(), c->sorted.as<u32>());
         rec(c, EV_EMIT1);
         c->sorted_ready = true;
@@ -861,12 +877,12 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
 #endif
     ENSURE(c->rbits, n4 / 32 + 8); ENSURE(c->rpre, n4 / 32 + 16); ENSURE(c->ridx, n4); ENSURE(c->rlist, n4);
     ENSURE(c->next, 2 * n4); ENSURE(c->owner, 2 * n4); ENSURE(c->local, 2 * n4); ENSURE(c->slist, 2 * n4);
-    ENSURE(c->snext, 2 * n4); ENSURE(c->ssum, 2 * n4); ENSURE(c->jnxt, 2 * n4); ENSURE(c->jval, 2 * n4);
+    ENSURE(c->sjump, 4 * n4); ENSURE(c->sjump2, 4 * n4);
     ENSURE(c->sorted, n4); ENSURE(c->sorted_r, n4);
     ENSURE(c->first, nn4); ENSURE(c->nflag, (size_t)n_nodes + 4); ENSURE(c->wflag, 3 * n4); ENSURE(c->widx, 3 * n4 + 4);
     ENSURE(c->node_wire1, nn4); ENSURE(c->node_wire, nn4);
-    ENSURE(c->pos_r, n4); ENSURE(c->erec, (size_t)n * sizeof(EmitRec)); ENSURE(c->ev_items, (size_t)kEvCap * 8); ENSURE(c->ev_key, (size_t)kEvCap * 4 + 4);
-    ENSURE(c->ev_cum, ((size_t)kEvCap + 1) * 4); ENSURE(c->ev_blk, (size_t)kEvBlocks * 4 + 64); ENSURE(c->cnode, (size_t)kEvCap * 4); ENSURE(c->gflag, n);
+    ENSURE(c->pos_r, n4); ENSURE(c->wire_r, n4); ENSURE(c->erec, (size_t)n * sizeof(EmitRec)); ENSURE(c->io_rank, (size_t)kEvCap * 4); ENSURE(c->ev_items, (size_t)kEvCap * 8); ENSURE(c->ev_sorted, (size_t)kEvCap * 8); ENSURE(c->ev_key, (size_t)kEvCap * 4 + 4);
+    ENSURE(c->ev_cum, ((size_t)kEvCap + 1) * 4); ENSURE(c->ev_blk, (size_t)kEvBlocks * 8 + 64); ENSURE(c->cnode, (size_t)kEvCap * 4); ENSURE(c->gflag, (size_t)n + 16);
     ENSURE(c->e_in0, n4); ENSURE(c->e_in1, n4); ENSURE(c->e_out, n4); ENSURE(c->e_op, n);
     ENSURE(c->scalars, SC_WORDS * 4);
     hipStream_t s = c->stream;

@@ -236,7 +236,7 @@ __global__ void k_dup_producer(u32 n, const u32* __restrict__ dup, const u32* __
 // produced nodes have consecutive ranks).
 constexpr int kRelThreads = 256, kRelRounds = 16, kRelTile = kRelThreads * kRelRounds;
 __global__ void __launch_bounds__(kRelThreads) k_relabel(u32 n_nodes, u32 n, u32 build, u32* prod1, const uint4* __restrict__ nrec, u32* dup,
-                                                         u32* orig, uint4* gate4, u64* desc, u32* counter, const u8* __restrict__ nflag, u32* ev) {
+                                                         u32* orig, uint4* gate4, u64* desc, u32* counter) {
     __shared__ u32 s_tile, s_wave[kRelThreads / 64];
     __shared__ u64 s_excl;
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
@@ -249,19 +249,13 @@ __global__ void __launch_bounds__(kRelThreads) k_relabel(u32 n_nodes, u32 n, u32
     uint4 rec[kRelRounds];
 #pragma unroll
     for (int i = 0; i < kRelRounds; ++i) { const u64 v = base + (u64)i * 64; rec[i] = v < n_nodes ? nrec[v] : make_uint4(0u, 0u, 0u, ~build << 8); }
-    u32 cnt = 0, n_io = 0, io_mask = 0;
+    u32 cnt = 0;
 #pragma unroll
     for (int i = 0; i < kRelRounds; ++i) {
-        const u64 v = base + (u64)i * 64;
-        const bool produced = (rec[i].w >> 8) == build;          // a record of THIS build: the node is produced
-        const bool io = produced && v < n_nodes && (nflag[v] & 3u) != 0u;      // ... and it is an input or output node (k_deps: kGateOutIO)
-        const u64 bal = __ballot(produced);
+        const u64 bal = __ballot((rec[i].w >> 8) == build);      // a record of THIS build: the node is produced
         pre[i] = cnt + (u32)__popcll(bal & lt_mask);
         cnt += (u32)__popcll(bal);
-        n_io += (u32)__popcll(__ballot(io));
-        io_mask |= io ? 1u << i : 0u;
     }
-    if (lane == 0 && n_io) atomicAdd(&ev[0], n_io);
     if (lane == 0) s_wave[wv] = cnt;
     __syncthreads();
     u32 wave_base = 0, tile_total = 0;
@@ -283,9 +277,36 @@ __global__ void __launch_bounds__(kRelThreads) k_relabel(u32 n_nodes, u32 n, u32
         const u32 rank = first + pre[i];
         if (rank < n) {                            // (always, unless two gates wrote one node: then all of this is redone)
             orig[rank] = rec[i].z;
-            gate4[rank] = make_uint4(rec[i].x, rec[i].y, (u32)v, (rec[i].w & 0xFFu) | ((io_mask >> i) & 1u ? 0x400u : 0u));
+            gate4[rank] = make_uint4(rec[i].x, rec[i].y, (u32)v, rec[i].w & 0xFFu);
         }
         prod1[v] = rank + 1u;
+    }
+}
+
+// The gates whose out node is an IO node (they hand out no wire: an EVENT of the positional numbering), found from the IO
+// nodes' side — a few thousand nodes instead of a flag per gate: io_rank[0 .. ev[0]) = their ranks.  A node listed twice (an
+// output named twice) counts once: bit 3 of its flag byte.  One atomic per wave on the counter.
+__global__ void __launch_bounds__(kThreads) k_io_gates(u32 n_in, const u32* __restrict__ in_nodes, u32 n_out, const u32* __restrict__ out_nodes,
+                                                       const u32* __restrict__ prod1, u8* nflag, u32* ev, u32* io_rank, u32 io_cap) {
+    const u32 lane = threadIdx.x & 63u, total = n_in + n_out;
+    for (u64 i0 = gtid() - lane; i0 < total; i0 += gstride()) {          // (whole waves: the ballot below wants every lane)
+        const u64 i = i0 + lane;
+        bool mine = false;
+        u32 rank = 0;
+        if (i < total) {
+            const u32 v = i < n_in ? in_nodes[i] : out_nodes[i - n_in], p1 = prod1[v];
+            if (p1) {
+                const u32 bit = 8u << (8u * (v & 3u));
+                mine = !(atomicOr(reinterpret_cast<u32*>(nflag) + (v >> 2), bit) & bit);
+                rank = p1 - 1u;
+            }
+        }
+        const u64 bal = __ballot(mine);
+        if (!bal) continue;
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(&ev[0], (u32)__popcll(bal));
+        const u32 k = rdlane(base, 0) + (u32)__popcll(bal & ((1ull << lane) - 1ull));
+        if (mine && k < io_cap) io_rank[k] = rank;
     }
 }
 
@@ -295,8 +316,8 @@ __global__ void __launch_bounds__(kRelThreads) k_relabel(u32 n_nodes, u32 n, u32
 // lh node is a CONSTANT-like node (un-produced and no IO node: it gets its wire where the walk first sees it) << 11 | rh
 // likewise << 12}: what the numbering kernels want to know about a gate's nodes comes along instead of costing scattered reads.
 // It also counts what bends the wire numbering away from "the gate at sorted position q gets wire n_in + q" (POSITIONAL
-// NUMBERING below): ev[0] = gates whose out node is an IO node, ev[1] = distinct constant-like nodes (bit 2 of the node's
-// flag byte: the first gate to set it lists the node in cnode[]).
+// NUMBERING below): ev[1] = distinct constant-like nodes (bit 2 of the node's flag byte: the first gate to set it lists the
+// node in cnode[]); ev[0] = gates whose out node is an IO node is k_io_gates' (the IO nodes are few: it walks THEM).
 constexpr u32 kGateLhUnprod = 0x100u, kGateRhUnprod = 0x200u, kGateOutIO = 0x400u, kGateLhConst = 0x800u, kGateRhConst = 0x1000u;
 __device__ __forceinline__ bool note_const_node(u32 v, u8* nflag, u32* ev, u32* cnode, u32 cnode_cap) {
     if (nflag[v] & 3u) return false;                                              // an input or output node: its wire is fixed
@@ -317,8 +338,7 @@ __global__ void k_deps(u32 n, const u32* __restrict__ lh, const u32* __restrict_
         if (ident) { r = make_uint4(lh[g], rh[g], out[g], (u32)op[g]); orig[g] = (u32)g; }
         else r = gate4[g];
         const u32 p0 = prod1[r.x], p1 = prod1[r.y];
-        u32 w = (r.w & (0xFFu | kGateOutIO)) | (p0 ? 0u : kGateLhUnprod) | (p1 ? 0u : kGateRhUnprod);      // (kGateOutIO: k_relabel's)
-        if (ident && (nflag[r.z] & 3u)) w |= kGateOutIO;
+        u32 w = (r.w & 0xFFu) | (p0 ? 0u : kGateLhUnprod) | (p1 ? 0u : kGateRhUnprod) | ((nflag[r.z] & 3u) ? kGateOutIO : 0u);
         if (!p0 && note_const_node(r.x, nflag, ev, cnode, cnode_cap)) w |= kGateLhConst;
         if (!p1 && note_const_node(r.y, nflag, ev, cnode, cnode_cap)) w |= kGateRhConst;
         gate4[g] = make_uint4(r.x, r.y, r.z, w);
@@ -463,43 +483,43 @@ __global__ void __launch_bounds__(kThreads) k_rank_mark(u32 m, const u32* __rest
 // only they get a record — ol[x] = sublist << 32 | exits before exit(x) inside the sublist: one random 8-byte write per node
 // instead of four 4-byte ones per node (owner[] keeps the index of the splitter elements only, written by k_rank_mark)
 __global__ void k_rank_walk(const u32* __restrict__ scount, const u32* __restrict__ rlist, const u32* __restrict__ slist,
-                            const u32* __restrict__ next, const u32* __restrict__ owner, u64* ol, u32* snext, u32* ssum) {
+                            const u32* __restrict__ next, const u32* __restrict__ owner, u64* ol, uint2* sjump) {
     const u32 S = *scount;
     const u32 head = 2 * rlist[0];
     for (u64 k = gtid(); k < S; k += gstride()) {
-        u32 e = slist[k], acc = 0;
+        u32 e = slist[k], acc = 0, nx;
         for (;;) {
             if (e & 1u) { ol[e >> 1] = ((u64)k << 32) | acc; ++acc; }
             const u32 e2 = next[e];
-            if (e2 == C2A_NONE) { snext[k] = C2A_NONE; break; }
-            if (is_splitter(e2, head)) { snext[k] = owner[e2]; break; }
+            if (e2 == C2A_NONE) { nx = C2A_NONE; break; }
+            if (is_splitter(e2, head)) { nx = owner[e2]; break; }
             e = e2;
         }
-        ssum[k] = acc;
+        sjump[k] = make_uint2(nx, acc);                           // {next sublist, exits in this one}: what k_rank_jump sums up
     }
 }
 
-// pointer jumping over the splitter list: after ceil(log2 S) rounds val[k] = sum over k..end
-__global__ void k_rank_jump(const u32* __restrict__ scount, const u32* __restrict__ nxt_in, const u32* __restrict__ val_in,
-                            u32* nxt_out, u32* val_out) {
+// pointer jumping over the splitter list, kJumpSpan elements per launch: an element takes over the sums of its next
+// kJumpSpan - 1 successors and points behind them, so the reach grows by that factor per launch and after
+// ceil(log_kJumpSpan S) launches val[k] = sum over k..end.  (Doubling — span 2 — was 19 launches of 7.4 µs for 312 000
+// splitters, most of it launch overhead: the arrays sit in L2.)
+constexpr u32 kJumpSpan = 8;
+__global__ void k_rank_jump(const u32* __restrict__ scount, const uint2* __restrict__ in, uint2* out) {
     const u32 S = *scount;
     for (u64 k = gtid(); k < S; k += gstride()) {
-        const u32 nx = nxt_in[k];
-        u32 v = val_in[k];
-        u32 nn = C2A_NONE;
-        if (nx != C2A_NONE) { v += val_in[nx]; nn = nxt_in[nx]; }
-        val_out[k] = v;
-        nxt_out[k] = nn;
+        uint2 a = in[k];                                          // {next, sum}: ONE gather per hop
+        for (u32 h = 1; h < kJumpSpan && a.x != C2A_NONE; ++h) { const uint2 b = in[a.x]; a = make_uint2(b.x, a.y + b.y); }
+        out[k] = a;
     }
 }
 
 // sorted[post-order index of x] = gate(x)   (== sorted.push(i), topological_sort.rs:46): the rank for the numbering kernels
 // behind this one, the original gate id for the caller
-__global__ void k_rank_final(u32 n, const u64* __restrict__ ol, const u32* __restrict__ suffix, const u32* __restrict__ orig,
+__global__ void k_rank_final(u32 n, const u64* __restrict__ ol, const uint2* __restrict__ suffix, const u32* __restrict__ orig,
                              uint2* sorted2) {
     for (u64 x = gtid(); x < n; x += gstride()) {
         const u64 r = ol[x];
-        const u32 post = (n - suffix[(u32)(r >> 32)]) + (u32)r;
+        const u32 post = (n - suffix[(u32)(r >> 32)].y) + (u32)r;
         sorted2[post] = make_uint2((u32)x, orig[x]);      // (ONE scattered 8-byte store; k_sorted_split makes the two arrays of it, streaming)
     }
 }
@@ -583,8 +603,7 @@ __global__ void k_mark_inputs(u32 n_in, const u32* __restrict__ in_nodes, u8* nf
     for (u64 i = gtid(); i < n_in; i += gstride()) nflag[in_nodes[i]] = 1;      // (all writers store the same byte)
 }
 // the per-node state of the wire numbering in one launch: no wire, not seen yet; then the input wires (compiler.rs:388-395)
-__global__ void k_node_init(u32 n_nodes, u32* node_wire1, u32* first, u32* ev_n) {
-    if (gtid() == 0) *ev_n = 0u;                                  // (the event list of the positional numbering starts empty)
+__global__ void k_node_init(u32 n_nodes, u32* node_wire1, u32* first) {
     for (u64 v = gtid(); v < n_nodes; v += gstride()) { node_wire1[v] = 0u; first[v] = 0xFFFFFFFFu; }
 }
 __global__ void k_input_wires(u32 n_in, const u32* __restrict__ in_nodes, u32* node_wire1) {
@@ -679,158 +698,183 @@ __global__ void k_emit(u32 n, const u32* __restrict__ sorted, const uint4* __res
 // is an IO node (:431-438).  The sorted order is topological, so a PRODUCED node is first seen as its producer's out: the gate
 // at sorted position q gets wire n_in + q — but for two kinds of EVENT that shift everything behind them: a gate whose out
 // node is an IO node hands out nothing (-1 from walk index 3q + 2 on), and a constant-like node (un-produced, no IO node)
-// takes a wire at the walk index it is first seen at (+1 from there on).  Events are few (k_relabel / k_deps count them; the
+// takes a wire at the walk index it is first seen at (+1 from there on).  Events are few (k_io_gates / k_deps count them; the
 // host takes the general path when they are more than kEvCap), so:
 //     wire of the out node at position q = n_in + q + D(3q + 2),   D(key) = sum of the deltas of the events before walk index key
 // with the events sorted by walk index (one workgroup, in LDS) and looked up through a table of blocks of walk indices.  A
-// gate then needs nothing but POSITIONS: its own and its producers' — pos_r[] is indexed by rank, producers sit a bounded
+// gate then needs nothing but its own position and its producers' wires — wire_r[] is indexed by rank, producers sit a bounded
 // distance before their consumers in rank space, so these gathers stay on chip; the sorted order is only ever written, one
-// scattered 32-byte record per gate {in0, in1, out, op, rank, original id}, which k_emit_split streams into the arrays of the
+// scattered 16-byte record per gate {in0, in1, rank, original id; the op in their top bits}, which k_emit_split streams into the arrays of the
 // ABI.  (The walk it replaces: one 16-byte gather + a scatter + two 4-byte gathers by node id per sorted position, in an
 // order that is local in no space — 0.76 ms for 10 M gates; this: 0.45.)
-//   k_pos_rank      pos_r[rank] = post-order position | IO-out tag; IO-out events; first walk index of every constant-like node
-//   k_const_events  one event per constant-like node
-//   k_event_sort    sorted events, running deltas, block table, the constant-like nodes' wires
-//   (k_assign_outputs: n_mid = n - IO-out events + constant-like nodes is known to the host)
-//   k_emit_rank     in0 / in1 / out by formula (IO nodes and un-produced nodes: by look-up), node -> wire, the 32-byte records
-//   k_emit_split    e_in0 / e_in1 / e_out / e_op / sorted_r / sorted
+//   k_io_events     one event per gate whose out node is an IO node (k_io_gates listed them)
+//   k_const_first / k_const_events   first walk index of every constant-like node, one event each
+//   k_event_rank / k_event_finish   sorted events, running deltas, block table, the constant-like nodes' wires
+//   (k_assign_outputs: n_mid = n - IO-out events + constant-like nodes)
+//   k_pos_rank      pos_r[rank] = post-order position, wire_r[rank] = wire of the gate's out node
+//   k_emit_rank     in0 / in1 = wire_r[] of the producers (un-produced nodes: by look-up), node -> wire, the 16-byte records
+//   k_emit_split    e_in0 / e_in1 / e_out (by formula from the position) / e_op / sorted_r / sorted
 // ------------------------------------------------------------------------------------------------
 #ifdef C2A_EMULATE
 constexpr u32 kEvCap = 64;            // (small, so that the CPU suite takes the general path too)
 #else
 constexpr u32 kEvCap = 4096;          // events one workgroup sorts in LDS
 #endif
-constexpr u32 kEvBlocks = 8192;      // entries of the block table at most (the host picks the block size: ev_shift)
-constexpr u32 kPosIO = 0x80000000u;   // pos_r[]: the gate's out node is an IO node (its wire is looked up, not computed)
+constexpr u32 kEvBlocks = 4096;      // entries of the block table at most (the host picks the block size: ev_shift) — 32 KB: it has to stay in
+                                     // the L1s (65 536 finer blocks, nearly all of them empty, one load per look-up — but from L2: k_emit_rank 0.54 ms instead of 0.41)
+// where the list ranking (ol / suffix as k_rank_final reads them) puts gate x — or, when the sorted order exists already
+// (c2a_topo_sort handed it to the caller), its inverse (k_eval_inverse into pos_r[]): FROM_SORTED
+struct PosSrc { u32 n; const u64* ol; const uint2* suffix; const u32* pos; };
+template <bool FROM_SORTED>
+__device__ __forceinline__ u32 pos_of(const PosSrc& S, u64 x) {
+    if (FROM_SORTED) return S.pos[x];
+    const u64 r = S.ol[x];
+    return (S.n - S.suffix[(u32)(r >> 32)].y) + (u32)r;
+}
+// the events.  No counters: the IO-out gates were listed by k_io_gates (io_rank[0 .. E1)), the constant-like nodes by k_deps
+// (cnode[0 .. E2)), the host knows both counts — event k of the first kind goes to ev_items[k], of the second to ev_items[E1 + k]
+// (one counter for all of them: 2 000 appends = 30 µs of same-address atomics).
+template <bool FROM_SORTED>
+__global__ void k_io_events(PosSrc S, u32 E1, const u32* __restrict__ io_rank, uint2* ev_items) {
+    for (u64 k = gtid(); k < E1; k += gstride()) ev_items[k] = make_uint2(((3u * pos_of<FROM_SORTED>(S, io_rank[k]) + 2u) << 1) | 1u, 0u);
+}
+// first[node] = the first walk index a constant-like node is seen at: the few gates whose flags say so (read sixteen at a time)
+constexpr u32 kGateConstBits = (kGateLhConst | kGateRhConst) >> 8;
+template <bool FROM_SORTED>
+__global__ void k_const_first(PosSrc S, const u8* __restrict__ gflag, const uint4* __restrict__ gate4, u32* first) {
+    const u64 n16 = ((u64)S.n + 15) / 16;                         // (the flag array is padded to whole 16-byte words)
+    for (u64 i = gtid(); i < n16; i += gstride()) {
+        const uint4 f = reinterpret_cast<const uint4*>(gflag)[i];
+        if (!((f.x | f.y | f.z | f.w) & (kGateConstBits * 0x01010101u))) continue;
+        const u32 word[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+        for (u32 k = 0; k < 16; ++k) {
+            const u32 w = ((word[k >> 2] >> (8u * (k & 3u))) & 0xFFu) << 8;
+            const u64 x = i * 16 + k;
+            if (x >= S.n || !(w & (kGateLhConst | kGateRhConst))) continue;
+            const u32 p = pos_of<FROM_SORTED>(S, x);
+            const uint4 g = gate4[x];
+            if (w & kGateLhConst) atomicMin(&first[g.x], 3u * p);
+            if (w & kGateRhConst) atomicMin(&first[g.y], 3u * p + 1u);
+        }
+    }
+}
+__global__ void k_const_events(u32 E1, u32 E2, const u32* __restrict__ cnode, const u32* __restrict__ first, uint2* ev_items) {
+    for (u64 k = gtid(); k < E2; k += gstride()) {
+        const u32 v = cnode[k];
+        ev_items[E1 + k] = make_uint2(first[v] << 1, v);          // (every listed node is an operand of some gate, and every gate is in the sorted order)
+    }
+}
 
-__device__ __forceinline__ void pos_note(u32 x, u32 p, const u8* __restrict__ gflag, const uint4* __restrict__ gate4, u32* pos_r, u32* first,
-                                         uint2* ev_items, u32* ev_n) {
-    const u32 w = (u32)gflag[x] << 8;
-    pos_r[x] = p | ((w & kGateOutIO) ? kPosIO : 0u);
-    if (w & kGateOutIO) { const u32 i = atomicAdd(ev_n, 1u); if (i < kEvCap) ev_items[i] = make_uint2(((3u * p + 2u) << 1) | 1u, 0u); }
-    if (w & (kGateLhConst | kGateRhConst)) {
-        const uint4 g = gate4[x];
-        if (w & kGateLhConst) atomicMin(&first[g.x], 3u * p);
-        if (w & kGateRhConst) atomicMin(&first[g.y], 3u * p + 1u);
+// The (<= kEvCap) events sorted by walk index.  Walk indices are unique, so an event's place is the number of smaller keys:
+// k_event_rank counts that with a wave per event (64 keys per ballot; a bitonic network in one workgroup took 74 µs for 4 096
+// keys — 78 rounds with a barrier each —, one workgroup counting for all events 134 µs: one CU), k_event_finish — one workgroup —
+// makes the exclusive running sum of the deltas, the table blk[b] = number of events before walk index b << shift, and the
+// wires of the constant-like nodes (their own event's formula).
+__global__ void __launch_bounds__(kThreads) k_event_rank(u32 E, const uint2* __restrict__ ev_items, uint2* ev_sorted) {
+    const u32 lane = threadIdx.x & 63u, wave = (u32)(gtid() >> 6), n_waves = (u32)(gstride() >> 6);
+    for (u32 e = wave; e < E; e += n_waves) {
+        const uint2 me = ev_items[e];
+        u32 place = 0;
+        for (u32 base = 0; base < E; base += 64u) {
+            const u32 j = base + lane;
+            place += (u32)__popcll(__ballot(j < E && ev_items[j].x < me.x));
+        }
+        if (lane == 0) ev_sorted[place] = me;
     }
 }
-// positions from the list ranking (ol / suffix as k_rank_final reads them) ...
-__global__ void k_pos_rank(u32 n, const u64* __restrict__ ol, const u32* __restrict__ suffix, const u8* __restrict__ gflag, const uint4* __restrict__ gate4,
-                           u32* pos_r, u32* first, uint2* ev_items, u32* ev_n) {
-    for (u64 x = gtid(); x < n; x += gstride()) {
-        const u64 r = ol[x];
-        pos_note((u32)x, (n - suffix[(u32)(r >> 32)]) + (u32)r, gflag, gate4, pos_r, first, ev_items, ev_n);
-    }
-}
-// ... or from a sorted order that exists already (c2a_topo_sort handed it to the caller)
-__global__ void k_pos_sorted(u32 n, const u32* __restrict__ sorted_r, const u8* __restrict__ gflag, const uint4* __restrict__ gate4,
-                             u32* pos_r, u32* first, uint2* ev_items, u32* ev_n) {
-    for (u64 p = gtid(); p < n; p += gstride()) pos_note(sorted_r[p], (u32)p, gflag, gate4, pos_r, first, ev_items, ev_n);
-}
-__global__ void k_const_events(const u32* __restrict__ n_const, const u32* __restrict__ cnode, const u32* __restrict__ first, uint2* ev_items, u32* ev_n) {
-    const u32 nc = *n_const < kEvCap ? *n_const : kEvCap;
-    for (u64 k = gtid(); k < nc; k += gstride()) {
-        const u32 v = cnode[k], i = atomicAdd(ev_n, 1u);
-        if (i < kEvCap) ev_items[i] = make_uint2(first[v] << 1, v);      // (every listed node is an operand of some gate, and every gate is in the sorted order)
-    }
-}
-
-// One workgroup: the (<= kEvCap) events sorted by walk index — walk indices are unique, so an event's place is the number of
-// smaller keys: every thread counts that for its (<= kEvCap / 1 024) events in one sweep over the keys in LDS (broadcast reads;
-// a bitonic network over 4 096 keys is 78 rounds with a barrier each: 74 µs, this: a few) —, the exclusive running sum of their
-// deltas, the table blk[b] = number of events before walk index b << shift, and the wires of the constant-like nodes (their own
-// event's formula).
 constexpr int kEvThreads = 1024;
-constexpr u32 kEvPer = (kEvCap + kEvThreads - 1) / kEvThreads;
-__global__ void __launch_bounds__(kEvThreads) k_event_sort(const u32* __restrict__ ev_n, const uint2* __restrict__ ev_items, u32 n, u32 n_in, u32 n_blk, u32 shift,
-                                                           u32* ev_key, int* ev_cum, u32* blk, u32* node_wire1, u32* n_mid) {
-    __shared__ u32 s_in[kEvCap], s_key[kEvCap], s_val[kEvCap];
+__global__ void __launch_bounds__(kEvThreads) k_event_finish(u32 E, const uint2* __restrict__ ev_sorted, u32 n, u32 n_in,
+                                                             u32* ev_key, int* ev_cum, u32* node_wire1, u32* n_mid) {
     __shared__ int s_part[kEvThreads];
     const u32 tid = threadIdx.x;
-    const u32 E = *ev_n < kEvCap ? *ev_n : kEvCap;
-    uint2 own[kEvPer];
-    u32 place[kEvPer];
-#pragma unroll
-    for (u32 k = 0; k < kEvPer; ++k) {
-        const u32 i = tid + k * kEvThreads;
-        own[k] = i < E ? ev_items[i] : make_uint2(0xFFFFFFFFu, 0u);
-        place[k] = 0;
-        if (i < kEvCap) s_in[i] = own[k].x;
-    }
-    __syncthreads();
-    for (u32 j = 0; j < E; ++j) {
-        const u32 kj = s_in[j];
-#pragma unroll
-        for (u32 k = 0; k < kEvPer; ++k) place[k] += kj < own[k].x ? 1u : 0u;
-    }
-#pragma unroll
-    for (u32 k = 0; k < kEvPer; ++k)
-        if (tid + k * kEvThreads < E) { s_key[place[k]] = own[k].x; s_val[place[k]] = own[k].y; }
-    __syncthreads();
     // running deltas: thread t owns the sorted events [t * per, (t + 1) * per)
     const u32 per = (E + kEvThreads - 1) / kEvThreads;
     const u32 i_lo = tid * per < E ? tid * per : E, i_hi = (tid + 1) * per < E ? (tid + 1) * per : E;
     int mine = 0;
-    for (u32 i = i_lo; i < i_hi; ++i) mine += (s_key[i] & 1u) ? -1 : 1;
+    for (u32 i = i_lo; i < i_hi; ++i) mine += (ev_sorted[i].x & 1u) ? -1 : 1;
     s_part[tid] = mine;
     __syncthreads();
     int before = 0;
     for (u32 t = 0; t < tid; ++t) before += s_part[t];      // (1 024 partial sums, read by everyone: broadcasts)
     for (u32 i = i_lo; i < i_hi; ++i) {
-        const u32 kv = s_key[i], key = kv >> 1;
+        const uint2 it = ev_sorted[i];
+        const u32 key = it.x >> 1;
         ev_key[i] = key;
         ev_cum[i] = before;
-        if (!(kv & 1u)) node_wire1[s_val[i]] = n_in + key / 3u + (u32)before + 1u;      // a constant-like node: the wire its own event hands out
-        before += (kv & 1u) ? -1 : 1;
+        if (!(it.x & 1u)) node_wire1[it.y] = n_in + key / 3u + (u32)before + 1u;      // a constant-like node: the wire its own event hands out
+        before += (it.x & 1u) ? -1 : 1;
     }
     if (tid == kEvThreads - 1) { ev_cum[E] = before; *n_mid = n + (u32)before; }      // (the last thread's running sum is the total: wires handed out in the walk, compiler.rs:440-441)
-    for (u32 b = tid; b < n_blk; b += kEvThreads) {
-        const u64 lim = (u64)b << shift;
-        u32 lo = 0, hi = E;
-        while (lo < hi) { const u32 m = (lo + hi) >> 1; if ((u64)(s_key[m] >> 1) < lim) lo = m + 1; else hi = m; }
-        blk[b] = lo;
+}
+// the look-up table: for the block b of walk indices [b << shift, (b + 1) << shift): {index of its first event | number of
+// events in it << 16, running delta at its start}: a look-up in a block without events is ONE 8-byte load.
+__device__ __forceinline__ u32 ev_lower_bound(const u32* __restrict__ key, u32 E, u64 lim) {
+    u32 lo = 0, hi = E;
+    while (lo < hi) { const u32 m = (lo + hi) >> 1; if ((u64)key[m] < lim) lo = m + 1; else hi = m; }
+    return lo;
+}
+__global__ void k_event_table(u32 E, u32 n_blk, u32 shift, const u32* __restrict__ ev_key, const int* __restrict__ ev_cum, uint2* tbl) {
+    for (u64 b = gtid(); b < n_blk; b += gstride()) {
+        const u32 lo = ev_lower_bound(ev_key, E, b << shift), hi = ev_lower_bound(ev_key, E, (b + 1) << shift);
+        tbl[b] = make_uint2(lo | (hi - lo) << 16, (u32)ev_cum[lo]);
     }
 }
 
-struct EvTable { const u32* key; const int* cum; const u32* blk; u32 shift; };
+struct EvTable { const u32* key; const int* cum; const uint2* tbl; u32 shift; };
 // D(key): sum of the deltas of the events before walk index `key`
 __device__ __forceinline__ int ev_delta(const EvTable& T, u32 key) {
-    const u32 b = key >> T.shift;
-    u32 lo = T.blk[b], hi = T.blk[b + 1];
+#ifdef C2A_EXP_NOLOOKUP
+    return 0;
+#endif
+    const uint2 e = T.tbl[key >> T.shift];
+    if (e.x < 0x10000u) return (int)e.y;                         // no event in this block: the delta at its start
+    u32 lo = e.x & 0xFFFFu, hi = lo + (e.x >> 16);
     while (lo < hi) { const u32 m = (lo + hi) >> 1; if (T.key[m] < key) lo = m + 1; else hi = m; }
     return T.cum[lo];
 }
-struct EmitRec { uint4 gate, ids; };      // {in0, in1, out, op}, {rank, original id, -, -}: one 32-byte store
-__global__ void k_emit_rank(u32 n, u32 n_in, const uint4* __restrict__ gate4, const u32* __restrict__ dep0, const u32* __restrict__ dep1,
-                            const u32* __restrict__ orig, const u32* __restrict__ pos_r, EvTable T, u32* node_wire1, EmitRec* erec) {
+// every gate's position and the wire of its out node (the formula; an IO node's wire is the node's), in rank order
+template <bool FROM_SORTED>
+__global__ void k_pos_rank(PosSrc S, u32 n_in, const u8* __restrict__ gflag, const uint4* __restrict__ gate4, const u32* __restrict__ node_wire1, EvTable T,
+                           u32* pos_r, u32* wire_r) {
+    for (u64 x = gtid(); x < S.n; x += gstride()) {
+        const u32 p = pos_of<FROM_SORTED>(S, x);
+        if (!FROM_SORTED) pos_r[x] = p;
+        wire_r[x] = (gflag[x] & (u8)(kGateOutIO >> 8)) ? node_wire1[gate4[x].z] - 1u : n_in + p + (u32)ev_delta(T, 3u * p + 2u);
+    }
+}
+// The record a gate leaves at its sorted position: {in0, in1, rank, original id} — 16 bytes, ONE scattered store per gate
+// (a 32-byte record is two store instructions, i.e. twice the scattered transactions).
+// Gate ids are below 2^29 (include/c2a.h), so the op code (5 bits) rides in the top bits of the two ids and bit 31 of the
+// second says "the out node is an IO node"; every other gate's out wire follows from its position (k_emit_split).
+// No table look-ups here (with three per gate this kernel took 0.41 ms, without 0.34): a gate's operands are its producers'
+// out wires, wire_r[] of a rank a bounded distance back.
+typedef uint4 EmitRec;
+__global__ void k_emit_rank(u32 n, const uint4* __restrict__ gate4, const u32* __restrict__ dep0, const u32* __restrict__ dep1,
+                            const u32* __restrict__ orig, const u32* __restrict__ pos_r, const u32* __restrict__ wire_r, u32* node_wire1, EmitRec* erec) {
     const XcdSweep R = xcd_sweep(n);
     for (u64 x = R.i; x < R.end; x += R.step) {
         const uint4 g = gate4[x];
-        const u32 px = pos_r[x], p = px & ~kPosIO;
-        const u32 d0 = dep0[x];
-        u32 in0, in1, out;
-        if (g.w & kGateLhUnprod) in0 = node_wire1[g.x] - 1u;                        // an input, a constant-like node (k_event_sort), an output nobody produces
-        else { const u32 q = pos_r[d0]; in0 = (q & kPosIO) ? node_wire1[g.x] - 1u : n_in + q + (u32)ev_delta(T, 3u * q + 2u); }
-        if (g.w & kGateRhUnprod) in1 = node_wire1[g.y] - 1u;
-        else {
-            const u32 d1 = dep1[x];                                                 // (dropped when it equals dep0: k_deps)
-            const u32 q = pos_r[d1 != C2A_NONE ? d1 : d0];
-            in1 = (q & kPosIO) ? node_wire1[g.y] - 1u : n_in + q + (u32)ev_delta(T, 3u * q + 2u);
-        }
-        if (px & kPosIO) out = node_wire1[g.z] - 1u;
-        else { out = n_in + p + (u32)ev_delta(T, 3u * p + 2u); node_wire1[g.z] = out + 1u; }
-        EmitRec e;
-        e.gate = make_uint4(in0, in1, out, g.w & 0xFFu);
-        e.ids = make_uint4((u32)x, orig[x], 0u, 0u);
-        erec[p] = e;
+        const u32 d0 = dep0[x], d1 = dep1[x];                                       // (dep1 is dropped when it equals dep0: k_deps)
+        // an un-produced node: an input, a constant-like node (k_event_finish), an output nobody produces
+        const u32 in0 = (g.w & kGateLhUnprod) ? node_wire1[g.x] - 1u : wire_r[d0];
+        const u32 in1 = (g.w & kGateRhUnprod) ? node_wire1[g.y] - 1u : wire_r[d1 != C2A_NONE ? d1 : d0];
+        const bool io = (g.w & kGateOutIO) != 0u;
+        if (!io) node_wire1[g.z] = wire_r[x] + 1u;                                  // node -> wire of the out node (near-streaming: out nodes ascend with the rank)
+        const u32 op = g.w & 0x1Fu;
+        erec[pos_r[x]] = make_uint4(in0, in1, (u32)x | (op & 7u) << 29, orig[x] | (op >> 3) << 29 | (io ? 0x80000000u : 0u));
     }
 }
 template <bool WITH_SORTED>
-__global__ void k_emit_split(u32 n, const EmitRec* __restrict__ erec, u32* e_in0, u32* e_in1, u32* e_out, u8* e_op, u32* sorted_r, u32* sorted) {
+__global__ void k_emit_split(u32 n, u32 n_in, const EmitRec* __restrict__ erec, const uint4* __restrict__ gate4, const u32* __restrict__ node_wire1, EvTable T,
+                             u32* e_in0, u32* e_in1, u32* e_out, u8* e_op, u32* sorted_r, u32* sorted) {
     for (u64 i = gtid(); i < n; i += gstride()) {
         const EmitRec e = erec[i];
-        e_in0[i] = e.gate.x; e_in1[i] = e.gate.y; e_out[i] = e.gate.z; e_op[i] = (u8)e.gate.w;
-        if (WITH_SORTED) { sorted_r[i] = e.ids.x; sorted[i] = e.ids.y; }
+        const u32 rank = e.z & 0x1FFFFFFFu;
+        e_in0[i] = e.x; e_in1[i] = e.y;
+        e_out[i] = (e.w & 0x80000000u) ? node_wire1[gate4[rank].z] - 1u : n_in + (u32)i + (u32)ev_delta(T, 3u * (u32)i + 2u);
+        e_op[i] = (u8)((e.z >> 29) | ((e.w >> 29) & 3u) << 3);
+        if (WITH_SORTED) { sorted_r[i] = rank; sorted[i] = e.w & 0x1FFFFFFFu; }
     }
 }
 
