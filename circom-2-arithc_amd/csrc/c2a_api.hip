@@ -27,7 +27,7 @@ struct DevBuf {
 enum Stage { ST_EMPTY = 0, ST_LOADED, ST_SORTED, ST_WIRED, ST_EMITTED, ST_BOOLIFIED };
 
 enum Ev { EV_PREP0, EV_PREP1, EV_PEEL1, EV_ORDER1, EV_WIRES0, EV_WIRES1, EV_EMIT0, EV_EMIT1, EV_BPREP0, EV_BPREP1,
-          EV_BMAP1, EV_BUILD0, EV_BUILD1, EV_KPEEL0, EV_KPEEL1, EV_COUNT };
+          EV_BMAP1, EV_BUILD0, EV_BUILD1, EV_KPEEL0, EV_KPEEL1, EV_ORDER_RB /* the order stage's numbers have been posted */, EV_COUNT };
 
 }  // namespace
 
@@ -87,6 +87,9 @@ struct c2a_ctx {
     c2a_bool_info binfo{};
     u32 bool_width = 0;
     u32 bool_max_aux = 0;          // most aux wires any template of that width has (scratch of the local verifier)
+    u64 op_hist[C2A_NUM_GATE_TYPES] = {};   // gates per type of the loaded circuit (c2a_load_gates looks at every op byte anyway): the totals of a
+                                   // boolify plan are sums over it — the plan needs no read-back in the middle of c2a_boolify
+    u32 host_tsize[20] = {}, host_taux[20] = {};      // T(op, w) / AUX(op, w) of the templates now on the device (bool_width)
 
     // device buffers
     DevBuf lh, rh, out, op, gate4, nrec, orig, in_nodes, out_nodes;
@@ -467,7 +470,13 @@ int do_order(c2a_ctx* c, bool defer_sorted) {
                       c->owner.as<u32>());
     static_assert(SC_SCOUNT == SC_MAXDEPTH + 1, "read as a pair");
     C2A_LAUNCH_NOSYNC(k_post_words, 1, 64, s, c->hrb_dev + 8, (const u32*)(c->scalars.as<u32>() + SC_MAXDEPTH), 2u, n_roots_p, 1u, (const u32*)(c->scalars.as<u32>() + SC_EV), 2u);
-    HIP_TRY(hipStreamSynchronize(s));
+    // The host wants the number of splitters (how many jump launches) — but not before the walk: the walk is queued first, sized
+    // for the expected count (its loop is grid-stride: any grid is correct), and the host waits for the posted words only, while
+    // the walk runs.  (A whole-stream synchronisation here was a 27 µs hole in front of the walk.)
+    HIP_TRY(hipEventRecord(c->ev[EV_ORDER_RB], s));
+    C2A_LAUNCH_NOSYNC(k_rank_walk, grid_for((u64)m / (1u << (32 - C2A_SPLIT_SHIFT)) + 1024u, 8192), kThreads, s, (const u32*)scount, c->rlist.as<u32>(), c->slist.as<u32>(),
+                      c->next.as<u32>(), (const u32*)c->owner.as<u32>(), c->local.as<u64>(), c->sjump.as<uint2>());
+    HIP_TRY(hipEventSynchronize(c->ev[EV_ORDER_RB]));
     const u32 sc[3] = {c->hrb[8], c->hrb[9], c->hrb[10]};      // depth of the DFS forest, splitters, roots
     const u32 S = sc[1];
     c->stats.max_depth = sc[0];
@@ -479,8 +488,6 @@ int do_order(c2a_ctx* c, bool defer_sorted) {
     c->n_ev_io = c->hrb[11]; c->n_ev_const = c->hrb[12];
     c->stats.numbering_events = c->hrb[11] + c->hrb[12];
     c->stats.numbering_path = c->positional ? 1u : 0u;
-    C2A_LAUNCH_NOSYNC(k_rank_walk, grid_for(S, 8192), kThreads, s, (const u32*)scount, c->rlist.as<u32>(), c->slist.as<u32>(),
-                      c->next.as<u32>(), (const u32*)c->owner.as<u32>(), c->local.as<u64>(), c->sjump.as<uint2>());
     // pointer jumping, ping-pong between the two {next, sum} arrays
     u32 rounds = 0;
     for (u64 reach = 1; reach < S; reach *= kJumpSpan) ++rounds;
@@ -835,11 +842,13 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     if ((n_in && !input_nodes) || (n_out && !output_nodes)) return fail(c, C2A_ERR_ARG, "c2a_load_gates: null IO lists");
     const u32 n = (u32)n64;
     // argument validation on the host copy (ids must address the node table; op must be an AGateType)
+    u64 hist[C2A_NUM_GATE_TYPES] = {};
     for (u64 g = 0; g < n; ++g) {
         if (lh[g] >= n_nodes || rh[g] >= n_nodes || out[g] >= n_nodes)
             return fail(c, C2A_ERR_ARG, "c2a_load_gates: node id >= n_nodes at gate " + std::to_string(g));
         if (op[g] >= C2A_NUM_GATE_TYPES)
             return fail(c, C2A_ERR_ARG, "c2a_load_gates: unknown gate type at gate " + std::to_string(g));
+        ++hist[op[g]];
     }
     for (u32 i = 0; i < n_in; ++i)
         if (input_nodes[i] >= n_nodes) return fail(c, C2A_ERR_ARG, "c2a_load_gates: input node id >= n_nodes");
@@ -847,6 +856,7 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
         if (output_nodes[i] >= n_nodes) return fail(c, C2A_ERR_ARG, "c2a_load_gates: output node id >= n_nodes");
     HIP_TRY(hipSetDevice(c->device));
     c->n = n; c->n_nodes = n_nodes; c->n_in = n_in; c->n_out = n_out;
+    std::memcpy(c->op_hist, hist, sizeof(hist));
     c->bool_planned = false; c->fmt_chunk_valid = false; c->pruned = false; c->gathered = false; c->peel_meta_valid = false; c->stats = c2a_stats{}; c->binfo = c2a_bool_info{};
     {   // the reference checks this BEFORE it sorts (compiler.rs:363-383 precede :408), so build_circuit must report it first
         std::vector<u32> a(input_nodes, input_nodes + n_in), b(output_nodes, output_nodes + n_out);
@@ -1040,16 +1050,17 @@ int bool_plan(c2a_ctx* c, uint32_t width) {
         HIP_TRY(hipStreamSynchronize(s));
         c->bool_width = width;
         c->bool_max_aux = max_aux;
+        std::memcpy(c->host_tsize, T.tsize, sizeof(T.tsize)); std::memcpy(c->host_taux, T.taux, sizeof(T.taux));
     }
     rec(c, EV_BPREP0);
     ENSURE(c->goff, ((size_t)n + 1) * 8); ENSURE(c->aoff, ((size_t)n + 1) * 8);
     // template sizes and aux-wire counts straight from the op bytes, both scanned in one launch
     int r = scan_1pass<2>(c, s, c->scan_tmp, n, ScanBoolSizes{c->e_op.as<u8>(), c->tables.as<BoolTables>()}, c->goff.as<u64>(), c->aoff.as<u64>());
     if (r) return r;
-    C2A_LAUNCH_NOSYNC(k_post_words, 1, 64, s, c->hrb_dev + 24, reinterpret_cast<const u32*>(c->goff.as<u64>() + n), 2u, reinterpret_cast<const u32*>(c->aoff.as<u64>() + n), 2u, (const u32*)nullptr, 0u);
-    HIP_TRY(hipStreamSynchronize(s));
-    const u64 totals[2] = {(u64)c->hrb[24] | ((u64)c->hrb[25] << 32), (u64)c->hrb[26] | ((u64)c->hrb[27] << 32)};
-    const u64 G = totals[0], AUX = totals[1];
+    // the totals (goff[n], aoff[n]) are sums over the gate types — known since c2a_load_gates: no read-back, the map kernel is
+    // queued right behind the scan
+    u64 G = 0, AUX = 0;
+    for (u32 op = 0; op < C2A_NUM_GATE_TYPES; ++op) { G += c->op_hist[op] * c->host_tsize[op]; AUX += c->op_hist[op] * c->host_taux[op]; }
     const u64 wires = (u64)c->wire_count * width + AUX;
     if (wires >= 0xFFFFFFFFull) return fail(c, C2A_ERR_OVERFLOW, "c2a_boolify: boolean wire ids exceed u32");
     c->binfo.n_gates = G; c->binfo.wire_count = wires; c->binfo.aux_total = AUX; c->binfo.width = width;
