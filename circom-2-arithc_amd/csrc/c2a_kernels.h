@@ -594,11 +594,12 @@ __global__ void k_serial_levels(u32 n, const u32* __restrict__ sorted_r, const u
 
 // ------------------------------------------------------------------------------------------------
 // wire numbering (compiler.rs:388-449) and gate emission (compiler.rs:451-464)
-// node_wire1[node] = wire id + 1 (0 = none); nflag bit0 = input node, bit1 = output node.
+// node_wire1[node] = wire id + 1 (0 = none); nflag bit0 = input node, bit1 = output node (bit2: listed as a constant-like
+// node by k_deps, bit3: listed as the out node of a gate by k_io_gates — readers of the IO flags mask with 3).
 // ------------------------------------------------------------------------------------------------
 // The IO flags of the nodes are set up in front of the sort (do_prep: nflag cleared, inputs marked, then outputs): k_deps
-// folds "the out node is an IO node" into the gate's payload record, where the out nodes lie in rank order, and the walk in
-// sorted order (k_walk) no longer pays a scattered read per gate for it.
+// folds "the out node is an IO node" into the gate's payload record, where the out nodes lie in rank order, and the numbering
+// behind the sort no longer pays a scattered read per gate for it.
 __global__ void k_mark_inputs(u32 n_in, const u32* __restrict__ in_nodes, u8* nflag) {
     for (u64 i = gtid(); i < n_in; i += gstride()) nflag[in_nodes[i]] = 1;      // (all writers store the same byte)
 }
