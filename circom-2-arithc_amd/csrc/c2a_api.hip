@@ -1127,7 +1127,6 @@ struct DeviceGuard {         // whatever path leaves the scope, the context's pr
 
 int bool_map_sharded(c2a_ctx* c) {
     const u32 N = 1 + (u32)c->peers.size();
-    hipStream_t s = c->stream;
     DeviceGuard guard(c->device);
     std::vector<u32> cut;
     std::vector<u64> qcut;

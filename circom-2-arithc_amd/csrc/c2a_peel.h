@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(256) k_peel_shallow(PeelArgs A, const u32* __r
     __shared__ u32 s_g[256], s_root[256], s_depth[256];       // gate (C2A_NONE: none), DFS root, depth
     __shared__ u64 s_str[256];                                // its string (one word: depth <= lvl)
     __shared__ u32 s_base, s_cnt;
-    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const u32 lane = threadIdx.x & 63u;
     const u32 cnt = in_cnt[blockIdx.x] < in_cap ? in_cnt[blockIdx.x] : in_cap;      // (what did not fit went to the flat list)
     const u32* src = in + (u64)blockIdx.x * in_cap;
     u32* dst = out + (u64)blockIdx.x * out_cap;

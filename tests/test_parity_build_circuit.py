@@ -529,5 +529,16 @@ def test_numbering_paths(variant, request, orc, c2a):
             assert st["numbering_path"] == (0 if walk or st["numbering_events"] > cap else 1), st
             seen[st["numbering_path"]] += 1
         assert seen[0] > 0 and (walk or seen[1] > 0), seen
+        # what the generators above do not make: a gate whose out node is an INPUT node, a constant read at both operands and
+        # first seen as rh, an output node nobody produces read as an operand, an output named twice, an operand produced by a
+        # gate that hands out no wire
+        u32 = lambda *v: np.array(v, dtype=np.uint32)
+        p = dict(lh=u32(1, 3, 5, 7, 8, 9, 6), rh=u32(3, 3, 6, 11, 4, 2, 7), out=u32(5, 6, 7, 8, 9, 10, 12),
+                 op=np.array([0, 7, 9, 10, 0, 7, 19], dtype=np.uint8), n_nodes=14, input_nodes=u32(1, 2, 7), output_nodes=u32(9, 9, 11))
+        for perm in (np.arange(7), np.array([6, 2, 4, 0, 5, 3, 1])):
+            q = dict(p, lh=p["lh"][perm], rh=p["rh"][perm], out=p["out"][perm], op=p["op"][perm])
+            st = _check_fused(be, orc, bm, q)
+            assert st["numbering_events"] == 2 + 2 and st["numbering_path"] == (0 if walk else 1), st      # gates 2, 4 + constants 3, 4
+            _compare(be, orc, q, check_serial=False)
     finally:
         be.close()
