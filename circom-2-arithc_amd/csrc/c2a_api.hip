@@ -1139,7 +1139,7 @@ int bool_map_sharded(c2a_ctx* c) {
     std::vector<TemplateEntry> tmpl_host;
     for (u32 k = 1; k < N; ++k) {
         PeerDev& P = c->peers[k - 1];
-        P.p_lo = cut[k]; P.p_hi = cut[k + 1]; P.q_lo = qcut[k]; P.q_hi = qcut[k + 1]; P.q_bias = qcut[k] & ~3ull;
+        P.p_lo = cut[k]; P.p_hi = cut[k + 1]; P.q_lo = qcut[k]; P.q_hi = qcut[k + 1]; P.q_bias = qcut[k] & ~15ull;      // (k_boolify stores op bytes 16 at a time: stored indices keep the gate index mod 16)
         const size_t np = P.p_hi - P.p_lo;
         const u64 cntq = P.q_hi - P.q_bias;
         HIP_TRY(hipSetDevice(P.device));
@@ -1154,7 +1154,7 @@ int bool_map_sharded(c2a_ctx* c) {
         int r;
         if ((r = ens(P.e_in0, np * 4)) || (r = ens(P.e_in1, np * 4)) || (r = ens(P.e_out, np * 4)) || (r = ens(P.e_op, np)) ||
             (r = ens(P.goff, (np + 1) * 8)) || (r = ens(P.aoff, (np + 1) * 8)) || (r = ens(P.tmpl, c->tmpl.cap)) || (r = ens(P.tables, sizeof(BoolTables))) ||
-            (r = ens(P.b_in0, (cntq + 8) * 4)) || (r = ens(P.b_in1, (cntq + 8) * 4)) || (r = ens(P.b_out, (cntq + 8) * 4)) || (r = ens(P.b_op, cntq + 8)) ||
+            (r = ens(P.b_in0, (cntq + 16) * 4)) || (r = ens(P.b_in1, (cntq + 16) * 4)) || (r = ens(P.b_out, (cntq + 16) * 4)) || (r = ens(P.b_op, cntq + 16)) ||
             (r = ens(P.acc, 16))) { (void)hipSetDevice(c->device); return r; }
         HIP_TRY(hipMemcpyPeerAsync(P.e_in0.p, P.device, c->e_in0.as<u32>() + P.p_lo, c->device, np * 4, P.stream));
         HIP_TRY(hipMemcpyPeerAsync(P.e_in1.p, P.device, c->e_in1.as<u32>() + P.p_lo, c->device, np * 4, P.stream));
@@ -1229,8 +1229,8 @@ int c2a_boolify_chunk(c2a_ctx* c, uint64_t first_gate, uint64_t n_gates, uint32_
     HIP_TRY(hipMemcpyAsync(&q[0], c->goff.as<u64>() + first_gate, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&q[1], c->goff.as<u64>() + first_gate + n_gates, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    const u64 cntq = q[1] - q[0], bias = q[0] & ~3ull, lead = q[0] - bias;
-    ENSURE(c->cb_in0, (cntq + 8) * 4); ENSURE(c->cb_in1, (cntq + 8) * 4); ENSURE(c->cb_out, (cntq + 8) * 4); ENSURE(c->cb_op, cntq + 8);
+    const u64 cntq = q[1] - q[0], bias = q[0] & ~15ull, lead = q[0] - bias;
+    ENSURE(c->cb_in0, (cntq + 32) * 4); ENSURE(c->cb_in1, (cntq + 32) * 4); ENSURE(c->cb_out, (cntq + 32) * 4); ENSURE(c->cb_op, cntq + 32);
     int r = bool_map(c, primary_src(c), (u32)first_gate, (u32)(first_gate + n_gates), bias, c->cb_in0.as<u32>(), c->cb_in1.as<u32>(),
                      c->cb_out.as<u32>(), c->cb_op.as<u8>());
     if (r) return r;
@@ -1714,7 +1714,7 @@ int c2a_format_bristol(c2a_ctx* c, int which, uint64_t first, uint64_t count, ch
         in0 = c->b_in0.as<u32>(); in1 = c->b_in1.as<u32>(); out = c->b_out.as<u32>(); op = c->b_op.as<u8>(); total = c->binfo.n_gates; break;
     case 2: {
         if (!c->bool_planned || !c->fmt_chunk_valid) return fail(c, C2A_ERR_STATE, "c2a_format_bristol: call c2a_boolify_chunk first");
-        const u64 lead = c->fmt_chunk_first - (c->fmt_chunk_first & ~3ull);
+        const u64 lead = c->fmt_chunk_first - (c->fmt_chunk_first & ~15ull);
         in0 = c->cb_in0.as<u32>() + lead; in1 = c->cb_in1.as<u32>() + lead; out = c->cb_out.as<u32>() + lead; op = c->cb_op.as<u8>() + lead;
         total = c->fmt_chunk_cnt; break;
     }

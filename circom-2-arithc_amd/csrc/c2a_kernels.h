@@ -869,6 +869,8 @@ __global__ void k_emit_rank(u32 n, const uint4* __restrict__ gate4, const u32* _
 template <bool WITH_SORTED>
 __global__ void k_emit_split(u32 n, u32 n_in, const EmitRec* __restrict__ erec, const uint4* __restrict__ gate4, const u32* __restrict__ node_wire1, EvTable T,
                              u32* e_in0, u32* e_in1, u32* e_out, u8* e_op, u32* sorted_r, u32* sorted) {
+    // (one position per lane: with four per lane — 16-byte stores into every stream — the record loads are 64 bytes apart
+    // between neighbouring lanes: 89 instead of 67 µs)
     for (u64 i = gtid(); i < n; i += gstride()) {
         const EmitRec e = erec[i];
         const u32 rank = e.z & 0x1FFFFFFFu;
@@ -974,32 +976,43 @@ __global__ void __launch_bounds__(kThreads) k_boolify(BoolArgs A, const BoolTabl
     }
     __syncthreads();
     const u32 total = s_goff[cnt];                       // boolean gates of this block (< 2^32 by construction)
-    const u32 head = (u32)((4 - (q0 & 3)) & 3);          // unaligned gates before the first 16-byte boundary
+    // the body starts at a boolean gate whose index is a multiple of 16 and covers whole groups of 16: a lane produces 4
+    // consecutive gates, the four lanes of a quad 16 — the u32 streams leave as one 16-byte store per lane, the op bytes as one
+    // 16-byte store per QUAD (lane 0 of it collects the three other words by DPP: as a 4-byte store per lane the op stream cost
+    // 12 % of the kernel for 8 % of its bytes — 4-byte-per-lane stores are issue-bound on gfx950)
+    const u32 head = (u32)((16 - (q0 & 15)) & 15);       // gates before the first 16-gate boundary
     const u32 r0 = head < total ? head : total;
-    const u32 r1 = r0 + ((total - r0) & ~3u);
+    const u32 r1 = r0 + ((total - r0) & ~15u);
     const u32* base_words = reinterpret_cast<const u32*>(s_base);
     typedef u32 u32x4 __attribute__((vector_size(16)));
-    // ---- aligned body: groups of 4 (r = block-relative index)
-    for (u32 r = r0 + 4u * tid; r < r1; r += 4u * kThreads) {
-        u32 idx = bool_owner(r, s_goff, cnt);
-        u32 start = s_goff[idx], bound = s_goff[idx + 1], top = s_top[idx];
-        u32 v0[4], v1[4], v2[4], vop = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            while (r + j >= bound) { ++idx; start = bound; bound = s_goff[idx + 1]; top = s_top[idx]; }
-            const uint4 e = A.tmpl[top + (r + j - start)];
-            v0[j] = base_words[idx * 4 + (e.x >> 30)] + (e.x & 0x3FFFFFFFu);
-            v1[j] = base_words[idx * 4 + (e.y >> 30)] + (e.y & 0x3FFFFFFFu);
-            v2[j] = base_words[idx * 4 + (e.z >> 30)] + (e.z & 0x3FFFFFFFu);
-            vop |= (e.w & 0xFFu) << (8 * j);
-        }
+    // ---- aligned body: groups of 4 (r = block-relative index).  r1 - r0 is a multiple of 16: the four lanes of a quad are in
+    // here together (the emulation wants the whole wave at the exchange: the loop runs per wave, lanes past the end idle)
+    for (u32 rw = r0 + 4u * (tid & ~63u); rw < r1; rw += 4u * kThreads) {
+        const u32 r = rw + 4u * (tid & 63u);
+        const bool act = r < r1;
+        u32 vop = 0;
         const u64 q = q0 + r - A.q_bias;
-        *reinterpret_cast<u32x4*>(A.b_in0 + q) = u32x4{v0[0], v0[1], v0[2], v0[3]};
-        *reinterpret_cast<u32x4*>(A.b_in1 + q) = u32x4{v1[0], v1[1], v1[2], v1[3]};
-        *reinterpret_cast<u32x4*>(A.b_out + q) = u32x4{v2[0], v2[1], v2[2], v2[3]};
-        *reinterpret_cast<u32*>(A.b_op + q) = vop;
+        if (act) {
+            u32 idx = bool_owner(r, s_goff, cnt);
+            u32 start = s_goff[idx], bound = s_goff[idx + 1], top = s_top[idx];
+            u32 v0[4], v1[4], v2[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                while (r + j >= bound) { ++idx; start = bound; bound = s_goff[idx + 1]; top = s_top[idx]; }
+                const uint4 e = A.tmpl[top + (r + j - start)];
+                v0[j] = base_words[idx * 4 + (e.x >> 30)] + (e.x & 0x3FFFFFFFu);
+                v1[j] = base_words[idx * 4 + (e.y >> 30)] + (e.y & 0x3FFFFFFFu);
+                v2[j] = base_words[idx * 4 + (e.z >> 30)] + (e.z & 0x3FFFFFFFu);
+                vop |= (e.w & 0xFFu) << (8 * j);
+            }
+            *reinterpret_cast<u32x4*>(A.b_in0 + q) = u32x4{v0[0], v0[1], v0[2], v0[3]};
+            *reinterpret_cast<u32x4*>(A.b_in1 + q) = u32x4{v1[0], v1[1], v1[2], v1[3]};
+            *reinterpret_cast<u32x4*>(A.b_out + q) = u32x4{v2[0], v2[1], v2[2], v2[3]};
+        }
+        const u32 o1 = quad_bcast<1>(vop), o2 = quad_bcast<2>(vop), o3 = quad_bcast<3>(vop);
+        if (act && (tid & 3u) == 0u) *reinterpret_cast<u32x4*>(A.b_op + q) = u32x4{vop, o1, o2, o3};
     }
-    // ---- unaligned head [0,r0) and tail [r1,total): at most 3 + 3 gates
+    // ---- head [0,r0) and tail [r1,total): at most 15 + 15 gates
     {
         const u32 nh = r0, nt = total - r1;
         if (tid < nh + nt) {

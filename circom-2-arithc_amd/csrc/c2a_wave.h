@@ -35,6 +35,15 @@ __device__ __forceinline__ u32 row_shl8(u32 v) {
     return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x108, 0xF, 0xF, false);
 #endif
 }
+// every lane takes the value of lane K of its quad (four neighbouring lanes): one DPP move
+template <int K> __device__ __forceinline__ u32 quad_bcast(u32 v) {
+#ifdef C2A_EMULATE
+    const u32 l = threadIdx.x & 63u;
+    return (u32)__shfl(v, (int)((l & ~3u) + K), 64);
+#else
+    return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, K * 0x55, 0xF, 0xF, false);      // quad_perm:[K,K,K,K]
+#endif
+}
 // a (all lanes) if the wave-uniform j is not 0, else b — without a branch
 __device__ __forceinline__ u32 select_uniform(u32 j, u32 a, u32 b) {
 #ifdef C2A_EMULATE
