@@ -56,6 +56,10 @@ struct c2a_ctx {
     std::string err;
     Stage stage = ST_EMPTY;
     int n_cu = 256;
+    u32 bool_threads = 1024;       // threads of a k_boolify workgroup (C2A_BOOL_THREADS: 256, 512, 1024).  What the kernel takes depends on where its 9.6 GB of
+                                   // output landed (tools/bool_alloc.py: the same process, context after context, 1.7 - 2.3 ms with 256 threads; PMC: DRAM write
+                                   // credit stalls x 3 in the slow ones, translation misses the same); 1 024 threads — a quarter of the workgroups in flight,
+                                   // each done four times sooner: the window of memory being written is a quarter as wide — 1.7 - 1.95
     u32 bool_chunk = 256;          // arithmetic gates per k_boolify workgroup: 128, 256 (measured best) or 512
     u32 peel_seed_chunk = 4;       // dataflow launch: seeds a wave takes at a time (1: the one counter they all hit cost 1.4 ms with 175 000 seeds; with the 33 000 the shallow passes leave: 2 / 4 / 8 / 16 = 7.72 / 7.70 / 7.78 / 7.85 ms)
     u32 peel_shallow = 4;          // levels behind the sinks done a whole level at once before the dataflow launch (>= 1, <= 48)
@@ -86,6 +90,7 @@ struct c2a_ctx {
     c2a_stats stats{};
     c2a_bool_info binfo{};
     u32 bool_width = 0;
+    u32 tmpl_copies = 1, tmpl_stride = 0;   // copies of the template table on the device (C2A_TMPL_COPIES), entries between them
     u32 bool_max_aux = 0;          // most aux wires any template of that width has (scratch of the local verifier)
     u64 op_hist[C2A_NUM_GATE_TYPES] = {};   // gates per type of the loaded circuit (c2a_load_gates looks at every op byte anyway): the totals of a
                                    // boolify plan are sums over it — the plan needs no read-back in the middle of c2a_boolify
@@ -774,11 +779,13 @@ int c2a_create(int n_devices, const int* device_ids, c2a_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
         c->n_cu = prop.multiProcessorCount;
+    if (const char* e = std::getenv("C2A_BOOL_THREADS")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 256 || v == 512 || v == 1024) c->bool_threads = v; }
     if (const char* e = std::getenv("C2A_BOOL_CHUNK")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 128 || v == 256 || v == 512) c->bool_chunk = v; }
     if (const char* e = std::getenv("C2A_PEEL_SEED_CHUNK")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 4096) c->peel_seed_chunk = v; }
     if (const char* e = std::getenv("C2A_PEEL_SHALLOW")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 48) c->peel_shallow = v; }
     if (const char* e = std::getenv("C2A_PEEL_WAVES")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 32) c->peel_waves = v; }
     if (const char* e = std::getenv("C2A_PEEL_RESERVE")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v <= 32) c->peel_reserve = v; }
+    if (const char* e = std::getenv("C2A_TMPL_COPIES")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 64) c->tmpl_copies = v; }
     if (const char* e = std::getenv("C2A_NUMBERING_WALK")) c->numbering_walk = e[0] == '1';
     if (const char* e = std::getenv("C2A_PEEL_FIFOS")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->peel_fifos = v; }
 #ifdef C2A_EMULATE
@@ -1043,9 +1050,11 @@ int bool_plan(c2a_ctx* c, uint32_t width) {
             max_aux = std::max<u32>(max_aux, tb.aux);
             all.insert(all.end(), tb.gates.begin(), tb.gates.end());
         }
-        ENSURE(c->tmpl, all.size() * sizeof(TemplateEntry));
+        c->tmpl_stride = ((u32)all.size() + 7u) / 8u * 8u + 8u * 5u;      // entries between two copies: whole 128-byte lines, an odd number of them on top
+        ENSURE(c->tmpl, (size_t)c->tmpl_copies * c->tmpl_stride * sizeof(TemplateEntry));
         ENSURE(c->tables, sizeof(BoolTables));
-        HIP_TRY(hipMemcpyAsync(c->tmpl.p, all.data(), all.size() * sizeof(TemplateEntry), hipMemcpyHostToDevice, s));
+        for (u32 k = 0; k < c->tmpl_copies; ++k)
+            HIP_TRY(hipMemcpyAsync(c->tmpl.as<TemplateEntry>() + (size_t)k * c->tmpl_stride, all.data(), all.size() * sizeof(TemplateEntry), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(c->tables.p, &T, sizeof(T), hipMemcpyHostToDevice, s));
         HIP_TRY(hipStreamSynchronize(s));
         c->bool_width = width;
@@ -1091,14 +1100,16 @@ int bool_map(c2a_ctx* c, const BoolSrc& S, u32 p_first, u32 p_end, u64 q_bias, u
     A.n = c->n; A.width = width; A.M = M; A.aux_base = (u64)M * width; A.out_base = (u64)M * width + c->binfo.aux_total;
     // (a shard holds its own slice of the emitted circuit: the kernel indexes by global sorted position)
     A.e_in0 = S.e_in0 - S.p_base; A.e_in1 = S.e_in1 - S.p_base; A.e_out = S.e_out - S.p_base; A.e_op = S.e_op - S.p_base;
-    A.goff = S.goff - S.p_base; A.aoff = S.aoff - S.p_base; A.tmpl = S.tmpl;
+    A.goff = S.goff - S.p_base; A.aoff = S.aoff - S.p_base; A.tmpl = S.tmpl; A.tmpl_copies = c->tmpl_copies; A.tmpl_stride = c->tmpl_stride;
     A.b_in0 = o_in0; A.b_in1 = o_in1; A.b_out = o_out; A.b_op = o_op;
     A.p_first = p_first; A.p_end = p_end; A.q_bias = q_bias;
     const u32 ch = c->bool_chunk;
     const u32 blocks = (p_end - p_first + ch - 1) / ch;
-    if (ch == 128) C2A_LAUNCH((k_boolify<128>), blocks, kThreads, S.stream, A, S.tables);
-    else if (ch == 512) C2A_LAUNCH((k_boolify<512>), blocks, kThreads, S.stream, A, S.tables);
-    else C2A_LAUNCH((k_boolify<256>), blocks, kThreads, S.stream, A, S.tables);
+    const u32 th = c->bool_threads;
+#define C2A_BOOL_CASE(CH, TH) if (ch == CH && th == TH) C2A_LAUNCH((k_boolify<CH, TH>), blocks, TH, S.stream, A, S.tables); else
+    C2A_BOOL_CASE(128, 256) C2A_BOOL_CASE(256, 256) C2A_BOOL_CASE(512, 256) C2A_BOOL_CASE(256, 512) C2A_BOOL_CASE(512, 1024)
+        C2A_LAUNCH((k_boolify<256, 1024>), blocks, 1024, S.stream, A, S.tables);
+#undef C2A_BOOL_CASE
     return C2A_OK;
 }
 

@@ -928,6 +928,7 @@ struct BoolArgs {
     const u64* goff;  // [n+1] first boolean gate of each arithmetic gate
     const u64* aoff;  // [n+1] first aux wire (relative) of each arithmetic gate
     const uint4* tmpl;
+    u32 tmpl_copies, tmpl_stride;      // the template table lies there tmpl_copies times, tmpl_stride entries apart
     u32* b_in0; u32* b_in1; u32* b_out; u8* b_op;
     u32 p_first;      // first arithmetic gate (sorted position) of this launch
     u32 p_end;        // one past the last
@@ -958,8 +959,8 @@ __device__ __forceinline__ u32 bool_owner(u32 r, const u32* s_goff, u32 cnt) {
 // Measured alternatives that LOST in interleaved same-session A/B runs (kept out of the tree): a start-bit map
 // + popcount instead of the search, a "four gates, one owner" fast path, software-pipelined template loads,
 // persistent workgroups with LDS-staged packed templates, non-temporal stores (profiles/r01_boolify_ab.txt).
-template <int CHUNK>
-__global__ void __launch_bounds__(kThreads) k_boolify(BoolArgs A, const BoolTables* __restrict__ T) {
+template <int CHUNK, int THREADS = kThreads>
+__global__ void __launch_bounds__(THREADS) k_boolify(BoolArgs A, const BoolTables* __restrict__ T) {
     __shared__ u32 s_goff[CHUNK + 1];       // first boolean gate of each arithmetic gate, relative to the block's first
     __shared__ uint4 s_base[CHUNK];         // wire bases per ref kind
     __shared__ u32 s_top[CHUNK];            // template offset
@@ -967,8 +968,8 @@ __global__ void __launch_bounds__(kThreads) k_boolify(BoolArgs A, const BoolTabl
     const u64 p0 = (u64)A.p_first + (u64)blockIdx.x * CHUNK;
     const u32 cnt = (u32)((A.p_end - p0) < (u64)CHUNK ? (A.p_end - p0) : (u64)CHUNK);
     const u64 q0 = A.goff[p0];
-    for (u32 i = tid; i <= cnt; i += kThreads) s_goff[i] = (u32)(A.goff[p0 + i] - q0);
-    for (u32 i = tid; i < cnt; i += kThreads) {
+    for (u32 i = tid; i <= cnt; i += THREADS) s_goff[i] = (u32)(A.goff[p0 + i] - q0);
+    for (u32 i = tid; i < cnt; i += THREADS) {
         const u32 wa = A.e_in0[p0 + i], wb = A.e_in1[p0 + i], wo = A.e_out[p0 + i];
         s_base[i] = make_uint4(bool_wire(wa, 0, A.width, A.M, A.out_base), bool_wire(wb, 0, A.width, A.M, A.out_base),
                                bool_wire(wo, 0, A.width, A.M, A.out_base), (u32)(A.aux_base + A.aoff[p0 + i]));
@@ -985,9 +986,10 @@ __global__ void __launch_bounds__(kThreads) k_boolify(BoolArgs A, const BoolTabl
     const u32 r1 = r0 + ((total - r0) & ~15u);
     const u32* base_words = reinterpret_cast<const u32*>(s_base);
     typedef u32 u32x4 __attribute__((vector_size(16)));
+    const uint4* __restrict__ tmpl = A.tmpl + (size_t)((blockIdx.x >> 3) % A.tmpl_copies) * A.tmpl_stride;
     // ---- aligned body: groups of 4 (r = block-relative index).  r1 - r0 is a multiple of 16: the four lanes of a quad are in
     // here together (the emulation wants the whole wave at the exchange: the loop runs per wave, lanes past the end idle)
-    for (u32 rw = r0 + 4u * (tid & ~63u); rw < r1; rw += 4u * kThreads) {
+    for (u32 rw = r0 + 4u * (tid & ~63u); rw < r1; rw += 4u * THREADS) {
         const u32 r = rw + 4u * (tid & 63u);
         const bool act = r < r1;
         u32 vop = 0;
@@ -999,7 +1001,7 @@ __global__ void __launch_bounds__(kThreads) k_boolify(BoolArgs A, const BoolTabl
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 while (r + j >= bound) { ++idx; start = bound; bound = s_goff[idx + 1]; top = s_top[idx]; }
-                const uint4 e = A.tmpl[top + (r + j - start)];
+                const uint4 e = tmpl[top + (r + j - start)];
                 v0[j] = base_words[idx * 4 + (e.x >> 30)] + (e.x & 0x3FFFFFFFu);
                 v1[j] = base_words[idx * 4 + (e.y >> 30)] + (e.y & 0x3FFFFFFFu);
                 v2[j] = base_words[idx * 4 + (e.z >> 30)] + (e.z & 0x3FFFFFFFu);
@@ -1018,7 +1020,7 @@ __global__ void __launch_bounds__(kThreads) k_boolify(BoolArgs A, const BoolTabl
         if (tid < nh + nt) {
             const u32 r = tid < nh ? tid : r1 + (tid - nh);
             const u32 lo = bool_owner(r, s_goff, cnt);
-            const uint4 e = A.tmpl[s_top[lo] + (r - s_goff[lo])];
+            const uint4 e = tmpl[s_top[lo] + (r - s_goff[lo])];
             const u64 q = q0 + r - A.q_bias;
             A.b_in0[q] = base_words[lo * 4 + (e.x >> 30)] + (e.x & 0x3FFFFFFFu);
             A.b_in1[q] = base_words[lo * 4 + (e.y >> 30)] + (e.y & 0x3FFFFFFFu);

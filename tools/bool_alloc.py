@@ -9,13 +9,17 @@ sys.path.insert(0, ROOT)
 import torch
 c2a = importlib.import_module("circom-2-arithc_amd")
 fg = c2a.synth.layered_dag(5000, 2000, seed=c2a.synth.SEED)
+VARIANTS = os.environ.get("BOOL_ALLOC_ENVS", "C2A_BOOL_CHUNK=256").split(";")      # e.g. "C2A_BOOL_CHUNK=256;C2A_BOOL_CHUNK=128"
 def one(tag):
+  for copies in VARIANTS:
+    for kv in copies.split(","):
+        k, v = kv.split("="); os.environ[k] = v
     with c2a.Backend(0) as be:
         be.load_gates(fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes)
         ts = []
-        for _ in range(5):
+        for _ in range(4):
             be.build_circuit(); be.boolify(32); ts.append(be.timings()["bool_map"])
-        print(f"{tag}: k_boolify ms " + " ".join(f"{t:.3f}" for t in ts), flush=True)
+        print(f"{tag} [{copies}]: k_boolify ms " + " ".join(f"{t:.3f}" for t in ts), flush=True)
 one("context 1 (fresh process)")
 one("context 2 (after context 1 was destroyed)")
 hog = [torch.empty(3 << 30, dtype=torch.uint8, device="cuda") for _ in range(8)]        # 24 GB held while the context allocates
