@@ -90,7 +90,6 @@ struct c2a_ctx {
     c2a_stats stats{};
     c2a_bool_info binfo{};
     u32 bool_width = 0;
-    u32 tmpl_copies = 1, tmpl_stride = 0;   // copies of the template table on the device (C2A_TMPL_COPIES), entries between them
     u32 bool_max_aux = 0;          // most aux wires any template of that width has (scratch of the local verifier)
     u64 op_hist[C2A_NUM_GATE_TYPES] = {};   // gates per type of the loaded circuit (c2a_load_gates looks at every op byte anyway): the totals of a
                                    // boolify plan are sums over it — the plan needs no read-back in the middle of c2a_boolify
@@ -785,7 +784,6 @@ int c2a_create(int n_devices, const int* device_ids, c2a_ctx** out) {
     if (const char* e = std::getenv("C2A_PEEL_SHALLOW")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 48) c->peel_shallow = v; }
     if (const char* e = std::getenv("C2A_PEEL_WAVES")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 32) c->peel_waves = v; }
     if (const char* e = std::getenv("C2A_PEEL_RESERVE")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v <= 32) c->peel_reserve = v; }
-    if (const char* e = std::getenv("C2A_TMPL_COPIES")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 64) c->tmpl_copies = v; }
     if (const char* e = std::getenv("C2A_NUMBERING_WALK")) c->numbering_walk = e[0] == '1';
     if (const char* e = std::getenv("C2A_PEEL_FIFOS")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->peel_fifos = v; }
 #ifdef C2A_EMULATE
@@ -1050,11 +1048,9 @@ int bool_plan(c2a_ctx* c, uint32_t width) {
             max_aux = std::max<u32>(max_aux, tb.aux);
             all.insert(all.end(), tb.gates.begin(), tb.gates.end());
         }
-        c->tmpl_stride = ((u32)all.size() + 7u) / 8u * 8u + 8u * 5u;      // entries between two copies: whole 128-byte lines, an odd number of them on top
-        ENSURE(c->tmpl, (size_t)c->tmpl_copies * c->tmpl_stride * sizeof(TemplateEntry));
+        ENSURE(c->tmpl, all.size() * sizeof(TemplateEntry));
         ENSURE(c->tables, sizeof(BoolTables));
-        for (u32 k = 0; k < c->tmpl_copies; ++k)
-            HIP_TRY(hipMemcpyAsync(c->tmpl.as<TemplateEntry>() + (size_t)k * c->tmpl_stride, all.data(), all.size() * sizeof(TemplateEntry), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->tmpl.p, all.data(), all.size() * sizeof(TemplateEntry), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(c->tables.p, &T, sizeof(T), hipMemcpyHostToDevice, s));
         HIP_TRY(hipStreamSynchronize(s));
         c->bool_width = width;
@@ -1100,7 +1096,7 @@ int bool_map(c2a_ctx* c, const BoolSrc& S, u32 p_first, u32 p_end, u64 q_bias, u
     A.n = c->n; A.width = width; A.M = M; A.aux_base = (u64)M * width; A.out_base = (u64)M * width + c->binfo.aux_total;
     // (a shard holds its own slice of the emitted circuit: the kernel indexes by global sorted position)
     A.e_in0 = S.e_in0 - S.p_base; A.e_in1 = S.e_in1 - S.p_base; A.e_out = S.e_out - S.p_base; A.e_op = S.e_op - S.p_base;
-    A.goff = S.goff - S.p_base; A.aoff = S.aoff - S.p_base; A.tmpl = S.tmpl; A.tmpl_copies = c->tmpl_copies; A.tmpl_stride = c->tmpl_stride;
+    A.goff = S.goff - S.p_base; A.aoff = S.aoff - S.p_base; A.tmpl = S.tmpl;
     A.b_in0 = o_in0; A.b_in1 = o_in1; A.b_out = o_out; A.b_op = o_op;
     A.p_first = p_first; A.p_end = p_end; A.q_bias = q_bias;
     const u32 ch = c->bool_chunk;

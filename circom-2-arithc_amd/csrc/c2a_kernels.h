@@ -928,7 +928,6 @@ struct BoolArgs {
     const u64* goff;  // [n+1] first boolean gate of each arithmetic gate
     const u64* aoff;  // [n+1] first aux wire (relative) of each arithmetic gate
     const uint4* tmpl;
-    u32 tmpl_copies, tmpl_stride;      // the template table lies there tmpl_copies times, tmpl_stride entries apart
     u32* b_in0; u32* b_in1; u32* b_out; u8* b_op;
     u32 p_first;      // first arithmetic gate (sorted position) of this launch
     u32 p_end;        // one past the last
@@ -986,7 +985,7 @@ __global__ void __launch_bounds__(THREADS) k_boolify(BoolArgs A, const BoolTable
     const u32 r1 = r0 + ((total - r0) & ~15u);
     const u32* base_words = reinterpret_cast<const u32*>(s_base);
     typedef u32 u32x4 __attribute__((vector_size(16)));
-    const uint4* __restrict__ tmpl = A.tmpl + (size_t)((blockIdx.x >> 3) % A.tmpl_copies) * A.tmpl_stride;
+    const uint4* __restrict__ tmpl = A.tmpl;
     // ---- aligned body: groups of 4 (r = block-relative index).  r1 - r0 is a multiple of 16: the four lanes of a quad are in
     // here together (the emulation wants the whole wave at the exchange: the loop runs per wave, lanes past the end idle)
     for (u32 rw = r0 + 4u * (tid & ~63u); rw < r1; rw += 4u * THREADS) {
