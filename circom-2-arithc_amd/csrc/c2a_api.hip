@@ -100,16 +100,16 @@ struct c2a_ctx {
     DevBuf prod1, dep0, dep1, cons_cnt, cons_off, eslot, aq_items, aq_pc, aq_seeds, aq_seeds1, aq_seed_flat, aq_seed_cnt, fill, meta, node, child, gstat, clist, pctl, pcold;
     DevBuf rbits, rpre, ridx, rlist, next, owner, local, slist, sjump, sjump2, sorted, sorted_r;
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op;
-    DevBuf pos_r, wire_r, erec, io_rank, ev_items, ev_sorted, ev_key, ev_cum, ev_blk, cnode, gflag;      // positional numbering (c2a_kernels.h POSITIONAL NUMBERING)
+    DevBuf pos_r, wire_r, erec, pblk, dpre, epre, gflag;      // positional numbering (c2a_kernels.h POSITIONAL NUMBERING)
     u32* hrb = nullptr;            // 256 words of host memory the device writes the end-of-stage numbers to (k_post_*) ...
     u32* hrb_dev = nullptr;        // ... as the device sees it.  Words 0-7: peel, 8-15: order, 16-23: wires, 24-31: boolify
     u32 rb_edges = 0, rb_dup = 0, rb_nmid = 0, rb_err = 0;  // read-back slots (edge count, duplicate-writer flag, wires handed out, in/out clash)
+    u32 nmid_add = 0;              // what the posted wire count is relative to (positional numbering: n + the events' net shift)
     bool has_dup = false;          // two gates write one node (compiler.rs:403-406 keeps the last): the general numbering path
-    bool positional = false;       // the circuit now sorted takes the positional numbering (one writer per node, few events)
+    bool positional = false;       // the circuit now sorted takes the positional numbering (one writer per node)
     bool sorted_ready = false;     // sorted[] / sorted_r[] are written (c2a_build_circuit leaves them to the emission's split pass)
     bool emitted_with_wires = false;   // the positional numbering has emitted the gates as well (do_emit has nothing left to do)
     const uint2* rank_suffix = nullptr;    // the splitter suffix sums the list ranking ended in (which of its ping-pong buffers)
-    u32 n_ev_io = 0, n_ev_const = 0;   // gates whose out node is an IO node / constant-like nodes of the circuit now sorted
     DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof, peel_trace;
     DevBuf tsz, asz, goff, aoff, tmpl, tables, b_in0, b_in1, b_out, b_op;
     DevBuf fmt_len, fmt_off, fmt_text, fmt_table, shard_cut, shard_qcut;
@@ -127,7 +127,7 @@ struct c2a_ctx {
         all = {&lh, &rh, &out, &op, &gate4, &nrec, &orig, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &aq_items, &aq_pc, &aq_seeds, &aq_seeds1, &aq_seed_flat, &aq_seed_cnt, &fill,
                &gstat, &clist, &pctl, &pcold, &meta, &node, &child, &rbits, &rpre, &ridx, &rlist, &next,
                &owner, &local, &slist, &sjump, &sjump2, &sorted, &sorted_r, &first, &nflag, &wflag, &widx, &node_wire1,
-               &node_wire, &e_in0, &e_in1, &e_out, &e_op, &pos_r, &wire_r, &erec, &io_rank, &ev_items, &ev_sorted, &ev_key, &ev_cum, &ev_blk, &cnode, &gflag, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &peel_trace, &tsz, &asz, &goff,
+               &node_wire, &e_in0, &e_in1, &e_out, &e_op, &pos_r, &wire_r, &erec, &pblk, &dpre, &epre, &gflag, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &peel_trace, &tsz, &asz, &goff,
                &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &fmt_len, &fmt_off, &fmt_text, &fmt_table, &shard_cut, &shard_qcut, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &ev_lcount, &ev_lbase, &ev_lorder, &ev_bar, &ev_io, &g_in0, &g_in1, &g_out, &g_op, &pr_rep, &pr_need, &pr_tin0, &pr_tin1, &pr_top, &pr_live, &pr_goff, &pr_counts, &p_in0, &p_in1, &p_out, &p_op, &cb_in0, &cb_in1, &cb_out, &cb_op};
     }
 };
@@ -135,7 +135,7 @@ struct c2a_ctx {
 namespace {
 
 // scalars block layout (u32 words unless noted)
-enum Scalar { SC_MAXDEPTH = 0, SC_SCOUNT = 1, SC_ERR = 2, SC_NMID = 3, SC_NROOTS = 4, SC_LEVELS = 5, SC_EV = 6 /*2 words: IO-out gates, constant-like nodes*/,
+enum Scalar { SC_MAXDEPTH = 0, SC_SCOUNT = 1, SC_ERR = 2, SC_NMID = 3, SC_NROOTS = 4, SC_LEVELS = 5,
               SC_DFS = 8 /*3 words*/, SC_DUP = 52,
               SC_TOTAL64 = 16 /* u64 slots from here: 16..31 */, SC_WORDS = 64 };
 
@@ -245,12 +245,9 @@ int do_prep(c2a_ctx* c, bool for_peel = true) {
     // (two gates wrote one node — never, for a circuit the reference's front-end built: these two leave at once)
     C2A_LAUNCH_NOSYNC(k_dup_clear, 512, kThreads, s, c->n_nodes, (const u32*)dup, c->prod1.as<u32>());
     C2A_LAUNCH_NOSYNC(k_dup_producer, 512, kThreads, s, n, (const u32*)dup, (const u32*)c->out.as<u32>(), c->prod1.as<u32>());
-    if (c->n_in + c->n_out)
-        C2A_LAUNCH(k_io_gates, grid_for((u64)c->n_in + c->n_out, 256), kThreads, s, c->n_in, (const u32*)c->in_nodes.as<u32>(), c->n_out, (const u32*)c->out_nodes.as<u32>(),
-                   (const u32*)c->prod1.as<u32>(), c->nflag.as<u8>(), c->scalars.as<u32>() + SC_EV, c->io_rank.as<u32>(), kEvCap);
     int r;
-    C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->out.as<u32>(), c->op.as<u8>(), dup, c->prod1.as<u32>(), c->nflag.as<u8>(), c->orig.as<u32>(),
-                      c->gate4.as<uint4>(), c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>(), c->scalars.as<u32>() + SC_EV, c->cnode.as<u32>(), kEvCap, c->gflag.as<u8>());
+    C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->out.as<u32>(), c->op.as<u8>(), dup, c->prod1.as<u32>(), (const u8*)c->nflag.as<u8>(), c->orig.as<u32>(),
+                      c->gate4.as<uint4>(), c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>(), c->gflag.as<u8>());
     if (!for_peel) return C2A_OK;
     r = scan_exclusive<u32>(c, c->cons_cnt.as<u32>(), c->cons_off.as<u32>(), n);
     if (r) return r;
@@ -473,7 +470,7 @@ int do_order(c2a_ctx* c, bool defer_sorted) {
     C2A_LAUNCH(k_rank_mark, std::max<u32>(1u, std::min<u32>(2048u, (m + kThreads * 8 - 1) / (kThreads * 8))), kThreads, s, m, c->rlist.as<u32>(), scount, c->slist.as<u32>(),
                       c->owner.as<u32>());
     static_assert(SC_SCOUNT == SC_MAXDEPTH + 1, "read as a pair");
-    C2A_LAUNCH_NOSYNC(k_post_words, 1, 64, s, c->hrb_dev + 8, (const u32*)(c->scalars.as<u32>() + SC_MAXDEPTH), 2u, n_roots_p, 1u, (const u32*)(c->scalars.as<u32>() + SC_EV), 2u);
+    C2A_LAUNCH_NOSYNC(k_post_words, 1, 64, s, c->hrb_dev + 8, (const u32*)(c->scalars.as<u32>() + SC_MAXDEPTH), 2u, n_roots_p, 1u, (const u32*)nullptr, 0u);
     // The host wants the number of splitters (how many jump launches) — but not before the walk: the walk is queued first, sized
     // for the expected count (its loop is grid-stride: any grid is correct), and the host waits for the posted words only, while
     // the walk runs.  (A whole-stream synchronisation here was a 27 µs hole in front of the walk.)
@@ -486,11 +483,9 @@ int do_order(c2a_ctx* c, bool defer_sorted) {
     c->stats.max_depth = sc[0];
     c->stats.n_splitters = S;
     c->stats.n_roots = sc[2];
-    // what bends the wire numbering away from "position q gets wire n_in + q" (k_io_gates / k_deps counted it): few events and one
-    // writer per node => the positional numbering, which needs no walk in sorted order (c2a_kernels.h POSITIONAL NUMBERING)
-    c->positional = !c->has_dup && !c->numbering_walk && (u64)c->hrb[11] + c->hrb[12] <= kEvCap;
-    c->n_ev_io = c->hrb[11]; c->n_ev_const = c->hrb[12];
-    c->stats.numbering_events = c->hrb[11] + c->hrb[12];
+    // one writer per node (what the reference's front-end builds) => the positional numbering, which needs no walk in sorted
+    // order (c2a_kernels.h POSITIONAL NUMBERING)
+    c->positional = !c->has_dup && !c->numbering_walk;
     c->stats.numbering_path = c->positional ? 1u : 0u;
     // pointer jumping, ping-pong between the two {next, sum} arrays
     u32 rounds = 0;
@@ -616,18 +611,12 @@ int do_topo_sort(c2a_ctx* c, u64* cycle_at, bool defer_sorted = false) {
 
 // the two words do_assign_wires reads back (the stream must have been synchronized)
 int finish_wires(c2a_ctx* c) {
-    c->rb_nmid = c->hrb[16]; c->rb_err = c->hrb[17];      // (k_post_words of do_assign_wires; the stream has drained since)
+    c->rb_nmid = c->hrb[16] + c->nmid_add; c->rb_err = c->hrb[17];      // (k_post_words of do_assign_wires; the stream has drained since)
+    if (c->positional) c->stats.numbering_events = c->hrb[18];
     if (c->rb_err) { c->stage = ST_SORTED; return fail(c, C2A_ERR_INCONSISTENCY, "Inconsistency: a node is used for both input and output"); }
     c->n_mid = c->rb_nmid;
     c->wire_count = c->n_in + c->rb_nmid + c->n_out;
     return C2A_OK;
-}
-
-// block size of the event table: the smallest power of two that keeps it within kEvBlocks entries
-inline u32 ev_shift(u32 n) {
-    u32 sh = 0;
-    while ((((u64)3 * n) >> sh) + 1 > kEvBlocks) ++sh;
-    return sh;
 }
 
 int do_assign_wires(c2a_ctx* c, bool defer_readback = false) {
@@ -643,27 +632,25 @@ int do_assign_wires(c2a_ctx* c, bool defer_readback = false) {
     const u32 G = grid_for(n, 4096);
     const u32* n_mid_p;
     int r;
+    const u32 PW = (n + 31u) / 32u;                 // 32-position blocks of the event bits
+    const u32* n_events_p = nullptr;
+    c->nmid_add = 0;
     if (c->positional && n) {
-        // POSITIONAL NUMBERING (c2a_kernels.h): positions, the few events that shift the numbering, then wires AND gates by formula
-        const u32 E1 = c->n_ev_io, E2 = c->n_ev_const;     // (k_io_gates / k_deps counted and listed them; do_order read the counts back)
+        // POSITIONAL NUMBERING (c2a_kernels.h): positions, the event bits that shift the numbering, then wires AND gates by formula
         const PosSrc S{n, c->local.as<u64>(), c->rank_suffix, c->pos_r.as<u32>()};
+        HIP_TRY(hipMemsetAsync(c->pblk.p, 0, (size_t)PW * 16, s));
         if (c->sorted_ready) {                          // (the staged calls: positions = the inverse of the order the caller has been given)
             C2A_LAUNCH_NOSYNC(k_eval_inverse, G, kThreads, s, n, c->sorted_r.as<u32>(), c->pos_r.as<u32>());
-            if (E1) C2A_LAUNCH_NOSYNC(k_io_events<true>, grid_for(E1, 64), kThreads, s, S, E1, (const u32*)c->io_rank.as<u32>(), c->ev_items.as<uint2>());
-            if (E2) C2A_LAUNCH_NOSYNC(k_const_first<true>, grid_for(((u64)n + 15) / 16, 4096), kThreads, s, S, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), c->first.as<u32>());
-        } else {
-            if (E1) C2A_LAUNCH_NOSYNC(k_io_events<false>, grid_for(E1, 64), kThreads, s, S, E1, (const u32*)c->io_rank.as<u32>(), c->ev_items.as<uint2>());
-            if (E2) C2A_LAUNCH_NOSYNC(k_const_first<false>, grid_for(((u64)n + 15) / 16, 4096), kThreads, s, S, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), c->first.as<u32>());
-        }
-        if (E2) C2A_LAUNCH_NOSYNC(k_const_events, grid_for(E2, 64), kThreads, s, E1, E2, (const u32*)c->cnode.as<u32>(), (const u32*)c->first.as<u32>(), c->ev_items.as<uint2>());
-        const u32 shift = ev_shift(n), n_blk = (u32)((((u64)3 * n) >> shift) + 1);
-        const u32 E = E1 + E2;
-        if (E) C2A_LAUNCH(k_event_rank, std::min<u32>((E + 3u) / 4u, 2048u), kThreads, s, E, (const uint2*)c->ev_items.as<uint2>(), c->ev_sorted.as<uint2>());
-        C2A_LAUNCH(k_event_finish, 1, kEvThreads, s, E, (const uint2*)c->ev_sorted.as<uint2>(), n, c->n_in, c->ev_key.as<u32>(),
-                   c->ev_cum.as<int>(), c->node_wire1.as<u32>(), c->scalars.as<u32>() + SC_NMID);
-        C2A_LAUNCH_NOSYNC(k_event_table, grid_for(n_blk, 256), kThreads, s, E, n_blk, shift, (const u32*)c->ev_key.as<u32>(), (const int*)c->ev_cum.as<int>(),
-                          c->ev_blk.as<uint2>());
-        n_mid_p = c->scalars.as<u32>() + SC_NMID;
+            C2A_LAUNCH_NOSYNC(k_pos_first<true>, G, kThreads, s, S, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), c->pos_r.as<u32>(), c->first.as<u32>());
+        } else
+            C2A_LAUNCH_NOSYNC(k_pos_first<false>, G, kThreads, s, S, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), c->pos_r.as<u32>(), c->first.as<u32>());
+        C2A_LAUNCH_NOSYNC(k_pos_bits, G, kThreads, s, n, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), (const u32*)c->pos_r.as<u32>(), (const u32*)c->first.as<u32>(),
+                          c->pblk.as<u32>());
+        r = scan_1pass<2>(c, s, c->scan_tmp, PW, ScanPosBits{c->pblk.as<uint4>()}, c->dpre.as<u32>(), c->epre.as<u32>());
+        if (r) return r;
+        n_mid_p = c->dpre.as<u32>() + PW;               // (the net shift of all events: the walk hands out n + that many wires, compiler.rs:440-441)
+        n_events_p = c->epre.as<u32>() + PW;
+        c->nmid_add = n;
     } else {
         if (n) {
             C2A_LAUNCH_NOSYNC(k_first_seen, G, kThreads, s, n, c->sorted_r.as<u32>(), (const uint4*)c->gate4.as<uint4>(),
@@ -682,22 +669,17 @@ int do_assign_wires(c2a_ctx* c, bool defer_readback = false) {
         n_mid_p = c->widx.as<u32>() + m;
     }
     if (c->n_out)
-        C2A_LAUNCH_NOSYNC(k_assign_outputs, grid_for(c->n_out, 1024), kThreads, s, c->n_out, c->out_nodes.as<u32>(), c->n_in,
+        C2A_LAUNCH_NOSYNC(k_assign_outputs, grid_for(c->n_out, 1024), kThreads, s, c->n_out, c->out_nodes.as<u32>(), c->n_in, c->nmid_add,
                           n_mid_p, c->node_wire1.as<u32>());
     rec(c, EV_WIRES1);
-    C2A_LAUNCH_NOSYNC(k_post_words, 1, 64, s, c->hrb_dev + 16, n_mid_p, 1u, (const u32*)(c->scalars.as<u32>() + SC_ERR), 1u, (const u32*)nullptr, 0u);
+    C2A_LAUNCH_NOSYNC(k_post_words, 1, 64, s, c->hrb_dev + 16, n_mid_p, 1u, (const u32*)(c->scalars.as<u32>() + SC_ERR), 1u, n_events_p, n_events_p ? 1u : 0u);
     if (c->positional && n) {
         // the gates' own out wires are part of node -> wire, and the formula that gives them gives in0 / in1 as well: the emission
         // belongs to this stage (do_emit finds it done)
         rec(c, EV_EMIT0);
-        const EvTable T{c->ev_key.as<u32>(), c->ev_cum.as<int>(), c->ev_blk.as<uint2>(), ev_shift(n)};
-        const PosSrc S{n, c->local.as<u64>(), c->rank_suffix, c->pos_r.as<u32>()};
-        if (c->sorted_ready)
-            C2A_LAUNCH_NOSYNC(k_pos_rank<true>, G, kThreads, s, S, c->n_in, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), (const u32*)c->node_wire1.as<u32>(), T,
-                              c->pos_r.as<u32>(), c->wire_r.as<u32>());
-        else
-            C2A_LAUNCH_NOSYNC(k_pos_rank<false>, G, kThreads, s, S, c->n_in, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), (const u32*)c->node_wire1.as<u32>(), T,
-                              c->pos_r.as<u32>(), c->wire_r.as<u32>());
+        const PosBits T{c->pblk.as<uint4>(), c->dpre.as<u32>()};
+        C2A_LAUNCH_NOSYNC(k_pos_rank, G, kThreads, s, n, c->n_in, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), (const u32*)c->pos_r.as<u32>(), T,
+                          c->node_wire1.as<u32>(), c->wire_r.as<u32>());
         C2A_LAUNCH_NOSYNC(k_emit_rank, G, kThreads, s, n, (const uint4*)c->gate4.as<uint4>(), (const u32*)c->dep0.as<u32>(), (const u32*)c->dep1.as<u32>(),
                           (const u32*)c->orig.as<u32>(), (const u32*)c->pos_r.as<u32>(), (const u32*)c->wire_r.as<u32>(), c->node_wire1.as<u32>(), c->erec.as<EmitRec>());
         if (c->sorted_ready)
@@ -896,8 +878,8 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     ENSURE(c->sorted, n4); ENSURE(c->sorted_r, n4);
     ENSURE(c->first, nn4); ENSURE(c->nflag, (size_t)n_nodes + 4); ENSURE(c->wflag, 3 * n4); ENSURE(c->widx, 3 * n4 + 4);
     ENSURE(c->node_wire1, nn4); ENSURE(c->node_wire, nn4);
-    ENSURE(c->pos_r, n4); ENSURE(c->wire_r, n4); ENSURE(c->erec, (size_t)n * sizeof(EmitRec)); ENSURE(c->io_rank, (size_t)kEvCap * 4); ENSURE(c->ev_items, (size_t)kEvCap * 8); ENSURE(c->ev_sorted, (size_t)kEvCap * 8); ENSURE(c->ev_key, (size_t)kEvCap * 4 + 4);
-    ENSURE(c->ev_cum, ((size_t)kEvCap + 1) * 4); ENSURE(c->ev_blk, (size_t)kEvBlocks * 8 + 64); ENSURE(c->cnode, (size_t)kEvCap * 4); ENSURE(c->gflag, (size_t)n + 16);
+    ENSURE(c->pos_r, n4); ENSURE(c->wire_r, n4); ENSURE(c->erec, (size_t)n * sizeof(EmitRec));
+    ENSURE(c->pblk, ((size_t)n / 32 + 2) * 16); ENSURE(c->dpre, ((size_t)n / 32 + 4) * 4); ENSURE(c->epre, ((size_t)n / 32 + 4) * 4); ENSURE(c->gflag, (size_t)n + 16);
     ENSURE(c->e_in0, n4); ENSURE(c->e_in1, n4); ENSURE(c->e_out, n4); ENSURE(c->e_op, n);
     ENSURE(c->scalars, SC_WORDS * 4);
     hipStream_t s = c->stream;

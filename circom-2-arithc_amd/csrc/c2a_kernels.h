@@ -283,54 +283,19 @@ __global__ void __launch_bounds__(kRelThreads) k_relabel(u32 n_nodes, u32 n, u32
     }
 }
 
-// The gates whose out node is an IO node (they hand out no wire: an EVENT of the positional numbering), found from the IO
-// nodes' side — a few thousand nodes instead of a flag per gate: io_rank[0 .. ev[0]) = their ranks.  A node listed twice (an
-// output named twice) counts once: bit 3 of its flag byte.  One atomic per wave on the counter.
-__global__ void __launch_bounds__(kThreads) k_io_gates(u32 n_in, const u32* __restrict__ in_nodes, u32 n_out, const u32* __restrict__ out_nodes,
-                                                       const u32* __restrict__ prod1, u8* nflag, u32* ev, u32* io_rank, u32 io_cap) {
-    const u32 lane = threadIdx.x & 63u, total = n_in + n_out;
-    for (u64 i0 = gtid() - lane; i0 < total; i0 += gstride()) {          // (whole waves: the ballot below wants every lane)
-        const u64 i = i0 + lane;
-        bool mine = false;
-        u32 rank = 0;
-        if (i < total) {
-            const u32 v = i < n_in ? in_nodes[i] : out_nodes[i - n_in], p1 = prod1[v];
-            if (p1) {
-                const u32 bit = 8u << (8u * (v & 3u));
-                mine = !(atomicOr(reinterpret_cast<u32*>(nflag) + (v >> 2), bit) & bit);
-                rank = p1 - 1u;
-            }
-        }
-        const u64 bal = __ballot(mine);
-        if (!bal) continue;
-        u32 base = 0;
-        if (lane == 0) base = atomicAdd(&ev[0], (u32)__popcll(bal));
-        const u32 k = rdlane(base, 0) + (u32)__popcll(bal & ((1ull << lane) - 1ull));
-        if (mine && k < io_cap) io_rank[k] = rank;
-    }
-}
-
 // deps closure (compiler.rs:408-421) + consumer counts, in rank space.  dep1 is dropped when equal to dep0: a second
 // visit of the same gate is a no-op in the DFS (topological_sort.rs:30-32).
 // The payload record gets five flags {lh node un-produced << 8 | rh node un-produced << 9 | out node is an IO node << 10 |
 // lh node is a CONSTANT-like node (un-produced and no IO node: it gets its wire where the walk first sees it) << 11 | rh
-// likewise << 12}: what the numbering kernels want to know about a gate's nodes comes along instead of costing scattered reads.
-// It also counts what bends the wire numbering away from "the gate at sorted position q gets wire n_in + q" (POSITIONAL
-// NUMBERING below): ev[1] = distinct constant-like nodes (bit 2 of the node's flag byte: the first gate to set it lists the
-// node in cnode[]); ev[0] = gates whose out node is an IO node is k_io_gates' (the IO nodes are few: it walks THEM).
+// likewise << 12}: what the numbering kernels want to know about a gate's nodes comes along instead of costing scattered reads
+// (the flags alone once more as a byte per gate: the passes of the POSITIONAL NUMBERING below that only want them).
+// Nothing is counted or listed here: the reference's front-end makes one named constant node per literal and template context
+// (process.rs:558-579), i.e. 5-30 % of a circuit's gates read one — a list appended to through one counter would be a million
+// same-address atomics.
 constexpr u32 kGateLhUnprod = 0x100u, kGateRhUnprod = 0x200u, kGateOutIO = 0x400u, kGateLhConst = 0x800u, kGateRhConst = 0x1000u;
-__device__ __forceinline__ bool note_const_node(u32 v, u8* nflag, u32* ev, u32* cnode, u32 cnode_cap) {
-    if (nflag[v] & 3u) return false;                                              // an input or output node: its wire is fixed
-    if (!(nflag[v] & 4u)) {
-        const u32 bit = 4u << (8u * (v & 3u));
-        const u32 old = atomicOr(reinterpret_cast<u32*>(nflag) + (v >> 2), bit);      // (the flag bytes are padded to whole words)
-        if (!(old & bit)) { const u32 i = atomicAdd(&ev[1], 1u); if (i < cnode_cap) cnode[i] = v; }
-    }
-    return true;
-}
 __global__ void k_deps(u32 n, const u32* __restrict__ lh, const u32* __restrict__ rh, const u32* __restrict__ out, const u8* __restrict__ op,
-                       const u32* __restrict__ dup, const u32* __restrict__ prod1, u8* nflag, u32* orig, uint4* gate4,
-                       u32* dep0, u32* dep1, u32* cons_cnt, u32* eslot, u32* ev, u32* cnode, u32 cnode_cap, u8* gflag) {
+                       const u32* __restrict__ dup, const u32* __restrict__ prod1, const u8* __restrict__ nflag, u32* orig, uint4* gate4,
+                       u32* dep0, u32* dep1, u32* cons_cnt, u32* eslot, u8* gflag) {
     const bool ident = *dup != 0u;
     const XcdSweep R = xcd_sweep(n);
     for (u64 g = R.i; g < R.end; g += R.step) {
@@ -339,10 +304,10 @@ __global__ void k_deps(u32 n, const u32* __restrict__ lh, const u32* __restrict_
         else r = gate4[g];
         const u32 p0 = prod1[r.x], p1 = prod1[r.y];
         u32 w = (r.w & 0xFFu) | (p0 ? 0u : kGateLhUnprod) | (p1 ? 0u : kGateRhUnprod) | ((nflag[r.z] & 3u) ? kGateOutIO : 0u);
-        if (!p0 && note_const_node(r.x, nflag, ev, cnode, cnode_cap)) w |= kGateLhConst;
-        if (!p1 && note_const_node(r.y, nflag, ev, cnode, cnode_cap)) w |= kGateRhConst;
+        if (!p0 && !(nflag[r.x] & 3u)) w |= kGateLhConst;             // (an input or output node: its wire is fixed)
+        if (!p1 && !(nflag[r.y] & 3u)) w |= kGateRhConst;
         gate4[g] = make_uint4(r.x, r.y, r.z, w);
-        gflag[g] = (u8)(w >> 8);                                  // (the flags alone, for the pass that only wants them: k_pos_rank)
+        gflag[g] = (u8)(w >> 8);
         const u32 d0 = p0 ? p0 - 1 : C2A_NONE;
         u32 d1 = p1 ? p1 - 1 : C2A_NONE;
         if (d1 == d0) d1 = C2A_NONE;
@@ -594,8 +559,7 @@ __global__ void k_serial_levels(u32 n, const u32* __restrict__ sorted_r, const u
 
 // ------------------------------------------------------------------------------------------------
 // wire numbering (compiler.rs:388-449) and gate emission (compiler.rs:451-464)
-// node_wire1[node] = wire id + 1 (0 = none); nflag bit0 = input node, bit1 = output node (bit2: listed as a constant-like
-// node by k_deps, bit3: listed as the out node of a gate by k_io_gates — readers of the IO flags mask with 3).
+// node_wire1[node] = wire id + 1 (0 = none); nflag bit0 = input node, bit1 = output node (readers mask with 3).
 // ------------------------------------------------------------------------------------------------
 // The IO flags of the nodes are set up in front of the sort (do_prep: nflag cleared, inputs marked, then outputs): k_deps
 // folds "the out node is an IO node" into the gate's payload record, where the out nodes lie in rank order, and the numbering
@@ -675,9 +639,10 @@ __global__ void k_assign_wires(u32 n, const u32* __restrict__ sorted, const uint
     }
 }
 
-__global__ void k_assign_outputs(u32 n_out, const u32* __restrict__ out_nodes, u32 n_in, const u32* __restrict__ n_mid,
+// (the wires handed out in the walk = add + *n_mid: the walk's own count, or n + the net shift of the positional numbering)
+__global__ void k_assign_outputs(u32 n_out, const u32* __restrict__ out_nodes, u32 n_in, u32 add, const u32* __restrict__ n_mid,
                                  u32* node_wire1) {
-    const u32 base = n_in + *n_mid;
+    const u32 base = n_in + add + *n_mid;
     for (u64 j = gtid(); j < n_out; j += gstride()) atomicMax(&node_wire1[out_nodes[j]], base + (u32)j + 1);   // :446-449
 }
 
@@ -699,30 +664,29 @@ __global__ void k_emit(u32 n, const u32* __restrict__ sorted, const uint4* __res
 // is an IO node (:431-438).  The sorted order is topological, so a PRODUCED node is first seen as its producer's out: the gate
 // at sorted position q gets wire n_in + q — but for two kinds of EVENT that shift everything behind them: a gate whose out
 // node is an IO node hands out nothing (-1 from walk index 3q + 2 on), and a constant-like node (un-produced, no IO node)
-// takes a wire at the walk index it is first seen at (+1 from there on).  Events are few (k_io_gates / k_deps count them; the
-// host takes the general path when they are more than kEvCap), so:
-//     wire of the out node at position q = n_in + q + D(3q + 2),   D(key) = sum of the deltas of the events before walk index key
-// with the events sorted by walk index (one workgroup, in LDS) and looked up through a table of blocks of walk indices.  A
-// gate then needs nothing but its own position and its producers' wires — wire_r[] is indexed by rank, producers sit a bounded
+// takes a wire at the walk index it is first seen at (+1 from there on: 3q if the gate at q reads it as lh, 3q + 1 as rh).
+// A circuit from the reference's unroller has MANY of both — a named constant node per literal and template context
+// (process.rs:558-579: 5-30 % of the gates read one), an output signal per template — so the events are kept as three BITS per
+// sorted position (A: the out node is an IO node, B0 / B1: the lh / rh operand is a constant-like node first seen here), in
+// 16-byte blocks of 32 positions {A, B0, B1, -} (5 MB for 10 M gates: the look-ups below are served by the L2s), with the net
+// shift in front of every block from ONE streaming scan over the blocks' population counts:
+//     D(q) = dpre[q / 32] + popc(B0 | below q) + popc(B1 | below q) - popc(A | below q)      (the events of positions < q)
+//     wire of a constant-like node first seen as lh of the gate at q = n_in + q + D(q), as rh: ... + B0(q)
+//     wire of the out node of the gate at q                           = n_in + q + D(q) + B0(q) + B1(q)
+// A gate then needs nothing but its own position and its producers' wires — wire_r[] is indexed by rank, producers sit a bounded
 // distance before their consumers in rank space, so these gathers stay on chip; the sorted order is only ever written, one
 // scattered 16-byte record per gate {in0, in1, rank, original id; the op in their top bits}, which k_emit_split streams into the arrays of the
 // ABI.  (The walk it replaces: one 16-byte gather + a scatter + two 4-byte gathers by node id per sorted position, in an
-// order that is local in no space — 0.76 ms for 10 M gates; this: 0.45.)
-//   k_io_events     one event per gate whose out node is an IO node (k_io_gates listed them)
-//   k_const_first / k_const_events   first walk index of every constant-like node, one event each
-//   k_event_rank / k_event_finish   sorted events, running deltas, block table, the constant-like nodes' wires
-//   (k_assign_outputs: n_mid = n - IO-out events + constant-like nodes)
-//   k_pos_rank      pos_r[rank] = post-order position, wire_r[rank] = wire of the gate's out node
+// order that is local in no space.)  Round 4 kept the events as a sorted list of at most 4 096 — which only the synthetic
+// headline graph (2 064 events) ever took.
+//   k_pos_first     pos_r[rank] = post-order position; first[node] = min walk index over the uses of a constant-like node
+//   k_pos_bits      the three bits of every position that has an event (atomicOr; gates without a flag touch nothing)
+//   (scan)          dpre[] = net shift in front of every block, epre[] = events in front of it (its total: a statistic)
+//   (k_assign_outputs: n_mid = n + net shift of all events)
+//   k_pos_rank      wire_r[rank] = wire of the gate's out node; the constant-like nodes' wires, by the gate that sees them first
 //   k_emit_rank     in0 / in1 = wire_r[] of the producers (un-produced nodes: by look-up), node -> wire, the 16-byte records
 //   k_emit_split    e_in0 / e_in1 / e_out (by formula from the position) / e_op / sorted_r / sorted
 // ------------------------------------------------------------------------------------------------
-#ifdef C2A_EMULATE
-constexpr u32 kEvCap = 64;            // (small, so that the CPU suite takes the general path too)
-#else
-constexpr u32 kEvCap = 4096;          // events one workgroup sorts in LDS
-#endif
-constexpr u32 kEvBlocks = 4096;      // entries of the block table at most (the host picks the block size: ev_shift) — 32 KB: it has to stay in
-                                     // the L1s (65 536 finer blocks, nearly all of them empty, one load per look-up — but from L2: k_emit_rank 0.54 ms instead of 0.41)
 // where the list ranking (ol / suffix as k_rank_final reads them) puts gate x — or, when the sorted order exists already
 // (c2a_topo_sort handed it to the caller), its inverse (k_eval_inverse into pos_r[]): FROM_SORTED
 struct PosSrc { u32 n; const u64* ol; const uint2* suffix; const u32* pos; };
@@ -732,124 +696,73 @@ __device__ __forceinline__ u32 pos_of(const PosSrc& S, u64 x) {
     const u64 r = S.ol[x];
     return (S.n - S.suffix[(u32)(r >> 32)].y) + (u32)r;
 }
-// the events.  No counters: the IO-out gates were listed by k_io_gates (io_rank[0 .. E1)), the constant-like nodes by k_deps
-// (cnode[0 .. E2)), the host knows both counts — event k of the first kind goes to ev_items[k], of the second to ev_items[E1 + k]
-// (one counter for all of them: 2 000 appends = 30 µs of same-address atomics).
+constexpr u32 kFlagOutIO = kGateOutIO >> 8, kFlagLhConst = kGateLhConst >> 8, kFlagRhConst = kGateRhConst >> 8;      // (bits of gflag[])
+constexpr u32 kFlagEvent = kFlagOutIO | kFlagLhConst | kFlagRhConst;
 template <bool FROM_SORTED>
-__global__ void k_io_events(PosSrc S, u32 E1, const u32* __restrict__ io_rank, uint2* ev_items) {
-    for (u64 k = gtid(); k < E1; k += gstride()) ev_items[k] = make_uint2(((3u * pos_of<FROM_SORTED>(S, io_rank[k]) + 2u) << 1) | 1u, 0u);
-}
-// first[node] = the first walk index a constant-like node is seen at: the few gates whose flags say so (read sixteen at a time)
-constexpr u32 kGateConstBits = (kGateLhConst | kGateRhConst) >> 8;
-template <bool FROM_SORTED>
-__global__ void k_const_first(PosSrc S, const u8* __restrict__ gflag, const uint4* __restrict__ gate4, u32* first) {
-    const u64 n16 = ((u64)S.n + 15) / 16;                         // (the flag array is padded to whole 16-byte words)
-    for (u64 i = gtid(); i < n16; i += gstride()) {
-        const uint4 f = reinterpret_cast<const uint4*>(gflag)[i];
-        if (!((f.x | f.y | f.z | f.w) & (kGateConstBits * 0x01010101u))) continue;
-        const u32 word[4] = {f.x, f.y, f.z, f.w};
-#pragma unroll
-        for (u32 k = 0; k < 16; ++k) {
-            const u32 w = ((word[k >> 2] >> (8u * (k & 3u))) & 0xFFu) << 8;
-            const u64 x = i * 16 + k;
-            if (x >= S.n || !(w & (kGateLhConst | kGateRhConst))) continue;
-            const u32 p = pos_of<FROM_SORTED>(S, x);
-            const uint4 g = gate4[x];
-            if (w & kGateLhConst) atomicMin(&first[g.x], 3u * p);
-            if (w & kGateRhConst) atomicMin(&first[g.y], 3u * p + 1u);
-        }
-    }
-}
-__global__ void k_const_events(u32 E1, u32 E2, const u32* __restrict__ cnode, const u32* __restrict__ first, uint2* ev_items) {
-    for (u64 k = gtid(); k < E2; k += gstride()) {
-        const u32 v = cnode[k];
-        ev_items[E1 + k] = make_uint2(first[v] << 1, v);          // (every listed node is an operand of some gate, and every gate is in the sorted order)
-    }
-}
-
-// The (<= kEvCap) events sorted by walk index.  Walk indices are unique, so an event's place is the number of smaller keys:
-// k_event_rank counts that with a wave per event (64 keys per ballot; a bitonic network in one workgroup took 74 µs for 4 096
-// keys — 78 rounds with a barrier each —, one workgroup counting for all events 134 µs: one CU), k_event_finish — one workgroup —
-// makes the exclusive running sum of the deltas, the table blk[b] = number of events before walk index b << shift, and the
-// wires of the constant-like nodes (their own event's formula).
-__global__ void __launch_bounds__(kThreads) k_event_rank(u32 E, const uint2* __restrict__ ev_items, uint2* ev_sorted) {
-    const u32 lane = threadIdx.x & 63u, wave = (u32)(gtid() >> 6), n_waves = (u32)(gstride() >> 6);
-    for (u32 e = wave; e < E; e += n_waves) {
-        const uint2 me = ev_items[e];
-        u32 place = 0;
-        for (u32 base = 0; base < E; base += 64u) {
-            const u32 j = base + lane;
-            place += (u32)__popcll(__ballot(j < E && ev_items[j].x < me.x));
-        }
-        if (lane == 0) ev_sorted[place] = me;
-    }
-}
-constexpr int kEvThreads = 1024;
-__global__ void __launch_bounds__(kEvThreads) k_event_finish(u32 E, const uint2* __restrict__ ev_sorted, u32 n, u32 n_in,
-                                                             u32* ev_key, int* ev_cum, u32* node_wire1, u32* n_mid) {
-    __shared__ int s_part[kEvThreads];
-    const u32 tid = threadIdx.x;
-    // running deltas: thread t owns the sorted events [t * per, (t + 1) * per)
-    const u32 per = (E + kEvThreads - 1) / kEvThreads;
-    const u32 i_lo = tid * per < E ? tid * per : E, i_hi = (tid + 1) * per < E ? (tid + 1) * per : E;
-    int mine = 0;
-    for (u32 i = i_lo; i < i_hi; ++i) mine += (ev_sorted[i].x & 1u) ? -1 : 1;
-    s_part[tid] = mine;
-    __syncthreads();
-    int before = 0;
-    for (u32 t = 0; t < tid; ++t) before += s_part[t];      // (1 024 partial sums, read by everyone: broadcasts)
-    for (u32 i = i_lo; i < i_hi; ++i) {
-        const uint2 it = ev_sorted[i];
-        const u32 key = it.x >> 1;
-        ev_key[i] = key;
-        ev_cum[i] = before;
-        if (!(it.x & 1u)) node_wire1[it.y] = n_in + key / 3u + (u32)before + 1u;      // a constant-like node: the wire its own event hands out
-        before += (it.x & 1u) ? -1 : 1;
-    }
-    if (tid == kEvThreads - 1) { ev_cum[E] = before; *n_mid = n + (u32)before; }      // (the last thread's running sum is the total: wires handed out in the walk, compiler.rs:440-441)
-}
-// the look-up table: for the block b of walk indices [b << shift, (b + 1) << shift): {index of its first event | number of
-// events in it << 16, running delta at its start}: a look-up in a block without events is ONE 8-byte load.
-__device__ __forceinline__ u32 ev_lower_bound(const u32* __restrict__ key, u32 E, u64 lim) {
-    u32 lo = 0, hi = E;
-    while (lo < hi) { const u32 m = (lo + hi) >> 1; if ((u64)key[m] < lim) lo = m + 1; else hi = m; }
-    return lo;
-}
-__global__ void k_event_table(u32 E, u32 n_blk, u32 shift, const u32* __restrict__ ev_key, const int* __restrict__ ev_cum, uint2* tbl) {
-    for (u64 b = gtid(); b < n_blk; b += gstride()) {
-        const u32 lo = ev_lower_bound(ev_key, E, b << shift), hi = ev_lower_bound(ev_key, E, (b + 1) << shift);
-        tbl[b] = make_uint2(lo | (hi - lo) << 16, (u32)ev_cum[lo]);
-    }
-}
-
-struct EvTable { const u32* key; const int* cum; const uint2* tbl; u32 shift; };
-// D(key): sum of the deltas of the events before walk index `key`
-__device__ __forceinline__ int ev_delta(const EvTable& T, u32 key) {
-#ifdef C2A_EXP_NOLOOKUP
-    return 0;
-#endif
-    const uint2 e = T.tbl[key >> T.shift];
-    if (e.x < 0x10000u) return (int)e.y;                         // no event in this block: the delta at its start
-    u32 lo = e.x & 0xFFFFu, hi = lo + (e.x >> 16);
-    while (lo < hi) { const u32 m = (lo + hi) >> 1; if (T.key[m] < key) lo = m + 1; else hi = m; }
-    return T.cum[lo];
-}
-// every gate's position and the wire of its out node (the formula; an IO node's wire is the node's), in rank order
-template <bool FROM_SORTED>
-__global__ void k_pos_rank(PosSrc S, u32 n_in, const u8* __restrict__ gflag, const uint4* __restrict__ gate4, const u32* __restrict__ node_wire1, EvTable T,
-                           u32* pos_r, u32* wire_r) {
+__global__ void k_pos_first(PosSrc S, const u8* __restrict__ gflag, const uint4* __restrict__ gate4, u32* pos_r, u32* first) {
     for (u64 x = gtid(); x < S.n; x += gstride()) {
         const u32 p = pos_of<FROM_SORTED>(S, x);
         if (!FROM_SORTED) pos_r[x] = p;
-        wire_r[x] = (gflag[x] & (u8)(kGateOutIO >> 8)) ? node_wire1[gate4[x].z] - 1u : n_in + p + (u32)ev_delta(T, 3u * p + 2u);
+        const u32 f = gflag[x];
+        if (!(f & (kFlagLhConst | kFlagRhConst))) continue;
+        const uint4 g = gate4[x];
+        if (f & kFlagLhConst) atomicMin(&first[g.x], 3u * p);
+        if (f & kFlagRhConst) atomicMin(&first[g.y], 3u * p + 1u);
+    }
+}
+__global__ void k_pos_bits(u32 n, const u8* __restrict__ gflag, const uint4* __restrict__ gate4, const u32* __restrict__ pos_r,
+                           const u32* __restrict__ first, u32* blk) {
+    for (u64 x = gtid(); x < n; x += gstride()) {
+        const u32 f = gflag[x];
+        if (!(f & kFlagEvent)) continue;
+        const u32 p = pos_r[x], bit = 1u << (p & 31u);
+        u32* w = blk + 4 * (u64)(p >> 5);
+        if (f & kFlagOutIO) atomicOr(w, bit);
+        if (!(f & (kFlagLhConst | kFlagRhConst))) continue;
+        const uint4 g = gate4[x];
+        if ((f & kFlagLhConst) && first[g.x] == 3u * p) atomicOr(w + 1, bit);
+        if ((f & kFlagRhConst) && first[g.y] == 3u * p + 1u) atomicOr(w + 2, bit);      // (lh == rh == the same constant: seen as lh)
+    }
+}
+// per block: {net shift, events} (the net shift may be negative: two's complement in 32 bits — the scan's sums are exact mod 2^32)
+struct ScanPosBits {
+    const uint4* blk;
+    __device__ __forceinline__ void operator()(u64 i, u32* x) const {
+        const uint4 w = blk[i];
+        const u32 a = (u32)__popc(w.x), b = (u32)__popc(w.y) + (u32)__popc(w.z);
+        x[0] = b - a; x[1] = a + b;
+    }
+};
+struct PosBits { const uint4* blk; const u32* dpre; };
+// n_in-less wire of what position p hands out first: p + D(p); b0 / b1 = the position's own B bits
+__device__ __forceinline__ u32 pos_base(const PosBits& T, u32 p, u32* b0, u32* b1) {
+    const uint4 w = T.blk[p >> 5];
+    const u32 bit = 1u << (p & 31u), lt = bit - 1u;
+    *b0 = (w.y & bit) ? 1u : 0u;
+    *b1 = (w.z & bit) ? 1u : 0u;
+    return p + T.dpre[p >> 5] + (u32)__popc(w.y & lt) + (u32)__popc(w.z & lt) - (u32)__popc(w.x & lt);
+}
+// the wire of every gate's out node (the formula; an IO node's wire is the node's), in rank order — and the wires of the
+// constant-like nodes, written by the gate that sees them first
+__global__ void k_pos_rank(u32 n, u32 n_in, const u8* __restrict__ gflag, const uint4* __restrict__ gate4, const u32* __restrict__ pos_r, PosBits T,
+                           u32* node_wire1, u32* wire_r) {
+    for (u64 x = gtid(); x < n; x += gstride()) {
+        const u32 f = gflag[x];
+        u32 b0, b1;
+        const u32 base = n_in + pos_base(T, pos_r[x], &b0, &b1);
+        if (b0 | b1) {
+            const uint4 g = gate4[x];
+            if (b0) node_wire1[g.x] = base + 1u;
+            if (b1) node_wire1[g.y] = base + b0 + 1u;
+        }
+        wire_r[x] = (f & kFlagOutIO) ? node_wire1[gate4[x].z] - 1u : base + b0 + b1;
     }
 }
 // The record a gate leaves at its sorted position: {in0, in1, rank, original id} — 16 bytes, ONE scattered store per gate
 // (a 32-byte record is two store instructions, i.e. twice the scattered transactions).
 // Gate ids are below 2^29 (include/c2a.h), so the op code (5 bits) rides in the top bits of the two ids and bit 31 of the
 // second says "the out node is an IO node"; every other gate's out wire follows from its position (k_emit_split).
-// No table look-ups here (with three per gate this kernel took 0.41 ms, without 0.34): a gate's operands are its producers'
-// out wires, wire_r[] of a rank a bounded distance back.
+// No look-ups of the event bits here: a gate's operands are its producers' out wires, wire_r[] of a rank a bounded distance back.
 typedef uint4 EmitRec;
 __global__ void k_emit_rank(u32 n, const uint4* __restrict__ gate4, const u32* __restrict__ dep0, const u32* __restrict__ dep1,
                             const u32* __restrict__ orig, const u32* __restrict__ pos_r, const u32* __restrict__ wire_r, u32* node_wire1, EmitRec* erec) {
@@ -857,7 +770,7 @@ __global__ void k_emit_rank(u32 n, const uint4* __restrict__ gate4, const u32* _
     for (u64 x = R.i; x < R.end; x += R.step) {
         const uint4 g = gate4[x];
         const u32 d0 = dep0[x], d1 = dep1[x];                                       // (dep1 is dropped when it equals dep0: k_deps)
-        // an un-produced node: an input, a constant-like node (k_event_finish), an output nobody produces
+        // an un-produced node: an input, a constant-like node (k_pos_rank), an output nobody produces
         const u32 in0 = (g.w & kGateLhUnprod) ? node_wire1[g.x] - 1u : wire_r[d0];
         const u32 in1 = (g.w & kGateRhUnprod) ? node_wire1[g.y] - 1u : wire_r[d1 != C2A_NONE ? d1 : d0];
         const bool io = (g.w & kGateOutIO) != 0u;
@@ -867,7 +780,7 @@ __global__ void k_emit_rank(u32 n, const uint4* __restrict__ gate4, const u32* _
     }
 }
 template <bool WITH_SORTED>
-__global__ void k_emit_split(u32 n, u32 n_in, const EmitRec* __restrict__ erec, const uint4* __restrict__ gate4, const u32* __restrict__ node_wire1, EvTable T,
+__global__ void k_emit_split(u32 n, u32 n_in, const EmitRec* __restrict__ erec, const uint4* __restrict__ gate4, const u32* __restrict__ node_wire1, PosBits T,
                              u32* e_in0, u32* e_in1, u32* e_out, u8* e_op, u32* sorted_r, u32* sorted) {
     // (one position per lane: with four per lane — 16-byte stores into every stream — the record loads are 64 bytes apart
     // between neighbouring lanes: 89 instead of 67 µs)
@@ -875,7 +788,9 @@ __global__ void k_emit_split(u32 n, u32 n_in, const EmitRec* __restrict__ erec, 
         const EmitRec e = erec[i];
         const u32 rank = e.z & 0x1FFFFFFFu;
         e_in0[i] = e.x; e_in1[i] = e.y;
-        e_out[i] = (e.w & 0x80000000u) ? node_wire1[gate4[rank].z] - 1u : n_in + (u32)i + (u32)ev_delta(T, 3u * (u32)i + 2u);
+        u32 b0, b1;
+        const u32 base = n_in + pos_base(T, (u32)i, &b0, &b1);
+        e_out[i] = (e.w & 0x80000000u) ? node_wire1[gate4[rank].z] - 1u : base + b0 + b1;
         e_op[i] = (u8)((e.z >> 29) | ((e.w >> 29) & 3u) << 3);
         if (WITH_SORTED) { sorted_r[i] = rank; sorted[i] = e.w & 0x1FFFFFFFu; }
     }

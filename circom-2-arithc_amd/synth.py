@@ -64,10 +64,17 @@ class FlatGates:
 
 def layered_dag(layers: int, layer_width: int, n_in: int = 4096, n_const: int = 64, window: int = 64,
                 mix: Sequence[Tuple[str, int]] = MIX_BITWISE, seed: int = SEED, permute: bool = True,
-                sparse_ids: bool = True) -> FlatGates:
+                sparse_ids: bool = True, const_frac: float = 0.0, out_frac: float = 0.0) -> FlatGates:
     """n = layers*layer_width gates; gate (k, j): lh uniform over layer k-1's outputs (layer 0: the
     primary inputs) => depth == layers; rh uniform over inputs, constants and the outputs of the previous
-    `window` layers; one distinct out node per gate; last layer's out nodes are the circuit outputs."""
+    `window` layers; one distinct out node per gate; last layer's out nodes are the circuit outputs.
+
+    REFERENCE-SHAPED extras (both 0 in the headline config, whose graph they leave bit-identical): the reference's
+    unroller makes one named constant node per literal and template context (src/process.rs:558-579, keys at
+    src/compiler.rs:354-359) — in the committed fixtures 5-30 % of the gates read an un-produced non-input node — and
+    names an output signal per template.  `const_frac` of the gates read a FRESH constant node as rh, created right
+    before their own out node (node ids follow the creation order, src/compiler.rs:497-500); `out_frac` of the gates
+    (besides the last layer) write a circuit output node."""
     L, Wd = int(layers), int(layer_width)
     n = L * Wd
     k = np.repeat(np.arange(L, dtype=np.int64), Wd)              # layer of each gate (generation order)
@@ -77,7 +84,13 @@ def layered_dag(layers: int, layer_width: int, n_in: int = 4096, n_const: int = 
 
     in_base, const_base, gate_base = 0, n_in, n_in + n_const     # logical node numbering
     # lh
-    lh_prev = gate_base + (k - 1) * Wd + (r_lh % np.uint64(Wd)).astype(np.int64)
+    # logical node order: inputs, shared constants, then per gate (generation order) [its fresh constant,] its out node
+    fresh = np.zeros(n, dtype=bool)
+    if const_frac > 0:
+        fresh = (splitmix64(seed, 6, n) % np.uint64(1 << 20)).astype(np.int64) < int(const_frac * (1 << 20))
+    n_fresh = int(fresh.sum())
+    out_of = gate_base + np.arange(n, dtype=np.int64) + np.cumsum(fresh)      # logical id of gate i's out node
+    lh_prev = out_of[np.maximum((k - 1) * Wd + (r_lh % np.uint64(Wd)).astype(np.int64), 0)]
     lh_in = in_base + (r_lh % np.uint64(n_in)).astype(np.int64)
     lh_log = np.where(k == 0, lh_in, lh_prev)
     # rh: pool = inputs + constants + outputs of layers [max(0,k-window), k)
@@ -86,9 +99,10 @@ def layered_dag(layers: int, layer_width: int, n_in: int = 4096, n_const: int = 
     idx = (r_rh % pool.astype(np.uint64)).astype(np.int64)
     rel = idx - (n_in + n_const)                                 # >=0 -> a gate output in the window
     lay = k - 1 - rel // Wd
-    rh_gate = gate_base + lay * Wd + rel % Wd
+    rh_gate = out_of[np.clip(lay * Wd + rel % Wd, 0, n - 1)]
     rh_log = np.where(idx < n_in + n_const, idx, rh_gate)
-    out_log = gate_base + np.arange(n, dtype=np.int64)
+    rh_log = np.where(fresh, out_of - 1, rh_log)
+    out_log = out_of
     # ops
     names = [m[0] for m in mix]
     wts = np.array([m[1] for m in mix], dtype=np.int64)
@@ -96,7 +110,7 @@ def layered_dag(layers: int, layer_width: int, n_in: int = 4096, n_const: int = 
     pick = np.searchsorted(cum, (r_op % np.uint64(cum[-1])).astype(np.int64), side="right")
     op = np.array([OP[nm] for nm in names], dtype=np.uint8)[pick]
 
-    n_log = n_in + n_const + n
+    n_log = n_in + n_const + n + n_fresh
     if sparse_ids:
         gaps = (splitmix64(seed, 4, n_log) & np.uint64(1)).astype(np.int64)
         node_id = 1 + np.arange(n_log, dtype=np.int64) + np.cumsum(gaps)
@@ -108,13 +122,17 @@ def layered_dag(layers: int, layer_width: int, n_in: int = 4096, n_const: int = 
     lh_id = node_id[lh_log].astype(np.uint32)
     rh_id = node_id[rh_log].astype(np.uint32)
     out_id = node_id[out_log].astype(np.uint32)
+    is_out = k == L - 1
+    if out_frac > 0:
+        is_out = is_out | ((splitmix64(seed, 7, n) % np.uint64(1 << 20)).astype(np.int64) < int(out_frac * (1 << 20)))
+    output_nodes = node_id[out_log[is_out]].astype(np.uint32)
+    const_nodes = np.concatenate([node_id[const_base:const_base + n_const], node_id[out_log[fresh] - 1]]).astype(np.uint32)
     if permute:
         perm = np.argsort(splitmix64(seed, 5, n), kind="stable")  # new gate id g <- generation index perm[g]
         lh_id, rh_id, out_id, op = lh_id[perm], rh_id[perm], out_id[perm], op[perm]
     return FlatGates(lh=lh_id, rh=rh_id, out=out_id, op=np.ascontiguousarray(op), n_nodes=n_nodes,
                      input_nodes=node_id[in_base:in_base + n_in].astype(np.uint32),
-                     output_nodes=node_id[gate_base + (L - 1) * Wd: gate_base + L * Wd].astype(np.uint32),
-                     const_nodes=node_id[const_base:const_base + n_const].astype(np.uint32),
+                     output_nodes=output_nodes, const_nodes=const_nodes,
                      layers=L, layer_width=Wd)
 
 
@@ -125,6 +143,10 @@ CONFIGS: Dict[str, dict] = {
     "sha256_standin": dict(layers=300, layer_width=100, n_in=512, n_const=64, window=16, mix=MIX_SHA),
     "keccak_standin": dict(layers=600, layer_width=250, n_in=1088, n_const=64, window=8, mix=MIX_SHA),
     "synthetic_10m": dict(layers=5000, layer_width=2000, n_in=4096, n_const=64, window=64, mix=MIX_BITWISE),
+    # the same graph shape with what a circuit from the reference's own unroller carries: a fresh constant node at a tenth of the
+    # gates, an output node at a twentieth (the headline graph has 64 constants and 2 000 outputs in 10 M gates)
+    "reference_shaped_10m": dict(layers=5000, layer_width=2000, n_in=4096, n_const=64, window=64, mix=MIX_BITWISE,
+                                 const_frac=0.10, out_frac=0.05),
 }
 
 

@@ -499,14 +499,13 @@ def test_numbering_paths(variant, request, orc, c2a):
     """The positional numbering (wires and gates by formula from the sorted positions + the few events that shift them:
     IO-node outputs, constant-like nodes — src/compiler.rs:423-464) and the walk in sorted order give what the reference's walk
     gives: random graphs with constants read at both operands, inputs and outputs produced by gates, un-produced output nodes
-    as operands; few events (the formula) and many (more than one workgroup sorts: the walk)."""
+    as operands; few events and many (constants at a tenth of the gates)."""
     import importlib
     from conftest import _Env
     bm = importlib.import_module("circom-2-arithc_amd.backend")
     kind, walk = variant
     with _Env(C2A_NUMBERING_WALK=walk):
         be = c2a.Backend(0, lib_path=request.getfixturevalue("emul_lib")) if kind == "emul" else c2a.Backend(0)
-    cap = 64 if kind == "emul" else 4096                 # (kEvCap of the build)
     rng = np.random.default_rng(77)
     seen = {0: 0, 1: 0}
     try:
@@ -518,7 +517,7 @@ def test_numbering_paths(variant, request, orc, c2a):
             except (orc.CyclicDependency, orc.Inconsistency):
                 continue
             st = _check_fused(be, orc, bm, p)
-            assert st["numbering_path"] == (0 if walk or st["numbering_events"] > cap else 1), st
+            assert st["numbering_path"] == (0 if walk else 1), st
             seen[st["numbering_path"]] += 1
             _compare(be, orc, p, check_serial=False)         # (the staged calls: positions from the sorted order that exists already)
         # layered graphs: 64 constants + `width` outputs = the events
@@ -526,9 +525,18 @@ def test_numbering_paths(variant, request, orc, c2a):
             fg = c2a.synth.layered_dag(layers, width, n_in=32, n_const=n_const, window=4, seed=5)
             p = dict(lh=fg.lh, rh=fg.rh, out=fg.out, op=fg.op, n_nodes=fg.n_nodes, input_nodes=fg.input_nodes, output_nodes=fg.output_nodes)
             st = _check_fused(be, orc, bm, p)
-            assert st["numbering_path"] == (0 if walk or st["numbering_events"] > cap else 1), st
+            assert st["numbering_path"] == (0 if walk else 1), st
             seen[st["numbering_path"]] += 1
-        assert seen[0] > 0 and (walk or seen[1] > 0), seen
+        # reference-shaped graphs (src/process.rs:558-579: a named constant node per literal and context; an output signal per
+        # template): a fresh constant at 10-30 % of the gates, an output node at 5-20 % — thousands of events
+        for layers, width, cf, of in ((40, 20, 0.3, 0.2), (30, 100, 0.1, 0.05), (10, 3000, 0.1, 0.05), (200, 9, 0.25, 0.1)):
+            fg = c2a.synth.layered_dag(layers, width, n_in=32, n_const=4, window=4, seed=9, const_frac=cf, out_frac=of)
+            p = dict(lh=fg.lh, rh=fg.rh, out=fg.out, op=fg.op, n_nodes=fg.n_nodes, input_nodes=fg.input_nodes, output_nodes=fg.output_nodes)
+            st = _check_fused(be, orc, bm, p)
+            assert st["numbering_path"] == (0 if walk else 1), st
+            assert walk or st["numbering_events"] >= int(0.8 * (cf + of) * fg.n), st
+            _compare(be, orc, p, check_serial=False)
+        assert seen[1 - walk] > 0 and seen[walk] == 0, seen
         # what the generators above do not make: a gate whose out node is an INPUT node, a constant read at both operands and
         # first seen as rh, an output node nobody produces read as an operand, an output named twice, an operand produced by a
         # gate that hands out no wire
@@ -538,7 +546,8 @@ def test_numbering_paths(variant, request, orc, c2a):
         for perm in (np.arange(7), np.array([6, 2, 4, 0, 5, 3, 1])):
             q = dict(p, lh=p["lh"][perm], rh=p["rh"][perm], out=p["out"][perm], op=p["op"][perm])
             st = _check_fused(be, orc, bm, q)
-            assert st["numbering_events"] == 2 + 2 and st["numbering_path"] == (0 if walk else 1), st      # gates 2, 4 + constants 3, 4
+            assert st["numbering_path"] == (0 if walk else 1), st
+            assert walk or st["numbering_events"] == 2 + 2, st      # gates 2, 4 + constants 3, 4 (counted by the positional numbering only)
             _compare(be, orc, q, check_serial=False)
     finally:
         be.close()
