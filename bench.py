@@ -175,9 +175,9 @@ def main():
     ap.add_argument("--width", type=int, default=32, help="--boolify-width")
     ap.add_argument("--layers", type=int, default=5000)
     ap.add_argument("--layer-width", type=int, default=2000)
-    ap.add_argument("--cpu-sample-layers", type=int, default=1,
-                    help="0 = skip the CPU baseline (name kept from the rounds when the faithful variant ran on a sample of the layers)")
-    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline (same as --cpu-sample-layers 0)")
+    ap.add_argument("--no-cpu-baseline", action="store_true",
+                    help="skip the CPU baseline (the oracle on the whole input, 1 host core: ~5 s structure-faithful build_circuit + ~4 s "
+                         "bit-blast of all gates at the default size) and, unless --check, the oracle check")
     ap.add_argument("--cpu-bool-chunk", type=int, default=1_000_000, help="sorted gates per chunk of the CPU bit-blast (all gates are timed)")
     ap.add_argument("--no-width64", action="store_true", help="skip the extra --boolify-width 64 step")
     ap.add_argument("--no-artefacts", action="store_true", help="skip the circuit.txt formatting measurement")
@@ -189,8 +189,6 @@ def main():
                     help="N>1: 'shard' (default) = ONE graph, sort replicated on every rank, boolify sharded by sorted-position "
                          "range (strong scaling, BASELINE's metric); 'replicas' = N independent graphs, one per GPU (throughput, weak)")
     args = ap.parse_args()
-    if args.no_cpu_baseline:
-        args.cpu_sample_layers = 0
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -277,7 +275,7 @@ def main():
     stages = {k: v / steps for k, v in stage_acc.items()}
     # ---- check (every rank: its own results against the oracle) — BASELINE.md §2: "outputs compared bit-for-bit"
     backend_mod = importlib.import_module("circom-2-arithc_amd.backend")
-    want_oracle = args.check or args.cpu_sample_layers > 0
+    want_oracle = args.check or not args.no_cpu_baseline
     circ = handle = None
     t_oracle_build = 0.0
     checked = None
@@ -350,7 +348,7 @@ def main():
         total_traffic = sum(k["hbm_bytes_per_launch"] * k.get("launches_per_step", 1) for k in pmc.values())
 
     cpu = None
-    if args.cpu_sample_layers > 0 and not replicas:
+    if not args.no_cpu_baseline and not replicas:
         cpu = cpu_baseline(fg, args.width, args.cpu_bool_chunk, circ, handle, t_oracle_build)
     if handle is not None:
         from oracle import oracle as orc

@@ -281,6 +281,7 @@ u32 peel_grid(c2a_ctx* c, bool stats, u32* n_primary) {
 int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
     const u32 n = c->n;
     hipStream_t s = c->stream;
+    c->peel_gave_up = false;                         // (only a watchdog abort observed in THIS launch may trigger the retry / the serial fall-back)
     const bool want_stats = std::getenv("C2A_PEEL_STATS") != nullptr;
     PeelArgs A;
     A.n = n; A.gstat = c->gstat.as<uint4>(); A.clist = c->clist.as<u32>();

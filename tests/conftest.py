@@ -121,7 +121,8 @@ def backend_wave(request, c2a):
 
 
 # (the dataflow launch under emulation: every wave is alive at once and C2A_EMUL_SEED shuffles the schedule per pass)
-PEEL_BACKENDS = [_variant("emul", "s1"), _variant("emul", "s2"), _variant("emul", "s3"), _variant("emul", "s4"), _variant("emul", "s5")]
+PEEL_BACKENDS = [_variant("emul", "s1"), _variant("emul", "s2"), _variant("emul", "s3"), _variant("emul", "s4"), _variant("emul", "s5"),
+                 _variant("hip", "s0")]       # (hip: the protocol on the hardware — memory ordering and visibility are not the emulator's)
 
 
 @pytest.fixture(params=PEEL_BACKENDS)

@@ -101,7 +101,7 @@ def test_bench_main_runs_its_two_rank_flow_on_cpus(emul_lib, tmp_path):
     port = 29700 + (os.getpid() % 1500)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                          "--layers", "14", "--layer-width", "24", "--cpu-sample-layers", "4", "--cpu-bool-chunk", "60", "--width", "8"],
+                          "--layers", "14", "--layer-width", "24", "--cpu-bool-chunk", "60", "--width", "8"],
                          env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.split("\n") if ln.startswith("{")]

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; tag=${1:-tl}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/tl_$tag
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$tag -- python $R/bench.py --steps 3 --warmup 1 --cpu-sample-layers 0 --no-width64 --no-artefacts --no-prune --no-cold --no-cpu-baseline > /tmp/tl_$tag.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$tag -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-width64 --no-artefacts --no-prune --no-cold  > /tmp/tl_$tag.log 2>&1
 f=$(find /tmp/tl_$tag -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
