@@ -70,7 +70,7 @@ struct c2a_ctx {
                                    // 2 000 gates per level 14.0 -> 14.5 ms, 4 000: 12.0 -> 9.3, 8 000: 12.8 -> 7.8, 50 000: 10.9 -> 7.3
     u32 build_no = 0;              // number of the last producer map on this context (tag of its node-table records: k_producer)
     u32 peel_run = 0;              // number of the last dataflow run on this context (tag of its hand-off entries)
-    u32 peel_epoch = 0;            // tag of the node words written by the last run (alternates; restarts after a clear)
+    u32 peel_epoch = 0;            // tag of the node words written by the last run (1 / 2 take turns; 0 after a clear)
     bool io_clash = false;         // a node is both an input and an output (compiler.rs:363-383), found at load time
     bool peel_meta_valid = false;  // meta[] / stats.levels describe the circuit now loaded (c2a_verify_boolify schedules by them)
     bool node_clear = true;        // node records must be zeroed before the next run (new graph, or a run that failed)
@@ -287,13 +287,15 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
     A.n = n; A.gstat = c->gstat.as<uint4>(); A.clist = c->clist.as<u32>();
     A.node = c->node.as<u64>(); A.fill = c->fill.as<u32>(); A.meta = c->meta.as<uint4>(); A.child = c->child.as<u32>();
     PeelCold cold;
-    // node words carry the tag of the run that wrote them: zeroed memory first sees tag 1, then the tag alternates (a word
+    // node words carry the tag of the run that wrote them: zeroed memory first sees tag 1, then 2 and 1 take turns (a word
     // left over from two runs ago holds the same value: the peel of one loaded graph is deterministic)
     if (c->node_clear) {
         HIP_TRY(hipMemsetAsync(c->node.p, 0, (size_t)n * kNodeWords * 8, s));
         c->peel_epoch = 0;
     }
-    c->peel_epoch ^= 1u;
+    // (1 and 2 take turns; in the first run after a clear every lane of a record must carry the run's tag — c2a_peel.h NODE RECORDS)
+    A.pad_thr = c->peel_epoch == 0 ? kThrExact : kThrPad;
+    c->peel_epoch = c->peel_epoch == 1u ? 2u : 1u;
     c->node_clear = true;                            // until this run has finished cleanly
     A.epoch = c->peel_epoch;
     u32 n_primary = 0;

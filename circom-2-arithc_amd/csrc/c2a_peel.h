@@ -11,14 +11,20 @@
 // except where the DFS roots are compared: word 2 of a gate's first static record is its ORIGINAL id, the "root" fields of
 // records and tree entries hold original ids, and a gate is its own root when no consumer's root has a smaller original id.
 //
-// NODE RECORDS.  Every gate owns one 512-byte record of 64 self-validating 8-byte words: bit 63 of a word is the tag of
-// the run that wrote it (a word is written by ONE agent-scope store, so it is never torn; a reader that sees the wrong
-// tag simply reads again — no flag, no fence, no acknowledgement wait anywhere on the path):
+// NODE RECORDS.  Every gate owns one 512-byte record of 64 self-validating 8-byte words: the top two bits of a word are the
+// tag of the run that wrote it (a word is written by ONE agent-scope store, so it is never torn; a reader that sees a stale
+// tag simply reads again — no flag, no fence, no acknowledgement wait anywhere on the path).  THREE states: 1 and 2 take
+// turns from run to run (a word of the run before is STALE), 0 is a word that no run has ever written — the buffer is
+// zeroed once per loaded graph —, i.e. the zero padding behind a SHORT record (a sink writes three header words, a gate of
+// the whole-level passes sixteen words): valid in every run but the first after the clear, where "not written yet" and
+// "never written" cannot be told apart and every lane must carry this run's tag (the reader's out-of-line path then
+// decides by the record's depth which lanes count).  Round 4 had ONE tag bit: the padding of short records looked valid in
+// every second run only — k_peel alternated between 6.95 and 7.20 ms with the run tag.
 //   word 0      root gate id << 32 | depth in the DFS tree
 //   word 1      reverse Kahn level << 32 | cprev (ancestor at the start of the node's current chunk; deep trees only)
 //   word 2      where a child's edge label goes in the string: word index << 8 | bit (no division on the hot path)
-//   words 3..63 the node's path string, ZERO-PADDED: 63 payload bits per word, bit j = label of the edge entering depth j+1
-// A string is held in chunks of kChunkBits = 61 x 63 = 3843 bits; a node keeps its CURRENT chunk only.  Comparing two
+//   words 3..63 the node's path string, ZERO-PADDED: 62 payload bits per word, bit j = label of the edge entering depth j+1
+// A string is held in chunks of kChunkBits = 61 x 62 = 3782 bits; a node keeps its CURRENT chunk only.  Comparing two
 // candidates P(a).la and P(b).lb that are shallower than a chunk (the 10 M-gate headline graph: depth 3 471): append
 // each label to its string, XOR, ballot, count trailing zeros — neither path can be a prefix of the other (that would be
 // a cycle), so the first differing bit decides and the zero padding needs no length masks.  A new node's string is its
@@ -74,10 +80,20 @@ constexpr u32 kIdMask = 0x7FFFFFFFu;
 constexpr u32 kNodeWords = 64;
 constexpr u32 kHdrWords = 3;
 constexpr u32 kStrWords = kNodeWords - kHdrWords;                     // 61
-constexpr u32 kWordBits = 63;
-constexpr u32 kChunkBits = kStrWords * kWordBits;                     // 3843
-constexpr u64 kTagBit = 1ull << 63;
-constexpr u64 kPayload = kTagBit - 1ull;
+constexpr u32 kWordBits = 62;
+constexpr u32 kChunkBits = kStrWords * kWordBits;                     // 3782
+constexpr u32 kTagShift = 62;
+constexpr u64 kPayload = (1ull << kTagShift) - 1ull;
+constexpr u32 kHdrMask = 0x3FFFFFFFu;                                 // the high half of a header word below the tag (gate ids are below 2^29)
+// A word is BAD (stale, or not there yet) by ONE compare of its high half: hi ^ (stale tag << 30) puts the stale tag at 0, a
+// never-written word between (1 or 2) and this run's tag at 3 — bad below 3 << 30 where this run's tag is required (the
+// header lanes always, every lane in the first run after the clear), bad below 1 << 30 where never-written counts as
+// zero padding.
+constexpr u32 kThrExact = 0xC0000000u, kThrPad = 0x40000000u;
+struct TagCheck { u32 flip; u32 thr; };                               // per lane: thr = lane < kHdrWords ? kThrExact : pad threshold of the run
+__device__ __forceinline__ TagCheck tag_check(u32 epoch, u32 pad_thr, u32 lane) { return TagCheck{(3u - epoch) << 30, lane < kHdrWords ? kThrExact : pad_thr}; }
+__device__ __forceinline__ bool tag_bad(const TagCheck& T, u64 w) { return ((u32)(w >> 32) ^ T.flip) < T.thr; }
+__device__ __forceinline__ bool tag_stale_or_never(u32 epoch, u64 w) { return (u32)(w >> kTagShift) != epoch; }      // (cold paths: this run's tag exactly)
 
 #ifdef C2A_EMULATE
 constexpr u32 kPollLimit = 1u << 16;        // (the emulation runs every wave of the launch side by side and switches at the back-offs: a poll is one turn of all the others)
@@ -113,7 +129,8 @@ struct PeelCold {
 };
 
 struct PeelArgs {
-    u32 epoch;                 // tag (0/1) of this run's node words
+    u32 epoch;                 // tag (1 / 2, taking turns) of this run's node words
+    u32 pad_thr;               // kThrExact in the first run after the node records were cleared, else kThrPad (NODE RECORDS above)
     u32 n;
     const uint4* gstat;        // [2n] {dep0, dep1, original gate id, cons_cnt} {cons_off[dep0], cons_cnt[dep0], cons_off[dep1], cons_cnt[dep1]}
     const u32* clist;          // [edges + 64] consumer | edge label << 31, grouped by producer
@@ -145,16 +162,16 @@ __device__ __forceinline__ u32 ld_a32(const u32* p) { return __hip_atomic_load(p
 __device__ __forceinline__ void st_a32(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __device__ __forceinline__ ull ld_word_time(const ull* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ u64 hdr0_word(u32 root, u32 depth) { return ((u64)(root & kIdMask) << 32) | depth; }
-__device__ __forceinline__ u64 hdr1_word(u32 level, u32 cprev) { return ((u64)(level & kIdMask) << 32) | cprev; }
-__device__ __forceinline__ u32 hdr_hi(u64 w) { return (u32)(w >> 32) & kIdMask; }
+__device__ __forceinline__ u64 hdr0_word(u32 root, u32 depth) { return ((u64)(root & kHdrMask) << 32) | depth; }
+__device__ __forceinline__ u64 hdr1_word(u32 level, u32 cprev) { return ((u64)(level & kHdrMask) << 32) | cprev; }
+__device__ __forceinline__ u32 hdr_hi(u64 w) { return (u32)(w >> 32) & kHdrMask; }
 
 // ---- out-of-line pieces of the deep-tree comparison (cold; plain by-value arguments so that the kernel's argument
 // block is never dragged into memory) ----
 __device__ __forceinline__ u64 ld_word_wait(const u64* p, u32 epoch, u32* ctl) {
     u64 v = ld_nw(p);
     u32 spins = 0;
-    while ((u32)(v >> 63) != epoch) {
+    while (tag_stale_or_never(epoch, v)) {
         if (++spins > (1u << 22)) { atomicAdd(&ctl[CTL_ABORT], 1u); break; }
         peel_sleep(4);
         v = ld_nw(p);
@@ -165,7 +182,7 @@ __device__ __forceinline__ u64 ld_rec_wait(const u64* node_base, u32 epoch, u32*
     const u64* p = node_base + (u64)node * kNodeWords + lane;
     u64 v = ld_nw(p);
     u32 spins = 0;
-    while (__ballot((u32)(v >> 63) != epoch) != 0ull) {
+    while (__ballot(tag_stale_or_never(epoch, v)) != 0ull) {
         if (++spins > (1u << 22)) { if (lane == 0) atomicAdd(&ctl[CTL_ABORT], 1u); break; }
         peel_sleep(4);
         v = ld_nw(p);
@@ -206,7 +223,7 @@ __device__ __attribute__((noinline)) u64 peel_reread(const u64* node_base, u32 e
     const u64* p = node_base + (u64)c * kNodeWords + lane;
     u32 polls = 0;
     for (;;) {
-        u64 badm = __ballot((u32)(w >> 63) != epoch);
+        u64 badm = __ballot(tag_stale_or_never(epoch, w));
         if ((badm & 1ull) == 0) badm &= needed_lanes((u32)rdlane64(w, 0));          // (word 0 is there: its depth says what else must be)
         if (badm == 0 || ++polls > kPollLimit) break;
         if ((polls & 63u) == 1u && __ballot(ld_a32(&ctl[CTL_ABORT]) != 0u) != 0ull) break;       // the launch is being given up: nobody waits any more
@@ -280,7 +297,7 @@ __global__ void __launch_bounds__(256) k_peel_sinks(PeelArgs A) {
     u32* out = A.seeds_w + (u64)blockIdx.x * A.region_cap;
     u32* counter = &A.seed_cnt_w[blockIdx.x];
     const u64 lt_mask = (1ull << lane) - 1ull;
-    const u64 tag = A.epoch ? kTagBit : 0ull;
+    const u64 tag = (u64)A.epoch << kTagShift;
     u32 done = 0;
     for (u64 base = (u64)blockIdx.x * 256; base < A.n; base += (u64)gridDim.x * 256) {
         const u64 g = base + threadIdx.x;
@@ -357,7 +374,7 @@ __global__ void __launch_bounds__(256) k_peel_shallow(PeelArgs A, const u32* __r
     const u32* src = in + (u64)blockIdx.x * in_cap;
     u32* dst = out + (u64)blockIdx.x * out_cap;
     u32* counter = &out_cnt[blockIdx.x];
-    const u64 tag = A.epoch ? kTagBit : 0ull;
+    const u64 tag = (u64)A.epoch << kTagShift;
     const u64 lt_mask = (1ull << lane) - 1ull;
     for (u32 base = 0; base < cnt; base += 256) {
         // ---- a LANE per gate: the smallest key, the tree entry, the tickets of its producers (every load of a gate waits
@@ -476,7 +493,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
     A.gstat = own_sgprs(A_in.gstat); A.clist = own_sgprs(A_in.clist); A.node = own_sgprs(A_in.node); A.fill = own_sgprs(A_in.fill);
     A.meta = own_sgprs(A_in.meta); A.child = own_sgprs(A_in.child); A.fifo = own_sgprs(A_in.fifo); A.q_pc = own_sgprs(A_in.q_pc);
     A.ctl = own_sgprs(A_in.ctl); A.cold = own_sgprs(A_in.cold);
-    A.epoch = own_sgpr(A_in.epoch); A.n_fifos = own_sgpr(A_in.n_fifos); A.q_cap = own_sgpr(A_in.q_cap); A.run = own_sgpr(A_in.run); A.n_primary = own_sgpr(A_in.n_primary); A.reserve_min = own_sgpr(A_in.reserve_min);
+    A.epoch = own_sgpr(A_in.epoch); A.pad_thr = own_sgpr(A_in.pad_thr); A.n_fifos = own_sgpr(A_in.n_fifos); A.q_cap = own_sgpr(A_in.q_cap); A.run = own_sgpr(A_in.run); A.n_primary = own_sgpr(A_in.n_primary); A.reserve_min = own_sgpr(A_in.reserve_min);
     const u32 lane = threadIdx.x;
     const u32 me = blockIdx.x;
     // this wave is one unit of work from now until it first runs out of work; BEGIN counts it before it moves
@@ -486,6 +503,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
         C2A_PIN(r);
     }
     const u32 epoch = A.epoch;
+    const TagCheck tagc = tag_check(epoch, A.pad_thr, lane);
     // byte offset of the word of a hand-off entry that this lane writes: lanes 8..15 words 0..7 (the pushed gate's static
     // records), lanes 32..39 words 8..15 (its first consumers, its id)
     const u32 ent_off = (lane >= 8u && lane < 16u) ? (lane - 8u) * 8u : ((lane >= 32u && lane < 40u) ? (lane - 24u) * 8u : C2A_NONE);
@@ -778,14 +796,15 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             // one candidate: its record must be all there (else read it again: out of line), then it meets the champion
             auto candidate = [&](u64& w, u32 e) {             // (w by reference: the cold path mends it in place, no copy)
                 const u32 c = e & kIdMask, el = e >> 31;
-                u64 badm = __ballot((u32)(w >> 63) != epoch);
+                u64 badm = __ballot(tag_bad(tagc, w));
                 if (C2A_UNLIKELY(badm != 0)) {
+                    badm = __ballot(tag_stale_or_never(epoch, w));
                     // not all there: a short record (a sink: header words only; a gate of the shallow passes: one line — what
                     // lies beyond the lanes its depth needs is zero padding whatever those words hold) or a record that is still
                     // on its way
                     if ((badm & 1ull) != 0 || (badm & needed_lanes((u32)rdlane64(w, 0))) != 0) {
                         w = peel_reread(A.node, epoch, A.ctl, c, w, lane);
-                        badm = __ballot((u32)(w >> 63) != epoch);
+                        badm = __ballot(tag_stale_or_never(epoch, w));
                         // It never arrived (or the launch is being given up already): fail loudly — ABORT tells the host, which
                         // discards the run — and leave the candidate out.  The chain goes on (no flag to carry through the hot
                         // path); once ABORT is up no re-read waits any more, chains run out and waiting waves leave.
@@ -793,14 +812,14 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                         // exit from the candidate: what merges behind this cold block is the record alone, no flag — 8.95 -> 8.58 ms)
                         if ((badm & 1ull) != 0 || (badm & needed_lanes((u32)rdlane64(w, 0))) != 0) {
                             if (lane == 0) atomicAdd(&A.ctl[CTL_ABORT], 1u); wave_join();
-                            w = ((u64)epoch << 63) | (lane == 0 ? (u64)kIdMask << 32 : 0ull);
+                            w = ((u64)epoch << kTagShift) | (lane == 0 ? (u64)kHdrMask << 32 : 0ull);
                         }
                     }
-                    if ((u32)(w >> 63) != epoch) w = (u64)epoch << 63;       // (the zero padding of a short record)
+                    if (tag_stale_or_never(epoch, w)) w = 0ull;       // (the zero padding of a short record, whatever those words hold)
                 }
                 const u64 h0 = rdlane64(w, 0);
                 const u32 croot = hdr_hi(h0), cdepth = (u32)h0;
-                const u32 clevel = (rdlane((u32)(w >> 32), 1) & kIdMask) + 1u;
+                const u32 clevel = (rdlane((u32)(w >> 32), 1) & kHdrMask) + 1u;
                 const u32 cpos = rdlane((u32)w, 2);
                 level = clevel > level ? clevel : level;
                 // the candidate's string with its edge label appended (meaningful while the chunk has room: cpos < kStrWords << 8)
@@ -913,10 +932,10 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             sstore_x4(&A.meta[gc], ch, depth, ch_root, my_label | (level << 1));
             if (C2A_LIKELY(ch != C2A_NONE)) sstore_x1(&A.child[2 * (u64)ch + my_label], gc);
             // (the three header words go into lanes 0..2 with v_writelane: a lane == k ladder is masked code)
-            const u32 tag_hi = epoch << 31;
+            const u32 tag_hi = epoch << 30;
             u32 w_lo = (u32)str, w_hi = (u32)(str >> 32) | tag_hi;
-            w_lo = wrlane_c<0>(depth, w_lo);  w_hi = wrlane_c<0>((ch_root & kIdMask) | tag_hi, w_hi);
-            w_lo = wrlane_c<1>(cprev, w_lo);  w_hi = wrlane_c<1>((level & kIdMask) | tag_hi, w_hi);
+            w_lo = wrlane_c<0>(depth, w_lo);  w_hi = wrlane_c<0>((ch_root & kHdrMask) | tag_hi, w_hi);
+            w_lo = wrlane_c<1>(cprev, w_lo);  w_hi = wrlane_c<1>((level & kHdrMask) | tag_hi, w_hi);
             w_lo = wrlane_c<2>(my_pos, w_lo); w_hi = wrlane_c<2>(tag_hi, w_hi);
             const u64 my_w = (u64)w_lo | ((u64)w_hi << 32);
             st_nw(&A.node[(u64)gc * kNodeWords + lane], my_w);
