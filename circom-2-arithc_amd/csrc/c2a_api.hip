@@ -68,6 +68,7 @@ struct c2a_ctx {
     u32 peel_fifos = 64;           // dataflow launch: hand-off arrays (a power of two <= 64)
     u32 peel_reserve = 0;          // dataflow launch: reserve waves per CU (join the hand-off lines on demand only).  Measured with 8:
                                    // 2 000 gates per level 14.0 -> 14.5 ms, 4 000: 12.0 -> 9.3, 8 000: 12.8 -> 7.8, 50 000: 10.9 -> 7.3
+    size_t peel_slots = 0; u32 peel_waves_used = 0; bool peel_want_stats = false;      // of the launch now queued (peel_launch -> peel_result)
     u32 build_no = 0;              // number of the last producer map on this context (tag of its node-table records: k_producer)
     u32 peel_run = 0;              // number of the last dataflow run on this context (tag of its hand-off entries)
     u32 peel_epoch = 0;            // tag of the node words written by the last run (1 / 2 take turns; 0 after a clear)
@@ -109,8 +110,9 @@ struct c2a_ctx {
     bool positional = false;       // the circuit now sorted takes the positional numbering (one writer per node)
     bool sorted_ready = false;     // sorted[] / sorted_r[] are written (c2a_build_circuit leaves them to the emission's split pass)
     bool emitted_with_wires = false;   // the positional numbering has emitted the gates as well (do_emit has nothing left to do)
+    u32 jump_rounds = 0; uint2* jump_a = nullptr; uint2* jump_b = nullptr;      // pointer jumping: launches queued, the ping-pong buffers as they stand
     const uint2* rank_suffix = nullptr;    // the splitter suffix sums the list ranking ended in (which of its ping-pong buffers)
-    DevBuf scan_tmp, scalars, dfs_state, dfs_stack, peel_prof, peel_trace;
+    DevBuf scan_tmp, scan_desc, scalars, dfs_state, dfs_stack, peel_prof, peel_trace;
     DevBuf tsz, asz, goff, aoff, tmpl, tables, b_in0, b_in1, b_out, b_op;
     DevBuf fmt_len, fmt_off, fmt_text, fmt_table, shard_cut, shard_qcut;
     u64 fmt_chunk_first = 0, fmt_chunk_cnt = 0;      // boolean gates held by the chunk buffers (c2a_boolify_chunk)
@@ -127,7 +129,7 @@ struct c2a_ctx {
         all = {&lh, &rh, &out, &op, &gate4, &nrec, &orig, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &aq_items, &aq_pc, &aq_seeds, &aq_seeds1, &aq_seed_flat, &aq_seed_cnt, &fill,
                &gstat, &clist, &pctl, &pcold, &meta, &node, &child, &rbits, &rpre, &ridx, &rlist, &next,
                &owner, &local, &slist, &sjump, &sjump2, &sorted, &sorted_r, &first, &nflag, &wflag, &widx, &node_wire1,
-               &node_wire, &e_in0, &e_in1, &e_out, &e_op, &pos_r, &wire_r, &erec, &pblk, &dpre, &epre, &gflag, &scan_tmp, &scalars, &dfs_state, &dfs_stack, &peel_prof, &peel_trace, &tsz, &asz, &goff,
+               &node_wire, &e_in0, &e_in1, &e_out, &e_op, &pos_r, &wire_r, &erec, &pblk, &dpre, &epre, &gflag, &scan_tmp, &scan_desc, &scalars, &dfs_state, &dfs_stack, &peel_prof, &peel_trace, &tsz, &asz, &goff,
                &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &fmt_len, &fmt_off, &fmt_text, &fmt_table, &shard_cut, &shard_qcut, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &ev_lcount, &ev_lbase, &ev_lorder, &ev_bar, &ev_io, &g_in0, &g_in1, &g_out, &g_op, &pr_rep, &pr_need, &pr_tin0, &pr_tin1, &pr_top, &pr_live, &pr_goff, &pr_counts, &p_in0, &p_in1, &p_out, &p_op, &cb_in0, &cb_in1, &cb_out, &cb_op};
     }
 };
@@ -135,7 +137,7 @@ struct c2a_ctx {
 namespace {
 
 // scalars block layout (u32 words unless noted)
-enum Scalar { SC_MAXDEPTH = 0, SC_SCOUNT = 1, SC_ERR = 2, SC_NMID = 3, SC_NROOTS = 4, SC_LEVELS = 5,
+enum Scalar { SC_MAXDEPTH = 0, SC_SCOUNT = 1, SC_ERR = 2, SC_NMID = 3, SC_NROOTS = 4, SC_LEVELS = 5, SC_PEELOK = 6 /* the dataflow launch ended cleanly and left no gate behind (k_post_peel) */,
               SC_DFS = 8 /*3 words*/, SC_DUP = 52,
               SC_TOTAL64 = 16 /* u64 slots from here: 16..31 */, SC_WORDS = 64 };
 
@@ -183,25 +185,31 @@ void rec(c2a_ctx* c, Ev e) {
 
 // one-launch exclusive scans (k_scan_stream): NC sums of the functor's element values into out0 (/ out1), n + 1 entries each
 // (out[n] = the total).  Descriptors + the ticket counter live in scan_tmp.
+inline size_t scan_desc_bytes(u64 n, int nc) { return (64 + (size_t)((n + kScanTile - 1) / kScanTile) * nc * 8 + 15) & ~(size_t)15; }
+// (region: descriptors that are zero already — the build's own scans, cleared by ONE k_clear in front of the build — or
+// nullptr: the context's scan_tmp, cleared here)
 template <int NC, class F, typename TOut>
-int scan_1pass(c2a_ctx* c, hipStream_t s, DevBuf& tmp, u64 n, F f, TOut* out0, TOut* out1) {
+int scan_1pass(c2a_ctx* c, hipStream_t s, DevBuf& tmp, u64 n, F f, TOut* out0, TOut* out1, void* region = nullptr) {
     if (n == 0) {
         HIP_TRY(hipMemsetAsync(out0, 0, sizeof(TOut), s));
         if (NC > 1) HIP_TRY(hipMemsetAsync(out1, 0, sizeof(TOut), s));
         return C2A_OK;
     }
     const u64 tiles = (n + kScanTile - 1) / kScanTile, groups = (tiles + ScanGeom<NC>::kGroup - 1) / ScanGeom<NC>::kGroup;
-    const size_t bytes = 64 + (size_t)tiles * NC * 8;
-    ENSURE(tmp, bytes);
-    HIP_TRY(hipMemsetAsync(tmp.p, 0, bytes, s));
-    C2A_LAUNCH((k_scan_stream<NC, F, TOut>), (u32)groups, ScanGeom<NC>::kThreads, s, n, f, out0, out1, tmp.as<u64>() + 8, tmp.as<u32>());
+    if (!region) {
+        const size_t bytes = scan_desc_bytes(n, NC);
+        ENSURE(tmp, bytes);
+        HIP_TRY(hipMemsetAsync(tmp.p, 0, bytes, s));
+        region = tmp.p;
+    }
+    C2A_LAUNCH((k_scan_stream<NC, F, TOut>), (u32)groups, ScanGeom<NC>::kThreads, s, n, f, out0, out1, reinterpret_cast<u64*>(region) + 8, reinterpret_cast<u32*>(region));
     return C2A_OK;
 }
 
 // exclusive scan of `in` (n entries, u32) into `out` (n+1 entries; out[n] = total).
 template <typename TOut>
-int scan_exclusive(c2a_ctx* c, const u32* in, TOut* out, u64 n) {
-    return scan_1pass<1>(c, c->stream, c->scan_tmp, n, ScanFromU32{in}, out, (TOut*)nullptr);
+int scan_exclusive(c2a_ctx* c, const u32* in, TOut* out, u64 n, void* region = nullptr) {
+    return scan_1pass<1>(c, c->stream, c->scan_tmp, n, ScanFromU32{in}, out, (TOut*)nullptr, region);
 }
 
 int read_scalars(c2a_ctx* c, u32* host, int first, int count) {
@@ -212,10 +220,61 @@ int read_scalars(c2a_ctx* c, u32* host, int first, int count) {
 
 // the scalars block cleared and the IO flags of the nodes set (compiler.rs:363-395: a node that is both raises SC_ERR) — in
 // front of k_deps, which folds "the out node is an IO node" into the payload records
+// The build's zeroing in ONE launch (k_clear): the scalars block, the node flags, the descriptors of the build's four scans
+// (one buffer, a region each: relabel, consumer counts, root bitmap, event bits), the dataflow launch's dummy ticket words /
+// hand-off ticket words / control block / seed-region counts, the root bitmap, the event bits of the positional numbering.
+struct BuildRegions { size_t relabel, cons, roots, bits, total; };
+BuildRegions build_regions(const c2a_ctx* c) {
+    BuildRegions R;
+    R.relabel = 0;
+    R.cons = R.relabel + ((64 + (size_t)(((u64)c->n_nodes + kRelTile - 1) / kRelTile) * 8 + 15) & ~(size_t)15);
+    R.roots = R.cons + scan_desc_bytes(c->n, 1);
+    R.bits = R.roots + scan_desc_bytes(((u64)c->n + 31) / 32, 1);
+    R.total = R.bits + scan_desc_bytes(((u64)c->n + 31) / 32, 2);
+    return R;
+}
+inline size_t fill_dummy_off(u32 n) { return (((size_t)n + 3) & ~(size_t)3) * 4; }      // bytes: the waves' dummy ticket words start on a 16-byte boundary behind fill[n]
+inline size_t seed_cnt_bytes(const c2a_ctx* c, u32 sink_blocks) { return (((size_t)(c->peel_shallow + 1) * sink_blocks + 16) * 4 + 15) & ~(size_t)15; }
+inline u32 sink_blocks_of(const c2a_ctx* c);
+int clear_for_build(c2a_ctx* c, bool peel_only = false) {
+    ClearList L{};
+    u64 run = 0;
+    auto add = [&](void* p, size_t bytes) { if (!bytes) return; L.p[L.cnt] = reinterpret_cast<uint4*>(p); run += (bytes + 15) / 16; L.end[L.cnt] = run; ++L.cnt; };
+    const u32 n = c->n;
+    if (!peel_only) {
+        add(c->scalars.p, SC_WORDS * 4);
+        add(c->nflag.p, (size_t)c->n_nodes);
+        if (n) {
+            const BuildRegions R = build_regions(c);
+            ENSURE(c->scan_desc, R.total);
+            add(c->scan_desc.p, R.total);
+            add(c->rbits.p, ((size_t)n + 31) / 32 * 4);
+            add(c->pblk.p, ((size_t)n + 31) / 32 * 16);
+        }
+    }
+    if (n && peel_only) {                            // (a second attempt: what the first one's order stage has used)
+        const BuildRegions R = build_regions(c);
+        add(c->scan_desc.as<char>() + R.roots, R.bits - R.roots);
+        add(c->rbits.p, ((size_t)n + 31) / 32 * 4);
+    }
+    if (n) {
+        const u32 sb = sink_blocks_of(c);
+        ENSURE(c->aq_pc, (size_t)c->peel_fifos * kPcStride * 8);
+        ENSURE(c->pctl, ((size_t)CTL_WORDS * 4 + 15) & ~(size_t)15);
+        ENSURE(c->aq_seed_cnt, seed_cnt_bytes(c, sb));
+        add(reinterpret_cast<char*>(c->fill.p) + fill_dummy_off(n), (size_t)kFillDummyStride * kFillDummyWaves * 4);
+        add(c->aq_pc.p, (size_t)c->peel_fifos * kPcStride * 8);
+        add(c->pctl.p, (size_t)CTL_WORDS * 4);
+        add(c->aq_seed_cnt.p, seed_cnt_bytes(c, sb));
+    }
+    static_assert(kClearMax >= 9, "regions of a build");
+    if (!L.cnt) return C2A_OK;
+    C2A_LAUNCH(k_clear, grid_for(run, 2048), kThreads, c->stream, L);
+    return C2A_OK;
+}
+
 int mark_io(c2a_ctx* c) {
     hipStream_t s = c->stream;
-    HIP_TRY(hipMemsetAsync(c->scalars.p, 0, SC_WORDS * 4, s));
-    HIP_TRY(hipMemsetAsync(c->nflag.p, 0, (size_t)c->n_nodes, s));
     if (c->n_in) C2A_LAUNCH_NOSYNC(k_mark_inputs, grid_for(c->n_in, 1024), kThreads, s, c->n_in, c->in_nodes.as<u32>(), c->nflag.as<u8>());
     if (c->n_out) C2A_LAUNCH_NOSYNC(k_mark_outputs, grid_for(c->n_out, 1024), kThreads, s, c->n_out, c->out_nodes.as<u32>(), c->nflag.as<u8>(), c->scalars.as<u32>() + SC_ERR);
     return C2A_OK;
@@ -227,8 +286,11 @@ int do_prep(c2a_ctx* c, bool for_peel = true) {
     const u32 n = c->n;
     hipStream_t s = c->stream;
     const u32 G = grid_for(n, 4096);
-    int r0 = mark_io(c);
+    int r0 = clear_for_build(c);
     if (r0) return r0;
+    if ((r0 = mark_io(c))) return r0;
+    const BuildRegions R = build_regions(c);
+    char* desc = c->scan_desc.as<char>();
     u32* dup = c->scalars.as<u32>() + SC_DUP;
     // (the node records carry the number of the build that wrote them — 24 bits — and are only ever cleared when that wraps)
     if (++c->build_no >= (1u << 24)) { HIP_TRY(hipMemsetAsync(c->nrec.p, 0, (size_t)c->n_nodes * 16, s)); c->build_no = 1; }
@@ -236,11 +298,8 @@ int do_prep(c2a_ctx* c, bool for_peel = true) {
                       c->cons_cnt.as<u32>(), for_peel ? c->fill.as<u32>() : (u32*)nullptr, for_peel ? c->child.as<uint2>() : (uint2*)nullptr);
     {
         const u64 tiles = ((u64)c->n_nodes + kRelTile - 1) / kRelTile;
-        const size_t bytes = 64 + (size_t)tiles * 8;
-        ENSURE(c->scan_tmp, bytes);
-        HIP_TRY(hipMemsetAsync(c->scan_tmp.p, 0, bytes, s));
         C2A_LAUNCH(k_relabel, (u32)tiles, kRelThreads, s, c->n_nodes, n, c->build_no, c->prod1.as<u32>(), (const uint4*)c->nrec.as<uint4>(), dup, c->orig.as<u32>(),
-                   c->gate4.as<uint4>(), c->scan_tmp.as<u64>() + 8, c->scan_tmp.as<u32>());
+                   c->gate4.as<uint4>(), reinterpret_cast<u64*>(desc + R.relabel) + 8, reinterpret_cast<u32*>(desc + R.relabel));
     }
     // (two gates wrote one node — never, for a circuit the reference's front-end built: these two leave at once)
     C2A_LAUNCH_NOSYNC(k_dup_clear, 512, kThreads, s, c->n_nodes, (const u32*)dup, c->prod1.as<u32>());
@@ -249,7 +308,7 @@ int do_prep(c2a_ctx* c, bool for_peel = true) {
     C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->out.as<u32>(), c->op.as<u8>(), dup, c->prod1.as<u32>(), (const u8*)c->nflag.as<u8>(), c->orig.as<u32>(),
                       c->gate4.as<uint4>(), c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>(), c->gflag.as<u8>());
     if (!for_peel) return C2A_OK;
-    r = scan_exclusive<u32>(c, c->cons_cnt.as<u32>(), c->cons_off.as<u32>(), n);
+    r = scan_exclusive<u32>(c, c->cons_cnt.as<u32>(), c->cons_off.as<u32>(), n, desc + R.cons);
     if (r) return r;
     C2A_LAUNCH_NOSYNC(k_gstat, G, kThreads, s, n, c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_off.as<u32>(),
                       c->eslot.as<u32>(), c->orig.as<u32>(), c->gstat.as<uint4>(), c->clist.as<u32>());
@@ -277,8 +336,13 @@ u32 peel_grid(c2a_ctx* c, bool stats, u32* n_primary) {
 #endif
 }
 
-// The whole peel as one dataflow launch (+ one grid-stride launch for the sinks): see c2a_peel.h.
-int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
+inline u32 sink_blocks_of(const c2a_ctx* c) { return grid_for(c->n, c->peel_sinks_blocks); }
+
+// The whole peel as one dataflow launch (+ one grid-stride launch for the sinks and one per whole-level pass): see c2a_peel.h.
+// QUEUES it — the control words, tickets and counts it starts from were zeroed by clear_for_build — and the kernel that posts
+// its numbers to the host and raises SC_PEELOK for the order stage queued right behind; peel_result() reads them once the host
+// has waited for the event behind the order stage's own posting.
+int peel_launch(c2a_ctx* c) {
     const u32 n = c->n;
     hipStream_t s = c->stream;
     c->peel_gave_up = false;                         // (only a watchdog abort observed in THIS launch may trigger the retry / the serial fall-back)
@@ -303,7 +367,6 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
     // the waves' dummy ticket words behind fill[n] (c2a_peel.h, SCALAR TICKETS): zero, and they stay zero (only 0 is ever
     // added); a ticket word is addressed by a 32-bit byte offset from fill
     if (waves > kFillDummyWaves || n >= (1u << 29)) { c->err = "peel: grid or gate count beyond the ticket words' addressing"; return C2A_ERR_ARG; }
-    HIP_TRY(hipMemsetAsync(c->fill.as<u32>() + n, 0, (size_t)kFillDummyStride * kFillDummyWaves * 4, s));
     // hand-off arrays: every slot is used once per run (no wrap-around).  A wave spreads its pushes round robin, so an
     // array receives at most pushes / n_fifos + waves entries, and a wave holds at most one unserved consumer ticket
     A.n_fifos = c->peel_fifos;
@@ -320,10 +383,6 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
     A.n_primary = n_primary;
     A.reserve_min = 4;
     if (waves <= n_primary) A.reserve_min = 0;       // no reserve waves: pushers need not count the entries nobody was in line for
-    ENSURE(c->aq_pc, (size_t)A.n_fifos * kPcStride * 8);
-    ENSURE(c->pctl, (size_t)CTL_WORDS * 4);
-    HIP_TRY(hipMemsetAsync(c->aq_pc.p, 0, (size_t)A.n_fifos * kPcStride * 8, s));
-    HIP_TRY(hipMemsetAsync(c->pctl.p, 0, (size_t)CTL_WORDS * 4, s));
     A.fifo = c->aq_items.as<u64>(); A.q_pc = c->aq_pc.as<u64>(); A.ctl = c->pctl.as<u32>();
     cold.stats = nullptr; cold.q_time = nullptr; cold.p_time = nullptr; cold.t_trace = nullptr;
     const char* trace_dir = want_stats ? std::getenv("C2A_PEEL_TRACE") : nullptr;
@@ -338,15 +397,13 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
         }
     }
     // seed regions: one per workgroup of the sinks pass; a workgroup sees at most gates_per_block gates, each claims <= 2 producers
-    const u32 sink_blocks = grid_for(n, c->peel_sinks_blocks);
+    const u32 sink_blocks = sink_blocks_of(c);
     const u64 gates_per_block = ((u64)n + (u64)sink_blocks * kThreads - 1) / ((u64)sink_blocks * kThreads) * kThreads;
     const u32 sink_cap = (u32)(2 * gates_per_block);
     // (region counts of the sinks pass and of every shallow pass behind it, then the length of the flat seed list)
     const u32 shallow = c->peel_shallow;
     const u32 l1_cap = 2 * sink_cap;
-    const size_t cnt_words = (size_t)(shallow + 1) * sink_blocks + 16;
-    ENSURE(c->aq_seeds, (size_t)sink_blocks * l1_cap * 4); ENSURE(c->aq_seed_cnt, cnt_words * 4);
-    HIP_TRY(hipMemsetAsync(c->aq_seed_cnt.p, 0, cnt_words * 4, s));
+    ENSURE(c->aq_seeds, (size_t)sink_blocks * l1_cap * 4);
     A.seeds_w = c->aq_seeds.as<u32>(); A.seed_cnt_w = c->aq_seed_cnt.as<u32>(); A.region_cap = sink_cap;
     A.proc_word = CTL_PROC; A.proc_mask = kAcctShards - 1u;
     // ... what those claim is done by k_peel_shallow, a whole level at once (level 1, 2, ... `peel_shallow`: far wider than the
@@ -377,8 +434,22 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
     else C2A_LAUNCH_CONCURRENT((k_peel<false>), waves, 64, s, A);
     rec(c, EV_KPEEL1);
     static_assert(CTL_PROCESSED == 0 && CTL_MAXLEVEL == 1 && CTL_ABORT == 2 && CTL_REREADS == 3, "the order k_post_peel writes them in");
-    C2A_LAUNCH(k_post_peel, 1, 64, s, c->hrb_dev, (const u32*)c->pctl.as<u32>(), (const u32*)(c->cons_off.as<u32>() + n), (const u32*)(c->scalars.as<u32>() + SC_DUP));
-    HIP_TRY(hipStreamSynchronize(s));
+    C2A_LAUNCH(k_post_peel, 1, 64, s, c->hrb_dev, (const u32*)c->pctl.as<u32>(), (const u32*)(c->cons_off.as<u32>() + n), (const u32*)(c->scalars.as<u32>() + SC_DUP), n,
+               c->scalars.as<u32>() + SC_PEELOK);
+    c->peel_slots = slots; c->peel_waves_used = waves; c->peel_want_stats = want_stats;
+    return C2A_OK;
+}
+
+// what the launch reported (hrb[0..5], posted by k_post_peel; the host has waited for an event behind it)
+int peel_result(c2a_ctx* c, u32* peeled_out) {
+    const u32 n = c->n;
+    const size_t slots = c->peel_slots;
+    const u32 waves = c->peel_waves_used;
+    const bool want_stats = c->peel_want_stats;
+    const char* trace_dir = want_stats ? std::getenv("C2A_PEEL_TRACE") : nullptr;
+    PeelCold cold;
+    cold.q_time = want_stats ? c->peel_prof.as<ull>() + 32 : nullptr; cold.p_time = want_stats ? cold.q_time + slots : nullptr;
+    struct { u32 n_fifos; } A{c->peel_fifos};
     u32 t4[4] = {c->hrb[0], c->hrb[1], c->hrb[2], c->hrb[3]};
 #ifdef C2A_EMULATE
     if (c->emul_peel_abort) { --c->emul_peel_abort; t4[CTL_ABORT] = 1; }      // (tests: a launch that "gave up", to exercise the retry and the serial fall-back)
@@ -440,47 +511,63 @@ int do_peel_classic(c2a_ctx* c, u32* peeled_out) {
     return C2A_OK;
 }
 
-int do_peel(c2a_ctx* c, u32* peeled_out) {
-    int r = do_peel_classic(c, peeled_out);
-    if (r == C2A_ERR_HIP && c->peel_gave_up) {
-        // the launch's watchdog tripped (a wave waited too long for a record or for global progress): once more on clean
-        // buffers — node records re-zeroed, tickets and child pointers reset — before this is reported as an error
-        std::fprintf(stderr, "[c2a] the dataflow peel gave up (%s); retrying once on clean buffers\n", c->err.c_str());
-        HIP_TRY(hipMemsetAsync(c->fill.p, 0, (size_t)c->n * 4, c->stream));
-        HIP_TRY(hipMemsetAsync(c->child.p, 0xFF, (size_t)c->n * 8, c->stream));
-        r = do_peel_classic(c, peeled_out);
-    }
-    return r;
+// jump launches that make a splitter list of S elements complete (the reach grows kJumpSpan-fold per launch)
+inline u32 jump_rounds(u64 S) {
+    u32 rounds = 0;
+    for (u64 reach = 1; reach < S; reach *= kJumpSpan) ++rounds;
+    return rounds;
 }
 
-int do_order(c2a_ctx* c, bool defer_sorted) {
+// The order stage, QUEUED behind the peel without a host round trip: its first kernels go by SC_PEELOK (k_post_peel) and do
+// nothing when the launch gave up or left gates behind; the walk and the jumps then find no splitter.  The number of jump
+// launches comes from an upper bound on the splitter count (a hash of the element number picks one element in 64: the mean
+// + 8 standard deviations; order_result checks the real count and queues what is missing — surplus launches only copy).
+// The host waits for the event behind the posted words, i.e. while the walk and the jumps run.
+int order_launch(c2a_ctx* c) {
     const u32 n = c->n;
     hipStream_t s = c->stream;
     const u32 G = grid_for(n, 4096);
+    const BuildRegions R = build_regions(c);
+    const u32* ok = c->scalars.as<u32>() + SC_PEELOK;
     // DFS roots (tree nodes without a parent) in ascending ORIGINAL gate id: a bit per id, a scan over the bitmap's words, the list
     const u32 W = (n + 31u) / 32u;
-    HIP_TRY(hipMemsetAsync(c->rbits.p, 0, (size_t)W * 4, s));
-    C2A_LAUNCH_NOSYNC(k_root_bits, G, kThreads, s, n, (const uint4*)c->meta.as<uint4>(), (const u32*)c->orig.as<u32>(), c->rbits.as<u32>());
-    int r = scan_1pass<1>(c, s, c->scan_tmp, W, ScanPopc{c->rbits.as<u32>()}, c->rpre.as<u32>(), (u32*)nullptr);
+    C2A_LAUNCH_NOSYNC(k_root_bits, G, kThreads, s, n, ok, (const uint4*)c->meta.as<uint4>(), (const u32*)c->orig.as<u32>(), c->rbits.as<u32>());
+    int r = scan_1pass<1>(c, s, c->scan_tmp, W, ScanPopc{c->rbits.as<u32>()}, c->rpre.as<u32>(), (u32*)nullptr, c->scan_desc.as<char>() + R.roots);
     if (r) return r;
     const u32* n_roots_p = c->rpre.as<u32>() + W;
-    C2A_LAUNCH_NOSYNC(k_root_list, G, kThreads, s, n, (const uint4*)c->meta.as<uint4>(), (const u32*)c->orig.as<u32>(), (const u32*)c->rbits.as<u32>(),
+    C2A_LAUNCH_NOSYNC(k_root_list, G, kThreads, s, n, ok, (const uint4*)c->meta.as<uint4>(), (const u32*)c->orig.as<u32>(), (const u32*)c->rbits.as<u32>(),
                       (const u32*)c->rpre.as<u32>(), c->ridx.as<u32>(), c->rlist.as<u32>());
-    C2A_LAUNCH(k_euler_next, G, kThreads, s, n, c->meta.as<uint4>(), c->child.as<u32>(),
+    C2A_LAUNCH(k_euler_next, G, kThreads, s, n, ok, c->meta.as<uint4>(), c->child.as<u32>(),
                c->ridx.as<u32>(), c->rlist.as<u32>(), n_roots_p, c->next.as<u32>(), c->scalars.as<u32>() + SC_MAXDEPTH);
     const u32 m = 2 * n;
     u32* scount = c->scalars.as<u32>() + SC_SCOUNT;
-    C2A_LAUNCH(k_rank_mark, std::max<u32>(1u, std::min<u32>(2048u, (m + kThreads * 8 - 1) / (kThreads * 8))), kThreads, s, m, c->rlist.as<u32>(), scount, c->slist.as<u32>(),
+    C2A_LAUNCH(k_rank_mark, std::max<u32>(1u, std::min<u32>(2048u, (m + kThreads * 8 - 1) / (kThreads * 8))), kThreads, s, m, ok, c->rlist.as<u32>(), scount, c->slist.as<u32>(),
                       c->owner.as<u32>());
     static_assert(SC_SCOUNT == SC_MAXDEPTH + 1, "read as a pair");
     C2A_LAUNCH_NOSYNC(k_post_words, 1, 64, s, c->hrb_dev + 8, (const u32*)(c->scalars.as<u32>() + SC_MAXDEPTH), 2u, n_roots_p, 1u, (const u32*)nullptr, 0u);
-    // The host wants the number of splitters (how many jump launches) — but not before the walk: the walk is queued first, sized
-    // for the expected count (its loop is grid-stride: any grid is correct), and the host waits for the posted words only, while
-    // the walk runs.  (A whole-stream synchronisation here was a 27 µs hole in front of the walk.)
     HIP_TRY(hipEventRecord(c->ev[EV_ORDER_RB], s));
-    C2A_LAUNCH_NOSYNC(k_rank_walk, grid_for((u64)m / (1u << (32 - C2A_SPLIT_SHIFT)) + 1024u, 8192), kThreads, s, (const u32*)scount, c->rlist.as<u32>(), c->slist.as<u32>(),
+    const u64 expect = (u64)m >> (32 - C2A_SPLIT_SHIFT);
+    u64 sd = 1;
+    while (sd * sd < expect) ++sd;
+    const u64 bound = expect + 8 * sd + 64;
+    C2A_LAUNCH_NOSYNC(k_rank_walk, grid_for(expect + 1024u, 8192), kThreads, s, (const u32*)scount, c->rlist.as<u32>(), c->slist.as<u32>(),
                       c->next.as<u32>(), (const u32*)c->owner.as<u32>(), c->local.as<u64>(), c->sjump.as<uint2>());
-    HIP_TRY(hipEventSynchronize(c->ev[EV_ORDER_RB]));
+    // pointer jumping, ping-pong between the two {next, sum} arrays
+    c->jump_rounds = jump_rounds(bound);
+    c->jump_a = c->sjump.as<uint2>(); c->jump_b = c->sjump2.as<uint2>();
+    for (u32 k = 0; k < c->jump_rounds; ++k) {
+        C2A_LAUNCH_NOSYNC(k_rank_jump, grid_for(bound, 4096), kThreads, s, (const u32*)scount, (const uint2*)c->jump_a, c->jump_b);
+        std::swap(c->jump_a, c->jump_b);
+    }
+    return C2A_OK;
+}
+
+// behind the host's wait for EV_ORDER_RB (and a peel that ended well): the stage's numbers, the jump launches an unlikely
+// splitter count still needs, and — unless the emission will write it — the sorted order
+int order_result(c2a_ctx* c, bool defer_sorted) {
+    const u32 n = c->n;
+    hipStream_t s = c->stream;
+    const u32 G = grid_for(n, 4096);
     const u32 sc[3] = {c->hrb[8], c->hrb[9], c->hrb[10]};      // depth of the DFS forest, splitters, roots
     const u32 S = sc[1];
     c->stats.max_depth = sc[0];
@@ -490,15 +577,11 @@ int do_order(c2a_ctx* c, bool defer_sorted) {
     // order (c2a_kernels.h POSITIONAL NUMBERING)
     c->positional = !c->has_dup && !c->numbering_walk;
     c->stats.numbering_path = c->positional ? 1u : 0u;
-    // pointer jumping, ping-pong between the two {next, sum} arrays
-    u32 rounds = 0;
-    for (u64 reach = 1; reach < S; reach *= kJumpSpan) ++rounds;
-    uint2 *ja = c->sjump.as<uint2>(), *jb = c->sjump2.as<uint2>();
-    for (u32 k = 0; k < rounds; ++k) {
-        C2A_LAUNCH_NOSYNC(k_rank_jump, grid_for(S, 4096), kThreads, s, (const u32*)scount, (const uint2*)ja, jb);
-        std::swap(ja, jb);
+    for (u32 need = jump_rounds(S); c->jump_rounds < need; ++c->jump_rounds) {
+        C2A_LAUNCH_NOSYNC(k_rank_jump, grid_for(S, 4096), kThreads, s, (const u32*)(c->scalars.as<u32>() + SC_SCOUNT), (const uint2*)c->jump_a, c->jump_b);
+        std::swap(c->jump_a, c->jump_b);
     }
-    const uint2* vl_a = ja;
+    const uint2* vl_a = c->jump_a;
     c->rank_suffix = vl_a;
     c->sorted_ready = !(defer_sorted && c->positional);
     if (!c->sorted_ready) return C2A_OK;            // (c2a_build_circuit: the emission's records carry the sorted order along)
@@ -558,8 +641,8 @@ int do_topo_sort(c2a_ctx* c, u64* cycle_at, bool defer_sorted = false) {
     c->stats.n_gates = n;
     if (cycle_at) *cycle_at = 0;
     if (n == 0) {                                    // (no gates: no levels, and that is valid level data)
-        int r0 = mark_io(c);
-        if (r0) return r0;
+        int r0 = clear_for_build(c);
+        if (r0 || (r0 = mark_io(c))) return r0;
         c->stage = ST_SORTED; c->peel_meta_valid = true;
         return C2A_OK;
     }
@@ -569,16 +652,33 @@ int do_topo_sort(c2a_ctx* c, u64* cycle_at, bool defer_sorted = false) {
     rec(c, EV_PREP1);
     u32 peeled = 0;
     c->serial_fallback = false;
-    r = do_peel(c, &peeled);
-    if (r == C2A_ERR_HIP && c->peel_gave_up) {
+    for (int attempt = 0;; ++attempt) {
+        if ((r = peel_launch(c))) return r;
+        rec(c, EV_PEEL1);
+        if ((r = order_launch(c))) return r;
+        HIP_TRY(hipEventSynchronize(c->ev[EV_ORDER_RB]));       // (the walk and the jumps run meanwhile)
+        r = peel_result(c, &peeled);
+        if (!(r == C2A_ERR_HIP && c->peel_gave_up)) break;
+        if (attempt == 0) {
+            // the launch's watchdog tripped (a wave waited too long for a record or for global progress): once more on clean
+            // buffers — node records re-zeroed, tickets and child pointers reset — before the serial DFS takes over
+            std::fprintf(stderr, "[c2a] the dataflow peel gave up (%s); retrying once on clean buffers\n", c->err.c_str());
+            HIP_TRY(hipMemsetAsync(c->fill.p, 0, (size_t)c->n * 4, c->stream));
+            HIP_TRY(hipMemsetAsync(c->child.p, 0xFF, (size_t)c->n * 8, c->stream));
+            HIP_TRY(hipMemsetAsync(c->scalars.as<u32>() + SC_MAXDEPTH, 0, 8, c->stream));
+            int rc = clear_for_build(c, true);
+            if (rc) return rc;
+            continue;
+        }
         // The dataflow launch gave up twice (its watchdog: a wave waited too long).  The reference's sort cannot fail on an
         // acyclic graph (topological_sort.rs:3-21), and neither may this one: the same DFS on one lane (exact, always
         // terminates, slow), the order in rank space and the reverse Kahn levels for what comes behind.
         if (!c->fallback_logged) { std::fprintf(stderr, "[c2a] the dataflow peel gave up twice (%s): sorting with the serial DFS instead\n", c->err.c_str()); c->fallback_logged = true; }
         c->serial_fallback = true;
         c->err.clear();
-    } else if (r) return r;
-    rec(c, EV_PEEL1);
+        break;
+    }
+    if (r && !c->serial_fallback) return r;
     c->stats.n_edges = c->rb_edges;                  // (read back with the launch's own counters)
     c->has_dup = c->rb_dup != 0;
     if (c->serial_fallback) {
@@ -604,7 +704,7 @@ int do_topo_sort(c2a_ctx* c, u64* cycle_at, bool defer_sorted = false) {
         if (status == 1) return fail(c, C2A_ERR_CYCLIC, "Cyclic dependency: detected at i=" + std::to_string(at));
         return fail(c, C2A_ERR_HIP, "internal: peel left gates behind but the serial DFS found no cycle");
     }
-    r = do_order(c, defer_sorted);
+    r = order_result(c, defer_sorted);
     if (r) return r;
     rec(c, EV_ORDER1);
     c->stage = ST_SORTED;
@@ -862,7 +962,7 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     ENSURE(c->nrec, (size_t)n_nodes * 16); ENSURE(c->orig, n4);
     ENSURE(c->in_nodes, (size_t)n_in * 4); ENSURE(c->out_nodes, (size_t)n_out * 4);
     ENSURE(c->prod1, nn4); ENSURE(c->dep0, n4); ENSURE(c->dep1, n4); ENSURE(c->cons_cnt, n4);
-    ENSURE(c->cons_off, n4 + 4); ENSURE(c->eslot, 2 * n4); ENSURE(c->fill, n4 + (size_t)kFillDummyStride * kFillDummyWaves * 4);
+    ENSURE(c->cons_off, n4 + 4); ENSURE(c->eslot, 2 * n4); ENSURE(c->fill, n4 + 16 + (size_t)kFillDummyStride * kFillDummyWaves * 4);
     ENSURE(c->meta, (size_t)n * 16); ENSURE(c->gstat, (size_t)n * 32); ENSURE(c->clist, 2 * n4 + 64 * 4);
     ENSURE(c->node, (size_t)n * kNodeWords * 8); ENSURE(c->child, 2 * n4);
     // a new graph needs clean node records (5 GB at 10 M gates, ~0.75 ms of HBM writes): cleared here, on a stream of its own,
@@ -875,11 +975,11 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
 #ifdef C2A_EMULATE
     c->build_no = c->emul_build_no;
 #endif
-    ENSURE(c->rbits, n4 / 32 + 8); ENSURE(c->rpre, n4 / 32 + 16); ENSURE(c->ridx, n4); ENSURE(c->rlist, n4);
+    ENSURE(c->rbits, n4 / 32 + 32); ENSURE(c->rpre, n4 / 32 + 16); ENSURE(c->ridx, n4); ENSURE(c->rlist, n4);
     ENSURE(c->next, 2 * n4); ENSURE(c->owner, 2 * n4); ENSURE(c->local, 2 * n4); ENSURE(c->slist, 2 * n4);
     ENSURE(c->sjump, 4 * n4); ENSURE(c->sjump2, 4 * n4);
     ENSURE(c->sorted, n4); ENSURE(c->sorted_r, n4);
-    ENSURE(c->first, nn4); ENSURE(c->nflag, (size_t)n_nodes + 4); ENSURE(c->wflag, 3 * n4); ENSURE(c->widx, 3 * n4 + 4);
+    ENSURE(c->first, nn4); ENSURE(c->nflag, (size_t)n_nodes + 16); ENSURE(c->wflag, 3 * n4); ENSURE(c->widx, 3 * n4 + 4);
     ENSURE(c->node_wire1, nn4); ENSURE(c->node_wire, nn4);
     ENSURE(c->pos_r, n4); ENSURE(c->wire_r, n4); ENSURE(c->erec, (size_t)n * sizeof(EmitRec));
     ENSURE(c->pblk, ((size_t)n / 32 + 2) * 16); ENSURE(c->dpre, ((size_t)n / 32 + 4) * 4); ENSURE(c->epre, ((size_t)n / 32 + 4) * 4); ENSURE(c->gflag, (size_t)n + 16);
@@ -921,7 +1021,7 @@ int c2a_topo_sort_serial(c2a_ctx* c, uint32_t* sorted, uint64_t* cycle_at) {
     c->positional = false; c->sorted_ready = true; c->emitted_with_wires = false;
     c->stats = c2a_stats{}; c->stats.n_gates = c->n;
     if (cycle_at) *cycle_at = 0;
-    if (c->n == 0) { int r0 = mark_io(c); if (r0) return r0; c->stage = ST_SORTED; return C2A_OK; }
+    if (c->n == 0) { int r0 = clear_for_build(c); if (r0 || (r0 = mark_io(c))) return r0; c->stage = ST_SORTED; return C2A_OK; }
     // the producer map, the relabelling and the deps closure only (no peel)
     int r = do_prep(c, false);
     if (r) return r;

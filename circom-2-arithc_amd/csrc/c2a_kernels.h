@@ -190,6 +190,20 @@ __global__ void __launch_bounds__(ScanGeom<NC>::kThreads) k_scan_stream(u64 n, F
     }
 }
 
+// ONE launch that zeroes everything a build wants zeroed (scalars, node flags, scan descriptors, the dataflow launch's control
+// words and tickets, the root bitmap, the event bits of the numbering): thirteen hipMemsetAsync per build — a launch and a gap
+// each — were ~70 us of a 13 ms step.  Regions are 16-byte aligned and padded; end[k] = 16-byte words up to and including region k.
+constexpr int kClearMax = 12;
+struct ClearList { uint4* p[kClearMax]; u64 end[kClearMax]; u32 cnt; };
+__global__ void k_clear(ClearList L) {
+    const u64 total = L.end[L.cnt - 1];
+    for (u64 i = gtid(); i < total; i += gstride()) {
+        u32 k = 0;
+        while (i >= L.end[k]) ++k;
+        L.p[k][i - (k ? L.end[k - 1] : 0ull)] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
 // element functors
 struct ScanFromU32 { const u32* in; __device__ __forceinline__ void operator()(u64 i, u32* x) const { x[0] = in[i]; } };
 
@@ -325,13 +339,17 @@ __global__ void k_deps(u32 n, const u32* __restrict__ lh, const u32* __restrict_
 // DFS roots = tree nodes without a parent, in ascending ORIGINAL gate id (topological_sort.rs:11-13) — the tree lives in
 // rank space, so: a bit per original id (1.25 MB for 10 M gates: the scattered atomics stay on chip), a scan over the bitmap's
 // words, and every root finds its index by a look-up in the two small arrays.
-__global__ void k_root_bits(u32 n, const uint4* __restrict__ meta, const u32* __restrict__ orig, u32* rbits) {
+// (*ok: the dataflow launch in front ended cleanly and left no gate behind — k_post_peel —; the order stage is queued BEHIND it
+// without a host round trip, and does nothing when it did not: the tree entries it would read are not there)
+__global__ void k_root_bits(u32 n, const u32* __restrict__ ok, const uint4* __restrict__ meta, const u32* __restrict__ orig, u32* rbits) {
+    if (!*ok) return;
     for (u64 r = gtid(); r < n; r += gstride())
         if (meta[r].x == C2A_NONE) { const u32 o = orig[r]; atomicOr(&rbits[o >> 5], 1u << (o & 31u)); }
 }
 struct ScanPopc { const u32* w; __device__ __forceinline__ void operator()(u64 i, u32* x) const { x[0] = (u32)__popc(w[i]); } };
-__global__ void k_root_list(u32 n, const uint4* __restrict__ meta, const u32* __restrict__ orig, const u32* __restrict__ rbits,
+__global__ void k_root_list(u32 n, const u32* __restrict__ ok, const uint4* __restrict__ meta, const u32* __restrict__ orig, const u32* __restrict__ rbits,
                             const u32* __restrict__ rpre, u32* ridx, u32* rlist) {
+    if (!*ok) return;
     for (u64 r = gtid(); r < n; r += gstride()) {
         if (meta[r].x != C2A_NONE) continue;
         const u32 o = orig[r];
@@ -344,10 +362,11 @@ __global__ void k_root_list(u32 n, const uint4* __restrict__ meta, const u32* __
 // element 2x = enter(x), 2x+1 = exit(x); the tour visits label-0 child, label-1 child, then exits.
 // child[2p + l] was written by the peel when the child picked (p, l) as its parent (NONE otherwise).
 // (also collects the depth of the DFS tree — a statistic — with one atomic per workgroup, never one per gate on a single word)
-__global__ void __launch_bounds__(kThreads) k_euler_next(u32 n, const uint4* __restrict__ meta,
+__global__ void __launch_bounds__(kThreads) k_euler_next(u32 n, const u32* __restrict__ ok, const uint4* __restrict__ meta,
                              const u32* __restrict__ child, const u32* __restrict__ ridx, const u32* __restrict__ rlist,
                              const u32* __restrict__ n_roots_p, u32* next, u32* maxdepth) {
     __shared__ u32 s_max[kThreads / 64];
+    if (!*ok) return;
     const u32 n_roots = *n_roots_p;
     u32 md = 0;
     for (u64 i = gtid(); i < n; i += gstride()) {
@@ -388,10 +407,11 @@ __device__ __forceinline__ bool is_splitter(u32 e, u32 head) { return e == head 
 // so a workgroup first COUNTS the splitters of its whole share (a run of whole 2 048-element tiles), reserves their places
 // with ONE atomic, and then hands the places out tile by tile.  (One reservation per tile was 9 766 returning atomics on one
 // word for the 10 M-gate graph, and those go one at a time, ~10 ns each: 100 of the kernel's 118 us.)
-__global__ void __launch_bounds__(kThreads) k_rank_mark(u32 m, const u32* __restrict__ rlist, u32* scount, u32* slist,
+__global__ void __launch_bounds__(kThreads) k_rank_mark(u32 m, const u32* __restrict__ ok, const u32* __restrict__ rlist, u32* scount, u32* slist,
                                                         u32* owner) {
     __shared__ u32 s_w[kThreads / 64];
     __shared__ u32 s_base;
+    if (!*ok) return;                            // (no splitter is counted: the walk and the jumps behind this find nothing to do)
     const u32 head = 2 * rlist[0];
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     constexpr u64 T = (u64)kThreads * 8;
@@ -996,12 +1016,15 @@ __global__ void k_post_words(u32* dst, const u32* a, u32 na, const u32* b, u32 n
     for (u32 i = threadIdx.x; i < nc; i += blockDim.x) dst[na + nb + i] = c3[i];
 }
 // the peel: gates done and the highest level (summed / maximised over their kAcctShards parts), gave up, re-reads, edges, duplicate writers
-__global__ void k_post_peel(u32* dst, const u32* ctl, const u32* edges, const u32* dup) {
+__global__ void k_post_peel(u32* dst, const u32* ctl, const u32* edges, const u32* dup, u32 n, u32* ok) {
     const u32 t = threadIdx.x;            // (one wave)
     u32 done = t < kAcctShards ? ctl[CTL_PROC + t * kAcctStride] : 0u, lvl = t < kAcctShards ? ctl[CTL_PROC + t * kAcctStride + 1] : 0u;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { done += __shfl_xor(done, off, 64); const u32 o = __shfl_xor(lvl, off, 64); lvl = o > lvl ? o : lvl; }
-    if (t == 0) { dst[0] = done; dst[1] = lvl; dst[2] = ctl[CTL_ABORT]; dst[3] = ctl[CTL_REREADS]; dst[4] = *edges; dst[5] = *dup; }
+    if (t == 0) {
+        dst[0] = done; dst[1] = lvl; dst[2] = ctl[CTL_ABORT]; dst[3] = ctl[CTL_REREADS]; dst[4] = *edges; dst[5] = *dup;
+        *ok = (ctl[CTL_ABORT] == 0u && done == n) ? 1u : 0u;      // (what the order stage, queued right behind, goes by)
+    }
 }
 
 // order-sensitive 64-bit checksum of a u32 stream: sum over i of mix(i, v[i]) (commutative combine of

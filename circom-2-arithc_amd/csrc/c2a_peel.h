@@ -508,7 +508,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
     // records), lanes 32..39 words 8..15 (its first consumers, its id)
     const u32 ent_off = (lane >= 8u && lane < 16u) ? (lane - 8u) * 8u : ((lane >= 32u && lane < 40u) ? (lane - 24u) * 8u : C2A_NONE);
     const u32 no_demand = A.reserve_min ? 0u : C2A_NONE;      // (one compare at the pusher: all ones = never tell anybody)
-    const u32 dummy_idx = A.n + me * kFillDummyStride; (void)dummy_idx;      // this wave's dummy ticket word (a line of its own behind fill[n])
+    const u32 dummy_idx = ((A.n + 3u) & ~3u) + me * kFillDummyStride; (void)dummy_idx;      // this wave's dummy ticket word (a line of its own behind fill[n], from a 16-byte boundary on)
     bool seeds_left = true;
     u32 region = 0, idx = 0, region_cnt = 0;
     u32 push_rr = me, pop_rr = me * 7u;      // round-robin cursors over the hand-off arrays
