@@ -116,3 +116,7 @@ def test_bench_main_runs_its_two_rank_flow_on_cpus(emul_lib, tmp_path):
     b = d["config"]["strong_scaling_bound"]["speedup_at_n_gpus"]
     assert 1.0 <= b["2"] <= b["8"] < 8.0
     assert d["cpu_baseline"]["kind"] == "port" and d["roofline"]["bound"] == "hbm"
+    # the same launch also ran the throughput region: N independent graphs, one per rank, every rank checked its own
+    ar = d["aggregate_replicas"]
+    assert ar["scaling"] == "weak" and ar["graphs"] == 2 and ar["value"] > 0 and ar["checked"]
+    assert all(r["replica_checked"] for r in d["per_rank"])
