@@ -41,7 +41,7 @@ struct PeerDev {
     DevBuf e_in0, e_in1, e_out, e_op, goff, aoff, tmpl, tables, b_in0, b_in1, b_out, b_op, acc;
     DevBuf fmt_len, fmt_off, fmt_text, fmt_table, scan_tmp;      // c2a_format_bristol prints a device's own gates on that device
     DevBuf vscratch;                                             // c2a_verify_boolify checks a device's own gates on that device
-    u32 tmpl_width = 0;
+    u32 tmpl_width = 0, tmpl_mask = 0;
 };
 
 struct c2a_ctx {
@@ -91,6 +91,7 @@ struct c2a_ctx {
     c2a_stats stats{};
     c2a_bool_info binfo{};
     u32 bool_width = 0;
+    u32 bool_op_mask = 0;          // gate types whose templates are on the device (for bool_width)
     u32 bool_max_aux = 0;          // most aux wires any template of that width has (scratch of the local verifier)
     u64 op_hist[C2A_NUM_GATE_TYPES] = {};   // gates per type of the loaded circuit (c2a_load_gates looks at every op byte anyway): the totals of a
                                    // boolify plan are sums over it — the plan needs no read-back in the middle of c2a_boolify
@@ -113,7 +114,8 @@ struct c2a_ctx {
     u32 jump_rounds = 0; uint2* jump_a = nullptr; uint2* jump_b = nullptr;      // pointer jumping: launches queued, the ping-pong buffers as they stand
     const uint2* rank_suffix = nullptr;    // the splitter suffix sums the list ranking ended in (which of its ping-pong buffers)
     DevBuf scan_tmp, scan_desc, scalars, dfs_state, dfs_stack, peel_prof, peel_trace;
-    DevBuf tsz, asz, goff, aoff, tmpl, tables, b_in0, b_in1, b_out, b_op;
+    DevBuf tsz, asz, goff, aoff, tmpl, tables, b_pool;
+    DevBuf b_in0, b_in1, b_out, b_op;      // VIEWS into b_pool (ensure_bool_out): one hipMalloc for the four streams of the boolean circuit — four cost a one-shot caller 0.9 ms
     DevBuf fmt_len, fmt_off, fmt_text, fmt_table, shard_cut, shard_qcut;
     u64 fmt_chunk_first = 0, fmt_chunk_cnt = 0;      // boolean gates held by the chunk buffers (c2a_boolify_chunk)
     bool fmt_chunk_valid = false;                    // ... of the circuit and plan now current (reset wherever the plan is)
@@ -130,7 +132,7 @@ struct c2a_ctx {
                &gstat, &clist, &pctl, &pcold, &meta, &node, &child, &rbits, &rpre, &ridx, &rlist, &next,
                &owner, &local, &slist, &sjump, &sjump2, &sorted, &sorted_r, &first, &nflag, &wflag, &widx, &node_wire1,
                &node_wire, &e_in0, &e_in1, &e_out, &e_op, &pos_r, &wire_r, &erec, &pblk, &dpre, &epre, &gflag, &scan_tmp, &scan_desc, &scalars, &dfs_state, &dfs_stack, &peel_prof, &peel_trace, &tsz, &asz, &goff,
-               &aoff, &tmpl, &tables, &b_in0, &b_in1, &b_out, &b_op, &fmt_len, &fmt_off, &fmt_text, &fmt_table, &shard_cut, &shard_qcut, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &ev_lcount, &ev_lbase, &ev_lorder, &ev_bar, &ev_io, &g_in0, &g_in1, &g_out, &g_op, &pr_rep, &pr_need, &pr_tin0, &pr_tin1, &pr_top, &pr_live, &pr_goff, &pr_counts, &p_in0, &p_in1, &p_out, &p_op, &cb_in0, &cb_in1, &cb_out, &cb_op};
+               &aoff, &tmpl, &tables, &b_pool, &fmt_len, &fmt_off, &fmt_text, &fmt_table, &shard_cut, &shard_qcut, &ev_produced, &ev_spos, &ev_aval, &ev_bval, &ev_lcount, &ev_lbase, &ev_lorder, &ev_bar, &ev_io, &g_in0, &g_in1, &g_out, &g_op, &pr_rep, &pr_need, &pr_tin0, &pr_tin1, &pr_top, &pr_live, &pr_goff, &pr_counts, &p_in0, &p_in1, &p_out, &p_op, &cb_in0, &cb_in1, &cb_out, &cb_op};
     }
 };
 
@@ -153,6 +155,16 @@ int fail(c2a_ctx* c, int code, const std::string& msg) {
             return fail(c, C2A_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));             \
     } while (0)
 
+int ensure(c2a_ctx* c, DevBuf& b, size_t bytes);
+// the four SoA streams of G boolean gates (+ 16 of slack each: k_boolify stores op bytes sixteen at a time) in ONE allocation
+int ensure_bool_out(c2a_ctx* c, u64 G) {
+    const size_t w4 = (((size_t)G + 16) * 4 + 4095) & ~(size_t)4095, w1 = ((size_t)G + 16 + 4095) & ~(size_t)4095;
+    int r = ensure(c, c->b_pool, 3 * w4 + w1);
+    if (r) return r;
+    char* p = c->b_pool.as<char>();
+    c->b_in0.p = p; c->b_in0.cap = w4; c->b_in1.p = p + w4; c->b_in1.cap = w4; c->b_out.p = p + 2 * w4; c->b_out.cap = w4; c->b_op.p = p + 3 * w4; c->b_op.cap = w1;
+    return C2A_OK;
+}
 int ensure(c2a_ctx* c, DevBuf& b, size_t bytes) {
     if (bytes == 0) bytes = 16;
     if (b.cap >= bytes) return C2A_OK;
@@ -829,6 +841,25 @@ int copy_out(c2a_ctx* c, void* host, const void* dev, size_t bytes) {
 
 }  // namespace
 
+#ifndef C2A_EMULATE
+// The runtime loads the code object and resolves a kernel on its FIRST launch: for a one-shot caller (the reference calls
+// build_circuit once per process, src/main.rs:28-32) that was 2.7 ms inside the first build's first stage.  Asking for the
+// attributes of the build's kernels does the same work here, next to the 100 ms the HIP context takes to come up.
+void warm_functions() {
+    hipFuncAttributes a;
+#define C2A_WARM(k) (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k))
+    C2A_WARM(k_clear); C2A_WARM(k_validate); C2A_WARM(k_mark_inputs); C2A_WARM(k_mark_outputs); C2A_WARM(k_producer); C2A_WARM(k_relabel); C2A_WARM(k_dup_clear);
+    C2A_WARM(k_dup_producer); C2A_WARM(k_deps); C2A_WARM(k_gstat); C2A_WARM(k_set_cold); C2A_WARM(k_peel_sinks); C2A_WARM(k_peel_shallow);
+    C2A_WARM(k_peel<false>); C2A_WARM(k_post_peel); C2A_WARM(k_root_bits); C2A_WARM(k_root_list); C2A_WARM(k_euler_next); C2A_WARM(k_rank_mark);
+    C2A_WARM(k_post_words); C2A_WARM(k_rank_walk); C2A_WARM(k_rank_jump); C2A_WARM(k_rank_final); C2A_WARM(k_sorted_split); C2A_WARM(k_node_init);
+    C2A_WARM(k_input_wires); C2A_WARM(k_pos_first<false>); C2A_WARM(k_pos_first<true>); C2A_WARM(k_pos_bits); C2A_WARM(k_assign_outputs); C2A_WARM(k_pos_rank);
+    C2A_WARM(k_emit_rank); C2A_WARM(k_emit_split<true>); C2A_WARM(k_emit_split<false>); C2A_WARM(k_unbias);
+    C2A_WARM((k_scan_stream<1, ScanFromU32, u32>)); C2A_WARM((k_scan_stream<1, ScanPopc, u32>)); C2A_WARM((k_scan_stream<2, ScanPosBits, u32>));
+    C2A_WARM((k_scan_stream<2, ScanBoolSizes, u64>)); C2A_WARM((k_boolify<256, 1024>));
+#undef C2A_WARM
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
@@ -894,6 +925,9 @@ int c2a_create(int n_devices, const int* device_ids, c2a_ctx** out) {
         if (hipSetDevice(P.device) != hipSuccess || hipStreamCreate(&P.stream) != hipSuccess) { (void)hipSetDevice(device_id); c2a_destroy(c); return C2A_ERR_HIP; }
     }
     (void)hipSetDevice(device_id);
+#ifndef C2A_EMULATE
+    if (std::getenv("C2A_NO_WARM") == nullptr) warm_functions();
+#endif
     *out = c;
     return C2A_OK;
 }
@@ -931,32 +965,16 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     if (n64 && (!lh || !rh || !out || !op)) return fail(c, C2A_ERR_ARG, "c2a_load_gates: null gate arrays");
     if ((n_in && !input_nodes) || (n_out && !output_nodes)) return fail(c, C2A_ERR_ARG, "c2a_load_gates: null IO lists");
     const u32 n = (u32)n64;
-    // argument validation on the host copy (ids must address the node table; op must be an AGateType)
-    u64 hist[C2A_NUM_GATE_TYPES] = {};
-    for (u64 g = 0; g < n; ++g) {
-        if (lh[g] >= n_nodes || rh[g] >= n_nodes || out[g] >= n_nodes)
-            return fail(c, C2A_ERR_ARG, "c2a_load_gates: node id >= n_nodes at gate " + std::to_string(g));
-        if (op[g] >= C2A_NUM_GATE_TYPES)
-            return fail(c, C2A_ERR_ARG, "c2a_load_gates: unknown gate type at gate " + std::to_string(g));
-        ++hist[op[g]];
-    }
+    // argument validation: the IO lists here, the gates on the device behind their copy (k_validate: ids must address the node
+    // table; op must be an AGateType)
     for (u32 i = 0; i < n_in; ++i)
         if (input_nodes[i] >= n_nodes) return fail(c, C2A_ERR_ARG, "c2a_load_gates: input node id >= n_nodes");
     for (u32 i = 0; i < n_out; ++i)
         if (output_nodes[i] >= n_nodes) return fail(c, C2A_ERR_ARG, "c2a_load_gates: output node id >= n_nodes");
     HIP_TRY(hipSetDevice(c->device));
     c->n = n; c->n_nodes = n_nodes; c->n_in = n_in; c->n_out = n_out;
-    std::memcpy(c->op_hist, hist, sizeof(hist));
     c->bool_planned = false; c->fmt_chunk_valid = false; c->pruned = false; c->gathered = false; c->peel_meta_valid = false; c->stats = c2a_stats{}; c->binfo = c2a_bool_info{};
-    {   // the reference checks this BEFORE it sorts (compiler.rs:363-383 precede :408), so build_circuit must report it first
-        std::vector<u32> a(input_nodes, input_nodes + n_in), b(output_nodes, output_nodes + n_out);
-        std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
-        c->io_clash = false;
-        for (size_t i = 0, j = 0; i < a.size() && j < b.size();) {
-            if (a[i] == b[j]) { c->io_clash = true; break; }
-            if (a[i] < b[j]) ++i; else ++j;
-        }
-    }
+    c->io_clash = false;
     const size_t n4 = (size_t)n * 4, nn4 = (size_t)n_nodes * 4;
     ENSURE(c->lh, n4); ENSURE(c->rh, n4); ENSURE(c->out, n4); ENSURE(c->op, n); ENSURE(c->gate4, (size_t)n * 16);
     ENSURE(c->nrec, (size_t)n_nodes * 16); ENSURE(c->orig, n4);
@@ -994,8 +1012,31 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     }
     if (n_in) HIP_TRY(hipMemcpyAsync(c->in_nodes.p, input_nodes, (size_t)n_in * 4, hipMemcpyHostToDevice, s));
     if (n_out) HIP_TRY(hipMemcpyAsync(c->out_nodes.p, output_nodes, (size_t)n_out * 4, hipMemcpyHostToDevice, s));
+    // behind the copies: the gates validated and counted by type, and "a node is both an input and an output" — the reference
+    // checks that BEFORE it sorts (compiler.rs:363-383 precede :408), so build_circuit must be able to report it first
+    enum { LD_HIST = 0, LD_BAD = 32, LD_CLASH = 33, LD_WORDS = 34 };
+    static_assert(LD_WORDS <= SC_WORDS && C2A_NUM_GATE_TYPES <= 32, "the scalars block holds the load's read-back");
+    u32 ld[LD_WORDS];
+    HIP_TRY(hipMemsetAsync(c->scalars.p, 0, SC_WORDS * 4, s));
+    HIP_TRY(hipMemsetAsync(c->scalars.as<u32>() + LD_BAD, 0xFF, 4, s));
+    if (n) C2A_LAUNCH(k_validate, grid_for(n, 2048), kThreads, s, n, (const u32*)c->lh.as<u32>(), (const u32*)c->rh.as<u32>(), (const u32*)c->out.as<u32>(), (const u8*)c->op.as<u8>(), n_nodes,
+                      (u32)C2A_NUM_GATE_TYPES, c->scalars.as<u32>() + LD_BAD, c->scalars.as<u32>() + LD_HIST);
+    if (n_in && n_out) {
+        HIP_TRY(hipMemsetAsync(c->nflag.p, 0, (size_t)n_nodes, s));
+        C2A_LAUNCH_NOSYNC(k_mark_inputs, grid_for(n_in, 1024), kThreads, s, n_in, c->in_nodes.as<u32>(), c->nflag.as<u8>());
+        C2A_LAUNCH_NOSYNC(k_mark_outputs, grid_for(n_out, 1024), kThreads, s, n_out, c->out_nodes.as<u32>(), c->nflag.as<u8>(), c->scalars.as<u32>() + LD_CLASH);
+    }
+    HIP_TRY(hipMemcpyAsync(ld, c->scalars.p, sizeof(ld), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipStreamSynchronize(c->aux));
+    if (ld[LD_BAD] != 0xFFFFFFFFu) {
+        const u64 g = ld[LD_BAD];
+        if (lh[g] >= n_nodes || rh[g] >= n_nodes || out[g] >= n_nodes)
+            return fail(c, C2A_ERR_ARG, "c2a_load_gates: node id >= n_nodes at gate " + std::to_string(g));
+        return fail(c, C2A_ERR_ARG, "c2a_load_gates: unknown gate type at gate " + std::to_string(g));
+    }
+    for (u32 t = 0; t < C2A_NUM_GATE_TYPES; ++t) c->op_hist[t] = ld[LD_HIST + t];
+    c->io_clash = ld[LD_CLASH] != 0;
     if (cleared) { c->node_clear = false; c->peel_epoch = 0; }
     c->stage = ST_LOADED;
     return C2A_OK;
@@ -1119,12 +1160,18 @@ int bool_plan(c2a_ctx* c, uint32_t width) {
     c->bool_planned = false; c->fmt_chunk_valid = false; c->pruned = false; c->gathered = false;      // (until this plan is complete; the chunk buffers belong to the plan before)
     hipStream_t s = c->stream;
     const u32 n = c->n;
-    // templates for this width (host-generated once per width, cached in HBM)
-    if (c->bool_width != width) {
+    // templates for this width (host-generated once per width and set of gate types, cached in HBM) — of the types the loaded
+    // circuit HAS only: the twenty of them are 0.2 M entries at width 32 (APow alone 178 100), 1.5 ms of a one-shot caller's
+    // first c2a_boolify for seven types of a few hundred entries
+    u32 need_mask = 0;
+    for (u32 op = 0; op < C2A_NUM_GATE_TYPES; ++op) if (c->op_hist[op]) need_mask |= 1u << op;
+    if (c->bool_width != width || (need_mask & ~c->bool_op_mask)) {
+        if (c->bool_width == width) need_mask |= c->bool_op_mask;
         std::vector<TemplateEntry> all;
-        BoolTables T;
+        BoolTables T{};
         u32 max_aux = 0;
         for (u32 op = 0; op < 20; ++op) {
+            if (!(need_mask >> op & 1u)) continue;
             TemplateBuilder tb(width);
             tb.build(op);
             T.toff[op] = (u32)all.size();
@@ -1139,6 +1186,7 @@ int bool_plan(c2a_ctx* c, uint32_t width) {
         HIP_TRY(hipMemcpyAsync(c->tables.p, &T, sizeof(T), hipMemcpyHostToDevice, s));
         HIP_TRY(hipStreamSynchronize(s));
         c->bool_width = width;
+        c->bool_op_mask = need_mask;
         c->bool_max_aux = max_aux;
         std::memcpy(c->host_tsize, T.tsize, sizeof(T.tsize)); std::memcpy(c->host_taux, T.taux, sizeof(T.taux));
     }
@@ -1225,7 +1273,7 @@ int bool_map_sharded(c2a_ctx* c) {
     { int r0 = shard_cuts(c, N, cut, qcut); if (r0) return r0; }
     c->shard0_hi = cut[1]; c->shard0_qhi = qcut[1];
     const u64 G0 = qcut[1];
-    ENSURE(c->b_in0, G0 * 4 + 16); ENSURE(c->b_in1, G0 * 4 + 16); ENSURE(c->b_out, G0 * 4 + 16); ENSURE(c->b_op, G0 + 16);
+    { int rb = ensure_bool_out(c, G0); if (rb) return rb; }
     rec(c, EV_BPREP1);
     // peers first (their copies and kernels overlap the primary's own shard)
     std::vector<TemplateEntry> tmpl_host;
@@ -1254,10 +1302,10 @@ int bool_map_sharded(c2a_ctx* c) {
         HIP_TRY(hipMemcpyPeerAsync(P.e_op.p, P.device, c->e_op.as<u8>() + P.p_lo, c->device, np, P.stream));
         HIP_TRY(hipMemcpyPeerAsync(P.goff.p, P.device, c->goff.as<u64>() + P.p_lo, c->device, (np + 1) * 8, P.stream));
         HIP_TRY(hipMemcpyPeerAsync(P.aoff.p, P.device, c->aoff.as<u64>() + P.p_lo, c->device, (np + 1) * 8, P.stream));
-        if (P.tmpl_width != c->bool_width) {
+        if (P.tmpl_width != c->bool_width || P.tmpl_mask != c->bool_op_mask) {
             HIP_TRY(hipMemcpyPeerAsync(P.tmpl.p, P.device, c->tmpl.p, c->device, c->tmpl.cap, P.stream));
             HIP_TRY(hipMemcpyPeerAsync(P.tables.p, P.device, c->tables.p, c->device, sizeof(BoolTables), P.stream));
-            P.tmpl_width = c->bool_width;
+            P.tmpl_width = c->bool_width; P.tmpl_mask = c->bool_op_mask;
         }
         const BoolSrc S{P.e_in0.as<u32>(), P.e_in1.as<u32>(), P.e_out.as<u32>(), P.e_op.as<u8>(), P.goff.as<u64>(), P.aoff.as<u64>(),
                         P.tmpl.as<uint4>(), P.tables.as<BoolTables>(), P.p_lo, P.stream};
@@ -1288,7 +1336,7 @@ int c2a_boolify(c2a_ctx* c, uint32_t width, c2a_bool_info* info) {
         if (r) return r;
     } else {
         const u64 G = c->binfo.n_gates;
-        ENSURE(c->b_in0, G * 4); ENSURE(c->b_in1, G * 4); ENSURE(c->b_out, G * 4); ENSURE(c->b_op, G);
+        if ((r = ensure_bool_out(c, G))) return r;
         rec(c, EV_BPREP1);
         r = bool_map(c, primary_src(c), 0, c->n, 0, c->b_in0.as<u32>(), c->b_in1.as<u32>(), c->b_out.as<u32>(), c->b_op.as<u8>());
         if (r) return r;
