@@ -75,6 +75,7 @@ struct c2a_ctx {
     bool io_clash = false;         // a node is both an input and an output (compiler.rs:363-383), found at load time
     bool peel_meta_valid = false;  // meta[] / stats.levels describe the circuit now loaded (c2a_verify_boolify schedules by them)
     bool node_clear = true;        // node records must be zeroed before the next run (new graph, or a run that failed)
+    bool peel_deep = false;        // the DFS tree of the loaded graph is deeper than one chunk of path string: the DEEP build of the dataflow launch
     bool peel_gave_up = false;     // the last dataflow launch ended by its watchdog (do_peel retries once on clean buffers, then do_topo_sort sorts serially)
     bool serial_fallback = false;  // ... and that happened for the circuit now loaded (logged once per context)
     bool fallback_logged = false;
@@ -338,8 +339,8 @@ u32 peel_grid(c2a_ctx* c, bool stats, u32* n_primary) {
     return 16;                                      // the emulation runs them one after the other
 #else
     int per_cu = 0;
-    hipError_t e = stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_peel<true>, 64, 0)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_peel<false>, 64, 0);
+    hipError_t e = stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_peel<true, true>, 64, 0)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_peel<false, true>, 64, 0);
     if (e != hipSuccess || per_cu < 1) per_cu = 1;
     const u32 w = std::min<u32>(c->peel_waves, (u32)per_cu);
     const u32 r = std::min<u32>(c->peel_reserve, (u32)per_cu - w);
@@ -442,8 +443,10 @@ int peel_launch(c2a_ctx* c) {
     // (every wave of the launch is alive at once under emulation too, interleaved at the back-offs — in a shuffled order per
     // C2A_EMUL_SEED: the ticket / hand-off / termination protocol is exercised without a GPU)
     rec(c, EV_KPEEL0);
-    if (want_stats) C2A_LAUNCH_CONCURRENT((k_peel<true>), waves, 64, s, A);
-    else C2A_LAUNCH_CONCURRENT((k_peel<false>), waves, 64, s, A);
+    // (trees deeper than one chunk of path string take the DEEP build of the launch: found out by the plain one, remembered per graph)
+    if (want_stats) { if (c->peel_deep) C2A_LAUNCH_CONCURRENT((k_peel<true, true>), waves, 64, s, A); else C2A_LAUNCH_CONCURRENT((k_peel<true, false>), waves, 64, s, A); }
+    else if (c->peel_deep) C2A_LAUNCH_CONCURRENT((k_peel<false, true>), waves, 64, s, A);
+    else C2A_LAUNCH_CONCURRENT((k_peel<false, false>), waves, 64, s, A);
     rec(c, EV_KPEEL1);
     static_assert(CTL_PROCESSED == 0 && CTL_MAXLEVEL == 1 && CTL_ABORT == 2 && CTL_REREADS == 3, "the order k_post_peel writes them in");
     C2A_LAUNCH(k_post_peel, 1, 64, s, c->hrb_dev, (const u32*)c->pctl.as<u32>(), (const u32*)(c->cons_off.as<u32>() + n), (const u32*)(c->scalars.as<u32>() + SC_DUP), n,
@@ -467,6 +470,7 @@ int peel_result(c2a_ctx* c, u32* peeled_out) {
     if (c->emul_peel_abort) { --c->emul_peel_abort; t4[CTL_ABORT] = 1; }      // (tests: a launch that "gave up", to exercise the retry and the serial fall-back)
 #endif
     c->rb_edges = c->hrb[4]; c->rb_dup = c->hrb[5];      // (ride along: one round trip)
+    const bool need_deep = c->hrb[6] != 0 && !c->peel_deep;
     if (want_stats) {
         ull st[32];
         HIP_TRY(hipMemcpy(st, c->peel_prof.p, 256, hipMemcpyDeviceToHost));
@@ -513,6 +517,7 @@ int peel_result(c2a_ctx* c, u32* peeled_out) {
         if (st[2]) std::fprintf(stderr, "[c2a peel stats] per hand-off entry: %.0f ns waiting for its two tickets, %.0f ns writing it\n", st[19] * 10.0 / st[2], (st[17] - st[19]) * 10.0 / st[2]);
     }
     c->peel_gave_up = t4[CTL_ABORT] != 0;
+    if (need_deep) { c->peel_deep = true; c->err = "dataflow peel: the DFS tree is deeper than one chunk of path string"; return C2A_ERR_HIP; }      // (the caller runs the DEEP launch)
     if (t4[CTL_ABORT]) return fail(c, C2A_ERR_HIP, "dataflow peel: watchdog tripped (" + std::to_string(t4[CTL_ABORT]) + " waves gave up waiting)");
     c->node_clear = false;
     *peeled_out = t4[CTL_PROCESSED];
@@ -664,6 +669,7 @@ int do_topo_sort(c2a_ctx* c, u64* cycle_at, bool defer_sorted = false) {
     rec(c, EV_PREP1);
     u32 peeled = 0;
     c->serial_fallback = false;
+    bool deep_before = c->peel_deep;
     for (int attempt = 0;; ++attempt) {
         if ((r = peel_launch(c))) return r;
         rec(c, EV_PEEL1);
@@ -671,10 +677,12 @@ int do_topo_sort(c2a_ctx* c, u64* cycle_at, bool defer_sorted = false) {
         HIP_TRY(hipEventSynchronize(c->ev[EV_ORDER_RB]));       // (the walk and the jumps run meanwhile)
         r = peel_result(c, &peeled);
         if (!(r == C2A_ERR_HIP && c->peel_gave_up)) break;
-        if (attempt == 0) {
+        const bool deep_switch = c->peel_deep && !deep_before;
+        if (deep_switch) { deep_before = true; --attempt; }      // (not a failure: the plain launch found the tree deeper than one chunk)
+        if (attempt <= 0) {
             // the launch's watchdog tripped (a wave waited too long for a record or for global progress): once more on clean
             // buffers — node records re-zeroed, tickets and child pointers reset — before the serial DFS takes over
-            std::fprintf(stderr, "[c2a] the dataflow peel gave up (%s); retrying once on clean buffers\n", c->err.c_str());
+            if (!deep_switch) std::fprintf(stderr, "[c2a] the dataflow peel gave up (%s); retrying once on clean buffers\n", c->err.c_str());
             HIP_TRY(hipMemsetAsync(c->fill.p, 0, (size_t)c->n * 4, c->stream));
             HIP_TRY(hipMemsetAsync(c->child.p, 0xFF, (size_t)c->n * 8, c->stream));
             HIP_TRY(hipMemsetAsync(c->scalars.as<u32>() + SC_MAXDEPTH, 0, 8, c->stream));
@@ -850,7 +858,7 @@ void warm_functions() {
 #define C2A_WARM(k) (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k))
     C2A_WARM(k_clear); C2A_WARM(k_validate); C2A_WARM(k_mark_inputs); C2A_WARM(k_mark_outputs); C2A_WARM(k_producer); C2A_WARM(k_relabel); C2A_WARM(k_dup_clear);
     C2A_WARM(k_dup_producer); C2A_WARM(k_deps); C2A_WARM(k_gstat); C2A_WARM(k_set_cold); C2A_WARM(k_peel_sinks); C2A_WARM(k_peel_shallow);
-    C2A_WARM(k_peel<false>); C2A_WARM(k_post_peel); C2A_WARM(k_root_bits); C2A_WARM(k_root_list); C2A_WARM(k_euler_next); C2A_WARM(k_rank_mark);
+    C2A_WARM((k_peel<false, false>)); C2A_WARM(k_post_peel); C2A_WARM(k_root_bits); C2A_WARM(k_root_list); C2A_WARM(k_euler_next); C2A_WARM(k_rank_mark);
     C2A_WARM(k_post_words); C2A_WARM(k_rank_walk); C2A_WARM(k_rank_jump); C2A_WARM(k_rank_final); C2A_WARM(k_sorted_split); C2A_WARM(k_node_init);
     C2A_WARM(k_input_wires); C2A_WARM(k_pos_first<false>); C2A_WARM(k_pos_first<true>); C2A_WARM(k_pos_bits); C2A_WARM(k_assign_outputs); C2A_WARM(k_pos_rank);
     C2A_WARM(k_emit_rank); C2A_WARM(k_emit_split<true>); C2A_WARM(k_emit_split<false>); C2A_WARM(k_unbias);
@@ -975,6 +983,7 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     c->n = n; c->n_nodes = n_nodes; c->n_in = n_in; c->n_out = n_out;
     c->bool_planned = false; c->fmt_chunk_valid = false; c->pruned = false; c->gathered = false; c->peel_meta_valid = false; c->stats = c2a_stats{}; c->binfo = c2a_bool_info{};
     c->io_clash = false;
+    c->peel_deep = false;
     const size_t n4 = (size_t)n * 4, nn4 = (size_t)n_nodes * 4;
     ENSURE(c->lh, n4); ENSURE(c->rh, n4); ENSURE(c->out, n4); ENSURE(c->op, n); ENSURE(c->gate4, (size_t)n * 16);
     ENSURE(c->nrec, (size_t)n_nodes * 16); ENSURE(c->orig, n4);

@@ -1043,7 +1043,7 @@ __global__ void k_post_peel(u32* dst, const u32* ctl, const u32* edges, const u3
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { done += __shfl_xor(done, off, 64); const u32 o = __shfl_xor(lvl, off, 64); lvl = o > lvl ? o : lvl; }
     if (t == 0) {
-        dst[0] = done; dst[1] = lvl; dst[2] = ctl[CTL_ABORT]; dst[3] = ctl[CTL_REREADS]; dst[4] = *edges; dst[5] = *dup;
+        dst[0] = done; dst[1] = lvl; dst[2] = ctl[CTL_ABORT]; dst[3] = ctl[CTL_REREADS]; dst[4] = *edges; dst[5] = *dup; dst[6] = ctl[CTL_NEEDDEEP];
         *ok = (ctl[CTL_ABORT] == 0u && done == n) ? 1u : 0u;      // (what the order stage, queued right behind, goes by)
     }
 }

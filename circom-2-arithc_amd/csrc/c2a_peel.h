@@ -22,7 +22,10 @@
 // every second run only — k_peel alternated between 6.95 and 7.20 ms with the run tag.
 //   word 0      root gate id << 32 | depth in the DFS tree
 //   word 1      reverse Kahn level << 32 | cprev (ancestor at the start of the node's current chunk; deep trees only)
-//   word 2      where a child's edge label goes in the string: word index << 8 | bit (no division on the hot path)
+//   word 2      high half: where a child's edge label goes in the string: word index << 8 | bit (no division on the hot path);
+//               low half: the ROOT KEY, the bit-reversed original id of the DFS root — a candidate's compare word of lane 2, so that
+//               ONE compare decides root and path: the lowest differing bit of the lowest differing lane, and whoever has a 0
+//               there wins (reversed, the highest differing bit of the ids comes first: the smaller root)
 //   words 3..63 the node's path string, ZERO-PADDED: 62 payload bits per word, bit j = label of the edge entering depth j+1
 // A string is held in chunks of kChunkBits = 61 x 62 = 3782 bits; a node keeps its CURRENT chunk only.  Comparing two
 // candidates P(a).la and P(b).lb that are shallower than a chunk (the 10 M-gate headline graph: depth 3 471): append
@@ -102,7 +105,7 @@ constexpr u32 kPollLimit = 1u << 21;        // ~1 s of polling for a record: giv
 #endif
 constexpr u32 kWatchdogChecks = 1u << 15;   // idle-side checks (one per 32 polls, ~100 us apart) without global progress
 // control block (u32 words; every hot word on its own 128-byte line)
-enum PeelCtl { CTL_PROCESSED = 0, CTL_MAXLEVEL = 1, CTL_ABORT = 2, CTL_REREADS = 3, CTL_DONE = 4, CTL_HEARTBEAT = 32, CTL_SEEDNEXT = 64,
+enum PeelCtl { CTL_PROCESSED = 0, CTL_MAXLEVEL = 1, CTL_ABORT = 2, CTL_REREADS = 3, CTL_DONE = 4, CTL_NEEDDEEP = 5, CTL_HEARTBEAT = 32, CTL_SEEDNEXT = 64,
                CTL_BEGIN = 128, CTL_END = CTL_BEGIN + 64 * 32, CTL_DEMAND = CTL_END + 64 * 32,
                // gates done (word 0) and the highest level seen (word 1), in kAcctShards parts like BEGIN / END: thousands of
                // workgroups (sinks pass, level-1 pass) and every wave of the launch report here as they leave, and atomics on
@@ -286,6 +289,16 @@ __global__ void k_gstat(u32 n, const u32* __restrict__ dep0, const u32* __restri
     }
 }
 
+__device__ __forceinline__ u64 c2a_brev64(u64 x) {
+#ifdef C2A_EMULATE
+    u64 r = 0;
+    for (int i = 0; i < 64; ++i) { r = (r << 1) | (x & 1ull); x >>= 1; }
+    return r;
+#else
+    return __brevll(x);
+#endif
+}
+__device__ __forceinline__ u32 c2a_brev32(u32 x) { return (u32)(c2a_brev64((u64)x) >> 32); }
 // ------------------------------------------------------------------------------------------------
 // sinks (gates nobody consumes: DFS roots of depth 0, no candidates) — a plain grid-stride pass; the producers they
 // claim seed the dataflow launch.  No shared counter: workgroup b appends to its own region under its own counter.
@@ -309,7 +322,7 @@ __global__ void __launch_bounds__(256) k_peel_sinks(PeelArgs A) {
                 A.meta[g] = make_uint4(C2A_NONE, 0u, gi.z, 0u);
                 A.node[g * kNodeWords] = tag | hdr0_word(gi.z, 0u);
                 A.node[g * kNodeWords + 1] = tag | hdr1_word(0u, C2A_NONE);
-                A.node[g * kNodeWords + 2] = tag;
+                A.node[g * kNodeWords + 2] = tag | c2a_brev32(gi.z);
                 const uint4 g2 = A.gstat[2 * g + 1];
                 const u32 deps[2] = {gi.x, gi.y}, cnts[2] = {g2.y, g2.w};
 #pragma unroll
@@ -354,15 +367,6 @@ __global__ void __launch_bounds__(256) k_peel_sinks(PeelArgs A) {
 // in ITS region of `out` (no shared counter; a region that is full sends the rest straight to the flat list: any claimed
 // gate may start a chain at any time), and the LAST pass moves its regions to one flat list (a single reservation per
 // workgroup): the seeds of the dataflow launch, which its waves take a few at a time.
-__device__ __forceinline__ u64 c2a_brev64(u64 x) {
-#ifdef C2A_EMULATE
-    u64 r = 0;
-    for (int i = 0; i < 64; ++i) { r = (r << 1) | (x & 1ull); x >>= 1; }
-    return r;
-#else
-    return __brevll(x);
-#endif
-}
 __global__ void __launch_bounds__(256) k_peel_shallow(PeelArgs A, const u32* __restrict__ cons_off, u32 lvl, u32 last, const u32* __restrict__ in, const u32* __restrict__ in_cnt, u32 in_cap,
                                                       u32* out, u32* out_cnt, u32 out_cap, u32* flat, u32* flat_total) {
     // what a lane decided about its gate, for the wave that writes the records
@@ -449,7 +453,7 @@ __global__ void __launch_bounds__(256) k_peel_shallow(PeelArgs A, const u32* __r
             u64 w = tag;
             if (l16 == 0) w |= hdr0_word(root, depth);
             else if (l16 == 1) w |= hdr1_word(lvl, C2A_NONE);
-            else if (l16 == 2) w |= (u64)depth;      // (where a child's label goes: word 0, bit `depth` — depth < 63 down here)
+            else if (l16 == 2) w |= ((u64)depth << 32) | c2a_brev32(root);      // (where a child's label goes: word 0, bit `depth` — depth < 62 down here —; the root key)
             else if (l16 == kHdrWords) w |= s_str[j];
             A.node[(u64)gj * kNodeWords + l16] = w;
         }
@@ -486,7 +490,10 @@ struct StepIO {
 
 // the dataflow launch: 64-thread workgroups (one wave each)
 template <int SET> struct StepSet { static constexpr int value = SET; };
-template <bool STATS>
+// DEEP: the DFS tree may be deeper than one chunk of path string (kChunkBits levels).  The launch WITHOUT it leaves the
+// chunk-boundary code out of the hot path (a compare and a branch per candidate, one more per step) and raises CTL_NEEDDEEP +
+// ABORT when a node fills its chunk: the host then runs the DEEP launch on clean buffers and remembers it for the loaded graph.
+template <bool STATS, bool DEEP>
 __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in) {
     SRegs sr;
     PeelArgs A = A_in;
@@ -504,6 +511,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
     }
     const u32 epoch = A.epoch;
     const TagCheck tagc = tag_check(epoch, A.pad_thr, lane);
+    const u32 cmp_hi_mask = lane == 2u ? 0u : kHdrMask;      // a record word -> its compare word: the payload; lane 2: the root key alone
     // byte offset of the word of a hand-off entry that this lane writes: lanes 8..15 words 0..7 (the pushed gate's static
     // records), lanes 32..39 words 8..15 (its first consumers, its id)
     const u32 ent_off = (lane >= 8u && lane < 16u) ? (lane - 8u) * 8u : ((lane >= 32u && lane < 40u) ? (lane - 24u) * 8u : C2A_NONE);
@@ -792,7 +800,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             const ull ph2 = STATS ? c2a_now() : 0;
             // ---- tournament of THIS gate
             u32 level = own_level + 1u;
-            if (!(ch_root < g_orig)) { ch = C2A_NONE; ch_el = 0; ch_root = g_orig; ch_depth = 0; ch_pos = 0; ch_w = 0; ch_x = 0; }
+            if (!(ch_root < g_orig)) { ch = C2A_NONE; ch_el = 0; ch_root = g_orig; ch_depth = 0; ch_pos = 0; ch_w = 0; ch_x = (u64)wrlane_c<2>(c2a_brev32(g_orig), 0u); }
             // one candidate: its record must be all there (else read it again: out of line), then it meets the champion
             auto candidate = [&](u64& w, u32 e) {             // (w by reference: the cold path mends it in place, no copy)
                 const u32 c = e & kIdMask, el = e >> 31;
@@ -808,11 +816,11 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                         // It never arrived (or the launch is being given up already): fail loudly — ABORT tells the host, which
                         // discards the run — and leave the candidate out.  The chain goes on (no flag to carry through the hot
                         // path); once ABORT is up no re-read waits any more, chains run out and waiting waves leave.
-                        // (left out = replaced by a record that loses to everything: DFS root 2^31 - 1, no gate has that id.  No early
+                        // (left out = replaced by a record that loses to everything: DFS root 2^30 - 1 and its root key, no gate has that id.  No early
                         // exit from the candidate: what merges behind this cold block is the record alone, no flag — 8.95 -> 8.58 ms)
                         if ((badm & 1ull) != 0 || (badm & needed_lanes((u32)rdlane64(w, 0))) != 0) {
                             if (lane == 0) atomicAdd(&A.ctl[CTL_ABORT], 1u); wave_join();
-                            w = ((u64)epoch << kTagShift) | (lane == 0 ? (u64)kHdrMask << 32 : 0ull);
+                            w = ((u64)epoch << kTagShift) | (lane == 0 ? (u64)kHdrMask << 32 : (lane == 2u ? (u64)c2a_brev32(kHdrMask) : 0ull));
                         }
                     }
                     if (tag_stale_or_never(epoch, w)) w = 0ull;       // (the zero padding of a short record, whatever those words hold)
@@ -820,30 +828,32 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                 const u64 h0 = rdlane64(w, 0);
                 const u32 croot = hdr_hi(h0), cdepth = (u32)h0;
                 const u32 clevel = (rdlane((u32)(w >> 32), 1) & kHdrMask) + 1u;
-                const u32 cpos = rdlane((u32)w, 2);
+                const u32 cpos = rdlane((u32)(w >> 32), 2) & kHdrMask;
                 level = clevel > level ? clevel : level;
                 // the candidate's string with its edge label appended (meaningful while the chunk has room: cpos < kStrWords << 8)
-                u64 x = w & kPayload;
+                u64 x = (u64)(u32)w | ((u64)((u32)(w >> 32) & cmp_hi_mask) << 32);
                 if (lane == kHdrWords + (cpos >> 8)) x |= (u64)el << (cpos & 255u);
-                // (the new champion is taken INSIDE each branch: a 0 / 1 merged over the branches becomes a lane mask, a scalar
-                // pair that is set, combined and tested with four instructions per branch)
-                auto take = [&]() { ch = c; ch_el = el; ch_root = croot; ch_depth = cdepth; ch_pos = cpos; ch_w = w; ch_x = x; };
-                if (C2A_UNLIKELY(croot != ch_root)) {      // (the first few DFS roots own nearly everything below them)
-                    if (croot < ch_root) take();                                     // a larger DFS root loses at once (also to [g] itself)
-                } else if (C2A_LIKELY((cdepth > ch_depth ? cdepth : ch_depth) < kChunkBits)) {
-                    // neither path is a prefix of the other (that would be a cycle), and the same node with the other label
-                    // differs in the appended bit: the first differing bit decides
+                C2A_OPAQUE(x);       // (built HERE, in front of the branches: behind them it is shared code, and the way back into it costs a flag)
+                // ONE decision, then ONE place where the champion changes.  The hot case — same DFS root as the champion (the first
+                // few roots own nearly everything below them), both paths inside one chunk — is one straight line; everything else
+                // (another root, deep trees) one block out of line that ends in the same decision.  (A take per branch made the
+                // compiler carry two flags through the branches: ten instructions per candidate of nothing but that.)
+                u32 win;
+                if (!DEEP || C2A_LIKELY((cdepth > ch_depth ? cdepth : ch_depth) < kChunkBits)) {
+                    // lane 2 holds the root keys: another DFS root decides there (the smaller original id wins; [g] itself is a
+                    // champion whose key is the gate's own id).  Same root: neither path is a prefix of the other (that would be a
+                    // cycle), and the same node with the other label differs in the appended bit — the first differing bit decides
                     const u64 d = x ^ ch_x;
-                    const u64 bal = __ballot(d != 0) & ~7ull;
+                    const u64 bal = __ballot(d != 0) & ~3ull;
                     const u32 L = ctz64(bal);
-                    if (((u32)(rdlane64(x, L) >> ctz64(rdlane64(d, L))) & 1u) == 0u) take();
-                } else if (c == ch) {
-                    if (el < ch_el) take();
-                } else {
-                    // (the result of an out-of-line call counts as divergent; left like that, every value that depends on the
-                    // champion would move to vector registers and the whole tournament would be compiled as divergent code)
-                    if (uniform(deep_less(A.node, epoch, A.ctl, c, el, cdepth, w, ch, ch_el, ch_depth, ch_w, lane) ? 1u : 0u)) take();
-                }
+                    win = ((u32)(rdlane64(x, L) >> ctz64(rdlane64(d, L))) & 1u) ^ 1u;
+                } else if (croot != ch_root) win = croot < ch_root ? 1u : 0u;      // a larger DFS root loses at once (also to [g] itself)
+                else if (c == ch) win = el < ch_el ? 1u : 0u;
+                // (the result of an out-of-line call counts as divergent; left like that, every value that depends on the
+                // champion would move to vector registers and the whole tournament would be compiled as divergent code)
+                else win = uniform(deep_less(A.node, epoch, A.ctl, c, el, cdepth, w, ch, ch_el, ch_depth, ch_w, lane) ? 1u : 0u);
+                // (as selects — nine of them, always — this measured slower than the branch: 7.33 against 7.25 ms for the stage)
+                if (win) { ch = c; ch_el = el; ch_root = croot; ch_depth = cdepth; ch_pos = cpos; ch_w = w; ch_x = x; }
             };
             // the (up to two) records loaded ahead ...
             if (C2A_LIKELY(cur.take >= 1)) {
@@ -912,16 +922,16 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             const ull ph3 = STATS ? c2a_now() : 0;
             // ---- the node: its string is the champion's string with the label appended — the register built above
             u32 depth = 0, my_label = 0, cprev = C2A_NONE, my_pos = 0;
-            u64 str = 0;
+            u64 str = ch_x;      // (a DFS root of its own: the empty string, lane 2 = its root key — the reset above)
             if (C2A_LIKELY(ch != C2A_NONE)) {
                 depth = ch_depth + 1; my_label = ch_el;
                 u32 wi = ch_pos >> 8, bp = ch_pos & 255u;
                 if (C2A_UNLIKELY(wi >= kStrWords)) {           // the parent filled its chunk: a fresh one, the parent is its anchor
+                    if (!DEEP) { if (lane == 0) { atomicAdd(&A.ctl[CTL_NEEDDEEP], 1u); atomicAdd(&A.ctl[CTL_ABORT], 1u); } wave_join(); }
                     cprev = ch; wi = 0; bp = 0;
-                    str = lane == kHdrWords ? (u64)my_label : 0ull;
+                    str = lane == kHdrWords ? (u64)my_label : (lane == 2u ? (u64)c2a_brev32(ch_root) : 0ull);
                 } else {
                     cprev = rdlane((u32)ch_w, 1);
-                    str = ch_x;
                 }
                 ++bp;
                 if (C2A_UNLIKELY(bp == kWordBits)) { bp = 0; ++wi; }
@@ -936,7 +946,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             u32 w_lo = (u32)str, w_hi = (u32)(str >> 32) | tag_hi;
             w_lo = wrlane_c<0>(depth, w_lo);  w_hi = wrlane_c<0>((ch_root & kHdrMask) | tag_hi, w_hi);
             w_lo = wrlane_c<1>(cprev, w_lo);  w_hi = wrlane_c<1>((level & kHdrMask) | tag_hi, w_hi);
-            w_lo = wrlane_c<2>(my_pos, w_lo); w_hi = wrlane_c<2>(tag_hi, w_hi);
+            w_hi = wrlane_c<2>(my_pos | tag_hi, w_hi);      // (lane 2's low half is the root key already: str carries it)
             const u64 my_w = (u64)w_lo | ((u64)w_hi << 32);
             st_nw(&A.node[(u64)gc * kNodeWords + lane], my_w);
             ++processed;

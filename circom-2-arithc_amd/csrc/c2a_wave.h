@@ -145,9 +145,11 @@ __device__ __forceinline__ u32 own_sgpr(u32 v) {
 #ifdef C2A_EMULATE
 #define C2A_PIN(v) ((void)0)
 #define C2A_OPAQUE(v) ((void)0)
+#define C2A_OPAQUE_S(v) ((void)0)
 #else
 #define C2A_PIN(v) asm volatile("" : "+v"(v) :: "memory")
 #define C2A_OPAQUE(v) asm volatile("" : "+v"(v))      /* the compiler knows nothing about v from here on (no hoisting of what is computed from it) */
+#define C2A_OPAQUE_S(v) asm volatile("" : "+s"(v))    /* ... a wave-uniform value (keeps two blocks that end alike from being merged) */
 #endif
 
 // SCALAR TICKETS.  A returning atomic of ONE lane does not need the vector memory path: gfx950 still has the scalar-memory

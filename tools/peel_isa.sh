@@ -12,6 +12,6 @@ s=s.replace('            ++processed;\n','            ++processed; asm volatile(
 open(p,'w').write(s)
 PY
 cd $tmp/p/q/csrc && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -mllvm -amdgpu-atomic-optimizer-strategy=None $EXTRA -S --cuda-device-only -o $tmp/c2a.s c2a_api.hip 2>/dev/null
-awk '/^_ZN3c2a6k_peelILb0EEEvNS_8PeelArgsE:/,/\.Lfunc_end/' $tmp/c2a.s > $out
+awk '/^_ZN3c2a6k_peelILb0ELb0EEEvNS_8PeelArgsE:/,/\.Lfunc_end/' $tmp/c2a.s > $out
 grep -n "C2AMARK" $out
 rm -rf $tmp
