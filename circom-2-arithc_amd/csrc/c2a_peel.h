@@ -236,6 +236,10 @@ __device__ __attribute__((noinline)) u64 peel_reread(const u64* node_base, u32 e
     if (polls && lane == 0) atomicAdd(&ctl[CTL_REREADS], polls);
     return w;
 }
+// the plain launch has met a node that fills its chunk: tell the host (which runs the DEEP build) and end the launch
+__device__ __attribute__((noinline)) void peel_need_deep(u32* ctl, u32 lane) {
+    if (lane == 0) { atomicAdd(&ctl[CTL_NEEDDEEP], 1u); atomicAdd(&ctl[CTL_ABORT], 1u); }
+}
 // Trees deeper than one chunk: bring the two nodes to the first chunk in which their paths can differ (cprev hops),
 // then compare that chunk.  wa_in / wb_in: the two nodes' own records (already in registers).
 __device__ __attribute__((noinline)) bool deep_less(const u64* node_base, u32 epoch, u32* ctl, u32 a, u32 la, u32 da, u64 wa_in,
@@ -625,7 +629,11 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
 #pragma unroll
                         for (int off = 32; off >= 1; off >>= 1) n_end += __shfl_xor(n_end, off, 64);
                         n_end = uniform(n_end);      // (a shuffle result counts as divergent: the branches below must not)
-                        u32 n_begin = lane < kAcctShards ? ld_a32(&A.ctl[CTL_BEGIN + lane * kAcctStride]) : 0u;
+                        // (BEGIN = the waves that started + every entry ever pushed; the latter IS the producer side of the hand-off
+                        // arrays' ticket words — a pusher's ticket is a returning atomic it waits for before its entry can be seen —,
+                        // so a push counts its unit with the atomic it needs anyway)
+                        u32 n_begin = (lane < kAcctShards ? ld_a32(&A.ctl[CTL_BEGIN + lane * kAcctStride]) : 0u) +
+                                      (lane < A.n_fifos ? (u32)ld_nw(&A.q_pc[(u64)lane * kPcStride]) : 0u);
 #pragma unroll
                         for (int off = 32; off >= 1; off >>= 1) n_begin += __shfl_xor(n_begin, off, 64);
                         n_begin = uniform(n_begin);
@@ -785,13 +793,12 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                 const u32 gsel = select_uniform(j0, row_shl8(cur.gw), cur.gw);
                 gi = make_uint4(rdlane(gsel, 0), rdlane(gsel, 1), rdlane(gsel, 2), rdlane(gsel, 3));
                 gi2 = make_uint4(rdlane(gsel, 4), rdlane(gsel, 5), rdlane(gsel, 6), rdlane(gsel, 7));
-                if (rmask == 3u) {
+                if (C2A_LIKELY(rmask == 3u)) {      // (two steps in three of the critical path push: that path falls through)
                     if (STATS) ++st_push;
                     // one of the hand-off arrays: the ticket now, the entry after the tournament; BEGIN counts the entry
                     // before anybody can see it
                     push_f = (push_rr++) & (A.n_fifos - 1u);
                     sreg_inc64<kSregPush>(sr, &A.q_pc[(u64)push_f * kPcStride]);
-                    sreg_inc32<kSregBegin>(sr, &A.ctl[CTL_BEGIN + (me & (kAcctShards - 1u)) * kAcctStride]);
                 }
                 // the consumers of nxt are already here (lanes 32 j0 ... of the prefetched lists) unless it has more than 32
                 issue(nx_set, nx, gi.x, gi.y, gi.w, gi2.x, gi2.y, gi2.z, gi2.w, cur.clp, 32u * j0, 32u, true, gc);
@@ -925,22 +932,21 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             u64 str = ch_x;      // (a DFS root of its own: the empty string, lane 2 = its root key — the reset above)
             if (C2A_LIKELY(ch != C2A_NONE)) {
                 depth = ch_depth + 1; my_label = ch_el;
-                u32 wi = ch_pos >> 8, bp = ch_pos & 255u;
-                if (C2A_UNLIKELY(wi >= kStrWords)) {           // the parent filled its chunk: a fresh one, the parent is its anchor
-                    if (!DEEP) { if (lane == 0) { atomicAdd(&A.ctl[CTL_NEEDDEEP], 1u); atomicAdd(&A.ctl[CTL_ABORT], 1u); } wave_join(); }
-                    cprev = ch; wi = 0; bp = 0;
-                    str = lane == kHdrWords ? (u64)my_label : (lane == 2u ? (u64)c2a_brev32(ch_root) : 0ull);
-                } else {
-                    cprev = rdlane((u32)ch_w, 1);
+                cprev = rdlane((u32)ch_w, 1);
+                u32 np = ch_pos + 1u;                          // where MY child's label goes: one bit on ...
+                if (C2A_UNLIKELY(ch_pos >= (kStrWords << 8))) {       // the parent filled its chunk: a fresh one, the parent is its anchor
+                    if (DEEP) {
+                        cprev = ch; np = 1u;
+                        str = lane == kHdrWords ? (u64)my_label : (lane == 2u ? (u64)c2a_brev32(ch_root) : 0ull);
+                    } else peel_need_deep(A.ctl, lane);        // (this launch is over: what it writes from here on is never read)
                 }
-                ++bp;
-                if (C2A_UNLIKELY(bp == kWordBits)) { bp = 0; ++wi; }
-                my_pos = (wi << 8) | bp;
+                if (C2A_UNLIKELY((np & 255u) == kWordBits)) np += 256u - kWordBits;      // ... or the first bit of the next word
+                my_pos = np;
             }
             // the tree entry and the child link: wave-uniform data, read by later launches only — SCALAR stores (no exec
             // shuffle, no moves into vector registers; written back at the end of the wave: sstore_flush)
             sstore_x4(&A.meta[gc], ch, depth, ch_root, my_label | (level << 1));
-            if (C2A_LIKELY(ch != C2A_NONE)) sstore_x1(&A.child[2 * (u64)ch + my_label], gc);
+            if (C2A_LIKELY(ch != C2A_NONE)) sstore_x1_at(A.child, (2u * ch + my_label) * 4u, gc);      // (gate ids are below 2^29: the byte offset fits 32 bits)
             // (the three header words go into lanes 0..2 with v_writelane: a lane == k ladder is masked code)
             const u32 tag_hi = epoch << 30;
             u32 w_lo = (u32)str, w_hi = (u32)(str >> 32) | tag_hi;

@@ -180,6 +180,7 @@ constexpr int kSregBase = 97, kSregBegin = 97, kSregPush = 98, kSregFill0 = 100,
 #ifdef C2A_EMULATE
 __device__ __forceinline__ void sstore_x4(uint4* p, u32 a, u32 b, u32 c, u32 d) { if ((threadIdx.x & 63u) == 0) *p = make_uint4(a, b, c, d); }
 __device__ __forceinline__ void sstore_x1(u32* p, u32 a) { if ((threadIdx.x & 63u) == 0) *p = a; }
+__device__ __forceinline__ void sstore_x1_at(u32* base, u32 byte_off, u32 a) { if ((threadIdx.x & 63u) == 0) base[byte_off / 4u] = a; }
 __device__ __forceinline__ void sstore_flush() {}
 #else
 typedef u32 c2a_v4u __attribute__((ext_vector_type(4)));
@@ -191,6 +192,11 @@ __device__ __forceinline__ void sstore_x4(uint4* p, u32 a, u32 b, u32 c, u32 d) 
 __device__ __forceinline__ void sstore_x1(u32* p, u32 a) {
     typedef __attribute__((address_space(1))) u32* G;
     asm volatile("s_store_dword %0, %1, 0x0" :: "s"(uniform(a)), "s"((G)p) : "memory");
+}
+// (the word at base + a 32-bit byte offset in a register: no 64-bit address arithmetic)
+__device__ __forceinline__ void sstore_x1_at(u32* base, u32 byte_off, u32 a) {
+    typedef __attribute__((address_space(1))) u32* G;
+    asm volatile("s_store_dword %0, %1, %2" :: "s"(uniform(a)), "s"((G)base), "s"(uniform(byte_off)) : "memory");
 }
 __device__ __forceinline__ void sstore_flush() { asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory"); }
 #endif
