@@ -710,8 +710,11 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             // the records of the first two consumers that are not the gate in hand (slots that are not loaded stay
             // UNDEFINED on purpose: merging a loaded value with a constant is a register copy, a copy is a use, and its wait
             // would land right behind the load)
+            // (a ballot per compare, the masks combined in scalar registers: the ballot of a combined condition is compiled as
+            // select + compare on top of the compares)
             const bool in_lanes = n_cons <= ccap;
-            u64 smask = __ballot(in_lanes && lane - cbase < n_cons && !(have_own && (scl & kIdMask) == own_id));
+            u64 smask = __ballot(lane - cbase < n_cons) & (in_lanes ? ~0ull : 0ull);
+            if (have_own) smask &= __ballot((scl & kIdMask) != own_id);
             S.take = 0;                  // (e0 / e1 stay undefined like w0 / w1: they are only looked at under take)
             if (C2A_LIKELY(smask != 0)) {
                 S.e0 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 1;
@@ -755,7 +758,10 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
         // The champion of a gate's tournament so far (wave-uniform); ch == NONE: the virtual-root candidate [g].  The gate
         // just finished stays in these registers as the first candidate of the next one: it is the champion to beat unless
         // its DFS root is not smaller than the next gate's own id (then the step starts from [g])
-        u32 ch = C2A_NONE, ch_el = 0, ch_root = C2A_NONE, ch_depth = 0, ch_pos = 0;
+        // The champion is kept as what a take has to copy and no more: its list entry (consumer | label << 31), where its child's
+        // label goes, its record and its compare word; depth, DFS root and level are read out of the record ONCE, when the
+        // tournament is over (per candidate that was two lane reads and three scalar instructions for values only the winner needs).
+        u32 ch_e = C2A_NONE, ch_root = C2A_NONE, ch_pos = 0;      // (ch_root: the root of the gate just finished / of [g] itself)
         u64 ch_w = 0, ch_x = 0;              // the champion's record / its string with the edge label appended
         // the gate just finished (a consumer of the gate in hand); at the start of a chain there is none: no gate has id NONE,
         // level NONE + 1 is 0, and a champion root of NONE (above) is smaller than no gate id — no flag to test
@@ -807,10 +813,10 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             const ull ph2 = STATS ? c2a_now() : 0;
             // ---- tournament of THIS gate
             u32 level = own_level + 1u;
-            if (!(ch_root < g_orig)) { ch = C2A_NONE; ch_el = 0; ch_root = g_orig; ch_depth = 0; ch_pos = 0; ch_w = 0; ch_x = (u64)wrlane_c<2>(c2a_brev32(g_orig), 0u); }
+            if (!(ch_root < g_orig)) { ch_e = C2A_NONE; ch_root = g_orig; ch_pos = 0; ch_w = 0; ch_x = (u64)wrlane_c<2>(c2a_brev32(g_orig), 0u); }
             // one candidate: its record must be all there (else read it again: out of line), then it meets the champion
             auto candidate = [&](u64& w, u32 e) {             // (w by reference: the cold path mends it in place, no copy)
-                const u32 c = e & kIdMask, el = e >> 31;
+                const u32 el = e >> 31;
                 u64 badm = __ballot(tag_bad(tagc, w));
                 if (C2A_UNLIKELY(badm != 0)) {
                     badm = __ballot(tag_stale_or_never(epoch, w));
@@ -818,7 +824,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                     // lies beyond the lanes its depth needs is zero padding whatever those words hold) or a record that is still
                     // on its way
                     if ((badm & 1ull) != 0 || (badm & needed_lanes((u32)rdlane64(w, 0))) != 0) {
-                        w = peel_reread(A.node, epoch, A.ctl, c, w, lane);
+                        w = peel_reread(A.node, epoch, A.ctl, e & kIdMask, w, lane);
                         badm = __ballot(tag_stale_or_never(epoch, w));
                         // It never arrived (or the launch is being given up already): fail loudly — ABORT tells the host, which
                         // discards the run — and leave the candidate out.  The chain goes on (no flag to carry through the hot
@@ -832,8 +838,6 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                     }
                     if (tag_stale_or_never(epoch, w)) w = 0ull;       // (the zero padding of a short record, whatever those words hold)
                 }
-                const u64 h0 = rdlane64(w, 0);
-                const u32 croot = hdr_hi(h0), cdepth = (u32)h0;
                 const u32 clevel = (rdlane((u32)(w >> 32), 1) & kHdrMask) + 1u;
                 const u32 cpos = rdlane((u32)(w >> 32), 2) & kHdrMask;
                 level = clevel > level ? clevel : level;
@@ -846,7 +850,13 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                 // (another root, deep trees) one block out of line that ends in the same decision.  (A take per branch made the
                 // compiler carry two flags through the branches: ten instructions per candidate of nothing but that.)
                 u32 win;
-                if (!DEEP || C2A_LIKELY((cdepth > ch_depth ? cdepth : ch_depth) < kChunkBits)) {
+                bool deep = false;
+                u32 cdepth = 0, ch_depth = 0;
+                if (DEEP) {      // (the plain build never looks at depths here: a node that fills its chunk ends that launch)
+                    cdepth = rdlane((u32)w, 0); ch_depth = ch_e != C2A_NONE ? rdlane((u32)ch_w, 0) : 0u;
+                    deep = !((cdepth > ch_depth ? cdepth : ch_depth) < kChunkBits);
+                }
+                if (C2A_LIKELY(!deep)) {
                     // lane 2 holds the root keys: another DFS root decides there (the smaller original id wins; [g] itself is a
                     // champion whose key is the gate's own id).  Same root: neither path is a prefix of the other (that would be a
                     // cycle), and the same node with the other label differs in the appended bit — the first differing bit decides
@@ -854,13 +864,19 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                     const u64 bal = __ballot(d != 0) & ~3ull;
                     const u32 L = ctz64(bal);
                     win = ((u32)(rdlane64(x, L) >> ctz64(rdlane64(d, L))) & 1u) ^ 1u;
-                } else if (croot != ch_root) win = croot < ch_root ? 1u : 0u;      // a larger DFS root loses at once (also to [g] itself)
-                else if (c == ch) win = el < ch_el ? 1u : 0u;
-                // (the result of an out-of-line call counts as divergent; left like that, every value that depends on the
-                // champion would move to vector registers and the whole tournament would be compiled as divergent code)
-                else win = uniform(deep_less(A.node, epoch, A.ctl, c, el, cdepth, w, ch, ch_el, ch_depth, ch_w, lane) ? 1u : 0u);
-                // (as selects — nine of them, always — this measured slower than the branch: 7.33 against 7.25 ms for the stage)
-                if (win) { ch = c; ch_el = el; ch_root = croot; ch_depth = cdepth; ch_pos = cpos; ch_w = w; ch_x = x; }
+                } else {
+                    const u32 croot = hdr_hi(rdlane64(w, 0)), c = e & kIdMask, ch = ch_e & kIdMask;
+                    if (croot != ch_root) win = croot < ch_root ? 1u : 0u;      // a larger DFS root loses at once (also to [g] itself)
+                    else if (c == ch) win = el < (ch_e >> 31) ? 1u : 0u;
+                    // (the result of an out-of-line call counts as divergent; left like that, every value that depends on the
+                    // champion would move to vector registers and the whole tournament would be compiled as divergent code)
+                    else win = uniform(deep_less(A.node, epoch, A.ctl, c, el, cdepth, w, ch, ch_e >> 31, ch_depth, ch_w, lane) ? 1u : 0u);
+                }
+                // (as selects — always — this measured slower than the branch: 7.33 against 7.25 ms for the stage)
+                if (win) {
+                    ch_e = e; ch_pos = cpos; ch_w = w; ch_x = x;
+                    if (DEEP) ch_root = hdr_hi(rdlane64(w, 0));       // (the deep compare of a later candidate goes by it; the plain build reads it at the end)
+                }
             };
             // the (up to two) records loaded ahead ...
             if (C2A_LIKELY(cur.take >= 1)) {
@@ -930,8 +946,11 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             // ---- the node: its string is the champion's string with the label appended — the register built above
             u32 depth = 0, my_label = 0, cprev = C2A_NONE, my_pos = 0;
             u64 str = ch_x;      // (a DFS root of its own: the empty string, lane 2 = its root key — the reset above)
-            if (C2A_LIKELY(ch != C2A_NONE)) {
-                depth = ch_depth + 1; my_label = ch_el;
+            const u32 ch = ch_e != C2A_NONE ? (ch_e & kIdMask) : C2A_NONE;
+            if (C2A_LIKELY(ch_e != C2A_NONE)) {
+                // (what only the winner is asked: depth and DFS root, out of its record)
+                const u64 h0 = rdlane64(ch_w, 0);
+                depth = (u32)h0 + 1; my_label = ch_e >> 31; ch_root = hdr_hi(h0);
                 cprev = rdlane((u32)ch_w, 1);
                 u32 np = ch_pos + 1u;                          // where MY child's label goes: one bit on ...
                 if (C2A_UNLIKELY(ch_pos >= (kStrWords << 8))) {       // the parent filled its chunk: a fresh one, the parent is its anchor
@@ -946,7 +965,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             // the tree entry and the child link: wave-uniform data, read by later launches only — SCALAR stores (no exec
             // shuffle, no moves into vector registers; written back at the end of the wave: sstore_flush)
             sstore_x4(&A.meta[gc], ch, depth, ch_root, my_label | (level << 1));
-            if (C2A_LIKELY(ch != C2A_NONE)) sstore_x1_at(A.child, (2u * ch + my_label) * 4u, gc);      // (gate ids are below 2^29: the byte offset fits 32 bits)
+            if (C2A_LIKELY(ch_e != C2A_NONE)) sstore_x1_at(A.child, (2u * ch + my_label) * 4u, gc);      // (gate ids are below 2^29: the byte offset fits 32 bits)
             // (the three header words go into lanes 0..2 with v_writelane: a lane == k ladder is masked code)
             const u32 tag_hi = epoch << 30;
             u32 w_lo = (u32)str, w_hi = (u32)(str >> 32) | tag_hi;
@@ -977,7 +996,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             own_node = gc; own_level = level;
             ch_x = str;
             if (lane == kHdrWords + (my_pos >> 8)) ch_x |= (u64)nxt_label << (my_pos & 255u);
-            ch = gc; ch_el = nxt_label; ch_depth = depth; ch_pos = my_pos; ch_w = my_w;
+            ch_e = gc | (nxt_label << 31); ch_pos = my_pos; ch_w = my_w;
             g = nxt;
             return false;
         };

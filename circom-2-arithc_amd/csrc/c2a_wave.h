@@ -49,7 +49,7 @@ __device__ __forceinline__ u32 select_uniform(u32 j, u32 a, u32 b) {
 #ifdef C2A_EMULATE
     return j ? a : b;
 #else
-    const u64 m = 0ull - (u64)(j & 1u);
+    const u64 m = (j & 1u) ? ~0ull : 0ull;
     u32 r;
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
     return r;
