@@ -158,6 +158,16 @@ struct PeelArgs {
 __device__ __forceinline__ u32 chunk_of(u32 depth) { return depth ? (depth - 1) / kChunkBits : 0u; }
 __device__ __forceinline__ u32 chunk_len(u32 depth) { return depth - chunk_of(depth) * kChunkBits; }
 __device__ __forceinline__ u32 ctz64(u64 x) { return (u32)__builtin_ctzll(x); }      // (callers never pass 0)
+// index of the lowest set bit of a wave-uniform mask, which it loses (s_ff1 + s_bitset0: `m &= m - 1` is three instructions)
+__device__ __forceinline__ u32 pop_lowest(u64& m) {
+    const u32 i = ctz64(m);
+#ifdef C2A_EMULATE
+    m &= m - 1;
+#else
+    asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(i));
+#endif
+    return i;
+}
 
 __device__ __forceinline__ u64 ld_nw(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_nw(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -717,31 +727,31 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             if (have_own) smask &= __ballot((scl & kIdMask) != own_id);
             S.take = 0;                  // (e0 / e1 stay undefined like w0 / w1: they are only looked at under take)
             if (C2A_LIKELY(smask != 0)) {
-                S.e0 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 1;
+                S.e0 = rdlane(scl, pop_lowest(smask)); S.take = 1;
                 S.w0 = ld_nw(&A.node[(u64)(S.e0 & kIdMask) * kNodeWords + lane]);
                 if (smask) {
-                    S.e1 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 2;
+                    S.e1 = rdlane(scl, pop_lowest(smask)); S.take = 2;
                     S.w1 = ld_nw(&A.node[(u64)(S.e1 & kIdMask) * kNodeWords + lane]);
                     // (a third and a fourth: one gate in six has more than two other consumers, and the cold loop below costs it
                     // two dependent round trips per candidate)
                     if (C2A_UNLIKELY(smask != 0)) {
-                        S.e2 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 3;
+                        S.e2 = rdlane(scl, pop_lowest(smask)); S.take = 3;
                         S.w2 = ld_nw(&A.node[(u64)(S.e2 & kIdMask) * kNodeWords + lane]);
                         if (C2A_UNLIKELY(smask != 0)) {
-                            S.e3 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 4;
+                            S.e3 = rdlane(scl, pop_lowest(smask)); S.take = 4;
                             S.w3 = ld_nw(&A.node[(u64)(S.e3 & kIdMask) * kNodeWords + lane]);
                             // (a fifth and a sixth: one gate in 45 — but one step in 15 of the critical path — has more than four)
                             if (C2A_UNLIKELY(smask != 0)) {
-                                S.e4 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 5;
+                                S.e4 = rdlane(scl, pop_lowest(smask)); S.take = 5;
                                 S.w4 = ld_nw(&A.node[(u64)(S.e4 & kIdMask) * kNodeWords + lane]);
                                 if (smask) {
-                                    S.e5 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 6;
+                                    S.e5 = rdlane(scl, pop_lowest(smask)); S.take = 6;
                                     S.w5 = ld_nw(&A.node[(u64)(S.e5 & kIdMask) * kNodeWords + lane]);
                                     if (smask) {
-                                        S.e6 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 7;
+                                        S.e6 = rdlane(scl, pop_lowest(smask)); S.take = 7;
                                         S.w6 = ld_nw(&A.node[(u64)(S.e6 & kIdMask) * kNodeWords + lane]);
                                         if (smask) {
-                                            S.e7 = rdlane(scl, ctz64(smask)); smask &= smask - 1; S.take = 8;
+                                            S.e7 = rdlane(scl, pop_lowest(smask)); S.take = 8;
                                             S.w7 = ld_nw(&A.node[(u64)(S.e7 & kIdMask) * kNodeWords + lane]);
                                         }
                                     }
@@ -765,7 +775,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
         u64 ch_w = 0, ch_x = 0;              // the champion's record / its string with the edge label appended
         // the gate just finished (a consumer of the gate in hand); at the start of a chain there is none: no gate has id NONE,
         // level NONE + 1 is 0, and a champion root of NONE (above) is smaller than no gate id — no flag to test
-        u32 own_node = C2A_NONE, own_level = C2A_NONE;
+        u32 own_node = C2A_NONE, own_lraw = 0;      // (own_lraw: its level as its record holds it — tag | level, the high half of word 1)
 
         // one step: `cur` is in hand (issued one step ago), `nx` receives the next one.  true = the chain ends (or abort)
         auto step = [&](auto cur_set, auto nx_set, StepIO& cur, StepIO& nx) -> bool {
@@ -812,7 +822,9 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             wave_priority(1);
             const ull ph2 = STATS ? c2a_now() : 0;
             // ---- tournament of THIS gate
-            u32 level = own_level + 1u;
+            // the reverse Kahn level = 1 + the highest level among the consumers: the maximum is taken over the RAW high halves of
+            // their records' word 1 (tag | level: every record of a run carries the same tag), masked and bumped once at the end
+            u32 lraw = own_lraw;
             if (!(ch_root < g_orig)) { ch_e = C2A_NONE; ch_root = g_orig; ch_pos = 0; ch_w = 0; ch_x = (u64)wrlane_c<2>(c2a_brev32(g_orig), 0u); }
             // one candidate: its record must be all there (else read it again: out of line), then it meets the champion
             auto candidate = [&](u64& w, u32 e) {             // (w by reference: the cold path mends it in place, no copy)
@@ -838,9 +850,9 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                     }
                     if (tag_stale_or_never(epoch, w)) w = 0ull;       // (the zero padding of a short record, whatever those words hold)
                 }
-                const u32 clevel = (rdlane((u32)(w >> 32), 1) & kHdrMask) + 1u;
+                const u32 clraw = rdlane((u32)(w >> 32), 1);
                 const u32 cpos = rdlane((u32)(w >> 32), 2) & kHdrMask;
-                level = clevel > level ? clevel : level;
+                lraw = clraw > lraw ? clraw : lraw;
                 // the candidate's string with its edge label appended (meaningful while the chunk has room: cpos < kStrWords << 8)
                 u64 x = (u64)(u32)w | ((u64)((u32)(w >> 32) & cmp_hi_mask) << 32);
                 if (lane == kHdrWords + (cpos >> 8)) x |= (u64)el << (cpos & 255u);
@@ -913,8 +925,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                                          !(cur.take >= 5 && blk == cur.e4) && !(cur.take >= 6 && blk == cur.e5) &&
                                          !(cur.take >= 7 && blk == cur.e6) && !(cur.take >= 8 && blk == cur.e7));
                     while (smask) {
-                        const u32 e = rdlane(blk, ctz64(smask));
-                        smask &= smask - 1;
+                        const u32 e = rdlane(blk, pop_lowest(smask));
                         u64 w = ld_nw(&A.node[(u64)(e & kIdMask) * kNodeWords + lane]);
                         C2A_PIN(w);                              // (consumed here: pending at the join it would cost the hot path a wait)
                         candidate(w, e);
@@ -964,6 +975,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             }
             // the tree entry and the child link: wave-uniform data, read by later launches only — SCALAR stores (no exec
             // shuffle, no moves into vector registers; written back at the end of the wave: sstore_flush)
+            const u32 level = (lraw & kHdrMask) + 1u;
             sstore_x4(&A.meta[gc], ch, depth, ch_root, my_label | (level << 1));
             if (C2A_LIKELY(ch_e != C2A_NONE)) sstore_x1_at(A.child, (2u * ch + my_label) * 4u, gc);      // (gate ids are below 2^29: the byte offset fits 32 bits)
             // (the three header words go into lanes 0..2 with v_writelane: a lane == k ladder is masked code)
@@ -993,7 +1005,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             // (levels grow along a chain: its last step has the highest)
             if (C2A_UNLIKELY(nxt == C2A_NONE)) { max_level = level > max_level ? level : max_level; return true; }      // the chain ends here
             // what the next step reuses: this gate as the first candidate of nxt (same DFS root: ch_root stays)
-            own_node = gc; own_level = level;
+            own_node = gc; own_lraw = level | tag_hi;
             ch_x = str;
             if (lane == kHdrWords + (my_pos >> 8)) ch_x |= (u64)nxt_label << (my_pos & 255u);
             ch_e = gc | (nxt_label << 31); ch_pos = my_pos; ch_w = my_w;
