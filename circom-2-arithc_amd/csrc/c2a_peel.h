@@ -808,7 +808,8 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                 // around the shift this was eleven instructions of flags)
                 const u32 gsel = select_uniform(j0, row_shl8(cur.gw), cur.gw);
                 gi = make_uint4(rdlane(gsel, 0), rdlane(gsel, 1), rdlane(gsel, 2), rdlane(gsel, 3));
-                gi2 = make_uint4(rdlane(gsel, 4), rdlane(gsel, 5), rdlane(gsel, 6), rdlane(gsel, 7));
+                // (a LOCAL: nothing of it is wanted behind the issue, and a value carried around the loop by reference is kept alive there)
+                const uint4 ngi2 = make_uint4(rdlane(gsel, 4), rdlane(gsel, 5), rdlane(gsel, 6), rdlane(gsel, 7));
                 if (C2A_LIKELY(rmask == 3u)) {      // (two steps in three of the critical path push: that path falls through)
                     if (STATS) ++st_push;
                     // one of the hand-off arrays: the ticket now, the entry after the tournament; BEGIN counts the entry
@@ -817,7 +818,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                     sreg_inc64<kSregPush>(sr, &A.q_pc[(u64)push_f * kPcStride]);
                 }
                 // the consumers of nxt are already here (lanes 32 j0 ... of the prefetched lists) unless it has more than 32
-                issue(nx_set, nx, gi.x, gi.y, gi.w, gi2.x, gi2.y, gi2.z, gi2.w, cur.clp, 32u * j0, 32u, true, gc);
+                issue(nx_set, nx, gi.x, gi.y, gi.w, ngi2.x, ngi2.y, ngi2.z, ngi2.w, cur.clp, 32u * j0, 32u, true, gc);
             }
             wave_priority(1);
             const ull ph2 = STATS ? c2a_now() : 0;
