@@ -22,7 +22,8 @@
 // every second run only — k_peel alternated between 6.95 and 7.20 ms with the run tag.
 //   word 0      root gate id << 32 | depth in the DFS tree
 //   word 1      reverse Kahn level << 32 | cprev (ancestor at the start of the node's current chunk; deep trees only)
-//   word 2      high half: where a child's edge label goes in the string: word index << 8 | bit (no division on the hot path);
+//   word 2      high half: where a child's edge label goes in the RECORD: lane (= header words + string word) << 8 | bit (no division,
+//               no offset on the hot path);
 //               low half: the ROOT KEY, the bit-reversed original id of the DFS root — a candidate's compare word of lane 2, so that
 //               ONE compare decides root and path: the lowest differing bit of the lowest differing lane, and whoever has a 0
 //               there wins (reversed, the highest differing bit of the ids comes first: the smaller root)
@@ -336,7 +337,7 @@ __global__ void __launch_bounds__(256) k_peel_sinks(PeelArgs A) {
                 A.meta[g] = make_uint4(C2A_NONE, 0u, gi.z, 0u);
                 A.node[g * kNodeWords] = tag | hdr0_word(gi.z, 0u);
                 A.node[g * kNodeWords + 1] = tag | hdr1_word(0u, C2A_NONE);
-                A.node[g * kNodeWords + 2] = tag | c2a_brev32(gi.z);
+                A.node[g * kNodeWords + 2] = tag | ((u64)(kHdrWords << 8) << 32) | c2a_brev32(gi.z);
                 const uint4 g2 = A.gstat[2 * g + 1];
                 const u32 deps[2] = {gi.x, gi.y}, cnts[2] = {g2.y, g2.w};
 #pragma unroll
@@ -467,7 +468,7 @@ __global__ void __launch_bounds__(256) k_peel_shallow(PeelArgs A, const u32* __r
             u64 w = tag;
             if (l16 == 0) w |= hdr0_word(root, depth);
             else if (l16 == 1) w |= hdr1_word(lvl, C2A_NONE);
-            else if (l16 == 2) w |= ((u64)depth << 32) | c2a_brev32(root);      // (where a child's label goes: word 0, bit `depth` — depth < 62 down here —; the root key)
+            else if (l16 == 2) w |= ((u64)((kHdrWords << 8) | depth) << 32) | c2a_brev32(root);      // (where a child's label goes: string word 0, bit `depth` — depth < 62 down here —; the root key)
             else if (l16 == kHdrWords) w |= s_str[j];
             A.node[(u64)gj * kNodeWords + l16] = w;
         }
@@ -771,7 +772,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
         // The champion is kept as what a take has to copy and no more: its list entry (consumer | label << 31), where its child's
         // label goes, its record and its compare word; depth, DFS root and level are read out of the record ONCE, when the
         // tournament is over (per candidate that was two lane reads and three scalar instructions for values only the winner needs).
-        u32 ch_e = C2A_NONE, ch_root = C2A_NONE, ch_pos = 0;      // (ch_root: the root of the gate just finished / of [g] itself)
+        u32 ch_e = C2A_NONE, ch_root = C2A_NONE, ch_pos = 0;      // (ch_pos: RAW, the high half of the record's word 2 — tag bits and all)      // (ch_root: the root of the gate just finished / of [g] itself)
         u64 ch_w = 0, ch_x = 0;              // the champion's record / its string with the edge label appended
         // the gate just finished (a consumer of the gate in hand); at the start of a chain there is none: no gate has id NONE,
         // level NONE + 1 is 0, and a champion root of NONE (above) is smaller than no gate id — no flag to test
@@ -852,11 +853,13 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                     if (tag_stale_or_never(epoch, w)) w = 0ull;       // (the zero padding of a short record, whatever those words hold)
                 }
                 const u32 clraw = rdlane((u32)(w >> 32), 1);
-                const u32 cpos = rdlane((u32)(w >> 32), 2) & kHdrMask;
+                const u32 cpos = rdlane((u32)(w >> 32), 2);      // (raw: lane << 8 | bit under the tag bits)
                 lraw = clraw > lraw ? clraw : lraw;
                 // the candidate's string with its edge label appended (meaningful while the chunk has room: cpos < kStrWords << 8)
                 u64 x = (u64)(u32)w | ((u64)((u32)(w >> 32) & cmp_hi_mask) << 32);
-                if (lane == kHdrWords + (cpos >> 8)) x |= (u64)el << (cpos & 255u);
+                // (the label as a VECTOR value — one lane holds it — shifted into place: a 64-bit scalar shift, two moves, two selects and
+                // two ORs otherwise)
+                x |= (u64)(lane == ((cpos >> 8) & 0x3FFFFFu) ? el : 0u) << (cpos & 63u);
                 C2A_OPAQUE(x);       // (built HERE, in front of the branches: behind them it is shared code, and the way back into it costs a flag)
                 // ONE decision, then ONE place where the champion changes.  The hot case — same DFS root as the champion (the first
                 // few roots own nearly everything below them), both paths inside one chunk — is one straight line; everything else
@@ -956,7 +959,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             }
             const ull ph3 = STATS ? c2a_now() : 0;
             // ---- the node: its string is the champion's string with the label appended — the register built above
-            u32 depth = 0, my_label = 0, cprev = C2A_NONE, my_pos = 0;
+            u32 depth = 0, my_label = 0, cprev = C2A_NONE, my_pos = kHdrWords << 8;
             u64 str = ch_x;      // (a DFS root of its own: the empty string, lane 2 = its root key — the reset above)
             const u32 ch = ch_e != C2A_NONE ? (ch_e & kIdMask) : C2A_NONE;
             if (C2A_LIKELY(ch_e != C2A_NONE)) {
@@ -964,10 +967,11 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                 const u64 h0 = rdlane64(ch_w, 0);
                 depth = (u32)h0 + 1; my_label = ch_e >> 31; ch_root = hdr_hi(h0);
                 cprev = rdlane((u32)ch_w, 1);
-                u32 np = ch_pos + 1u;                          // where MY child's label goes: one bit on ...
-                if (C2A_UNLIKELY(ch_pos >= (kStrWords << 8))) {       // the parent filled its chunk: a fresh one, the parent is its anchor
+                const u32 ppos = ch_pos & kHdrMask;
+                u32 np = ppos + 1u;                            // where MY child's label goes: one bit on ...
+                if (C2A_UNLIKELY(ppos >= (kNodeWords << 8))) {       // the parent filled its chunk: a fresh one, the parent is its anchor
                     if (DEEP) {
-                        cprev = ch; np = 1u;
+                        cprev = ch; np = (kHdrWords << 8) | 1u;
                         str = lane == kHdrWords ? (u64)my_label : (lane == 2u ? (u64)c2a_brev32(ch_root) : 0ull);
                     } else peel_need_deep(A.ctl, lane);        // (this launch is over: what it writes from here on is never read)
                 }
@@ -1008,7 +1012,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             // what the next step reuses: this gate as the first candidate of nxt (same DFS root: ch_root stays)
             own_node = gc; own_lraw = level | tag_hi;
             ch_x = str;
-            if (lane == kHdrWords + (my_pos >> 8)) ch_x |= (u64)nxt_label << (my_pos & 255u);
+            ch_x |= (u64)(lane == (my_pos >> 8) ? nxt_label : 0u) << (my_pos & 63u);
             ch_e = gc | (nxt_label << 31); ch_pos = my_pos; ch_w = my_w;
             g = nxt;
             return false;
