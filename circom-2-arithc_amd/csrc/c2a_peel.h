@@ -22,12 +22,14 @@
 // every second run only — k_peel alternated between 6.95 and 7.20 ms with the run tag.
 //   word 0      root gate id << 32 | depth in the DFS tree
 //   word 1      reverse Kahn level << 32 | cprev (ancestor at the start of the node's current chunk; deep trees only)
-//   word 2      high half: where a child's edge label goes in the RECORD: lane (= header words + string word) << 8 | bit (no division,
-//               no offset on the hot path);
-//               low half: the ROOT KEY, the bit-reversed original id of the DFS root — a candidate's compare word of lane 2, so that
-//               ONE compare decides root and path: the lowest differing bit of the lowest differing lane, and whoever has a 0
-//               there wins (reversed, the highest differing bit of the ids comes first: the smaller root)
-//   words 3..63 the node's path string, ZERO-PADDED: 62 payload bits per word, bit j = label of the edge entering depth j+1
+//   word 2      high half: where a child's edge label goes in the RECORD: lane (= header words + string word) << 8 | shift (no
+//               division, no offset on the hot path);
+//               low half: the ROOT KEY, the original id of the DFS root — a candidate's compare word of lane 2, so that ONE
+//               compare decides root and path: the lowest differing lane, and whoever holds the SMALLER word there wins
+//   words 3..63 the node's path string, ZERO-PADDED, MOST SIGNIFICANT FIRST: 62 payload bits per word, the label of the edge
+//               entering depth j + 1 at bit 61 - j % 62 of word j / 62 — the lexicographic order of two paths is the numeric order
+//               of their first differing words (round 4 stored the first label at bit 0: a compare was four lane reads and a
+//               chain of scalar bit tricks; this is two vector compares and a bit test)
 // A string is held in chunks of kChunkBits = 61 x 62 = 3782 bits; a node keeps its CURRENT chunk only.  Comparing two
 // candidates P(a).la and P(b).lb that are shallower than a chunk (the 10 M-gate headline graph: depth 3 471): append
 // each label to its string, XOR, ballot, count trailing zeros — neither path can be a prefix of the other (that would be
@@ -204,21 +206,18 @@ __device__ __forceinline__ u64 ld_rec_wait(const u64* node_base, u32 epoch, u32*
     return v;
 }
 // bit j of the string chunk held one word per lane
-__device__ __forceinline__ u32 str_bit(u64 w, u32 j) { return (u32)(rdlane64(w, kHdrWords + j / kWordBits) >> (j % kWordBits)) & 1u; }
+__device__ __forceinline__ u32 str_bit(u64 w, u32 j) { return (u32)(rdlane64(w, kHdrWords + j / kWordBits) >> (kWordBits - 1u - j % kWordBits)) & 1u; }
 // P(a).la < P(b).lb by lengths (general form: chunks of any fill)
 __device__ __forceinline__ bool str_less_len(u64 wa, u32 lena, u32 la, u64 wb, u32 lenb, u32 lb, u32 lane) {
     const u32 minlen = lena < lenb ? lena : lenb;
     const u32 lo = (lane - kHdrWords) * kWordBits;
-    u64 x = (wa ^ wb) & kPayload;
-    if (lane < kHdrWords || lo >= minlen) x = 0;
-    else if (minlen - lo < kWordBits) x &= (1ull << (minlen - lo)) - 1ull;
-    const u64 bal = __ballot(x != 0);
-    if (bal) {
-        const u32 L = ctz64(bal);
-        const u64 xl = rdlane64(x, L);
-        const u64 al = rdlane64(wa, L);
-        return ((al >> ctz64(xl)) & 1ull) == 0;
-    }
+    // (the first k bits of a word are its TOP k payload bits)
+    u64 m = kPayload;
+    if (lane < kHdrWords || lo >= minlen) m = 0;
+    else if (minlen - lo < kWordBits) m = kPayload & ~((1ull << (kWordBits - (minlen - lo))) - 1ull);
+    const u64 a = wa & m, b = wb & m;
+    const u64 bal = __ballot(a != b);
+    if (bal) return ((__ballot(a < b) >> ctz64(bal)) & 1ull) != 0;
     if (lena == lenb) return la < lb;
     if (lena < lenb) return la < str_bit(wb, lena);
     return str_bit(wa, lenb) < lb;
@@ -256,7 +255,7 @@ __device__ __attribute__((noinline)) void peel_need_deep(u32* ctl, u32 lane) {
 __device__ __attribute__((noinline)) bool deep_less(const u64* node_base, u32 epoch, u32* ctl, u32 a, u32 la, u32 da, u64 wa_in,
                                                     u32 b, u32 lb, u32 db, u64 wb_in, u32 lane) {
 #define C2A_CPREV(x) ((u32)ld_word_wait(node_base + (u64)(x) * kNodeWords + 1, epoch, ctl))
-#define C2A_BIT0(x) ((u32)ld_word_wait(node_base + (u64)(x) * kNodeWords + kHdrWords, epoch, ctl) & 1u)
+#define C2A_BIT0(x) ((u32)(ld_word_wait(node_base + (u64)(x) * kNodeWords + kHdrWords, epoch, ctl) >> (kWordBits - 1u)) & 1u)
     u32 ia = chunk_of(da), ib = chunk_of(db);
     u32 lena = chunk_len(da), lenb = chunk_len(db);
     u32 below_a = C2A_NONE, below_b = C2A_NONE;
@@ -304,16 +303,6 @@ __global__ void k_gstat(u32 n, const u32* __restrict__ dep0, const u32* __restri
     }
 }
 
-__device__ __forceinline__ u64 c2a_brev64(u64 x) {
-#ifdef C2A_EMULATE
-    u64 r = 0;
-    for (int i = 0; i < 64; ++i) { r = (r << 1) | (x & 1ull); x >>= 1; }
-    return r;
-#else
-    return __brevll(x);
-#endif
-}
-__device__ __forceinline__ u32 c2a_brev32(u32 x) { return (u32)(c2a_brev64((u64)x) >> 32); }
 // ------------------------------------------------------------------------------------------------
 // sinks (gates nobody consumes: DFS roots of depth 0, no candidates) — a plain grid-stride pass; the producers they
 // claim seed the dataflow launch.  No shared counter: workgroup b appends to its own region under its own counter.
@@ -337,7 +326,7 @@ __global__ void __launch_bounds__(256) k_peel_sinks(PeelArgs A) {
                 A.meta[g] = make_uint4(C2A_NONE, 0u, gi.z, 0u);
                 A.node[g * kNodeWords] = tag | hdr0_word(gi.z, 0u);
                 A.node[g * kNodeWords + 1] = tag | hdr1_word(0u, C2A_NONE);
-                A.node[g * kNodeWords + 2] = tag | ((u64)(kHdrWords << 8) << 32) | c2a_brev32(gi.z);
+                A.node[g * kNodeWords + 2] = tag | ((u64)((kHdrWords << 8) | (kWordBits - 1u)) << 32) | gi.z;
                 const uint4 g2 = A.gstat[2 * g + 1];
                 const u32 deps[2] = {gi.x, gi.y}, cnts[2] = {g2.y, g2.w};
 #pragma unroll
@@ -375,7 +364,7 @@ __global__ void __launch_bounds__(256) k_peel_sinks(PeelArgs A) {
 // starts kept all 2 048 waves busy for the launch's first 0.5 ms while the hand-off entries of that time, the critical path
 // among them, waited for its end (tools/peel_trace.py: the path began 0.54 ms into the launch).  Down here the paths are
 // short — a gate of level L is at most L deep, its string fits ONE word — so a LANE decides a gate: its key is (DFS root,
-// bit-reversed string with the edge label appended), the smallest key among its consumers wins (reversed, the first bit of
+// string with the edge label appended), the smallest key among its consumers wins (stored most significant first, the first bit of
 // a string is the most significant: integer order = lexicographic order; neither path is a prefix of the other, so zero
 // padding decides nothing), if that root is smaller than the gate's own id (else the gate is a DFS root itself).  A wave
 // per gate then writes the 64-word record.  Workgroup b takes region b of the pass before, collects the producers it claims
@@ -405,7 +394,7 @@ __global__ void __launch_bounds__(256) k_peel_shallow(PeelArgs A, const u32* __r
             const uint4 gi = A.gstat[2 * (u64)g], gi2 = A.gstat[2 * (u64)g + 1];
             const u32 g_off = cons_off[g], g_orig = gi.z;
             u32 b_root = C2A_NONE, b_c = C2A_NONE, b_el = 0, b_depth = 0;
-            u64 b_rev = 0, b_x = 0;
+            u64 b_x = 0;
             // (records of the passes before: plain loads; a sink's record has header words only — its string is empty.  The
             // loads of up to eight consumers go out TOGETHER, list entries, then header words, then strings: three round
             // trips per gate instead of three per consumer)
@@ -413,9 +402,8 @@ __global__ void __launch_bounds__(256) k_peel_shallow(PeelArgs A, const u32* __r
                 const u32 c = e & kIdMask, el = e >> 31;
                 const u64 h0 = h0w & kPayload;
                 const u32 croot = hdr_hi(h0), cdepth = (u32)h0;
-                const u64 x = (cdepth ? (sw & kPayload) : 0ull) | ((u64)el << cdepth);
-                const u64 rev = c2a_brev64(x);
-                if (croot < b_root || (croot == b_root && rev < b_rev)) { b_root = croot; b_rev = rev; b_c = c; b_el = el; b_depth = cdepth; b_x = x; }
+                const u64 x = (cdepth ? (sw & kPayload) : 0ull) | ((u64)el << (kWordBits - 1u - cdepth));
+                if (croot < b_root || (croot == b_root && x < b_x)) { b_root = croot; b_c = c; b_el = el; b_depth = cdepth; b_x = x; }
             };
             constexpr u32 kTogether = 8;
             u32 ee[kTogether]; u64 hh[kTogether], ss[kTogether];
@@ -468,7 +456,7 @@ __global__ void __launch_bounds__(256) k_peel_shallow(PeelArgs A, const u32* __r
             u64 w = tag;
             if (l16 == 0) w |= hdr0_word(root, depth);
             else if (l16 == 1) w |= hdr1_word(lvl, C2A_NONE);
-            else if (l16 == 2) w |= ((u64)((kHdrWords << 8) | depth) << 32) | c2a_brev32(root);      // (where a child's label goes: string word 0, bit `depth` — depth < 62 down here —; the root key)
+            else if (l16 == 2) w |= ((u64)((kHdrWords << 8) | (kWordBits - 1u - depth)) << 32) | root;      // (where a child's label goes: string word 0, `depth` bits down — depth < 62 here —; the root key)
             else if (l16 == kHdrWords) w |= s_str[j];
             A.node[(u64)gj * kNodeWords + l16] = w;
         }
@@ -827,7 +815,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             // the reverse Kahn level = 1 + the highest level among the consumers: the maximum is taken over the RAW high halves of
             // their records' word 1 (tag | level: every record of a run carries the same tag), masked and bumped once at the end
             u32 lraw = own_lraw;
-            if (!(ch_root < g_orig)) { ch_e = C2A_NONE; ch_root = g_orig; ch_pos = 0; ch_w = 0; ch_x = (u64)wrlane_c<2>(c2a_brev32(g_orig), 0u); }
+            if (!(ch_root < g_orig)) { ch_e = C2A_NONE; ch_root = g_orig; ch_pos = 0; ch_w = 0; ch_x = (u64)wrlane_c<2>(g_orig, 0u); }
             // one candidate: its record must be all there (else read it again: out of line), then it meets the champion
             auto candidate = [&](u64& w, u32 e) {             // (w by reference: the cold path mends it in place, no copy)
                 const u32 el = e >> 31;
@@ -847,7 +835,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                         // exit from the candidate: what merges behind this cold block is the record alone, no flag — 8.95 -> 8.58 ms)
                         if ((badm & 1ull) != 0 || (badm & needed_lanes((u32)rdlane64(w, 0))) != 0) {
                             if (lane == 0) atomicAdd(&A.ctl[CTL_ABORT], 1u); wave_join();
-                            w = ((u64)epoch << kTagShift) | (lane == 0 ? (u64)kHdrMask << 32 : (lane == 2u ? (u64)c2a_brev32(kHdrMask) : 0ull));
+                            w = ((u64)epoch << kTagShift) | (lane == 0 ? (u64)kHdrMask << 32 : (lane == 2u ? (u64)kHdrMask : 0ull));
                         }
                     }
                     if (tag_stale_or_never(epoch, w)) w = 0ull;       // (the zero padding of a short record, whatever those words hold)
@@ -876,10 +864,9 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                     // lane 2 holds the root keys: another DFS root decides there (the smaller original id wins; [g] itself is a
                     // champion whose key is the gate's own id).  Same root: neither path is a prefix of the other (that would be a
                     // cycle), and the same node with the other label differs in the appended bit — the first differing bit decides
-                    const u64 d = x ^ ch_x;
-                    const u64 bal = __ballot(d != 0) & ~3ull;
-                    const u32 L = ctz64(bal);
-                    win = ((u32)(rdlane64(x, L) >> ctz64(rdlane64(d, L))) & 1u) ^ 1u;
+                    // (strings are stored most significant first: the lowest differing lane, and there the smaller word)
+                    const u64 ne = __ballot(x != ch_x) & ~3ull, lt = __ballot(x < ch_x);
+                    win = (u32)(lt >> ctz64(ne)) & 1u;
                 } else {
                     const u32 croot = hdr_hi(rdlane64(w, 0)), c = e & kIdMask, ch = ch_e & kIdMask;
                     if (croot != ch_root) win = croot < ch_root ? 1u : 0u;      // a larger DFS root loses at once (also to [g] itself)
@@ -959,7 +946,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             }
             const ull ph3 = STATS ? c2a_now() : 0;
             // ---- the node: its string is the champion's string with the label appended — the register built above
-            u32 depth = 0, my_label = 0, cprev = C2A_NONE, my_pos = kHdrWords << 8;
+            u32 depth = 0, my_label = 0, cprev = C2A_NONE, my_pos = (kHdrWords << 8) | (kWordBits - 1u);
             u64 str = ch_x;      // (a DFS root of its own: the empty string, lane 2 = its root key — the reset above)
             const u32 ch = ch_e != C2A_NONE ? (ch_e & kIdMask) : C2A_NONE;
             if (C2A_LIKELY(ch_e != C2A_NONE)) {
@@ -968,14 +955,14 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                 depth = (u32)h0 + 1; my_label = ch_e >> 31; ch_root = hdr_hi(h0);
                 cprev = rdlane((u32)ch_w, 1);
                 const u32 ppos = ch_pos & kHdrMask;
-                u32 np = ppos + 1u;                            // where MY child's label goes: one bit on ...
+                u32 np = ppos - 1u;                            // where MY child's label goes: one bit down ...
                 if (C2A_UNLIKELY(ppos >= (kNodeWords << 8))) {       // the parent filled its chunk: a fresh one, the parent is its anchor
                     if (DEEP) {
-                        cprev = ch; np = (kHdrWords << 8) | 1u;
-                        str = lane == kHdrWords ? (u64)my_label : (lane == 2u ? (u64)c2a_brev32(ch_root) : 0ull);
+                        cprev = ch; np = (kHdrWords << 8) | (kWordBits - 2u);
+                        str = lane == kHdrWords ? (u64)my_label << (kWordBits - 1u) : (lane == 2u ? (u64)ch_root : 0ull);
                     } else peel_need_deep(A.ctl, lane);        // (this launch is over: what it writes from here on is never read)
                 }
-                if (C2A_UNLIKELY((np & 255u) == kWordBits)) np += 256u - kWordBits;      // ... or the first bit of the next word
+                if (C2A_UNLIKELY((ppos & 255u) == 0u)) np = ppos + 256u + kWordBits - 1u;      // ... or the top bit of the next word
                 my_pos = np;
             }
             // the tree entry and the child link: wave-uniform data, read by later launches only — SCALAR stores (no exec
