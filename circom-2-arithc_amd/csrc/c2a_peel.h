@@ -80,6 +80,10 @@
 #include "c2a_platform.h"
 #include "c2a_wave.h"
 
+#ifndef C2A_PRIO_TOUR
+#define C2A_PRIO_TOUR 1      /* wave priority from the issue of the next step to the end of the step (3 in front of it) */
+#endif
+
 namespace c2a {
 
 constexpr u32 kIdMask = 0x7FFFFFFFu;
@@ -809,7 +813,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                 // the consumers of nxt are already here (lanes 32 j0 ... of the prefetched lists) unless it has more than 32
                 issue(nx_set, nx, gi.x, gi.y, gi.w, ngi2.x, ngi2.y, ngi2.z, ngi2.w, cur.clp, 32u * j0, 32u, true, gc);
             }
-            wave_priority(1);
+            wave_priority(C2A_PRIO_TOUR);
             const ull ph2 = STATS ? c2a_now() : 0;
             // ---- tournament of THIS gate
             // the reverse Kahn level = 1 + the highest level among the consumers: the maximum is taken over the RAW high halves of

@@ -84,7 +84,7 @@ __device__ __forceinline__ void peel_sleep(int units) {
 // first: otherwise the compiler threads the jump into both sides of the `if (lane == 0)`, the loop exit becomes a join of
 // a divergent branch, and every value carried around that loop is handled as divergent (vector registers, masked code).
 template <int P> __device__ __forceinline__ void wave_priority_() {
-#ifndef C2A_EMULATE
+#if !defined(C2A_EMULATE) && !defined(C2A_NO_PRIO)
     __builtin_amdgcn_s_setprio(P);
 #endif
 }
