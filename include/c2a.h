@@ -84,9 +84,11 @@ typedef struct c2a_stats {
     uint32_t path_chunks;        /* 3843-bit path-string chunks the deepest DFS path spans (1 = every tournament is one round trip) */
     uint32_t peel_rereads;       /* times a wave read a candidate record again because a word of it had not arrived yet */
     uint32_t numbering_events;   /* what shifts the wire numbering away from "sorted position q gets wire n_in + q": gates whose out node
-                                    is an IO node + constant-like nodes (un-produced, no IO node) — src/compiler.rs:431-438 */
-    uint32_t numbering_path;     /* 1: positional numbering (one writer per node, few events: wires and gates by formula from the
-                                    positions); 0: the walk in sorted order (duplicate writers, many events, or a serial sort) */
+                                    is an IO node + constant-like nodes (un-produced, no IO node) — src/compiler.rs:431-438; counted by
+                                    the positional numbering (numbering_path == 1; 0 otherwise), any number of them */
+    uint32_t numbering_path;     /* 1: positional numbering (every node has one writer: wires and gates by formula from the sorted
+                                    positions and three event bits per position); 0: the walk in sorted order (duplicate writers, a
+                                    serial sort, or C2A_NUMBERING_WALK=1) */
 } c2a_stats;
 
 /*
