@@ -67,8 +67,9 @@
 // claimed every one of its candidates is in a step that is running (or done) on some resident wave; a wave only ever
 // waits for such a record, the graph is acyclic, so every wait ends.
 // Termination: two counters that only grow (kept in 64 parts).  BEGIN counts units of work when they come into being: a
-// wave that starts (one unit until it first runs out of work), and every pushed entry — counted by the pusher, with a
-// returning atomic, BEFORE the entry is visible.  END counts a unit when the wave that worked on it runs out of work.
+// wave that starts (one unit until it first runs out of work), and every pushed entry — which is counted by the ticket its
+// pusher takes on the array anyway (BEGIN = wave starts + the producer sides of the arrays' ticket words): a returning atomic
+// the pusher waits for BEFORE the entry is visible.  END counts a unit when the wave that worked on it runs out of work.
 // END never passes BEGIN, so "END (read first) == BEGIN (read afterwards)" means they were equal at every moment in
 // between: nothing active, nothing in flight, nobody can push any more.  How entries travel (which array, whose ticket)
 // plays no part in it, and co-residency of the grid is not required: a wave that starts late adds its unit, finds the
