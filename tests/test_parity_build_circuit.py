@@ -551,3 +551,46 @@ def test_numbering_paths(variant, request, orc, c2a):
             _compare(be, orc, q, check_serial=False)
     finally:
         be.close()
+
+
+def test_load_gates_argument_errors(backend, orc, c2a):
+    """c2a_load_gates validates its payload — node ids must address the node table, op bytes must be AGateType discriminants
+    (src/a_gate_type.rs:8-27) — on the DEVICE behind the copy (k_validate; round 4: a host loop over all gates): the FIRST
+    offending gate is named, node ids before the op byte of the same gate, the context stays unloaded, and a good payload loads
+    right after."""
+    fg = c2a.synth.layered_dag(12, 300, n_in=8, n_const=2, window=3, seed=3)       # 3 600 gates: several workgroups
+    good = (fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes)
+    import importlib as _il
+    BackendError = _il.import_module("circom-2-arithc_amd.backend").BackendError
+
+    def bad(which, at, value):
+        a = [np.array(x, copy=True) if isinstance(x, np.ndarray) else x for x in good]
+        a[which][at] = value
+        return a
+
+    cases = [(bad(0, 2777, fg.n_nodes), "node id >= n_nodes at gate 2777"), (bad(1, 5, fg.n_nodes + 7), "node id >= n_nodes at gate 5"),
+             (bad(2, 3599, 0xFFFFFFFF), "node id >= n_nodes at gate 3599"), (bad(3, 1234, 20), "unknown gate type at gate 1234"),
+             (bad(3, 0, 255), "unknown gate type at gate 0")]
+    # two offenders: the first one is reported; a bad op and a bad id in ONE gate: the id
+    two = bad(3, 3000, 99); two[0][100] = fg.n_nodes
+    cases.append((two, "node id >= n_nodes at gate 100"))
+    both = bad(3, 40, 77); both[2][40] = fg.n_nodes + 1
+    cases.append((both, "node id >= n_nodes at gate 40"))
+    for args, msg in cases:
+        with pytest.raises(BackendError, match=msg):
+            backend.load_gates(*args)
+        with pytest.raises(BackendError, match="no gates loaded"):
+            backend.topo_sort()
+    with pytest.raises(BackendError, match="input node id >= n_nodes"):
+        backend.load_gates(*good[:5], np.array([fg.n_nodes], np.uint32), fg.output_nodes)
+    with pytest.raises(BackendError, match="output node id >= n_nodes"):
+        backend.load_gates(*good[:5], fg.input_nodes, np.array([1, fg.n_nodes + 3], np.uint32))
+    backend.load_gates(*good)
+    exp = orc.build_circuit(*good, mode=1)
+    np.testing.assert_array_equal(backend.topo_sort(), exp.sorted)
+    # "a node is both an input and an output" is found on the device at load time too and reported by build_circuit BEFORE the sort
+    clash = list(good)
+    clash[6] = np.concatenate([fg.output_nodes, fg.input_nodes[:1]])
+    backend.load_gates(*clash)
+    with pytest.raises(c2a.Inconsistency):
+        backend.build_circuit()
