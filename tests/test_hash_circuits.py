@@ -124,8 +124,9 @@ def test_hash_circuit_known_answers(name, width, max_len, make, n_gates, n_in, n
     bi = backend.boolify(width)
     T = np.array([orc.template_size(o, width)[0] for o in range(20)], dtype=np.int64)
     assert bi.n_gates == int(T[exp.op].sum())
-    np.testing.assert_array_equal(backend.eval(ins, cst, width=width, boolean=True), want)
-    on_gpu = "hip" in backend.version       # (under the host emulation a pass over 1-2 M boolean gates takes 20-50 s: the image above is enough there)
+    on_gpu = "hip" in backend.version       # (under the host emulation a pass over 1-2 M boolean gates takes 20-50 s: one boolean image — SHA-256's — is enough there)
+    if on_gpu or width == 32:
+        np.testing.assert_array_equal(backend.eval(ins, cst, width=width, boolean=True), want)
     if on_gpu:
         checked, bad = backend.verify_boolify(seed=3)
         assert checked == circ.wire_count * 64 and bad == 0

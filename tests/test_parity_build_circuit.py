@@ -529,7 +529,7 @@ def test_numbering_paths(variant, request, orc, c2a):
             seen[st["numbering_path"]] += 1
         # reference-shaped graphs (src/process.rs:558-579: a named constant node per literal and context; an output signal per
         # template): a fresh constant at 10-30 % of the gates, an output node at 5-20 % — thousands of events
-        for layers, width, cf, of in ((40, 20, 0.3, 0.2), (30, 100, 0.1, 0.05), (10, 3000, 0.1, 0.05), (200, 9, 0.25, 0.1)):
+        for layers, width, cf, of in ((40, 20, 0.3, 0.2), (30, 100, 0.1, 0.05), (5, 2100, 0.1, 0.05), (120, 9, 0.25, 0.1)):
             fg = c2a.synth.layered_dag(layers, width, n_in=32, n_const=4, window=4, seed=9, const_frac=cf, out_frac=of)
             p = dict(lh=fg.lh, rh=fg.rh, out=fg.out, op=fg.op, n_nodes=fg.n_nodes, input_nodes=fg.input_nodes, output_nodes=fg.output_nodes)
             st = _check_fused(be, orc, bm, p)
