@@ -155,3 +155,210 @@ def config(name: str, seed: int = SEED, scale: Optional[float] = None) -> FlatGa
     if scale is not None:
         kw["layers"] = max(1, int(kw["layers"] * scale))
     return layered_dag(seed=seed, **kw)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Families beyond layered_dag (every large graph used to come from that one generator — Poisson(2) fan-out,
+# a 64-layer window, no trees).  The reference's deps closure (src/compiler.rs:408-421) allows ANY fan-out and ANY distance:
+# a broadcast selector or a scale factor feeds a whole layer (tests/circuits/machine-learning/ in the reference), a reduction
+# is an in-tree, and a real circuit is a tiling of sub-circuits.  All of them: seeded, pure numpy, gate ids permuted unless
+# said otherwise, sparse node ids in creation order like layered_dag.
+# ------------------------------------------------------------------------------------------------------------------------
+def _finish(lh_log, rh_log, out_log, op, n_log, n_in, const_log, out_mask, seed, permute, sparse_ids, layers, width):
+    """logical node numbers (creation order) -> sparse raw ids, gate ids permuted: the tail of layered_dag, shared"""
+    n = int(lh_log.shape[0])
+    if sparse_ids:
+        gaps = (splitmix64(seed, 4, n_log) & np.uint64(1)).astype(np.int64)
+        node_id = 1 + np.arange(n_log, dtype=np.int64) + np.cumsum(gaps)
+    else:
+        node_id = 1 + np.arange(n_log, dtype=np.int64)
+    n_nodes = int(node_id[-1]) + 1
+    assert n_nodes < 2 ** 32
+    lh_id, rh_id, out_id = node_id[lh_log].astype(np.uint32), node_id[rh_log].astype(np.uint32), node_id[out_log].astype(np.uint32)
+    output_nodes = node_id[out_log[out_mask]].astype(np.uint32)
+    if permute:
+        perm = np.argsort(splitmix64(seed, 5, n), kind="stable")
+        lh_id, rh_id, out_id, op = lh_id[perm], rh_id[perm], out_id[perm], op[perm]
+    return FlatGates(lh=lh_id, rh=rh_id, out=out_id, op=np.ascontiguousarray(op), n_nodes=n_nodes,
+                     input_nodes=node_id[:n_in].astype(np.uint32), output_nodes=output_nodes,
+                     const_nodes=node_id[const_log].astype(np.uint32), layers=int(layers), layer_width=int(width))
+
+
+def _pick_ops(mix, r_op):
+    names = [m[0] for m in mix]
+    cum = np.cumsum(np.array([m[1] for m in mix], dtype=np.int64))
+    pick = np.searchsorted(cum, (r_op % np.uint64(cum[-1])).astype(np.int64), side="right")
+    return np.array([OP[nm] for nm in names], dtype=np.uint8)[pick]
+
+
+def hub_dag(layers: int, layer_width: int, n_in: int = 4096, n_const: int = 64, window: int = 64,
+            mix: Sequence[Tuple[str, int]] = MIX_BITWISE, seed: int = SEED, permute: bool = True, sparse_ids: bool = True,
+            small_frac: float = 0.01, small_lo: float = 17.0, small_alpha: float = 2.2, small_cap: float = 900.0,
+            big: int = 300, big_lo: float = 1e3, big_hi: float = 1e4, mega: Sequence[float] = (0.1, 0.03, 0.01),
+            p_hub: float = 0.45) -> FlatGates:
+    """layered_dag's skeleton (lh from the previous layer => depth == layers) with HUBS: produced nodes that many gates read.
+    `small_frac` of the gates are small hubs (Pareto weights from `small_lo`, capped), `big` gates are big ones (log-uniform
+    weights big_lo..big_hi), and every entry f of `mega` is one gate in the first layers that a fraction f of ALL gates reads
+    (0.1 of 10 M gates: a fan-out of 10^6).  A gate's rh goes to a mega hub with probability f each, else with probability
+    `p_hub` to a small / big hub of ANY earlier layer in proportion to the weights (consumers at many depths), else where
+    layered_dag would send it.  With fan-in 2 the edges are 2 n: "1 % of the nodes with a fan-out of 10^2-10^4" does not fit —
+    1 % of the nodes with 17-900, 300 (per 10 M) with 10^3-10^4 and three with 10^5-10^6 does."""
+    L, Wd = int(layers), int(layer_width)
+    n = L * Wd
+    k = np.repeat(np.arange(L, dtype=np.int64), Wd)
+    r_lh, r_rh, r_op = splitmix64(seed, 1, n), splitmix64(seed, 2, n), splitmix64(seed, 3, n)
+    gate_base = n_in + n_const
+    out_of = gate_base + np.arange(n, dtype=np.int64)
+    lh_prev = out_of[np.maximum((k - 1) * Wd + (r_lh % np.uint64(Wd)).astype(np.int64), 0)]
+    lh_log = np.where(k == 0, (r_lh % np.uint64(n_in)).astype(np.int64), lh_prev)
+    back = np.minimum(k, window)
+    pool = n_in + n_const + back * Wd
+    idx = (r_rh % pool.astype(np.uint64)).astype(np.int64)
+    rel = idx - (n_in + n_const)
+    lay = k - 1 - rel // Wd
+    rh_log = np.where(idx < n_in + n_const, idx, out_of[np.clip(lay * Wd + rel % Wd, 0, n - 1)])
+    # ---- the hubs: generation indices (below the last layer), weights
+    u = lambda stream, cnt: (splitmix64(seed, stream, cnt) >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    n_small = int(small_frac * n)
+    n_big = max(0, int(round(big * n / 1e7)))
+    hub_idx = np.unique((splitmix64(seed, 8, n_small + n_big) % np.uint64(max(1, n - Wd))).astype(np.int64))
+    H = len(hub_idx)
+    w = np.minimum(small_lo * (1.0 - u(9, H)) ** (-1.0 / (small_alpha - 1.0 + 1e-9)), small_cap)
+    is_big = np.zeros(H, dtype=bool)
+    if n_big and H:
+        is_big[(splitmix64(seed, 10, n_big) % np.uint64(H)).astype(np.int64)] = True
+        w = np.where(is_big, big_lo * (big_hi / big_lo) ** u(11, H), w)
+    cumw = np.cumsum(w)
+    r_sel, r_pick = u(12, n), u(13, n)
+    cnt = np.searchsorted(hub_idx, k * Wd, side="left")                     # hubs in strictly earlier layers
+    take = (r_sel < p_hub) & (cnt > 0)
+    tot = np.where(cnt > 0, cumw[np.maximum(cnt, 1) - 1], 1.0)
+    pick = np.minimum(np.searchsorted(cumw, r_pick * tot, side="right"), np.maximum(cnt, 1) - 1)
+    if H:
+        rh_log = np.where(take, out_of[hub_idx[pick]], rh_log)
+    # ---- the mega hubs: one gate each in the first layers, read by a fraction f of the gates of every later layer
+    r_m = u(14, n)
+    lo = 0.0
+    for j, f in enumerate(mega):
+        g_m = int(splitmix64(seed, 15 + j, 1)[0] % np.uint64(max(1, min(n - Wd, max(Wd, n // 100)))))
+        hit = (r_m >= lo) & (r_m < lo + f) & (k > g_m // Wd)
+        rh_log = np.where(hit, out_of[g_m], rh_log)
+        lo += f
+    op = _pick_ops(mix, r_op)
+    return _finish(lh_log, rh_log, out_of, op, n_in + n_const + n, n_in, np.arange(n_in, n_in + n_const), k == L - 1, seed, permute,
+                   sparse_ids, L, Wd)
+
+
+def reduction_forest(n: int, width: int = 2000, n_in: int = 4096, n_const: int = 64, mix: Sequence[Tuple[str, int]] = MIX_BITWISE,
+                     seed: int = SEED, permute: bool = True, sparse_ids: bool = True, p_merge: float = 0.4,
+                     p_chain: float = 0.3) -> FlatGates:
+    """In-trees: every gate's out node is read by AT MOST ONE gate (fan-out 1; no claim ticket is ever needed, and every gate
+    with two produced operands hands one of them off).  Built in rounds over a pool of about `width` unread outputs: a fraction
+    `p_merge` of the pool is paired up (a gate reads two of them), `p_chain` is extended (a gate reads one of them and an
+    input), the rest waits; fresh leaves (both operands inputs) keep the pool at `width`.  Subtrees of very different depths
+    meet at a merge; what is still unread at the end are the roots of the forest = the circuit outputs."""
+    rng = np.random.default_rng(seed)
+    lh_parts, rh_parts = [], []
+    pool = np.empty(0, dtype=np.int64)          # generation indices of gates whose out node nobody reads yet
+    g, rounds = 0, 0
+    gate_base = n_in + n_const
+    while g < n:
+        rounds += 1
+        P = len(pool)
+        pool = pool[rng.permutation(P)]
+        a = min(int(p_merge * P) // 2 * 2, 2 * (n - g))
+        merges = a // 2
+        b = min(int(p_chain * P), n - g - merges)
+        leaves = min(max(width - (P - merges), 1 if P == 0 else 0), n - g - merges - b)
+        m_l, m_r = pool[:merges], pool[merges:a]
+        c_p = pool[a:a + b]
+        ext = rng.integers(0, n_in + n_const, size=b + 2 * leaves)
+        side = rng.integers(0, 2, size=b).astype(bool)                    # which operand of a chain gate is the produced one
+        lh_parts += [gate_base + m_l, np.where(side, gate_base + c_p, ext[:b]), ext[b:b + leaves]]
+        rh_parts += [gate_base + m_r, np.where(side, ext[:b], gate_base + c_p), ext[b + leaves:]]
+        made = merges + b + leaves
+        pool = np.concatenate([pool[a + b:], np.arange(g, g + made, dtype=np.int64)])
+        g += made
+    lh_log, rh_log = np.concatenate(lh_parts).astype(np.int64), np.concatenate(rh_parts).astype(np.int64)
+    assert len(lh_log) == n
+    out_of = gate_base + np.arange(n, dtype=np.int64)
+    roots = np.zeros(n, dtype=bool)
+    roots[pool] = True
+    op = _pick_ops(mix, splitmix64(seed, 3, n))
+    return _finish(lh_log, rh_log, out_of, op, gate_base + n, n_in, np.arange(n_in, n_in + n_const), roots, seed, permute, sparse_ids,
+                   rounds, width)
+
+
+def tile_block(lh, rh, out, op, n_nodes, in_nodes, out_nodes, copies: int, shape: str = "chain", seed: int = SEED,
+               permute: bool = False) -> FlatGates:
+    """`copies` instances of ONE real circuit's flat gate list (e.g. the SHA-256 compression of tests/golden/circuits/), wired
+    into a chain or a binary (Merkle) tree by numpy id offsets — no parser run per copy.  in_nodes / out_nodes: the block's
+    input and output nodes in their canonical order, len(in_nodes) == 2 * len(out_nodes).  chain: the first half of copy c's
+    inputs are copy c - 1's outputs; tree (heap order, leaves last, i.e. created first in node-id terms): the two halves of a
+    copy's inputs are its two children's outputs.  Copy ids are laid out so that node ids follow the creation order (a child
+    before its parent), like the reference's counter (src/compiler.rs:497-500).  Gate ids stay in the unroller's order unless
+    `permute`."""
+    lh, rh, out = (np.asarray(x, dtype=np.int64) for x in (lh, rh, out))
+    in_nodes, out_nodes = np.asarray(in_nodes, dtype=np.int64), np.asarray(out_nodes, dtype=np.int64)
+    nb, half = len(lh), len(out_nodes)
+    assert len(in_nodes) == 2 * half and copies >= 1
+    N = int(n_nodes)
+    # creation slot of copy c (its node-id offset is slot * N): chain: c; tree: children are created before their parent
+    if shape == "chain":
+        slot = np.arange(copies, dtype=np.int64)
+        src = [(c - 1, None) if c else (None, None) for c in range(copies)]
+    else:
+        slot = (copies - 1 - np.arange(copies, dtype=np.int64))             # heap index 0 = the root: created last
+        src = [(2 * c + 1 if 2 * c + 1 < copies else None, 2 * c + 2 if 2 * c + 2 < copies else None) for c in range(copies)]
+    off = slot * N
+    LH = (lh[None, :] + off[:, None])
+    RH = (rh[None, :] + off[:, None])
+    OUT = (out[None, :] + off[:, None])
+    # an input node of copy c that is fed by another copy's output: substitute wherever it is read
+    remap_from, remap_to = [], []
+    fed = np.zeros((copies, 2 * half), dtype=bool)
+    for c, (s0, s1) in enumerate(src):
+        for h, s in enumerate((s0, s1)):
+            if s is None:
+                continue
+            remap_from.append(in_nodes[h * half:(h + 1) * half] + off[c])
+            remap_to.append(out_nodes + off[s])
+            fed[c, h * half:(h + 1) * half] = True
+    if remap_from:
+        rf, rt = np.concatenate(remap_from), np.concatenate(remap_to)
+        order = np.argsort(rf)
+        rf, rt = rf[order], rt[order]
+        def sub(A):
+            flat = A.reshape(-1)
+            pos = np.minimum(np.searchsorted(rf, flat), len(rf) - 1)
+            hit = rf[pos] == flat
+            return np.where(hit, rt[pos], flat).reshape(A.shape)
+        LH, RH = sub(LH), sub(RH)
+    # gate order: copy by copy in creation order (what an unroller walking the tree bottom-up would append)
+    by_slot = np.argsort(slot)
+    lh_f, rh_f, out_f = LH[by_slot].reshape(-1), RH[by_slot].reshape(-1), OUT[by_slot].reshape(-1)
+    op_f = np.tile(np.asarray(op, dtype=np.uint8), copies)
+    inputs = np.concatenate([(in_nodes + off[c])[~fed[c]] for c in by_slot])
+    final = 0 if shape != "chain" else copies - 1
+    outputs = out_nodes + off[final]
+    if permute:
+        perm = np.argsort(splitmix64(seed, 5, nb * copies), kind="stable")
+        lh_f, rh_f, out_f, op_f = lh_f[perm], rh_f[perm], out_f[perm], op_f[perm]
+    return FlatGates(lh=lh_f.astype(np.uint32), rh=rh_f.astype(np.uint32), out=out_f.astype(np.uint32), op=np.ascontiguousarray(op_f),
+                     n_nodes=N * copies, input_nodes=inputs.astype(np.uint32), output_nodes=outputs.astype(np.uint32),
+                     const_nodes=np.empty(0, np.uint32), layers=copies, layer_width=nb)
+
+
+# the new families at the sizes the GPU suite (1 M) and tools/stress.sh (10 M) run them at: name -> callable(scale)
+def family(name: str, n_target: int = 1_000_000, seed: int = SEED) -> FlatGates:
+    Wd = 2000
+    L = max(8, n_target // Wd)
+    if name == "hub":
+        return hub_dag(L, Wd, seed=seed)
+    if name == "hub_mild":            # hubs of 17-900 only (no big, no mega ones): the fan-outs a broadcast inside one layer makes
+        return hub_dag(L, Wd, seed=seed, big=0, mega=())
+    if name == "window_all":          # rh uniform over ALL earlier layers: no locality at any distance
+        return layered_dag(L, Wd, window=L, seed=seed)
+    if name == "forest":
+        return reduction_forest(L * Wd, width=Wd, seed=seed)
+    raise KeyError(name)
