@@ -71,7 +71,8 @@ class _Stats(ctypes.Structure):
                 ("max_depth", ctypes.c_uint32), ("n_roots", ctypes.c_uint32), ("n_splitters", ctypes.c_uint32),
                 ("level_launches", ctypes.c_uint32), ("peel_waves", ctypes.c_uint32),
                 ("path_chunks", ctypes.c_uint32), ("peel_rereads", ctypes.c_uint32),
-                ("numbering_events", ctypes.c_uint32), ("numbering_path", ctypes.c_uint32)]
+                ("numbering_events", ctypes.c_uint32), ("numbering_path", ctypes.c_uint32),
+                ("n_relays", ctypes.c_uint32), ("verifier", ctypes.c_uint32)]
 
 
 @dataclass
@@ -91,7 +92,7 @@ class BoolInfo:
         return np.where(W < M, W * w + bit, M * w + self.aux_total + (W - M) * w + bit)
 
 
-ABI_VERSION = 6          # == C2A_ABI_VERSION of include/c2a.h this binding was written against
+ABI_VERSION = 7          # == C2A_ABI_VERSION of include/c2a.h this binding was written against
 
 _EXPORTS = ["c2a_abi_version", "c2a_visible_devices", "c2a_create", "c2a_device_count", "c2a_format_bristol", "c2a_destroy", "c2a_last_error", "c2a_version", "c2a_load_gates", "c2a_topo_sort",
             "c2a_topo_sort_serial", "c2a_assign_wires", "c2a_emit_gates", "c2a_build_circuit", "c2a_boolify",

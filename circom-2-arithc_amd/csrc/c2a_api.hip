@@ -100,6 +100,7 @@ struct c2a_ctx {
 
     // device buffers
     DevBuf lh, rh, out, op, gate4, nrec, orig, in_nodes, out_nodes;
+    DevBuf rbase, poff;            // hubs (c2a_peel.h HUBS AND RELAYS): where a hub's relays start; where a gate's / relay's own consumer list starts
     DevBuf prod1, dep0, dep1, cons_cnt, cons_off, eslot, aq_items, aq_pc, aq_seeds, aq_seeds1, aq_seed_flat, aq_seed_cnt, fill, meta, node, child, gstat, clist, pctl, pcold;
     DevBuf rbits, rpre, ridx, rlist, next, owner, local, slist, sjump, sjump2, sorted, sorted_r;
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op;
@@ -129,7 +130,7 @@ struct c2a_ctx {
     std::vector<DevBuf*> all;
 
     c2a_ctx() {
-        all = {&lh, &rh, &out, &op, &gate4, &nrec, &orig, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &aq_items, &aq_pc, &aq_seeds, &aq_seeds1, &aq_seed_flat, &aq_seed_cnt, &fill,
+        all = {&rbase, &poff, &lh, &rh, &out, &op, &gate4, &nrec, &orig, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &aq_items, &aq_pc, &aq_seeds, &aq_seeds1, &aq_seed_flat, &aq_seed_cnt, &fill,
                &gstat, &clist, &pctl, &pcold, &meta, &node, &child, &rbits, &rpre, &ridx, &rlist, &next,
                &owner, &local, &slist, &sjump, &sjump2, &sorted, &sorted_r, &first, &nflag, &wflag, &widx, &node_wire1,
                &node_wire, &e_in0, &e_in1, &e_out, &e_op, &pos_r, &wire_r, &erec, &pblk, &dpre, &epre, &gflag, &scan_tmp, &scan_desc, &scalars, &dfs_state, &dfs_stack, &peel_prof, &peel_trace, &tsz, &asz, &goff,
@@ -141,6 +142,7 @@ namespace {
 
 // scalars block layout (u32 words unless noted)
 enum Scalar { SC_MAXDEPTH = 0, SC_SCOUNT = 1, SC_ERR = 2, SC_NMID = 3, SC_NROOTS = 4, SC_LEVELS = 5, SC_PEELOK = 6 /* the dataflow launch ended cleanly and left no gate behind (k_post_peel) */,
+              SC_RELAYS = 7 /* relays handed out to the hubs of this build (ScanConsHub) */,
               SC_DFS = 8 /*3 words*/, SC_DUP = 52,
               SC_TOTAL64 = 16 /* u64 slots from here: 16..31 */, SC_WORDS = 64 };
 
@@ -246,6 +248,7 @@ BuildRegions build_regions(const c2a_ctx* c) {
     R.total = R.bits + scan_desc_bytes(((u64)c->n + 31) / 32, 2);
     return R;
 }
+inline u32 n_all_of(u32 n) { return n + (u32)relay_cap(n); }                         // real gates + room for the relays of its hubs (c2a_peel.h)
 inline size_t fill_dummy_off(u32 n) { return (((size_t)n + 3) & ~(size_t)3) * 4; }      // bytes: the waves' dummy ticket words start on a 16-byte boundary behind fill[n]
 inline size_t seed_cnt_bytes(const c2a_ctx* c, u32 sink_blocks) { return (((size_t)(c->peel_shallow + 1) * sink_blocks + 16) * 4 + 15) & ~(size_t)15; }
 inline u32 sink_blocks_of(const c2a_ctx* c);
@@ -275,7 +278,7 @@ int clear_for_build(c2a_ctx* c, bool peel_only = false) {
         ENSURE(c->aq_pc, (size_t)c->peel_fifos * kPcStride * 8);
         ENSURE(c->pctl, ((size_t)CTL_WORDS * 4 + 15) & ~(size_t)15);
         ENSURE(c->aq_seed_cnt, seed_cnt_bytes(c, sb));
-        add(reinterpret_cast<char*>(c->fill.p) + fill_dummy_off(n), (size_t)kFillDummyStride * kFillDummyWaves * 4);
+        add(reinterpret_cast<char*>(c->fill.p) + fill_dummy_off(n_all_of(n)), (size_t)kFillDummyStride * kFillDummyWaves * 4);
         add(c->aq_pc.p, (size_t)c->peel_fifos * kPcStride * 8);
         add(c->pctl.p, (size_t)CTL_WORDS * 4);
         add(c->aq_seed_cnt.p, seed_cnt_bytes(c, sb));
@@ -321,10 +324,12 @@ int do_prep(c2a_ctx* c, bool for_peel = true) {
     C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->out.as<u32>(), c->op.as<u8>(), dup, c->prod1.as<u32>(), (const u8*)c->nflag.as<u8>(), c->orig.as<u32>(),
                       c->gate4.as<uint4>(), c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>(), c->gflag.as<u8>());
     if (!for_peel) return C2A_OK;
-    r = scan_exclusive<u32>(c, c->cons_cnt.as<u32>(), c->cons_off.as<u32>(), n, desc + R.cons);
+    // (the scan of the consumer counts also hands every hub — more than kHubMin consumers — the ids of its relays)
+    r = scan_1pass<1>(c, s, c->scan_tmp, n, ScanConsHub{c->cons_cnt.as<u32>(), c->rbase.as<u32>(), c->scalars.as<u32>() + SC_RELAYS}, c->cons_off.as<u32>(), (u32*)nullptr, desc + R.cons);
     if (r) return r;
     C2A_LAUNCH_NOSYNC(k_gstat, G, kThreads, s, n, c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_off.as<u32>(),
-                      c->eslot.as<u32>(), c->orig.as<u32>(), c->gstat.as<uint4>(), c->clist.as<u32>());
+                      c->eslot.as<u32>(), c->orig.as<u32>(), (const u32*)c->rbase.as<u32>(), c->gstat.as<uint4>(), c->clist.as<u32>(), c->poff.as<u32>(),
+                      c->fill.as<u32>(), c->child.as<uint2>());
     return C2A_OK;
 }
 
@@ -361,13 +366,14 @@ int peel_launch(c2a_ctx* c) {
     c->peel_gave_up = false;                         // (only a watchdog abort observed in THIS launch may trigger the retry / the serial fall-back)
     const bool want_stats = std::getenv("C2A_PEEL_STATS") != nullptr;
     PeelArgs A;
-    A.n = n; A.gstat = c->gstat.as<uint4>(); A.clist = c->clist.as<u32>();
+    const u32 n_all = n_all_of(n);
+    A.n = n; A.n_all = n_all; A.gstat = c->gstat.as<uint4>(); A.clist = c->clist.as<u32>();
     A.node = c->node.as<u64>(); A.fill = c->fill.as<u32>(); A.meta = c->meta.as<uint4>(); A.child = c->child.as<u32>();
     PeelCold cold;
     // node words carry the tag of the run that wrote them: zeroed memory first sees tag 1, then 2 and 1 take turns (a word
     // left over from two runs ago holds the same value: the peel of one loaded graph is deterministic)
     if (c->node_clear) {
-        HIP_TRY(hipMemsetAsync(c->node.p, 0, (size_t)n * kNodeWords * 8, s));
+        HIP_TRY(hipMemsetAsync(c->node.p, 0, (size_t)n_all * kNodeWords * 8, s));
         c->peel_epoch = 0;
     }
     // (1 and 2 take turns; in the first run after a clear every lane of a record must carry the run's tag — c2a_peel.h NODE RECORDS)
@@ -379,11 +385,11 @@ int peel_launch(c2a_ctx* c) {
     const u32 waves = peel_grid(c, want_stats, &n_primary);
     // the waves' dummy ticket words behind fill[n] (c2a_peel.h, SCALAR TICKETS): zero, and they stay zero (only 0 is ever
     // added); a ticket word is addressed by a 32-bit byte offset from fill
-    if (waves > kFillDummyWaves || n >= (1u << 29)) { c->err = "peel: grid or gate count beyond the ticket words' addressing"; return C2A_ERR_ARG; }
+    if (waves > kFillDummyWaves || n_all >= (1u << 29)) { c->err = "peel: grid or gate count beyond the ticket words' addressing"; return C2A_ERR_ARG; }
     // hand-off arrays: every slot is used once per run (no wrap-around).  A wave spreads its pushes round robin, so an
     // array receives at most pushes / n_fifos + waves entries, and a wave holds at most one unserved consumer ticket
     A.n_fifos = c->peel_fifos;
-    A.q_cap = n / A.n_fifos + 2 * waves + 64;
+    A.q_cap = n_all / A.n_fifos + 2 * waves + 64;
     const size_t slots = (size_t)A.n_fifos * A.q_cap;
     if (slots >= (1ull << 32)) { c->err = "peel: hand-off slots beyond 32-bit addressing"; return C2A_ERR_ARG; }
     // (slots are never cleared between runs: every word of an entry carries the number of the run that wrote it)
@@ -404,8 +410,8 @@ int peel_launch(c2a_ctx* c) {
         HIP_TRY(hipMemsetAsync(c->peel_prof.p, 0, 256 + 2 * slots * 8, s));
         cold.stats = c->peel_prof.as<ull>(); cold.q_time = c->peel_prof.as<ull>() + 32; cold.p_time = cold.q_time + slots;
         if (trace_dir) {
-            ENSURE(c->peel_trace, (size_t)n * 24);
-            HIP_TRY(hipMemsetAsync(c->peel_trace.p, 0, (size_t)n * 24, s));
+            ENSURE(c->peel_trace, (size_t)n_all * 24);
+            HIP_TRY(hipMemsetAsync(c->peel_trace.p, 0, (size_t)n_all * 24, s));
             cold.t_trace = c->peel_trace.as<ull>();
         }
     }
@@ -423,8 +429,8 @@ int peel_launch(c2a_ctx* c) {
     // body of the graph), and what the LAST of these passes claims starts the chains of the dataflow launch (collected per
     // workgroup first, then moved to ONE list the waves of the launch take seed_chunk at a time; its length stays on the
     // device: the word behind the region counts)
-    ENSURE(c->aq_seeds1, (size_t)sink_blocks * l1_cap * 4); ENSURE(c->aq_seed_flat, ((size_t)n + 64) * 4);
-    cold.cons_off = c->cons_off.as<u32>();
+    ENSURE(c->aq_seeds1, (size_t)sink_blocks * l1_cap * 4); ENSURE(c->aq_seed_flat, ((size_t)n_all + 64) * 4);
+    cold.cons_off = c->poff.as<u32>();
     cold.seeds = c->aq_seed_flat.as<u32>(); cold.seed_total = c->aq_seed_cnt.as<u32>() + (size_t)(shallow + 1) * sink_blocks; cold.seed_chunk = c->peel_seed_chunk;
     // what only the edges of the launch touch travels as one small block in HBM (keeps the kernel's scalar registers free)
     // (written by a one-thread launch that takes it by value: a copy from this stack object would need a host round trip)
@@ -437,7 +443,7 @@ int peel_launch(c2a_ctx* c) {
         u32* cnts = c->aq_seed_cnt.as<u32>();
         const u32* in = (lvl & 1u) ? c->aq_seeds.as<u32>() : c->aq_seeds1.as<u32>();
         u32* out = (lvl & 1u) ? c->aq_seeds1.as<u32>() : c->aq_seeds.as<u32>();
-        C2A_LAUNCH(k_peel_shallow, sink_blocks, kThreads, s, A, (const u32*)c->cons_off.as<u32>(), lvl, lvl == shallow ? 1u : 0u, in, (const u32*)(cnts + (size_t)(lvl - 1) * sink_blocks), lvl == 1 ? sink_cap : l1_cap,
+        C2A_LAUNCH(k_peel_shallow, sink_blocks, kThreads, s, A, (const u32*)c->poff.as<u32>(), lvl, lvl == shallow ? 1u : 0u, in, (const u32*)(cnts + (size_t)(lvl - 1) * sink_blocks), lvl == 1 ? sink_cap : l1_cap,
                    out, cnts + (size_t)lvl * sink_blocks, l1_cap, c->aq_seed_flat.as<u32>(), cnts + (size_t)(shallow + 1) * sink_blocks);
     }
     // (every wave of the launch is alive at once under emulation too, interleaved at the back-offs — in a shuffled order per
@@ -450,7 +456,9 @@ int peel_launch(c2a_ctx* c) {
     rec(c, EV_KPEEL1);
     static_assert(CTL_PROCESSED == 0 && CTL_MAXLEVEL == 1 && CTL_ABORT == 2 && CTL_REREADS == 3, "the order k_post_peel writes them in");
     C2A_LAUNCH(k_post_peel, 1, 64, s, c->hrb_dev, (const u32*)c->pctl.as<u32>(), (const u32*)(c->cons_off.as<u32>() + n), (const u32*)(c->scalars.as<u32>() + SC_DUP), n,
-               c->scalars.as<u32>() + SC_PEELOK);
+               (const u32*)(c->scalars.as<u32>() + SC_RELAYS), c->scalars.as<u32>() + SC_PEELOK);
+    // the relays leave the DFS tree again (nothing to do without hubs: the launch is a look at one word)
+    C2A_LAUNCH_NOSYNC(k_relay_fix, 256, kThreads, s, n, (const u32*)(c->scalars.as<u32>() + SC_PEELOK), (const u32*)(c->scalars.as<u32>() + SC_RELAYS), c->meta.as<uint4>(), c->child.as<u32>());
     c->peel_slots = slots; c->peel_waves_used = waves; c->peel_want_stats = want_stats;
     return C2A_OK;
 }
@@ -525,6 +533,7 @@ int peel_result(c2a_ctx* c, u32* peeled_out) {
     c->stats.level_launches = 2;
     c->stats.peel_waves = waves;
     c->stats.peel_rereads = t4[CTL_REREADS];
+    c->stats.n_relays = c->hrb[7];
     return C2A_OK;
 }
 
@@ -683,8 +692,8 @@ int do_topo_sort(c2a_ctx* c, u64* cycle_at, bool defer_sorted = false) {
             // the launch's watchdog tripped (a wave waited too long for a record or for global progress): once more on clean
             // buffers — node records re-zeroed, tickets and child pointers reset — before the serial DFS takes over
             if (!deep_switch) std::fprintf(stderr, "[c2a] the dataflow peel gave up (%s); retrying once on clean buffers\n", c->err.c_str());
-            HIP_TRY(hipMemsetAsync(c->fill.p, 0, (size_t)c->n * 4, c->stream));
-            HIP_TRY(hipMemsetAsync(c->child.p, 0xFF, (size_t)c->n * 8, c->stream));
+            HIP_TRY(hipMemsetAsync(c->fill.p, 0, (size_t)n_all_of(c->n) * 4, c->stream));
+            HIP_TRY(hipMemsetAsync(c->child.p, 0xFF, (size_t)n_all_of(c->n) * 8, c->stream));
             HIP_TRY(hipMemsetAsync(c->scalars.as<u32>() + SC_MAXDEPTH, 0, 8, c->stream));
             int rc = clear_for_build(c, true);
             if (rc) return rc;
@@ -989,15 +998,18 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     ENSURE(c->nrec, (size_t)n_nodes * 16); ENSURE(c->orig, n4);
     ENSURE(c->in_nodes, (size_t)n_in * 4); ENSURE(c->out_nodes, (size_t)n_out * 4);
     ENSURE(c->prod1, nn4); ENSURE(c->dep0, n4); ENSURE(c->dep1, n4); ENSURE(c->cons_cnt, n4);
-    ENSURE(c->cons_off, n4 + 4); ENSURE(c->eslot, 2 * n4); ENSURE(c->fill, n4 + 16 + (size_t)kFillDummyStride * kFillDummyWaves * 4);
-    ENSURE(c->meta, (size_t)n * 16); ENSURE(c->gstat, (size_t)n * 32); ENSURE(c->clist, 2 * n4 + 64 * 4);
-    ENSURE(c->node, (size_t)n * kNodeWords * 8); ENSURE(c->child, 2 * n4);
+    // (what the dataflow launch keeps per gate has room for the relays of the hubs behind the n gates: c2a_peel.h HUBS AND RELAYS)
+    const size_t na = n_all_of(n), na4 = na * 4, rcap = (size_t)relay_cap(n);
+    ENSURE(c->cons_off, n4 + 4); ENSURE(c->eslot, 2 * n4); ENSURE(c->fill, na4 + 16 + (size_t)kFillDummyStride * kFillDummyWaves * 4);
+    ENSURE(c->meta, na * 16); ENSURE(c->gstat, na * 32); ENSURE(c->clist, 2 * n4 + 64 * 4 + (rcap + 64) * 4);
+    ENSURE(c->node, na * kNodeWords * 8); ENSURE(c->child, 2 * na4); ENSURE(c->rbase, n4); ENSURE(c->poff, na4);
     // a new graph needs clean node records (5 GB at 10 M gates, ~0.75 ms of HBM writes): cleared here, on a stream of its own,
     // beside the host-to-device copies below — a one-shot caller (the reference calls build_circuit once per process) never
     // waits for it, and a step on a loaded graph does not need it (the run tag alternates)
     c->node_clear = true;
     bool cleared = false;
-    if (n && hipMemsetAsync(c->node.p, 0, (size_t)n * kNodeWords * 8, c->aux) == hipSuccess) cleared = true;
+    if (n && hipMemsetAsync(c->node.p, 0, na * kNodeWords * 8, c->aux) == hipSuccess) cleared = true;
+    if (n) C2A_LAUNCH_NOSYNC(k_relay_list, grid_for(rcap, 1024), kThreads, c->aux, n, (u32)rcap, c->clist.as<u32>());
     if (n_nodes) { HIP_TRY(hipMemsetAsync(c->nrec.p, 0, (size_t)n_nodes * 16, c->aux)); c->build_no = 0; }      // (no record of any build)
 #ifdef C2A_EMULATE
     c->build_no = c->emul_build_no;
@@ -1623,6 +1635,7 @@ static int verify_local(c2a_ctx* c, u64 seed, u64* n_checked, u64* n_mismatch) {
     }
     if (n_checked) *n_checked = (u64)c->n * 64;
     if (n_mismatch) *n_mismatch = bad;
+    c->stats.verifier = 2;                           // (every device checked its own gates locally: c2a.h c2a_stats)
     return C2A_OK;
 }
 
@@ -1658,6 +1671,7 @@ int c2a_verify_boolify(c2a_ctx* c, uint64_t seed, uint64_t* n_checked, uint64_t*
     if (n && (r = barrier_gave_up(c, "c2a_verify_boolify"))) return r;
     if (n_checked) *n_checked = (u64)wc * 64;
     if (n_mismatch) *n_mismatch = bad;
+    c->stats.verifier = 1;                           // (both circuits simulated wire by wire)
     return C2A_OK;
 }
 

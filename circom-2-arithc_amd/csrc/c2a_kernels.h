@@ -206,6 +206,16 @@ __global__ void k_clear(ClearList L) {
 
 // element functors
 struct ScanFromU32 { const u32* in; __device__ __forceinline__ void operator()(u64 i, u32* x) const { x[0] = in[i]; } };
+// the consumer counts, and on the way every HUB (more than kHubMin consumers: c2a_peel.h HUBS AND RELAYS) is handed the ids of
+// its relays — a run of relay_count(c) from ONE counter (hubs are rare; which hub gets which run does not matter)
+struct ScanConsHub {
+    const u32* in; u32* rbase; u32* total;
+    __device__ __forceinline__ void operator()(u64 i, u32* x) const {
+        const u32 c = in[i];
+        x[0] = c;
+        if (c > kHubMin) rbase[i] = atomicAdd(total, relay_count(c));
+    }
+};
 
 // ------------------------------------------------------------------------------------------------
 // argument validation of c2a_load_gates on the device, behind the copy (the host loop over all gates it replaces was 5.8 of the
@@ -1037,14 +1047,15 @@ __global__ void k_post_words(u32* dst, const u32* a, u32 na, const u32* b, u32 n
     for (u32 i = threadIdx.x; i < nc; i += blockDim.x) dst[na + nb + i] = c3[i];
 }
 // the peel: gates done and the highest level (summed / maximised over their kAcctShards parts), gave up, re-reads, edges, duplicate writers
-__global__ void k_post_peel(u32* dst, const u32* ctl, const u32* edges, const u32* dup, u32 n, u32* ok) {
+__global__ void k_post_peel(u32* dst, const u32* ctl, const u32* edges, const u32* dup, u32 n, const u32* relays, u32* ok) {
     const u32 t = threadIdx.x;            // (one wave)
     u32 done = t < kAcctShards ? ctl[CTL_PROC + t * kAcctStride] : 0u, lvl = t < kAcctShards ? ctl[CTL_PROC + t * kAcctStride + 1] : 0u;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { done += __shfl_xor(done, off, 64); const u32 o = __shfl_xor(lvl, off, 64); lvl = o > lvl ? o : lvl; }
     if (t == 0) {
-        dst[0] = done; dst[1] = lvl; dst[2] = ctl[CTL_ABORT]; dst[3] = ctl[CTL_REREADS]; dst[4] = *edges; dst[5] = *dup; dst[6] = ctl[CTL_NEEDDEEP];
-        *ok = (ctl[CTL_ABORT] == 0u && done == n) ? 1u : 0u;      // (what the order stage, queued right behind, goes by)
+        // (the relays of the hubs are gates of the launch too: it has done n + *relays when nothing is left behind)
+        dst[0] = done - *relays; dst[1] = lvl; dst[2] = ctl[CTL_ABORT]; dst[3] = ctl[CTL_REREADS]; dst[4] = *edges; dst[5] = *dup; dst[6] = ctl[CTL_NEEDDEEP]; dst[7] = *relays;
+        *ok = (ctl[CTL_ABORT] == 0u && done == n + *relays) ? 1u : 0u;      // (what the order stage, queued right behind, goes by)
     }
 }
 

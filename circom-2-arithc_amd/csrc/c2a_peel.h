@@ -75,6 +75,20 @@
 // plays no part in it, and co-residency of the grid is not required: a wave that starts late adds its unit, finds the
 // seed pool empty, ends it, and sees the counters equal.  (One waiting wave in 64 looks at the counters every 32 polls
 // and raises a DONE flag for the others; every wave looks for itself once in 1024 polls.)
+// HUBS AND RELAYS.  A step loads eight candidate records ahead and takes the rest of a consumer list eight at a time, on ONE
+// wave: fine for the fan-outs a circuit mostly has, not for a produced node that a thousand — or a million — gates read (a
+// broadcast selector, a scale factor: compiler.rs:408-421 allows any fan-out).  k_gstat therefore gives every gate with more than
+// kHubMin consumers a TREE OF RELAYS: virtual gates n, n + 1, ... (behind the real ones in every per-gate array), each the only
+// "producer" of at most kRelayFan consumers — a segment of the hub's consumer list as it lies; the next level's relays consume
+// the relays; the hub's own consumers are the (at most kHubMin) relays of the top level.  A relay is an ordinary gate to the
+// launch — tickets, a record, a chain step — with the edge to its parent labelled 0, a root key no gate can have (it is never
+// its own DFS root) and a level that does not count (the reverse Kahn levels stay exact).  Its tournament picks the smallest
+// path among its segment, the parent's among the relays: the hub ends up with the smallest of all, with one more 0 bit per relay
+// level behind the real label.  Those extra bits change no comparison: two paths that both run through the hub carry them at
+// the same place, and any other pair differs before them (neither is a prefix of the other).  The work of a hub's tournament is
+// thereby spread over as many waves as it has segments, and over TIME: a relay runs when the last of its sixteen consumers is
+// claimed, not when the hub is.  k_relay_fix (behind the launch) takes the relays out of the tree again: the hub's parent is
+// the consumer its bottom relay chose, with that edge's label.
 // Watchdog: lack of GLOBAL progress (a heartbeat the working waves bump) — a long critical path followed by one wave is
 // not an error.
 #pragma once
@@ -127,9 +141,33 @@ constexpr u32 kAcctStride = 32;
 constexpr u32 kFillDummyStride = 32;        // u32 words between two waves' dummy ticket words behind fill[n]
 constexpr u32 kFillDummyWaves = 8192;       // ... of at most this many waves (256 CUs x 32)
 
+// ---- hubs and relays (HUBS AND RELAYS above) ----
+#ifndef C2A_RELAY_FAN
+#define C2A_RELAY_FAN 16
+#endif
+#ifndef C2A_HUB_MIN
+#define C2A_HUB_MIN 16
+#endif
+constexpr u32 kRelayFan = C2A_RELAY_FAN;    // consumers of one relay: eight records loaded ahead + one batch of the list loop
+constexpr u32 kHubMin = C2A_HUB_MIN;        // a gate with MORE consumers than this gets a relay tree
+constexpr u32 kShallowSkip = C2A_NONE - 1u; // (k_peel_shallow: a lane whose gate turned out to be a relay)
+constexpr u32 kRelayOrig = kHdrMask;        // a relay's "original id" (word 2 of its first static record): above every gate id, so it is never its own DFS root — and how a step knows a relay
+static_assert(kRelayFan >= 8 && kRelayFan <= 32 && kHubMin >= kRelayFan && kHubMin <= 32, "a relay's consumers and a hub's top-level relays fit the prefetched half list (32 lanes)");
+__host__ __device__ constexpr u32 relay_ceil(u32 a) { return (a + kRelayFan - 1u) / kRelayFan; }
+// relays of a hub with N > kHubMin consumers (all levels), and where its top level starts / how many relays that level has
+__host__ __device__ constexpr u32 relay_count(u32 N) { u32 c = relay_ceil(N), t = c; while (c > kHubMin) { c = relay_ceil(c); t += c; } return t; }
+struct RelayTop { u32 off, cnt; };
+__host__ __device__ constexpr RelayTop relay_top(u32 N) { u32 c = relay_ceil(N), o = 0; while (c > kHubMin) { o += c; c = relay_ceil(c); } return RelayTop{o, c}; }
+// The relays of ALL hubs together: at most kRelayNum / kRelayDen per edge (worst case: a hub just above kHubMin), and a graph
+// of n gates has at most 2 n edges — the per-gate arrays of the launch hold n + relay_cap(n) entries.
+constexpr u32 kRelayNum = relay_count(kHubMin + 1u), kRelayDen = kHubMin + 1u;
+constexpr bool relay_bound_holds() { for (u32 N = kHubMin + 1u; N < 5000u; ++N) if ((u64)relay_count(N) * kRelayDen > (u64)N * kRelayNum) return false; return true; }
+static_assert(relay_bound_holds(), "relay_count(N) <= N * kRelayNum / kRelayDen");
+__host__ __device__ constexpr u64 relay_cap(u64 n) { return (2 * n * kRelayNum + kRelayDen - 1) / kRelayDen + 64; }
+
 // what only the edges of the launch touch (kept out of the kernel's scalar registers)
 struct PeelCold {
-    const u32* cons_off;       // [n + 1] where a gate's own consumer list starts in clist (chain starts and the cold list loop only)
+    const u32* cons_off;       // [n_all] where a gate's own consumer list starts in clist (chain starts and the list loop only): poff of k_gstat
     const u32* seeds;          // [*seed_total] the gates the launch starts chains from (claimed by the last k_peel_shallow pass), one flat list
     const u32* seed_total;     // how many (device side: the host never learns it)
     u32 seed_chunk;            // a wave takes this many at a time
@@ -142,9 +180,10 @@ struct PeelCold {
 struct PeelArgs {
     u32 epoch;                 // tag (1 / 2, taking turns) of this run's node words
     u32 pad_thr;               // kThrExact in the first run after the node records were cleared, else kThrPad (NODE RECORDS above)
-    u32 n;
-    const uint4* gstat;        // [2n] {dep0, dep1, original gate id, cons_cnt} {cons_off[dep0], cons_cnt[dep0], cons_off[dep1], cons_cnt[dep1]}
-    const u32* clist;          // [edges + 64] consumer | edge label << 31, grouped by producer
+    u32 n;                     // real gates (the sinks pass walks these; relays are never sinks)
+    u32 n_all;                 // n + relay_cap(n): entries of every per-gate array below (the waves' dummy ticket words lie behind fill[n_all])
+    const uint4* gstat;        // [2 n_all] {dep0, dep1, original gate id, cons_cnt} {cons_off[dep0], cons_cnt[dep0], cons_off[dep1], cons_cnt[dep1]}
+    const u32* clist;          // [2n + 64 | relay_cap + 64] consumer | edge label << 31, grouped by producer; behind the real edges: entry i = relay i (the consumer lists of relays' parents)
     u64* node;                 // [n][64] node records
     u32* fill;                 // [n] claim tickets taken so far (zeroed per run)
     uint4* meta;               // [n] {parent | NONE, depth, root, label | level << 1}: read by later launches only
@@ -290,21 +329,89 @@ __device__ __attribute__((noinline)) bool deep_less(const u64* node_base, u32 ep
 // static per-gate data of the dataflow launch (after the consumer counts have been scanned):
 // gstat and the consumer lists (eslot[2g + l] = index of edge (g, l) in its producer's list, from k_deps)
 // ------------------------------------------------------------------------------------------------
+// The relays above relay `idx` of level `lvl_off` (HUBS AND RELAYS): written by ONE thread — the one that holds the first edge
+// of the bottom relay's segment goes on upwards while the relay it just wrote is the first of ITS parent's segment.
+// Hub h: N consumers at clist[off_h ...), relays n + b ...; xbase: where entry i = relay i starts in clist.
+__device__ __forceinline__ void write_relays(u32 n, u32 h, u32 N, u32 off_h, u32 b, u32 j, u32 xbase, uint4* gstat, u32* poff, u32* fill, uint2* child) {
+    u32 cnt_lvl = relay_ceil(N), lvl_off = 0, idx = j;
+    u32 list_off = off_h + j * kRelayFan, list_cnt = N - j * kRelayFan < kRelayFan ? N - j * kRelayFan : kRelayFan;
+    for (;;) {
+        const u64 r = (u64)n + b + lvl_off + idx;
+        const bool top = cnt_lvl <= kHubMin;
+        const u32 pj = idx / kRelayFan;
+        const u32 parent = top ? h : n + b + lvl_off + cnt_lvl + pj;
+        const u32 p_off = xbase + b + lvl_off + (top ? 0u : pj * kRelayFan);
+        const u32 p_cnt = top ? cnt_lvl : (cnt_lvl - pj * kRelayFan < kRelayFan ? cnt_lvl - pj * kRelayFan : kRelayFan);
+        gstat[2 * r] = make_uint4(parent, C2A_NONE, kRelayOrig, list_cnt);
+        gstat[2 * r + 1] = make_uint4(p_off, p_cnt, 0u, 0u);
+        poff[r] = list_off;
+        fill[r] = 0u;
+        child[r] = make_uint2(C2A_NONE, C2A_NONE);
+        if (top || idx % kRelayFan != 0u) break;
+        list_off = p_off; list_cnt = p_cnt; lvl_off += cnt_lvl; idx = pj; cnt_lvl = relay_ceil(cnt_lvl);
+    }
+}
 __global__ void k_gstat(u32 n, const u32* __restrict__ dep0, const u32* __restrict__ dep1, const u32* __restrict__ cons_off,
-                        const u32* __restrict__ eslot, const u32* __restrict__ orig, uint4* gstat, u32* clist) {
+                        const u32* __restrict__ eslot, const u32* __restrict__ orig, const u32* __restrict__ rbase, uint4* gstat, u32* clist,
+                        u32* poff, u32* fill, uint2* child) {
     // (the consumer count of a gate is the difference of two neighbouring offsets — cons_off has n + 1 entries —: ONE
     // 8-byte access per producer instead of two 4-byte ones in two arrays.  Word 2 of a gate's first record is its ORIGINAL
     // id — what the DFS roots are compared by, topological_sort.rs:11-13; the launch works in rank space, c2a_kernels.h
-    // RELABELLING —; the offset of its own consumer list is only wanted off the hot path and is read from cons_off there)
+    // RELABELLING —; the offset of its own consumer list is only wanted off the hot path and is read from poff there.
+    // A producer with more than kHubMin consumers is a HUB (rbase[]: where its relays start, handed out by the scan of the
+    // counts): the edge goes to the relay that owns its slot of the hub's list, the hub's own list are its top-level relays)
     const XcdSweep R = xcd_sweep(n);
+    const u32 xbase = 2u * n + 64u;
     for (u64 g = R.i; g < R.end; g += R.step) {
-        const u32 d0 = dep0[g], d1 = dep1[g];
+        u32 d0 = dep0[g], d1 = dep1[g];
         const u32 o = cons_off[g];
-        gstat[2 * g] = make_uint4(d0, d1, orig[g], cons_off[g + 1] - o);
+        u32 own_cnt = cons_off[g + 1] - o, own_off = o;
+        if (own_cnt > kHubMin) { const RelayTop T = relay_top(own_cnt); own_off = xbase + rbase[g] + T.off; own_cnt = T.cnt; }
         uint4 g2 = make_uint4(0, 0, 0, 0);
-        if (d0 != C2A_NONE) { g2.x = cons_off[d0]; g2.y = cons_off[(u64)d0 + 1] - g2.x; clist[g2.x + eslot[2 * g]] = (u32)g; }
-        if (d1 != C2A_NONE) { g2.z = cons_off[d1]; g2.w = cons_off[(u64)d1 + 1] - g2.z; clist[g2.z + eslot[2 * g + 1]] = (u32)g | 0x80000000u; }
+        if (d0 != C2A_NONE) {
+            const u32 off = cons_off[d0], cnt = cons_off[(u64)d0 + 1] - off, slot = eslot[2 * g];
+            clist[off + slot] = (u32)g;
+            g2.x = off; g2.y = cnt;
+            if (cnt > kHubMin) {
+                const u32 b = rbase[d0], j = slot / kRelayFan;
+                if (slot % kRelayFan == 0u) write_relays(n, d0, cnt, off, b, j, xbase, gstat, poff, fill, child);
+                d0 = n + b + j; g2.x = off + j * kRelayFan; g2.y = cnt - j * kRelayFan < kRelayFan ? cnt - j * kRelayFan : kRelayFan;
+            }
+        }
+        if (d1 != C2A_NONE) {
+            const u32 off = cons_off[d1], cnt = cons_off[(u64)d1 + 1] - off, slot = eslot[2 * g + 1];
+            clist[off + slot] = (u32)g | 0x80000000u;
+            g2.z = off; g2.w = cnt;
+            if (cnt > kHubMin) {
+                const u32 b = rbase[d1], j = slot / kRelayFan;
+                if (slot % kRelayFan == 0u) write_relays(n, d1, cnt, off, b, j, xbase, gstat, poff, fill, child);
+                d1 = n + b + j; g2.z = off + j * kRelayFan; g2.w = cnt - j * kRelayFan < kRelayFan ? cnt - j * kRelayFan : kRelayFan;
+            }
+        }
+        gstat[2 * g] = make_uint4(d0, d1, orig[g], own_cnt);
         gstat[2 * g + 1] = g2;
+        poff[g] = own_off;
+    }
+}
+// entry i of the relay part of clist = relay i, edge label 0 (the consumer lists of relays' parents are runs of it): once per loaded graph
+__global__ void k_relay_list(u32 n, u32 cap, u32* clist) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (u64)gridDim.x * blockDim.x) clist[2ull * n + 64ull + i] = n + (u32)i;
+}
+// Behind the launch: the relays leave the DFS tree.  A BOTTOM relay (its champion is a real gate c, over an edge labelled l)
+// stands for the hub iff the chain of relays above it chose it all the way up: then the hub's parent is c and its label l;
+// else nobody hangs below (c, l).  (ok: the launch ended cleanly; n_relays: relays of this build, on the device)
+__global__ void k_relay_fix(u32 n, const u32* __restrict__ ok, const u32* __restrict__ n_relays, uint4* meta, u32* child) {
+    if (!*ok) return;
+    const u32 R = *n_relays;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < R; i += (u64)gridDim.x * blockDim.x) {
+        const u64 r = (u64)n + i;
+        const uint4 m = meta[r];
+        if (m.x >= n) continue;                      // (a relay of a higher level: its champion is a relay)
+        const u32 l = m.w & 1u;
+        u32 x = child[2 * r];
+        while (x != C2A_NONE && x >= n) x = child[2 * (u64)x];
+        child[2 * (u64)m.x + l] = x;
+        if (x != C2A_NONE) { uint4 mx = meta[x]; mx.x = m.x; mx.w = (mx.w & ~1u) | l; meta[x] = mx; }
     }
 }
 
@@ -394,9 +501,30 @@ __global__ void __launch_bounds__(256) k_peel_shallow(PeelArgs A, const u32* __r
         // for the one before: 256 gates wait together)
         const u32 i = base + threadIdx.x;
         u32 g = C2A_NONE, rdy[2] = {C2A_NONE, C2A_NONE};
+        uint4 gi = make_uint4(0u, 0u, 0u, 0u);
         if (i < cnt) {
             g = src[i];
-            const uint4 gi = A.gstat[2 * (u64)g], gi2 = A.gstat[2 * (u64)g + 1];
+            gi = A.gstat[2 * (u64)g];
+            // a RELAY (c2a_peel.h HUBS AND RELAYS) is not for these passes — its level does not count and its string need not fit
+            // a word —: it starts a chain of the dataflow launch (and is counted there)
+        }
+        {
+            // (one reservation per wave — a hub of a million sinks has tens of thousands of relays claimed by the sinks pass —;
+            // the workgroup reports its whole region as done below: minus these)
+            const bool relay = i < cnt && gi.z == kRelayOrig;
+            const u64 rm = __ballot(relay);
+            if (rm) {
+                u32 b = 0;
+                if (lane == (u32)ctz64(rm)) {
+                    b = atomicAdd(flat_total, (u32)__popcll(rm));
+                    atomicAdd(&A.ctl[CTL_PROC + (blockIdx.x & (kAcctShards - 1u)) * kAcctStride], 0u - (u32)__popcll(rm));
+                }
+                b = __shfl(b, (int)ctz64(rm), 64);
+                if (relay) { flat[b + (u32)__popcll(rm & lt_mask)] = g; g = kShallowSkip; }
+            }
+        }
+        if (i < cnt && g != kShallowSkip) {
+            const uint4 gi2 = A.gstat[2 * (u64)g + 1];
             const u32 g_off = cons_off[g], g_orig = gi.z;
             u32 b_root = C2A_NONE, b_c = C2A_NONE, b_el = 0, b_depth = 0;
             u64 b_x = 0;
@@ -457,6 +585,7 @@ __global__ void __launch_bounds__(256) k_peel_shallow(PeelArgs A, const u32* __r
         for (u32 j = threadIdx.x >> 4; j < 256; j += 16) {
             const u32 gj = s_g[j];
             if (gj == C2A_NONE) break;               // (the gates of a batch are its first lanes)
+            if (gj == kShallowSkip) continue;        // (a relay: passed on to the launch)
             const u32 root = s_root[j], depth = s_depth[j], l16 = threadIdx.x & 15u;
             u64 w = tag;
             if (l16 == 0) w |= hdr0_word(root, depth);
@@ -524,7 +653,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
     // records), lanes 32..39 words 8..15 (its first consumers, its id)
     const u32 ent_off = (lane >= 8u && lane < 16u) ? (lane - 8u) * 8u : ((lane >= 32u && lane < 40u) ? (lane - 24u) * 8u : C2A_NONE);
     const u32 no_demand = A.reserve_min ? 0u : C2A_NONE;      // (one compare at the pusher: all ones = never tell anybody)
-    const u32 dummy_idx = ((A.n + 3u) & ~3u) + me * kFillDummyStride; (void)dummy_idx;      // this wave's dummy ticket word (a line of its own behind fill[n], from a 16-byte boundary on)
+    const u32 dummy_idx = ((A.n_all + 3u) & ~3u) + me * kFillDummyStride; (void)dummy_idx;      // this wave's dummy ticket word (a line of its own behind fill[n_all], from a 16-byte boundary on)
     bool seeds_left = true;
     u32 region = 0, idx = 0, region_cnt = 0;
     u32 push_rr = me, pop_rr = me * 7u;      // round-robin cursors over the hand-off arrays
@@ -909,22 +1038,52 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                     }
                 }
             }
-            // ... then — cold — the consumer list itself, one record at a time, when it holds more than that
+            // ... then — cold — the consumer list itself when it holds more than that: EIGHT records in flight at a time, like the
+            // hot path (round 5 loaded one per memory round trip: ~1 us per consumer, on one wave, with everything upstream of the
+            // gate waiting).  With the relay trees no list is longer than max(kHubMin, kRelayFan) entries: one batch.
             if (C2A_UNLIKELY(cur.more != 0)) {
                 const u32 g_off = uniform(A.cold->cons_off[gc]);
                 for (u32 eb = 0; eb < g_cnt; eb += 64) {
                     u32 blk = A.clist[g_off + eb + lane];
-                    C2A_PIN(blk);                                // (consumed here, like w below)
+                    C2A_PIN(blk);                                // (consumed here, like the records below)
                     u64 smask = __ballot(eb + lane < g_cnt && !((blk & kIdMask) == own_node) &&
                                          !(cur.take >= 1 && blk == cur.e0) && !(cur.take >= 2 && blk == cur.e1) &&
                                          !(cur.take >= 3 && blk == cur.e2) && !(cur.take >= 4 && blk == cur.e3) &&
                                          !(cur.take >= 5 && blk == cur.e4) && !(cur.take >= 6 && blk == cur.e5) &&
                                          !(cur.take >= 7 && blk == cur.e6) && !(cur.take >= 8 && blk == cur.e7));
                     while (smask) {
-                        const u32 e = rdlane(blk, pop_lowest(smask));
-                        u64 w = ld_nw(&A.node[(u64)(e & kIdMask) * kNodeWords + lane]);
-                        C2A_PIN(w);                              // (consumed here: pending at the join it would cost the hot path a wait)
-                        candidate(w, e);
+                        // (lanes beyond the batch load the batch's first record again: no branch around a load, and a value that
+                        // is never looked at)
+                        u32 c_e0, c_e1, c_e2, c_e3, c_e4, c_e5, c_e6, c_e7, c_n = 0;
+                        c_e0 = rdlane(blk, pop_lowest(smask)); ++c_n;
+                        c_e1 = c_e2 = c_e3 = c_e4 = c_e5 = c_e6 = c_e7 = c_e0;
+                        if (smask) { c_e1 = rdlane(blk, pop_lowest(smask)); ++c_n; }
+                        if (smask) { c_e2 = rdlane(blk, pop_lowest(smask)); ++c_n; }
+                        if (smask) { c_e3 = rdlane(blk, pop_lowest(smask)); ++c_n; }
+                        if (smask) { c_e4 = rdlane(blk, pop_lowest(smask)); ++c_n; }
+                        if (smask) { c_e5 = rdlane(blk, pop_lowest(smask)); ++c_n; }
+                        if (smask) { c_e6 = rdlane(blk, pop_lowest(smask)); ++c_n; }
+                        if (smask) { c_e7 = rdlane(blk, pop_lowest(smask)); ++c_n; }
+                        u64 c_w0 = ld_nw(&A.node[(u64)(c_e0 & kIdMask) * kNodeWords + lane]);
+                        u64 c_w1 = ld_nw(&A.node[(u64)(c_e1 & kIdMask) * kNodeWords + lane]);
+                        u64 c_w2 = ld_nw(&A.node[(u64)(c_e2 & kIdMask) * kNodeWords + lane]);
+                        u64 c_w3 = ld_nw(&A.node[(u64)(c_e3 & kIdMask) * kNodeWords + lane]);
+                        u64 c_w4 = ld_nw(&A.node[(u64)(c_e4 & kIdMask) * kNodeWords + lane]);
+                        u64 c_w5 = ld_nw(&A.node[(u64)(c_e5 & kIdMask) * kNodeWords + lane]);
+                        u64 c_w6 = ld_nw(&A.node[(u64)(c_e6 & kIdMask) * kNodeWords + lane]);
+                        u64 c_w7 = ld_nw(&A.node[(u64)(c_e7 & kIdMask) * kNodeWords + lane]);
+                        // (consumed here: pending at the join they would cost the hot path a wait)
+                        C2A_PIN(c_w0); C2A_PIN(c_w1); C2A_PIN(c_w2); C2A_PIN(c_w3); C2A_PIN(c_w4); C2A_PIN(c_w5); C2A_PIN(c_w6); C2A_PIN(c_w7);
+                        // ONE instance of the tournament code for the batch: the records move up a register per round
+#pragma unroll 1
+                        for (u32 k = 0; k < c_n; ++k) {
+                            candidate(c_w0, c_e0);
+                            c_w0 = c_w1; c_w1 = c_w2; c_w2 = c_w3; c_w3 = c_w4; c_w4 = c_w5; c_w5 = c_w6; c_w6 = c_w7;
+                            c_e0 = c_e1; c_e1 = c_e2; c_e2 = c_e3; c_e3 = c_e4; c_e4 = c_e5; c_e5 = c_e6; c_e6 = c_e7;
+                        }
+                        // (a long list is work too: the watchdog goes by this)
+                        if (lane == 0) atomicAdd(&A.ctl[CTL_HEARTBEAT], 1u);
+                        wave_join();
                     }
                 }
             }
@@ -972,7 +1131,8 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             }
             // the tree entry and the child link: wave-uniform data, read by later launches only — SCALAR stores (no exec
             // shuffle, no moves into vector registers; written back at the end of the wave: sstore_flush)
-            const u32 level = (lraw & kHdrMask) + 1u;
+            // (a relay's level does not count — the reverse Kahn levels of the real gates stay exact —: HUBS AND RELAYS)
+            const u32 level = (lraw & kHdrMask) + (g_orig != kRelayOrig ? 1u : 0u);
             sstore_x4(&A.meta[gc], ch, depth, ch_root, my_label | (level << 1));
             if (C2A_LIKELY(ch_e != C2A_NONE)) sstore_x1_at(A.child, (2u * ch + my_label) * 4u, gc);      // (gate ids are below 2^29: the byte offset fits 32 bits)
             // (the three header words go into lanes 0..2 with v_writelane: a lane == k ladder is masked code)

@@ -76,12 +76,13 @@ typedef struct c2a_stats {
     uint64_t n_gates;
     uint64_t n_edges;            /* dependency edges after dedupe */
     uint32_t levels;             /* reverse Kahn levels */
-    uint32_t max_depth;          /* depth of the DFS tree */
+    uint32_t max_depth;          /* length of the longest path string of the DFS tree = its depth, plus one for every relay level under a
+                                    hub on that path (n_relays below; equal to the depth of the DFS tree when the circuit has no hub) */
     uint32_t n_roots;            /* DFS roots (children of the virtual root) */
     uint32_t n_splitters;        /* list-ranking sublists */
     uint32_t level_launches;     /* peel kernel launches: 2 (the sinks pass + the one dataflow launch) */
     uint32_t peel_waves;         /* single-wave workgroups of the dataflow launch (CUs x min(knob, occupancy query)) */
-    uint32_t path_chunks;        /* 3843-bit path-string chunks the deepest DFS path spans (1 = every tournament is one round trip) */
+    uint32_t path_chunks;        /* path-string chunks (61 words of 62 bits: 3782 bits) the deepest DFS path spans (1 = every tournament is one round trip) */
     uint32_t peel_rereads;       /* times a wave read a candidate record again because a word of it had not arrived yet */
     uint32_t numbering_events;   /* what shifts the wire numbering away from "sorted position q gets wire n_in + q": gates whose out node
                                     is an IO node + constant-like nodes (un-produced, no IO node) — src/compiler.rs:431-438; counted by
@@ -89,6 +90,12 @@ typedef struct c2a_stats {
     uint32_t numbering_path;     /* 1: positional numbering (every node has one writer: wires and gates by formula from the sorted
                                     positions and three event bits per position); 0: the walk in sorted order (duplicate writers, a
                                     serial sort, or C2A_NUMBERING_WALK=1) */
+    uint32_t n_relays;           /* virtual gates the sort added under HUBS — produced nodes with more than 16 consumers (a broadcast
+                                    selector, a scale factor: src/compiler.rs:408-421 allows any fan-out): a hub's consumers are compared
+                                    sixteen at a time by a tree of relays instead of one after the other (0 for a circuit without hubs) */
+    uint32_t verifier;           /* which check the last c2a_verify_boolify ran: 1 = both circuits simulated wire by wire on 64 vectors
+                                    (single-device context), 2 = every device checked its own gates locally (multi-device context:
+                                    64 vectors through each gate's template, every wire it names must be its own); 0 = none yet */
 } c2a_stats;
 
 /*
@@ -107,7 +114,7 @@ const char* c2a_last_error(const c2a_ctx* ctx);
 const char* c2a_version(void);
 /* Bumped whenever a signature or a struct layout of this header changes (round 2 changed c2a_create and c2a_stats without
  * a signal): a binding built against another header must refuse to go on.  c2a_abi_version() == C2A_ABI_VERSION. */
-#define C2A_ABI_VERSION 6
+#define C2A_ABI_VERSION 7
 int c2a_abi_version(void);
 
 /*
