@@ -97,7 +97,7 @@ ABI_VERSION = 7          # == C2A_ABI_VERSION of include/c2a.h this binding was 
 _EXPORTS = ["c2a_abi_version", "c2a_visible_devices", "c2a_create", "c2a_device_count", "c2a_format_bristol", "c2a_destroy", "c2a_last_error", "c2a_version", "c2a_load_gates", "c2a_topo_sort",
             "c2a_topo_sort_serial", "c2a_assign_wires", "c2a_emit_gates", "c2a_build_circuit", "c2a_boolify",
             "c2a_bool_read", "c2a_template_size", "c2a_checksum", "c2a_get_timings", "c2a_get_stats", "c2a_verify_boolify",
-            "c2a_debug_patch_bool_op", "c2a_boolify_plan", "c2a_boolify_chunk", "c2a_boolify_shard_range", "c2a_eval", "c2a_boolify_prune", "c2a_pruned_read"]
+            "c2a_debug_patch_bool_op", "c2a_debug_peel_abort", "c2a_debug_set_build_no", "c2a_debug_hot_every", "c2a_boolify_plan", "c2a_boolify_chunk", "c2a_boolify_shard_range", "c2a_eval", "c2a_boolify_prune", "c2a_pruned_read"]
 
 
 def library_path() -> str:
@@ -171,6 +171,9 @@ def load_library(lib_path: Optional[str] = None):
     L.c2a_eval.argtypes = [vp, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, u64p, ctypes.c_uint32, u32p, u64p, u64p]
     L.c2a_debug_patch_bool_op.restype = ctypes.c_int
     L.c2a_debug_patch_bool_op.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint8]
+    for name in ("c2a_debug_peel_abort", "c2a_debug_set_build_no", "c2a_debug_hot_every"):
+        getattr(L, name).restype = ctypes.c_int
+        getattr(L, name).argtypes = [vp, ctypes.c_uint32]
     L.c2a_get_timings.restype = ctypes.c_int
     L.c2a_get_timings.argtypes = [vp, ctypes.POINTER(_Timings)]
     L.c2a_get_stats.restype = ctypes.c_int
@@ -415,6 +418,18 @@ class Backend:
                                        len(cst), _p(cw, ctypes.c_uint32) if len(cst) else None,
                                        _p(cv, ctypes.c_uint64) if len(cst) else None, _p(out, ctypes.c_uint64) if out.size else None))
         return out
+
+    def debug_peel_abort(self, launches: int):
+        """tests: the next `launches` dataflow launches count as given up (retry, then the serial DFS)"""
+        self._check(self._lib.c2a_debug_peel_abort(self._ctx, int(launches)))
+
+    def debug_set_build_no(self, build_no: int):
+        """tests: continue the build numbers (tags of the node-table records) from here; after load_gates"""
+        self._check(self._lib.c2a_debug_set_build_no(self._ctx, int(build_no)))
+
+    def debug_hot_every(self, ticket: int):
+        """tests: the consumer ticket from which a producer counts as hot (power of two)"""
+        self._check(self._lib.c2a_debug_hot_every(self._ctx, int(ticket)))
 
     def debug_patch_bool_op(self, index: int, new_op: int):
         """Fault injection for the verifier's tests."""

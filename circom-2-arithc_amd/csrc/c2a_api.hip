@@ -80,10 +80,8 @@ struct c2a_ctx {
     bool serial_fallback = false;  // ... and that happened for the circuit now loaded (logged once per context)
     bool fallback_logged = false;
     bool numbering_walk = false;   // C2A_NUMBERING_WALK=1: never the positional numbering (tests and A/B runs: the walk in sorted order on any circuit)
-#ifdef C2A_EMULATE
-    u32 emul_peel_abort = 0;       // tests only (C2A_EMUL_PEEL_ABORT): this many dataflow launches are treated as given up
-    u32 emul_build_no = 0;         // tests only (C2A_EMUL_BUILD_NO): the build number a freshly loaded graph starts from
-#endif
+    u32 debug_peel_abort = 0;      // tests only (c2a_debug_peel_abort): this many dataflow launches are treated as given up
+    u32 hot_every = kHotEvery;     // k_deps: the consumer ticket that makes a producer "hot" (c2a_debug_hot_every lowers it for the tests)
 
     // problem
     u32 n = 0, n_nodes = 0, n_in = 0, n_out = 0;
@@ -100,7 +98,6 @@ struct c2a_ctx {
 
     // device buffers
     DevBuf lh, rh, out, op, gate4, nrec, orig, in_nodes, out_nodes;
-    DevBuf rbase, poff;            // hubs (c2a_peel.h HUBS AND RELAYS): where a hub's relays start; where a gate's / relay's own consumer list starts
     DevBuf prod1, dep0, dep1, cons_cnt, cons_off, eslot, aq_items, aq_pc, aq_seeds, aq_seeds1, aq_seed_flat, aq_seed_cnt, fill, meta, node, child, gstat, clist, pctl, pcold;
     DevBuf rbits, rpre, ridx, rlist, next, owner, local, slist, sjump, sjump2, sorted, sorted_r;
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op;
@@ -130,7 +127,7 @@ struct c2a_ctx {
     std::vector<DevBuf*> all;
 
     c2a_ctx() {
-        all = {&rbase, &poff, &lh, &rh, &out, &op, &gate4, &nrec, &orig, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &aq_items, &aq_pc, &aq_seeds, &aq_seeds1, &aq_seed_flat, &aq_seed_cnt, &fill,
+        all = {&lh, &rh, &out, &op, &gate4, &nrec, &orig, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &aq_items, &aq_pc, &aq_seeds, &aq_seeds1, &aq_seed_flat, &aq_seed_cnt, &fill,
                &gstat, &clist, &pctl, &pcold, &meta, &node, &child, &rbits, &rpre, &ridx, &rlist, &next,
                &owner, &local, &slist, &sjump, &sjump2, &sorted, &sorted_r, &first, &nflag, &wflag, &widx, &node_wire1,
                &node_wire, &e_in0, &e_in1, &e_out, &e_op, &pos_r, &wire_r, &erec, &pblk, &dpre, &epre, &gflag, &scan_tmp, &scan_desc, &scalars, &dfs_state, &dfs_stack, &peel_prof, &peel_trace, &tsz, &asz, &goff,
@@ -142,9 +139,11 @@ namespace {
 
 // scalars block layout (u32 words unless noted)
 enum Scalar { SC_MAXDEPTH = 0, SC_SCOUNT = 1, SC_ERR = 2, SC_NMID = 3, SC_NROOTS = 4, SC_LEVELS = 5, SC_PEELOK = 6 /* the dataflow launch ended cleanly and left no gate behind (k_post_peel) */,
-              SC_RELAYS = 7 /* relays handed out to the hubs of this build (ScanConsHub) */,
+              SC_RELAYS = 7 /* relays that ran in this build (k_relay_fix; a statistic) */, SC_HUBS = 53 /* k_gstat wrote a relay: the circuit has a hub */,
               SC_DFS = 8 /*3 words*/, SC_DUP = 52,
-              SC_TOTAL64 = 16 /* u64 slots from here: 16..31 */, SC_WORDS = 64 };
+              SC_TOTAL64 = 16 /* u64 slots from here: 16..31 */, SC_HOT = 64 /* 1 + kHotMax words: the hot producers k_deps found (c2a_kernels.h HOT PRODUCERS) */,
+              SC_WORDS = 64 + 1 + 64 + 3 };
+static_assert(SC_WORDS >= SC_HOT + 1 + (int)kHotMax && SC_WORDS % 4 == 0, "the hot list lives behind the scalars (cleared with them by k_clear)");
 
 int fail(c2a_ctx* c, int code, const std::string& msg) {
     if (c) c->err = msg;
@@ -321,15 +320,13 @@ int do_prep(c2a_ctx* c, bool for_peel = true) {
     C2A_LAUNCH_NOSYNC(k_dup_clear, 512, kThreads, s, c->n_nodes, (const u32*)dup, c->prod1.as<u32>());
     C2A_LAUNCH_NOSYNC(k_dup_producer, 512, kThreads, s, n, (const u32*)dup, (const u32*)c->out.as<u32>(), c->prod1.as<u32>());
     int r;
-    C2A_LAUNCH_NOSYNC(k_deps, G, kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->out.as<u32>(), c->op.as<u8>(), dup, c->prod1.as<u32>(), (const u8*)c->nflag.as<u8>(), c->orig.as<u32>(),
-                      c->gate4.as<uint4>(), c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>(), c->gflag.as<u8>());
+    C2A_LAUNCH(k_deps, G, kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->out.as<u32>(), c->op.as<u8>(), dup, c->prod1.as<u32>(), (const u8*)c->nflag.as<u8>(), c->orig.as<u32>(),
+                      c->gate4.as<uint4>(), c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>(), c->gflag.as<u8>(), c->scalars.as<u32>() + SC_HOT, c->hot_every);
     if (!for_peel) return C2A_OK;
-    // (the scan of the consumer counts also hands every hub — more than kHubMin consumers — the ids of its relays)
-    r = scan_1pass<1>(c, s, c->scan_tmp, n, ScanConsHub{c->cons_cnt.as<u32>(), c->rbase.as<u32>(), c->scalars.as<u32>() + SC_RELAYS}, c->cons_off.as<u32>(), (u32*)nullptr, desc + R.cons);
+    r = scan_exclusive<u32>(c, c->cons_cnt.as<u32>(), c->cons_off.as<u32>(), n, desc + R.cons);
     if (r) return r;
     C2A_LAUNCH_NOSYNC(k_gstat, G, kThreads, s, n, c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_off.as<u32>(),
-                      c->eslot.as<u32>(), c->orig.as<u32>(), (const u32*)c->rbase.as<u32>(), c->gstat.as<uint4>(), c->clist.as<u32>(), c->poff.as<u32>(),
-                      c->fill.as<u32>(), c->child.as<uint2>());
+                      c->eslot.as<u32>(), c->orig.as<u32>(), c->gstat.as<uint4>(), c->clist.as<u32>(), c->fill.as<u32>(), c->child.as<uint2>(), c->scalars.as<u32>() + SC_HUBS);
     return C2A_OK;
 }
 
@@ -430,7 +427,7 @@ int peel_launch(c2a_ctx* c) {
     // workgroup first, then moved to ONE list the waves of the launch take seed_chunk at a time; its length stays on the
     // device: the word behind the region counts)
     ENSURE(c->aq_seeds1, (size_t)sink_blocks * l1_cap * 4); ENSURE(c->aq_seed_flat, ((size_t)n_all + 64) * 4);
-    cold.cons_off = c->poff.as<u32>();
+    cold.cons_off = c->cons_off.as<u32>(); cold.n = n;
     cold.seeds = c->aq_seed_flat.as<u32>(); cold.seed_total = c->aq_seed_cnt.as<u32>() + (size_t)(shallow + 1) * sink_blocks; cold.seed_chunk = c->peel_seed_chunk;
     // what only the edges of the launch touch travels as one small block in HBM (keeps the kernel's scalar registers free)
     // (written by a one-thread launch that takes it by value: a copy from this stack object would need a host round trip)
@@ -443,7 +440,7 @@ int peel_launch(c2a_ctx* c) {
         u32* cnts = c->aq_seed_cnt.as<u32>();
         const u32* in = (lvl & 1u) ? c->aq_seeds.as<u32>() : c->aq_seeds1.as<u32>();
         u32* out = (lvl & 1u) ? c->aq_seeds1.as<u32>() : c->aq_seeds.as<u32>();
-        C2A_LAUNCH(k_peel_shallow, sink_blocks, kThreads, s, A, (const u32*)c->poff.as<u32>(), lvl, lvl == shallow ? 1u : 0u, in, (const u32*)(cnts + (size_t)(lvl - 1) * sink_blocks), lvl == 1 ? sink_cap : l1_cap,
+        C2A_LAUNCH(k_peel_shallow, sink_blocks, kThreads, s, A, (const u32*)c->cons_off.as<u32>(), lvl, lvl == shallow ? 1u : 0u, in, (const u32*)(cnts + (size_t)(lvl - 1) * sink_blocks), lvl == 1 ? sink_cap : l1_cap,
                    out, cnts + (size_t)lvl * sink_blocks, l1_cap, c->aq_seed_flat.as<u32>(), cnts + (size_t)(shallow + 1) * sink_blocks);
     }
     // (every wave of the launch is alive at once under emulation too, interleaved at the back-offs — in a shuffled order per
@@ -456,9 +453,10 @@ int peel_launch(c2a_ctx* c) {
     rec(c, EV_KPEEL1);
     static_assert(CTL_PROCESSED == 0 && CTL_MAXLEVEL == 1 && CTL_ABORT == 2 && CTL_REREADS == 3, "the order k_post_peel writes them in");
     C2A_LAUNCH(k_post_peel, 1, 64, s, c->hrb_dev, (const u32*)c->pctl.as<u32>(), (const u32*)(c->cons_off.as<u32>() + n), (const u32*)(c->scalars.as<u32>() + SC_DUP), n,
-               (const u32*)(c->scalars.as<u32>() + SC_RELAYS), c->scalars.as<u32>() + SC_PEELOK);
-    // the relays leave the DFS tree again (nothing to do without hubs: the launch is a look at one word)
-    C2A_LAUNCH_NOSYNC(k_relay_fix, 256, kThreads, s, n, (const u32*)(c->scalars.as<u32>() + SC_PEELOK), (const u32*)(c->scalars.as<u32>() + SC_RELAYS), c->meta.as<uint4>(), c->child.as<u32>());
+               c->scalars.as<u32>() + SC_PEELOK);
+    // the relays leave the DFS tree again (without hubs the launch is a look at two words)
+    C2A_LAUNCH(k_relay_fix, 512, kThreads, s, n, (u32)relay_cap(n), (const u32*)(c->scalars.as<u32>() + SC_PEELOK), (const u32*)(c->scalars.as<u32>() + SC_HUBS), c->meta.as<uint4>(), c->child.as<u32>(),
+               c->scalars.as<u32>() + SC_RELAYS);
     c->peel_slots = slots; c->peel_waves_used = waves; c->peel_want_stats = want_stats;
     return C2A_OK;
 }
@@ -474,9 +472,7 @@ int peel_result(c2a_ctx* c, u32* peeled_out) {
     cold.q_time = want_stats ? c->peel_prof.as<ull>() + 32 : nullptr; cold.p_time = want_stats ? cold.q_time + slots : nullptr;
     struct { u32 n_fifos; } A{c->peel_fifos};
     u32 t4[4] = {c->hrb[0], c->hrb[1], c->hrb[2], c->hrb[3]};
-#ifdef C2A_EMULATE
-    if (c->emul_peel_abort) { --c->emul_peel_abort; t4[CTL_ABORT] = 1; }      // (tests: a launch that "gave up", to exercise the retry and the serial fall-back)
-#endif
+    if (c->debug_peel_abort) { --c->debug_peel_abort; t4[CTL_ABORT] = 1; }    // (tests: a launch that "gave up", to exercise the retry and the serial fall-back — c2a_debug_peel_abort)
     c->rb_edges = c->hrb[4]; c->rb_dup = c->hrb[5];      // (ride along: one round trip)
     const bool need_deep = c->hrb[6] != 0 && !c->peel_deep;
     if (want_stats) {
@@ -533,7 +529,6 @@ int peel_result(c2a_ctx* c, u32* peeled_out) {
     c->stats.level_launches = 2;
     c->stats.peel_waves = waves;
     c->stats.peel_rereads = t4[CTL_REREADS];
-    c->stats.n_relays = c->hrb[7];
     return C2A_OK;
 }
 
@@ -570,7 +565,7 @@ int order_launch(c2a_ctx* c) {
     C2A_LAUNCH(k_rank_mark, std::max<u32>(1u, std::min<u32>(2048u, (m + kThreads * 8 - 1) / (kThreads * 8))), kThreads, s, m, ok, c->rlist.as<u32>(), scount, c->slist.as<u32>(),
                       c->owner.as<u32>());
     static_assert(SC_SCOUNT == SC_MAXDEPTH + 1, "read as a pair");
-    C2A_LAUNCH_NOSYNC(k_post_words, 1, 64, s, c->hrb_dev + 8, (const u32*)(c->scalars.as<u32>() + SC_MAXDEPTH), 2u, n_roots_p, 1u, (const u32*)nullptr, 0u);
+    C2A_LAUNCH_NOSYNC(k_post_words, 1, 64, s, c->hrb_dev + 8, (const u32*)(c->scalars.as<u32>() + SC_MAXDEPTH), 2u, n_roots_p, 1u, (const u32*)(c->scalars.as<u32>() + SC_RELAYS), 1u);
     HIP_TRY(hipEventRecord(c->ev[EV_ORDER_RB], s));
     const u64 expect = (u64)m >> (32 - C2A_SPLIT_SHIFT);
     u64 sd = 1;
@@ -599,6 +594,7 @@ int order_result(c2a_ctx* c, bool defer_sorted) {
     c->stats.max_depth = sc[0];
     c->stats.n_splitters = S;
     c->stats.n_roots = sc[2];
+    c->stats.n_relays = c->hrb[11];
     // one writer per node (what the reference's front-end builds) => the positional numbering, which needs no walk in sorted
     // order (c2a_kernels.h POSITIONAL NUMBERING)
     c->positional = !c->has_dup && !c->numbering_walk;
@@ -919,10 +915,6 @@ int c2a_create(int n_devices, const int* device_ids, c2a_ctx** out) {
     if (const char* e = std::getenv("C2A_PEEL_RESERVE")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v <= 32) c->peel_reserve = v; }
     if (const char* e = std::getenv("C2A_NUMBERING_WALK")) c->numbering_walk = e[0] == '1';
     if (const char* e = std::getenv("C2A_PEEL_FIFOS")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->peel_fifos = v; }
-#ifdef C2A_EMULATE
-    if (const char* e = std::getenv("C2A_EMUL_PEEL_ABORT")) c->emul_peel_abort = (u32)std::strtoul(e, nullptr, 10);
-    if (const char* e = std::getenv("C2A_EMUL_BUILD_NO")) c->emul_build_no = (u32)std::strtoul(e, nullptr, 10);      // tests: start the build numbers near their wrap
-#endif
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return C2A_ERR_HIP; }
     if (hipStreamCreate(&c->aux) != hipSuccess) { c->aux = hipStream_t{}; c2a_destroy(c); return C2A_ERR_HIP; }
     {
@@ -1002,18 +994,18 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     const size_t na = n_all_of(n), na4 = na * 4, rcap = (size_t)relay_cap(n);
     ENSURE(c->cons_off, n4 + 4); ENSURE(c->eslot, 2 * n4); ENSURE(c->fill, na4 + 16 + (size_t)kFillDummyStride * kFillDummyWaves * 4);
     ENSURE(c->meta, na * 16); ENSURE(c->gstat, na * 32); ENSURE(c->clist, 2 * n4 + 64 * 4 + (rcap + 64) * 4);
-    ENSURE(c->node, na * kNodeWords * 8); ENSURE(c->child, 2 * na4); ENSURE(c->rbase, n4); ENSURE(c->poff, na4);
+    ENSURE(c->node, na * kNodeWords * 8); ENSURE(c->child, 2 * na4);
     // a new graph needs clean node records (5 GB at 10 M gates, ~0.75 ms of HBM writes): cleared here, on a stream of its own,
     // beside the host-to-device copies below — a one-shot caller (the reference calls build_circuit once per process) never
     // waits for it, and a step on a loaded graph does not need it (the run tag alternates)
     c->node_clear = true;
     bool cleared = false;
     if (n && hipMemsetAsync(c->node.p, 0, na * kNodeWords * 8, c->aux) == hipSuccess) cleared = true;
-    if (n) C2A_LAUNCH_NOSYNC(k_relay_list, grid_for(rcap, 1024), kThreads, c->aux, n, (u32)rcap, c->clist.as<u32>());
+    if (n) {                                         // (the relay part of the consumer lists, "no relay here" in the relays' tree entries: once per loaded graph)
+        C2A_LAUNCH_NOSYNC(k_relay_list, grid_for(rcap, 1024), kThreads, c->aux, n, (u32)rcap, c->clist.as<u32>());
+        C2A_LAUNCH_NOSYNC(k_relay_clear, grid_for(rcap, 1024), kThreads, c->aux, n, (u32)rcap, c->meta.as<uint4>());
+    }
     if (n_nodes) { HIP_TRY(hipMemsetAsync(c->nrec.p, 0, (size_t)n_nodes * 16, c->aux)); c->build_no = 0; }      // (no record of any build)
-#ifdef C2A_EMULATE
-    c->build_no = c->emul_build_no;
-#endif
     ENSURE(c->rbits, n4 / 32 + 32); ENSURE(c->rpre, n4 / 32 + 16); ENSURE(c->ridx, n4); ENSURE(c->rlist, n4);
     ENSURE(c->next, 2 * n4); ENSURE(c->owner, 2 * n4); ENSURE(c->local, 2 * n4); ENSURE(c->slist, 2 * n4);
     ENSURE(c->sjump, 4 * n4); ENSURE(c->sjump2, 4 * n4);
@@ -1932,6 +1924,28 @@ int c2a_format_bristol(c2a_ctx* c, int which, uint64_t first, uint64_t count, ch
         total_bytes += bytes;
     }
     *written = total_bytes;
+    return C2A_OK;
+}
+
+int c2a_debug_peel_abort(c2a_ctx* c, uint32_t launches) {
+    if (!c) return C2A_ERR_ARG;
+    c->debug_peel_abort = launches;
+    return C2A_OK;
+}
+
+int c2a_debug_set_build_no(c2a_ctx* c, uint32_t build_no) {
+    if (!c) return C2A_ERR_ARG;
+    if (c->stage < ST_LOADED || build_no >= (1u << 24)) return fail(c, C2A_ERR_ARG, "c2a_debug_set_build_no: load gates first; build numbers have 24 bits");
+    HIP_TRY(hipSetDevice(c->device));
+    // (records of builds up to this number may be in the table: start from a clean one, as after a load)
+    HIP_TRY(hipMemsetAsync(c->nrec.p, 0, (size_t)c->n_nodes * 16, c->stream));
+    c->build_no = build_no;
+    return C2A_OK;
+}
+
+int c2a_debug_hot_every(c2a_ctx* c, uint32_t ticket) {
+    if (!c || ticket < 2 || (ticket & (ticket - 1)) != 0) return C2A_ERR_ARG;
+    c->hot_every = ticket;
     return C2A_OK;
 }
 

@@ -206,16 +206,6 @@ __global__ void k_clear(ClearList L) {
 
 // element functors
 struct ScanFromU32 { const u32* in; __device__ __forceinline__ void operator()(u64 i, u32* x) const { x[0] = in[i]; } };
-// the consumer counts, and on the way every HUB (more than kHubMin consumers: c2a_peel.h HUBS AND RELAYS) is handed the ids of
-// its relays — a run of relay_count(c) from ONE counter (hubs are rare; which hub gets which run does not matter)
-struct ScanConsHub {
-    const u32* in; u32* rbase; u32* total;
-    __device__ __forceinline__ void operator()(u64 i, u32* x) const {
-        const u32 c = in[i];
-        x[0] = c;
-        if (c > kHubMin) rbase[i] = atomicAdd(total, relay_count(c));
-    }
-};
 
 // ------------------------------------------------------------------------------------------------
 // argument validation of c2a_load_gates on the device, behind the copy (the host loop over all gates it replaces was 5.8 of the
@@ -338,29 +328,80 @@ __global__ void __launch_bounds__(kRelThreads) k_relabel(u32 n_nodes, u32 n, u32
 // (process.rs:558-579), i.e. 5-30 % of a circuit's gates read one — a list appended to through one counter would be a million
 // same-address atomics.
 constexpr u32 kGateLhUnprod = 0x100u, kGateRhUnprod = 0x200u, kGateOutIO = 0x400u, kGateLhConst = 0x800u, kGateRhConst = 0x1000u;
-__global__ void k_deps(u32 n, const u32* __restrict__ lh, const u32* __restrict__ rh, const u32* __restrict__ out, const u8* __restrict__ op,
+// HOT PRODUCERS.  The consumer tickets are returning atomics on cons_cnt[producer], and atomics on ONE word go one at a time,
+// ~11 ns apiece: a produced node that a million gates read (a hub: compiler.rs:408-421 allows any fan-out) was 11 ms of
+// same-address atomics in this kernel.  Matching the lanes' producers against each other in every wave costs every graph
+// 0.1 ms of ballots (measured); instead the hot producers are found ON THE WAY: the lane that draws ticket kHotEvery - 1 —
+// exactly one lane per producer with that many consumers — appends the producer to a short list (hot[0] = entries claimed,
+// hot[1 + e] = rank + 1, 0 = not written yet), every wave looks at the list's length once per round (one word; zero on a
+// circuit without such a hub), and the lanes that name a listed producer do NOT draw a ticket: the wave counts them (lane e of
+// run_v = its pending tickets on entry e), draws ONE range per entry when it has seen all its gates and fills their slots in
+// on a second walk over its own gates.  A fan-out of 10^6: 16 384 single tickets + one per wave = 0.4 ms instead of 11.
+constexpr u32 kHotMax = 64, kHotEvery = 1u << 14, kHotPending = 0x80000000u;
+__global__ void __launch_bounds__(kThreads) k_deps(u32 n, const u32* __restrict__ lh, const u32* __restrict__ rh, const u32* __restrict__ out, const u8* __restrict__ op,
                        const u32* __restrict__ dup, const u32* __restrict__ prod1, const u8* __restrict__ nflag, u32* orig, uint4* gate4,
-                       u32* dep0, u32* dep1, u32* cons_cnt, u32* eslot, u8* gflag) {
+                       u32* dep0, u32* dep1, u32* cons_cnt, u32* eslot, u8* gflag, u32* hot, u32 hot_every) {
     const bool ident = *dup != 0u;
     const XcdSweep R = xcd_sweep(n);
-    for (u64 g = R.i; g < R.end; g += R.step) {
-        uint4 r;
-        if (ident) { r = make_uint4(lh[g], rh[g], out[g], (u32)op[g]); orig[g] = (u32)g; }
-        else r = gate4[g];
-        const u32 p0 = prod1[r.x], p1 = prod1[r.y];
-        u32 w = (r.w & 0xFFu) | (p0 ? 0u : kGateLhUnprod) | (p1 ? 0u : kGateRhUnprod) | ((nflag[r.z] & 3u) ? kGateOutIO : 0u);
-        if (!p0 && !(nflag[r.x] & 3u)) w |= kGateLhConst;             // (an input or output node: its wire is fixed)
-        if (!p1 && !(nflag[r.y] & 3u)) w |= kGateRhConst;
-        gate4[g] = make_uint4(r.x, r.y, r.z, w);
-        gflag[g] = (u8)(w >> 8);
-        const u32 d0 = p0 ? p0 - 1 : C2A_NONE;
-        u32 d1 = p1 ? p1 - 1 : C2A_NONE;
-        if (d1 == d0) d1 = C2A_NONE;
-        dep0[g] = d0;
-        dep1[g] = d1;
+    const u32 lane = threadIdx.x & 63u;
+    const u64 lt_mask = (1ull << lane) - 1ull;
+    u32 run_v = 0;                                 // lane e: tickets this wave owes the hot producer of entry e
+    bool any_pending = false;                      // (wave-uniform)
+    // (every lane of a wave goes round the same number of times: the hot producers are handled wave by wave)
+    for (u64 gb = R.i - lane; gb < R.end; gb += R.step) {
+        const u64 g = gb + lane;
+        const bool live = g < R.end;
+        u32 d0 = C2A_NONE, d1 = C2A_NONE;
+        if (live) {
+            uint4 r;
+            if (ident) { r = make_uint4(lh[g], rh[g], out[g], (u32)op[g]); orig[g] = (u32)g; }
+            else r = gate4[g];
+            const u32 p0 = prod1[r.x], p1 = prod1[r.y];
+            u32 w = (r.w & 0xFFu) | (p0 ? 0u : kGateLhUnprod) | (p1 ? 0u : kGateRhUnprod) | ((nflag[r.z] & 3u) ? kGateOutIO : 0u);
+            if (!p0 && !(nflag[r.x] & 3u)) w |= kGateLhConst;             // (an input or output node: its wire is fixed)
+            if (!p1 && !(nflag[r.y] & 3u)) w |= kGateRhConst;
+            gate4[g] = make_uint4(r.x, r.y, r.z, w);
+            gflag[g] = (u8)(w >> 8);
+            d0 = p0 ? p0 - 1 : C2A_NONE;
+            d1 = p1 ? p1 - 1 : C2A_NONE;
+            if (d1 == d0) d1 = C2A_NONE;
+            dep0[g] = d0;
+            dep1[g] = d1;
+        }
         // eslot[2g + l] = index of the edge (g, l) in its producer's consumer list
-        eslot[2 * g] = d0 != C2A_NONE ? atomicAdd(&cons_cnt[d0], 1u) : 0u;
-        eslot[2 * g + 1] = d1 != C2A_NONE ? atomicAdd(&cons_cnt[d1], 1u) : 0u;
+        bool t0 = d0 != C2A_NONE, t1 = d1 != C2A_NONE;
+        u32 s0 = 0, s1 = 0;
+        // (ONE lane's view of the list for the whole wave — the list grows while the kernel runs)
+        u32 hc = rdlane(ld_a32(&hot[0]), 0);
+        if (hc) {
+            hc = hc < kHotMax ? hc : kHotMax;
+            for (u32 e = 0; e < hc; ++e) {
+                const u32 hv = rdlane(ld_a32(&hot[1 + e]), 0);
+                const bool h0 = t0 && d0 + 1u == hv, h1 = t1 && d1 + 1u == hv;      // (hv 0 — not written yet — matches nothing: d + 1 of a wanted ticket is never 0)
+                const u64 m0 = __ballot(h0), m1 = __ballot(h1);
+                if ((m0 | m1) == 0ull) continue;
+                const u32 r = (u32)__shfl((int)run_v, (int)e, 64);
+                if (h0) { s0 = kHotPending | (e << 24) | (r + (u32)__popcll(m0 & lt_mask)); t0 = false; }
+                if (h1) { s1 = kHotPending | (e << 24) | (r + (u32)__popcll(m0) + (u32)__popcll(m1 & lt_mask)); t1 = false; }
+                if (lane == e) run_v += (u32)__popcll(m0) + (u32)__popcll(m1);
+                any_pending = true;
+            }
+        }
+        if (t0) { s0 = atomicAdd(&cons_cnt[d0], 1u); if (s0 == hot_every - 1u) { const u32 i = atomicAdd(&hot[0], 1u); if (i < kHotMax) st_a32(&hot[1 + i], d0 + 1u); } }
+        if (t1) { s1 = atomicAdd(&cons_cnt[d1], 1u); if (s1 == hot_every - 1u) { const u32 i = atomicAdd(&hot[0], 1u); if (i < kHotMax) st_a32(&hot[1 + i], d1 + 1u); } }
+        if (live) { eslot[2 * g] = s0; eslot[2 * g + 1] = s1; }
+    }
+    if (!any_pending) return;
+    // one range of tickets per hot entry for the whole wave, then the slots of the edges that waited for it
+    u32 base_v = 0;
+    if (run_v) base_v = atomicAdd(&cons_cnt[ld_a32(&hot[1 + lane]) - 1u], run_v);
+    for (u64 gb = R.i - lane; gb < R.end; gb += R.step) {
+        const u64 g = gb + lane;
+        const bool live = g < R.end;
+        const u32 s0 = live ? eslot[2 * g] : 0u, s1 = live ? eslot[2 * g + 1] : 0u;
+        const u32 b0 = (u32)__shfl((int)base_v, (int)((s0 >> 24) & 63u), 64), b1 = (u32)__shfl((int)base_v, (int)((s1 >> 24) & 63u), 64);
+        if (s0 & kHotPending) eslot[2 * g] = b0 + (s0 & 0xFFFFFFu);
+        if (s1 & kHotPending) eslot[2 * g + 1] = b1 + (s1 & 0xFFFFFFu);
     }
 }
 
@@ -1047,15 +1088,15 @@ __global__ void k_post_words(u32* dst, const u32* a, u32 na, const u32* b, u32 n
     for (u32 i = threadIdx.x; i < nc; i += blockDim.x) dst[na + nb + i] = c3[i];
 }
 // the peel: gates done and the highest level (summed / maximised over their kAcctShards parts), gave up, re-reads, edges, duplicate writers
-__global__ void k_post_peel(u32* dst, const u32* ctl, const u32* edges, const u32* dup, u32 n, const u32* relays, u32* ok) {
+__global__ void k_post_peel(u32* dst, const u32* ctl, const u32* edges, const u32* dup, u32 n, u32* ok) {
     const u32 t = threadIdx.x;            // (one wave)
     u32 done = t < kAcctShards ? ctl[CTL_PROC + t * kAcctStride] : 0u, lvl = t < kAcctShards ? ctl[CTL_PROC + t * kAcctStride + 1] : 0u;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { done += __shfl_xor(done, off, 64); const u32 o = __shfl_xor(lvl, off, 64); lvl = o > lvl ? o : lvl; }
     if (t == 0) {
-        // (the relays of the hubs are gates of the launch too: it has done n + *relays when nothing is left behind)
-        dst[0] = done - *relays; dst[1] = lvl; dst[2] = ctl[CTL_ABORT]; dst[3] = ctl[CTL_REREADS]; dst[4] = *edges; dst[5] = *dup; dst[6] = ctl[CTL_NEEDDEEP]; dst[7] = *relays;
-        *ok = (ctl[CTL_ABORT] == 0u && done == n + *relays) ? 1u : 0u;      // (what the order stage, queued right behind, goes by)
+        // (done: REAL gates — the relays of the hubs run in the launch too and are not counted; one that is left behind has a gate left behind above it)
+        dst[0] = done; dst[1] = lvl; dst[2] = ctl[CTL_ABORT]; dst[3] = ctl[CTL_REREADS]; dst[4] = *edges; dst[5] = *dup; dst[6] = ctl[CTL_NEEDDEEP];
+        *ok = (ctl[CTL_ABORT] == 0u && done == n) ? 1u : 0u;      // (what the order stage, queued right behind, goes by)
     }
 }
 

@@ -143,10 +143,10 @@ constexpr u32 kFillDummyWaves = 8192;       // ... of at most this many waves (2
 
 // ---- hubs and relays (HUBS AND RELAYS above) ----
 #ifndef C2A_RELAY_FAN
-#define C2A_RELAY_FAN 16
+#define C2A_RELAY_FAN 8
 #endif
 #ifndef C2A_HUB_MIN
-#define C2A_HUB_MIN 16
+#define C2A_HUB_MIN 8
 #endif
 constexpr u32 kRelayFan = C2A_RELAY_FAN;    // consumers of one relay: eight records loaded ahead + one batch of the list loop
 constexpr u32 kHubMin = C2A_HUB_MIN;        // a gate with MORE consumers than this gets a relay tree
@@ -164,10 +164,24 @@ constexpr u32 kRelayNum = relay_count(kHubMin + 1u), kRelayDen = kHubMin + 1u;
 constexpr bool relay_bound_holds() { for (u32 N = kHubMin + 1u; N < 5000u; ++N) if ((u64)relay_count(N) * kRelayDen > (u64)N * kRelayNum) return false; return true; }
 static_assert(relay_bound_holds(), "relay_count(N) <= N * kRelayNum / kRelayDen");
 __host__ __device__ constexpr u64 relay_cap(u64 n) { return (2 * n * kRelayNum + kRelayDen - 1) / kRelayDen + 64; }
+// WHICH relays a hub gets follows from where its consumer list lies: relays floor(off * kRelayNum / kRelayDen) ... of a hub whose
+// list starts at edge `off` — the lists of two hubs are disjoint runs of edges, a hub of N consumers needs at most
+// floor(N * kRelayNum / kRelayDen) relays, and floor(a + b) >= floor(a) + floor(b): the runs of relays are disjoint too.  No
+// counter, no table, no pass over the gates to hand them out (a counter took one same-address atomic per hub: 0.5 ms for 50 000).
+__host__ __device__ constexpr u32 relay_base(u32 off) { return (u32)((u64)off * kRelayNum / kRelayDen); }
+// where a gate's OWN consumer list starts in clist (chain starts and the list loop of a step only; a chain step gets its producers'
+// lists with their static records): a relay keeps it in word 2 of its second static record (a relay has no second producer), a hub's
+// list are its top-level relays, any other gate's is where the scan of the counts put it
+__device__ __forceinline__ u32 own_list_off(u32 n, const u32* cons_off, const uint4* gstat, u32 g) {
+    if (g >= n) return gstat[2 * (u64)g + 1].z;
+    const u32 o = cons_off[g], N = cons_off[(u64)g + 1] - o;
+    return N > kHubMin ? 2u * n + 64u + relay_base(o) + relay_top(N).off : o;
+}
 
 // what only the edges of the launch touch (kept out of the kernel's scalar registers)
 struct PeelCold {
-    const u32* cons_off;       // [n_all] where a gate's own consumer list starts in clist (chain starts and the list loop only): poff of k_gstat
+    const u32* cons_off;       // [n + 1] the scan of the consumer counts (own_list_off: chain starts and the list loop only)
+    u32 n;                     // real gates (ids from n on are relays)
     const u32* seeds;          // [*seed_total] the gates the launch starts chains from (claimed by the last k_peel_shallow pass), one flat list
     const u32* seed_total;     // how many (device side: the host never learns it)
     u32 seed_chunk;            // a wave takes this many at a time
@@ -332,7 +346,7 @@ __device__ __attribute__((noinline)) bool deep_less(const u64* node_base, u32 ep
 // The relays above relay `idx` of level `lvl_off` (HUBS AND RELAYS): written by ONE thread — the one that holds the first edge
 // of the bottom relay's segment goes on upwards while the relay it just wrote is the first of ITS parent's segment.
 // Hub h: N consumers at clist[off_h ...), relays n + b ...; xbase: where entry i = relay i starts in clist.
-__device__ __forceinline__ void write_relays(u32 n, u32 h, u32 N, u32 off_h, u32 b, u32 j, u32 xbase, uint4* gstat, u32* poff, u32* fill, uint2* child) {
+__device__ __forceinline__ void write_relays(u32 n, u32 h, u32 N, u32 off_h, u32 b, u32 j, u32 xbase, uint4* gstat, u32* fill, uint2* child) {
     u32 cnt_lvl = relay_ceil(N), lvl_off = 0, idx = j;
     u32 list_off = off_h + j * kRelayFan, list_cnt = N - j * kRelayFan < kRelayFan ? N - j * kRelayFan : kRelayFan;
     for (;;) {
@@ -343,8 +357,7 @@ __device__ __forceinline__ void write_relays(u32 n, u32 h, u32 N, u32 off_h, u32
         const u32 p_off = xbase + b + lvl_off + (top ? 0u : pj * kRelayFan);
         const u32 p_cnt = top ? cnt_lvl : (cnt_lvl - pj * kRelayFan < kRelayFan ? cnt_lvl - pj * kRelayFan : kRelayFan);
         gstat[2 * r] = make_uint4(parent, C2A_NONE, kRelayOrig, list_cnt);
-        gstat[2 * r + 1] = make_uint4(p_off, p_cnt, 0u, 0u);
-        poff[r] = list_off;
+        gstat[2 * r + 1] = make_uint4(p_off, p_cnt, list_off, 0u);      // (word 2: the relay's OWN list — it has no second producer, and any offset into clist will do there)
         fill[r] = 0u;
         child[r] = make_uint2(C2A_NONE, C2A_NONE);
         if (top || idx % kRelayFan != 0u) break;
@@ -352,29 +365,28 @@ __device__ __forceinline__ void write_relays(u32 n, u32 h, u32 N, u32 off_h, u32
     }
 }
 __global__ void k_gstat(u32 n, const u32* __restrict__ dep0, const u32* __restrict__ dep1, const u32* __restrict__ cons_off,
-                        const u32* __restrict__ eslot, const u32* __restrict__ orig, const u32* __restrict__ rbase, uint4* gstat, u32* clist,
-                        u32* poff, u32* fill, uint2* child) {
+                        const u32* __restrict__ eslot, const u32* __restrict__ orig, uint4* gstat, u32* clist, u32* fill, uint2* child, u32* has_hubs) {
     // (the consumer count of a gate is the difference of two neighbouring offsets — cons_off has n + 1 entries —: ONE
     // 8-byte access per producer instead of two 4-byte ones in two arrays.  Word 2 of a gate's first record is its ORIGINAL
     // id — what the DFS roots are compared by, topological_sort.rs:11-13; the launch works in rank space, c2a_kernels.h
-    // RELABELLING —; the offset of its own consumer list is only wanted off the hot path and is read from poff there.
-    // A producer with more than kHubMin consumers is a HUB (rbase[]: where its relays start, handed out by the scan of the
-    // counts): the edge goes to the relay that owns its slot of the hub's list, the hub's own list are its top-level relays)
+    // RELABELLING —; the offset of its own consumer list is only wanted off the hot path: own_list_off.
+    // A producer with more than kHubMin consumers is a HUB: the edge goes to the relay that owns its slot of the hub's list, the
+    // hub's own list are its top-level relays (relay_base: which relays a hub gets follows from where its list lies))
     const XcdSweep R = xcd_sweep(n);
     const u32 xbase = 2u * n + 64u;
     for (u64 g = R.i; g < R.end; g += R.step) {
         u32 d0 = dep0[g], d1 = dep1[g];
         const u32 o = cons_off[g];
-        u32 own_cnt = cons_off[g + 1] - o, own_off = o;
-        if (own_cnt > kHubMin) { const RelayTop T = relay_top(own_cnt); own_off = xbase + rbase[g] + T.off; own_cnt = T.cnt; }
+        u32 own_cnt = cons_off[g + 1] - o;
+        if (own_cnt > kHubMin) own_cnt = relay_top(own_cnt).cnt;
         uint4 g2 = make_uint4(0, 0, 0, 0);
         if (d0 != C2A_NONE) {
             const u32 off = cons_off[d0], cnt = cons_off[(u64)d0 + 1] - off, slot = eslot[2 * g];
             clist[off + slot] = (u32)g;
             g2.x = off; g2.y = cnt;
             if (cnt > kHubMin) {
-                const u32 b = rbase[d0], j = slot / kRelayFan;
-                if (slot % kRelayFan == 0u) write_relays(n, d0, cnt, off, b, j, xbase, gstat, poff, fill, child);
+                const u32 b = relay_base(off), j = slot / kRelayFan;
+                if (slot % kRelayFan == 0u) { write_relays(n, d0, cnt, off, b, j, xbase, gstat, fill, child); if (slot == 0u) *has_hubs = 1u; }
                 d0 = n + b + j; g2.x = off + j * kRelayFan; g2.y = cnt - j * kRelayFan < kRelayFan ? cnt - j * kRelayFan : kRelayFan;
             }
         }
@@ -383,29 +395,38 @@ __global__ void k_gstat(u32 n, const u32* __restrict__ dep0, const u32* __restri
             clist[off + slot] = (u32)g | 0x80000000u;
             g2.z = off; g2.w = cnt;
             if (cnt > kHubMin) {
-                const u32 b = rbase[d1], j = slot / kRelayFan;
-                if (slot % kRelayFan == 0u) write_relays(n, d1, cnt, off, b, j, xbase, gstat, poff, fill, child);
+                const u32 b = relay_base(off), j = slot / kRelayFan;
+                if (slot % kRelayFan == 0u) { write_relays(n, d1, cnt, off, b, j, xbase, gstat, fill, child); if (slot == 0u) *has_hubs = 1u; }
                 d1 = n + b + j; g2.z = off + j * kRelayFan; g2.w = cnt - j * kRelayFan < kRelayFan ? cnt - j * kRelayFan : kRelayFan;
             }
         }
         gstat[2 * g] = make_uint4(d0, d1, orig[g], own_cnt);
         gstat[2 * g + 1] = g2;
-        poff[g] = own_off;
     }
 }
 // entry i of the relay part of clist = relay i, edge label 0 (the consumer lists of relays' parents are runs of it): once per loaded graph
 __global__ void k_relay_list(u32 n, u32 cap, u32* clist) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (u64)gridDim.x * blockDim.x) clist[2ull * n + 64ull + i] = n + (u32)i;
 }
+// the tree entries of the relay range say "no relay here" (parent NONE - 1: a relay that ran has a parent, and a relay is never a DFS
+// root): once per loaded graph — every build of it writes the same relays
+constexpr u32 kNoRelay = C2A_NONE - 1u;
+__global__ void k_relay_clear(u32 n, u32 cap, uint4* meta) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (u64)gridDim.x * blockDim.x) meta[(u64)n + i] = make_uint4(kNoRelay, 0u, 0u, 0u);
+}
 // Behind the launch: the relays leave the DFS tree.  A BOTTOM relay (its champion is a real gate c, over an edge labelled l)
 // stands for the hub iff the chain of relays above it chose it all the way up: then the hub's parent is c and its label l;
-// else nobody hangs below (c, l).  (ok: the launch ended cleanly; n_relays: relays of this build, on the device)
-__global__ void k_relay_fix(u32 n, const u32* __restrict__ ok, const u32* __restrict__ n_relays, uint4* meta, u32* child) {
-    if (!*ok) return;
-    const u32 R = *n_relays;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < R; i += (u64)gridDim.x * blockDim.x) {
+// else nobody hangs below (c, l).  (ok: the launch ended cleanly; has_hubs: k_gstat wrote a relay in this build — without hubs
+// this launch is a look at two words; *count: relays that ran, a statistic)
+__global__ void __launch_bounds__(256) k_relay_fix(u32 n, u32 cap, const u32* __restrict__ ok, const u32* __restrict__ has_hubs, uint4* meta, u32* child, u32* count) {
+    __shared__ u32 s_cnt[4];
+    if (!*ok || !*has_hubs) return;
+    u32 mine = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (u64)gridDim.x * blockDim.x) {
         const u64 r = (u64)n + i;
         const uint4 m = meta[r];
+        if (m.x == kNoRelay) continue;
+        ++mine;
         if (m.x >= n) continue;                      // (a relay of a higher level: its champion is a relay)
         const u32 l = m.w & 1u;
         u32 x = child[2 * r];
@@ -413,6 +434,11 @@ __global__ void k_relay_fix(u32 n, const u32* __restrict__ ok, const u32* __rest
         child[2 * (u64)m.x + l] = x;
         if (x != C2A_NONE) { uint4 mx = meta[x]; mx.x = m.x; mx.w = (mx.w & ~1u) | l; meta[x] = mx; }
     }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
+    if ((threadIdx.x & 63u) == 0) s_cnt[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) { const u32 t = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]; if (t) atomicAdd(count, t); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -660,7 +686,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
     u32 demand_seen = 0;                     // (reserve waves) the demand count this wave has answered
     u32 held = 0;                            // this wave holds a consumer ticket that has not been served yet ...
     u64 held_slot = 0;                       // ... for this slot
-    u32 processed = 0, max_level = 0, iters = 0;
+    u32 processed = 0, beats = 0, max_level = 0, iters = 0;
     u32 st_pops = 0, st_polls = 0, st_push = 0, st_seeds = 0;
     ull st_busy = 0, st_idle = 0, st_t0 = STATS ? c2a_now() : 0;
     ull ph_w1 = 0, ph_w2 = 0, ph_w3 = 0;
@@ -696,7 +722,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             // static data of a seed (a chain step gets all of this prefetched by the step before; a popped gate brings it
             // along); consumed HERE, in scalar registers where wave-uniform: a load still pending at the loop header would
             // cost every chain step a wait
-            const u32 g_off = uniform(A.cold->cons_off[g]);
+            const u32 g_off = uniform(own_list_off(uniform(A.cold->n), A.cold->cons_off, A.gstat, g));
             gi = uniform4(A.gstat[2 * (u64)g]);
             gi2 = uniform4(A.gstat[2 * (u64)g + 1]);
             cl0 = A.clist[g_off + lane];                                     // clist is padded by 64 entries
@@ -1042,7 +1068,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             // hot path (round 5 loaded one per memory round trip: ~1 us per consumer, on one wave, with everything upstream of the
             // gate waiting).  With the relay trees no list is longer than max(kHubMin, kRelayFan) entries: one batch.
             if (C2A_UNLIKELY(cur.more != 0)) {
-                const u32 g_off = uniform(A.cold->cons_off[gc]);
+                const u32 g_off = uniform(own_list_off(uniform(A.cold->n), A.cold->cons_off, A.gstat, gc));
                 for (u32 eb = 0; eb < g_cnt; eb += 64) {
                     u32 blk = A.clist[g_off + eb + lane];
                     C2A_PIN(blk);                                // (consumed here, like the records below)
@@ -1131,8 +1157,9 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             }
             // the tree entry and the child link: wave-uniform data, read by later launches only — SCALAR stores (no exec
             // shuffle, no moves into vector registers; written back at the end of the wave: sstore_flush)
-            // (a relay's level does not count — the reverse Kahn levels of the real gates stay exact —: HUBS AND RELAYS)
-            const u32 level = (lraw & kHdrMask) + (g_orig != kRelayOrig ? 1u : 0u);
+            // (a relay's level does not count — the reverse Kahn levels of the real gates stay exact —, nor is it a gate done: HUBS AND RELAYS)
+            const u32 real = g_orig != kRelayOrig ? 1u : 0u;
+            const u32 level = (lraw & kHdrMask) + real;
             sstore_x4(&A.meta[gc], ch, depth, ch_root, my_label | (level << 1));
             if (C2A_LIKELY(ch_e != C2A_NONE)) sstore_x1_at(A.child, (2u * ch + my_label) * 4u, gc);      // (gate ids are below 2^29: the byte offset fits 32 bits)
             // (the three header words go into lanes 0..2 with v_writelane: a lane == k ladder is masked code)
@@ -1143,8 +1170,8 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             w_hi = wrlane_c<2>(my_pos | tag_hi, w_hi);      // (lane 2's low half is the root key already: str carries it)
             const u64 my_w = (u64)w_lo | ((u64)w_hi << 32);
             st_nw(&A.node[(u64)gc * kNodeWords + lane], my_w);
-            ++processed;
-            if (C2A_UNLIKELY((processed & 63u) == 0) && lane == 0) atomicAdd(&A.ctl[CTL_HEARTBEAT], 1u);
+            processed += real;
+            if (C2A_UNLIKELY((++beats & 63u) == 0) && lane == 0) atomicAdd(&A.ctl[CTL_HEARTBEAT], 1u);
             if (STATS) {
                 const ull ph4 = c2a_now();
                 if (dt_trace && lane == 0) {

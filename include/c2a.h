@@ -248,6 +248,16 @@ int c2a_eval(c2a_ctx* ctx, int which, uint32_t width, uint32_t n_vectors, const 
              const uint32_t* const_wires, const uint64_t* const_values, uint64_t* outputs);
 /* Fault injection for the tests of the verifier: overwrite the op of one boolean gate in HBM. */
 int c2a_debug_patch_bool_op(c2a_ctx* ctx, uint64_t index, uint8_t new_op);
+/* Fault injection for the tests of the sort that cannot fail (src/topological_sort.rs:3-21 always terminates on an acyclic graph):
+ * the next `launches` dataflow launches are treated as if their watchdog had tripped — one: the retry on clean buffers; two: the
+ * serial DFS takes over (c2a_topo_sort then costs what c2a_topo_sort_serial costs: one lane, ~0.7 us per gate and edge). */
+int c2a_debug_peel_abort(c2a_ctx* ctx, uint32_t launches);
+/* Tests: the number the next build's node-table records are tagged with follows `build_no` (24 bits; the table is cleared when the
+ * numbers wrap).  After c2a_load_gates. */
+int c2a_debug_set_build_no(c2a_ctx* ctx, uint32_t build_no);
+/* Tests: a producer counts as HOT — its consumers take their list slots one range per wave instead of one same-address atomic each —
+ * from its `ticket`-th consumer on (a power of two; default 16 384). */
+int c2a_debug_hot_every(c2a_ctx* ctx, uint32_t ticket);
 
 int c2a_get_timings(c2a_ctx* ctx, c2a_timings* t);
 int c2a_get_stats(c2a_ctx* ctx, c2a_stats* s);

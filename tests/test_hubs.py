@@ -1,8 +1,8 @@
 """HUBS — produced nodes that many gates read — and the graph families beyond synth.layered_dag.
 
 The reference's deps closure allows any fan-out and any distance (/root/reference/src/compiler.rs:408-421); its DFS walks
-them all the same (src/topological_sort.rs:42-44).  Here a gate with more than 16 consumers gets a tree of RELAYS
-(circom-2-arithc_amd/csrc/c2a_peel.h HUBS AND RELAYS): virtual gates that compare its consumers sixteen at a time.  Every
+them all the same (src/topological_sort.rs:42-44).  Here a gate with more than 8 consumers gets a tree of RELAYS
+(circom-2-arithc_amd/csrc/c2a_peel.h HUBS AND RELAYS): virtual gates that compare its consumers eight at a time.  Every
 result must stay bit-identical to the oracle's — sorted ids, node -> wire, emitted gates —, the reverse Kahn levels must not
 count the relays, and the relay count is a function of the fan-outs alone."""
 import importlib
@@ -14,7 +14,7 @@ import pytest
 from conftest import BACKENDS, _Env  # noqa: F401
 from test_parity_build_circuit import _compare
 
-RELAY_FAN, HUB_MIN = 16, 16
+RELAY_FAN, HUB_MIN = 8, 8
 
 
 def relay_count(N):
@@ -75,9 +75,9 @@ def _star(rng, n_cons, chain, hub_gate_first, deep_tail=0):
                 input_nodes=np.array([1, 2], np.uint32), output_nodes=np.array([base + n_cons + chain], np.uint32))
 
 
-@pytest.mark.parametrize("n_cons,own_root", [(17, False), (33, True), (256, False), (257, True), (700, False), (5000, False)])
+@pytest.mark.parametrize("n_cons,own_root", [(9, False), (17, True), (64, False), (65, True), (700, False), (5000, False)])
 def test_one_hub_relay_levels(backend, orc, n_cons, own_root):
-    """17 consumers: two relays; 256: sixteen, one level; 257: a second level; 5 000: three (313 + 20 + 2).  own_root: the hub has
+    """9 consumers: two relays; 64: eight, one level; 65: a second level; 5 000: four (625 + 79 + 10 + 2).  own_root: the hub has
     the smallest gate id — the DFS starts there (topological_sort.rs:11-13), every relay chain ends in a hub that takes none."""
     if n_cons > 1000 and "emul" in backend.version:
         n_cons = 1100                                            # (the emulation runs every wave of the launch as a fiber: keep it short)
@@ -133,6 +133,41 @@ def test_cycle_through_a_hub_is_reported_like_the_reference(backend, orc):
     hub_gate = int(np.where(p["out"] == 10)[0][0])
     p["lh"][hub_gate] = 10 + 1 + 80 + 9                          # the hub now reads the end of the chain above its own consumers
     assert _compare(backend, orc, p, check_serial=True) == "cyclic"
+
+
+def test_hot_producers_take_their_slots_a_wave_at_a_time(backend, orc):
+    """k_deps hands a HOT producer's consumers their list slots one range per wave (c2a_kernels.h HOT PRODUCERS) from its
+    16 384th consumer on; with the threshold lowered (c2a_debug_hot_every) the small stars here take that path: three hubs in
+    one graph — two hot ones and one below the threshold — both edges, lh == rh consumers."""
+    rng = np.random.default_rng(12)
+    backend.debug_hot_every(32)
+    sizes = (700, 300, 20)
+    n = 3 + sum(sizes) + 40
+    perm = rng.permutation(n)
+    lh = np.empty(n, np.uint32); rh = np.empty(n, np.uint32); out = np.empty(n, np.uint32)
+    for h in range(3):
+        g = perm[h]
+        lh[g], rh[g], out[g] = 1, 2, 10 + h
+    k = 3
+    for h, sz in enumerate(sizes):
+        for _ in range(sz):
+            g = perm[k]
+            other = 10 + int(rng.integers(0, 3)) if rng.random() < 0.3 else (13 + int(rng.integers(0, k - 3)) if k > 3 and rng.random() < 0.5 else 2)
+            r = rng.random()
+            lh[g], rh[g] = (10 + h, other) if r < 0.45 else ((other, 10 + h) if r < 0.9 else (10 + h, 10 + h))
+            out[g] = 13 + k - 3
+            k += 1
+    for j in range(40):
+        g = perm[k]
+        lh[g] = 13 + int(rng.integers(0, k - 3)); rh[g] = 13 + int(rng.integers(0, k - 3)); out[g] = 13 + k - 3
+        k += 1
+    p = dict(lh=lh, rh=rh, out=out, op=rng.integers(0, 20, n).astype(np.uint8), n_nodes=13 + n + 2,
+             input_nodes=np.array([1, 2], np.uint32), output_nodes=np.array([13 + n - 4], np.uint32))
+    try:
+        assert _compare(backend, orc, p, check_serial=False) == "ok"
+        assert backend.stats()["n_relays"] == expected_relays(lh, rh, out)
+    finally:
+        backend.debug_hot_every(1 << 14)
 
 
 def _hubby_random(rng, n):

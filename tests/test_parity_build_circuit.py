@@ -396,46 +396,43 @@ def test_connection_with_an_unknown_signal_merges_with_the_placeholder_node(c2a,
     assert sorted(lit.nodes) == sorted(host.nodes) == [1, 3, 4]
 
 
-def test_serial_fallback_when_the_dataflow_launch_gives_up(orc, c2a, emul_lib):
+def test_serial_fallback_when_the_dataflow_launch_gives_up(backend, orc, c2a):
     """A sort that cannot give up (topological_sort.rs:3-21 always terminates on an acyclic graph): when the dataflow launch and
-    its retry both end by their watchdog — simulated here by the emulated build's C2A_EMUL_PEEL_ABORT hook — c2a_topo_sort sorts
+    its retry both end by their watchdog — simulated here by the c2a_debug_peel_abort hook, on the hardware too — c2a_topo_sort sorts
     with the serial DFS instead of failing, the numbering and the emission are the oracle's, and the reverse Kahn levels it
     derives let the level-parallel evaluator run."""
-    import os
-    from conftest import _Env
     fg = c2a.synth.layered_dag(25, 12, n_in=8, n_const=3, window=4, mix=tuple(m for m in c2a.synth.MIX_ALL if m[0] != "APow"), seed=77)
     p = dict(lh=fg.lh, rh=fg.rh, out=fg.out, op=fg.op, n_nodes=fg.n_nodes, input_nodes=fg.input_nodes, output_nodes=fg.output_nodes)
-    with _Env(C2A_EMUL_PEEL_ABORT=2):
-        be = c2a.Backend(0, lib_path=emul_lib)
-    try:
-        assert _compare(be, orc, p, check_serial=False) == "ok"          # first build: both launches "gave up" -> serial DFS
-        st = be.stats()
-        assert st["levels"] >= 25
-        # the evaluator schedules by the levels of the fall-back
-        nw, wc = be.assign_wires()
-        in0, in1, out, op = be.emit_gates()
-        rng = np.random.default_rng(3)
-        ins = rng.integers(0, 2 ** 32, (len(fg.input_nodes), 8), dtype=np.uint64)
-        consts = {int(nw[nd]): 5 + k for k, nd in enumerate(fg.const_nodes) if nw[nd] != 0xFFFFFFFF}
-        vals = np.zeros((wc, 8), np.uint64)
-        vals[:len(fg.input_nodes)] = ins
-        for w, v in consts.items():
-            vals[w] = v
-        circ = orc.ArithCircuit(sorted=np.empty(0, np.uint32), in0=in0, in1=in1, out=out, op=op, node_wire=np.empty(0, np.uint32),
-                                wire_count=wc, n_in=len(fg.input_nodes), n_out=len(fg.output_nodes))
-        orc.eval_arith(circ, 32, vals)
-        np.testing.assert_array_equal(be.eval(ins, consts, width=32), vals[wc - len(fg.output_nodes):])
-        # the hook is spent: the next build takes the dataflow launch again, same results
-        assert _compare(be, orc, p, check_serial=False) == "ok"
-        # a cyclic graph through the fall-back still reports the reference's message
-        be.close()
-        with _Env(C2A_EMUL_PEEL_ABORT=2):
-            be = c2a.Backend(0, lib_path=emul_lib)
-        cyc = dict(lh=np.array([5, 6, 7], np.uint32), rh=np.array([1, 1, 5], np.uint32), out=np.array([6, 5, 8], np.uint32),
-                   op=np.zeros(3, np.uint8), n_nodes=9, input_nodes=np.array([1], np.uint32), output_nodes=np.array([8], np.uint32))
-        assert _compare(be, orc, cyc, check_serial=False) == "cyclic"
-    finally:
-        be.close()
+    be = backend
+    be.debug_peel_abort(2)
+    assert _compare(be, orc, p, check_serial=False) == "ok"          # first build: both launches "gave up" -> serial DFS
+    st = be.stats()
+    assert st["levels"] >= 25
+    # the evaluator schedules by the levels of the fall-back
+    nw, wc = be.assign_wires()
+    in0, in1, out, op = be.emit_gates()
+    rng = np.random.default_rng(3)
+    ins = rng.integers(0, 2 ** 32, (len(fg.input_nodes), 8), dtype=np.uint64)
+    consts = {int(nw[nd]): 5 + k for k, nd in enumerate(fg.const_nodes) if nw[nd] != 0xFFFFFFFF}
+    vals = np.zeros((wc, 8), np.uint64)
+    vals[:len(fg.input_nodes)] = ins
+    for w, v in consts.items():
+        vals[w] = v
+    circ = orc.ArithCircuit(sorted=np.empty(0, np.uint32), in0=in0, in1=in1, out=out, op=op, node_wire=np.empty(0, np.uint32),
+                            wire_count=wc, n_in=len(fg.input_nodes), n_out=len(fg.output_nodes))
+    orc.eval_arith(circ, 32, vals)
+    np.testing.assert_array_equal(be.eval(ins, consts, width=32), vals[wc - len(fg.output_nodes):])
+    # the hook is spent: the next build takes the dataflow launch again, same results
+    assert _compare(be, orc, p, check_serial=False) == "ok"
+    # ONE launch given up: the retry on clean buffers gives the dataflow launch's own result
+    be.debug_peel_abort(1)
+    assert _compare(be, orc, p, check_serial=False) == "ok"
+    # a cyclic graph through the fall-back still reports the reference's message
+    be.debug_peel_abort(2)
+    cyc = dict(lh=np.array([5, 6, 7], np.uint32), rh=np.array([1, 1, 5], np.uint32), out=np.array([6, 5, 8], np.uint32),
+               op=np.zeros(3, np.uint8), n_nodes=9, input_nodes=np.array([1], np.uint32), output_nodes=np.array([8], np.uint32))
+    assert _compare(be, orc, cyc, check_serial=False) == "cyclic"
+    be.debug_peel_abort(0)
 
 
 def test_node_ids_without_creation_order(backend, orc, c2a):
@@ -450,23 +447,21 @@ def test_node_ids_without_creation_order(backend, orc, c2a):
         assert _compare(backend, orc, p) == "ok"
 
 
-def test_build_numbers_wrap(orc, c2a, emul_lib):
+def test_build_numbers_wrap(backend, orc, c2a):
     """The node-table records are tagged with the number of the build that wrote them (24 bits) instead of being cleared per
-    build; when the number wraps the table is cleared once.  Builds across the wrap give the same results (emulator hook:
-    the numbering starts two short of the wrap)."""
-    from conftest import _Env
+    build; when the number wraps the table is cleared once.  Builds across the wrap give the same results (c2a_debug_set_build_no:
+    the numbering goes on from two short of the wrap — on the hardware too)."""
     fg = c2a.synth.layered_dag(30, 40, n_in=16, n_const=3, window=6, mix=c2a.synth.MIX_BITWISE, seed=5)       # (1 200 gates: the XCD-aware sweeps too)
     p = dict(lh=fg.lh, rh=fg.rh, out=fg.out, op=fg.op, n_nodes=fg.n_nodes, input_nodes=fg.input_nodes, output_nodes=fg.output_nodes)
-    with _Env(C2A_EMUL_BUILD_NO=(1 << 24) - 3):
-        be = c2a.Backend(0, lib_path=emul_lib)
-    try:
-        assert _compare(be, orc, p, check_serial=False) == "ok"
-        be.load_gates(p["lh"], p["rh"], p["out"], p["op"], p["n_nodes"], p["input_nodes"], p["output_nodes"])
-        exp = orc.build_circuit(p["lh"], p["rh"], p["out"], p["op"], p["n_nodes"], p["input_nodes"], p["output_nodes"], mode=1)
-        for _ in range(5):                                   # ... - 2, - 1, wrap -> 1, 2, 3
-            np.testing.assert_array_equal(be.topo_sort(), exp.sorted)
-    finally:
-        be.close()
+    be = backend
+    be.load_gates(p["lh"], p["rh"], p["out"], p["op"], p["n_nodes"], p["input_nodes"], p["output_nodes"])
+    be.debug_set_build_no((1 << 24) - 3)
+    exp = orc.build_circuit(p["lh"], p["rh"], p["out"], p["op"], p["n_nodes"], p["input_nodes"], p["output_nodes"], mode=1)
+    for _ in range(5):                                       # ... - 2, - 1, wrap -> 1, 2, 3
+        np.testing.assert_array_equal(be.topo_sort(), exp.sorted)
+    nw, wc = be.assign_wires()
+    assert wc == exp.wire_count
+    np.testing.assert_array_equal(nw, exp.node_wire)
 
 
 def _check_fused(be, orc, bm, p, want_path=None):
