@@ -139,7 +139,7 @@ namespace {
 
 // scalars block layout (u32 words unless noted)
 enum Scalar { SC_MAXDEPTH = 0, SC_SCOUNT = 1, SC_ERR = 2, SC_NMID = 3, SC_NROOTS = 4, SC_LEVELS = 5, SC_PEELOK = 6 /* the dataflow launch ended cleanly and left no gate behind (k_post_peel) */,
-              SC_RELAYS = 7 /* relays that ran in this build (k_relay_fix; a statistic) */, SC_HUBS = 53 /* k_gstat wrote a relay: the circuit has a hub */,
+              SC_RELAYS = 7 /* relays of all hubs of this build (k_gstat) */,
               SC_DFS = 8 /*3 words*/, SC_DUP = 52,
               SC_TOTAL64 = 16 /* u64 slots from here: 16..31 */, SC_HOT = 64 /* 1 + kHotMax words: the hot producers k_deps found (c2a_kernels.h HOT PRODUCERS) */,
               SC_WORDS = 64 + 1 + 64 + 3 };
@@ -325,8 +325,8 @@ int do_prep(c2a_ctx* c, bool for_peel = true) {
     if (!for_peel) return C2A_OK;
     r = scan_exclusive<u32>(c, c->cons_cnt.as<u32>(), c->cons_off.as<u32>(), n, desc + R.cons);
     if (r) return r;
-    C2A_LAUNCH_NOSYNC(k_gstat, G, kThreads, s, n, c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_off.as<u32>(),
-                      c->eslot.as<u32>(), c->orig.as<u32>(), c->gstat.as<uint4>(), c->clist.as<u32>(), c->fill.as<u32>(), c->child.as<uint2>(), c->scalars.as<u32>() + SC_HUBS);
+    C2A_LAUNCH(k_gstat, G, kThreads, s, n, c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_off.as<u32>(),
+               (const uint2*)c->eslot.as<uint2>(), c->orig.as<u32>(), c->gstat.as<uint4>(), c->clist.as<u32>(), c->fill.as<u32>(), c->child.as<uint2>(), c->scalars.as<u32>() + SC_RELAYS);
     return C2A_OK;
 }
 
@@ -453,10 +453,7 @@ int peel_launch(c2a_ctx* c) {
     rec(c, EV_KPEEL1);
     static_assert(CTL_PROCESSED == 0 && CTL_MAXLEVEL == 1 && CTL_ABORT == 2 && CTL_REREADS == 3, "the order k_post_peel writes them in");
     C2A_LAUNCH(k_post_peel, 1, 64, s, c->hrb_dev, (const u32*)c->pctl.as<u32>(), (const u32*)(c->cons_off.as<u32>() + n), (const u32*)(c->scalars.as<u32>() + SC_DUP), n,
-               c->scalars.as<u32>() + SC_PEELOK);
-    // the relays leave the DFS tree again (without hubs the launch is a look at two words)
-    C2A_LAUNCH(k_relay_fix, 512, kThreads, s, n, (u32)relay_cap(n), (const u32*)(c->scalars.as<u32>() + SC_PEELOK), (const u32*)(c->scalars.as<u32>() + SC_HUBS), c->meta.as<uint4>(), c->child.as<u32>(),
-               c->scalars.as<u32>() + SC_RELAYS);
+               (const u32*)(c->scalars.as<u32>() + SC_RELAYS), c->scalars.as<u32>() + SC_PEELOK);
     c->peel_slots = slots; c->peel_waves_used = waves; c->peel_want_stats = want_stats;
     return C2A_OK;
 }
@@ -529,6 +526,7 @@ int peel_result(c2a_ctx* c, u32* peeled_out) {
     c->stats.level_launches = 2;
     c->stats.peel_waves = waves;
     c->stats.peel_rereads = t4[CTL_REREADS];
+    c->stats.n_relays = c->hrb[7];
     return C2A_OK;
 }
 
@@ -565,7 +563,7 @@ int order_launch(c2a_ctx* c) {
     C2A_LAUNCH(k_rank_mark, std::max<u32>(1u, std::min<u32>(2048u, (m + kThreads * 8 - 1) / (kThreads * 8))), kThreads, s, m, ok, c->rlist.as<u32>(), scount, c->slist.as<u32>(),
                       c->owner.as<u32>());
     static_assert(SC_SCOUNT == SC_MAXDEPTH + 1, "read as a pair");
-    C2A_LAUNCH_NOSYNC(k_post_words, 1, 64, s, c->hrb_dev + 8, (const u32*)(c->scalars.as<u32>() + SC_MAXDEPTH), 2u, n_roots_p, 1u, (const u32*)(c->scalars.as<u32>() + SC_RELAYS), 1u);
+    C2A_LAUNCH_NOSYNC(k_post_words, 1, 64, s, c->hrb_dev + 8, (const u32*)(c->scalars.as<u32>() + SC_MAXDEPTH), 2u, n_roots_p, 1u, (const u32*)nullptr, 0u);
     HIP_TRY(hipEventRecord(c->ev[EV_ORDER_RB], s));
     const u64 expect = (u64)m >> (32 - C2A_SPLIT_SHIFT);
     u64 sd = 1;
@@ -594,7 +592,6 @@ int order_result(c2a_ctx* c, bool defer_sorted) {
     c->stats.max_depth = sc[0];
     c->stats.n_splitters = S;
     c->stats.n_roots = sc[2];
-    c->stats.n_relays = c->hrb[11];
     // one writer per node (what the reference's front-end builds) => the positional numbering, which needs no walk in sorted
     // order (c2a_kernels.h POSITIONAL NUMBERING)
     c->positional = !c->has_dup && !c->numbering_walk;
@@ -1001,10 +998,7 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     c->node_clear = true;
     bool cleared = false;
     if (n && hipMemsetAsync(c->node.p, 0, na * kNodeWords * 8, c->aux) == hipSuccess) cleared = true;
-    if (n) {                                         // (the relay part of the consumer lists, "no relay here" in the relays' tree entries: once per loaded graph)
-        C2A_LAUNCH_NOSYNC(k_relay_list, grid_for(rcap, 1024), kThreads, c->aux, n, (u32)rcap, c->clist.as<u32>());
-        C2A_LAUNCH_NOSYNC(k_relay_clear, grid_for(rcap, 1024), kThreads, c->aux, n, (u32)rcap, c->meta.as<uint4>());
-    }
+    if (n) C2A_LAUNCH_NOSYNC(k_relay_list, grid_for(rcap, 1024), kThreads, c->aux, n, (u32)rcap, c->clist.as<u32>());      // (the relay part of the consumer lists: once per loaded graph)
     if (n_nodes) { HIP_TRY(hipMemsetAsync(c->nrec.p, 0, (size_t)n_nodes * 16, c->aux)); c->build_no = 0; }      // (no record of any build)
     ENSURE(c->rbits, n4 / 32 + 32); ENSURE(c->rpre, n4 / 32 + 16); ENSURE(c->ridx, n4); ENSURE(c->rlist, n4);
     ENSURE(c->next, 2 * n4); ENSURE(c->owner, 2 * n4); ENSURE(c->local, 2 * n4); ENSURE(c->slist, 2 * n4);

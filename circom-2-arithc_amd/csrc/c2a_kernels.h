@@ -444,16 +444,17 @@ __global__ void __launch_bounds__(kThreads) k_euler_next(u32 n, const u32* __res
     for (u64 i = gtid(); i < n; i += gstride()) {
         const u32 x = (u32)i;
         md = meta[x].y > md ? meta[x].y : md;
-        const u32 c0 = child[2 * i], c1 = child[2 * i + 1];
+        // (tree_child / tree_parent: the relays of a hub — c2a_peel.h HUBS AND RELAYS — are skipped where the tree is read)
+        const u32 c0 = tree_child(n, child, child[2 * i]), c1 = tree_child(n, child, child[2 * i + 1]);
         next[2 * i] = c0 != C2A_NONE ? 2 * c0 : (c1 != C2A_NONE ? 2 * c1 : 2 * x + 1);
-        const uint4 m = meta[x];
+        const TreeParent P = tree_parent(n, meta, meta[x]);
         u32 nx;
-        if (m.x == C2A_NONE) {
+        if (P.p == C2A_NONE) {
             const u32 k = ridx[x];
             nx = k + 1 < n_roots ? 2 * rlist[k + 1] : C2A_NONE;
         } else {
-            const u32 s1 = (m.w & 1u) == 0 ? child[2 * (u64)m.x + 1] : C2A_NONE;
-            nx = s1 != C2A_NONE ? 2 * s1 : 2 * m.x + 1;
+            const u32 s1 = P.label == 0 ? tree_child(n, child, child[2 * (u64)P.p + 1]) : C2A_NONE;
+            nx = s1 != C2A_NONE ? 2 * s1 : 2 * P.p + 1;
         }
         next[2 * i + 1] = nx;
     }
@@ -1088,15 +1089,17 @@ __global__ void k_post_words(u32* dst, const u32* a, u32 na, const u32* b, u32 n
     for (u32 i = threadIdx.x; i < nc; i += blockDim.x) dst[na + nb + i] = c3[i];
 }
 // the peel: gates done and the highest level (summed / maximised over their kAcctShards parts), gave up, re-reads, edges, duplicate writers
-__global__ void k_post_peel(u32* dst, const u32* ctl, const u32* edges, const u32* dup, u32 n, u32* ok) {
+__global__ void k_post_peel(u32* dst, const u32* ctl, const u32* edges, const u32* dup, u32 n, const u32* relay_total, u32* ok) {
     const u32 t = threadIdx.x;            // (one wave)
     u32 done = t < kAcctShards ? ctl[CTL_PROC + t * kAcctStride] : 0u, lvl = t < kAcctShards ? ctl[CTL_PROC + t * kAcctStride + 1] : 0u;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { done += __shfl_xor(done, off, 64); const u32 o = __shfl_xor(lvl, off, 64); lvl = o > lvl ? o : lvl; }
     if (t == 0) {
-        // (done: REAL gates — the relays of the hubs run in the launch too and are not counted; one that is left behind has a gate left behind above it)
-        dst[0] = done; dst[1] = lvl; dst[2] = ctl[CTL_ABORT]; dst[3] = ctl[CTL_REREADS]; dst[4] = *edges; dst[5] = *dup; dst[6] = ctl[CTL_NEEDDEEP];
-        *ok = (ctl[CTL_ABORT] == 0u && done == n) ? 1u : 0u;      // (what the order stage, queued right behind, goes by)
+        // (the relays of the hubs are steps of the launch too: n + *relay_total when nothing is left behind; reported: gates done = steps minus relays —
+        // a relay that did not run has a gate above it that did not either)
+        const u32 relays = *relay_total;
+        dst[0] = done - relays; dst[1] = lvl; dst[2] = ctl[CTL_ABORT]; dst[3] = ctl[CTL_REREADS]; dst[4] = *edges; dst[5] = *dup; dst[6] = ctl[CTL_NEEDDEEP]; dst[7] = relays;
+        *ok = (ctl[CTL_ABORT] == 0u && done == n + relays) ? 1u : 0u;      // (what the order stage, queued right behind, goes by)
     }
 }
 

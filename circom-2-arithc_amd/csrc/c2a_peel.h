@@ -87,8 +87,8 @@
 // level behind the real label.  Those extra bits change no comparison: two paths that both run through the hub carry them at
 // the same place, and any other pair differs before them (neither is a prefix of the other).  The work of a hub's tournament is
 // thereby spread over as many waves as it has segments, and over TIME: a relay runs when the last of its sixteen consumers is
-// claimed, not when the hub is.  k_relay_fix (behind the launch) takes the relays out of the tree again: the hub's parent is
-// the consumer its bottom relay chose, with that edge's label.
+// claimed, not when the hub is.  Where the tree is read afterwards (k_euler_next: tree_child / tree_parent) the relays are
+// skipped again: the hub's parent is the consumer its bottom relay chose, with that edge's label.
 // Watchdog: lack of GLOBAL progress (a heartbeat the working waves bump) — a long critical path followed by one wave is
 // not an error.
 #pragma once
@@ -151,6 +151,7 @@ constexpr u32 kFillDummyWaves = 8192;       // ... of at most this many waves (2
 constexpr u32 kRelayFan = C2A_RELAY_FAN;    // consumers of one relay: eight records loaded ahead + one batch of the list loop
 constexpr u32 kHubMin = C2A_HUB_MIN;        // a gate with MORE consumers than this gets a relay tree
 constexpr u32 kShallowSkip = C2A_NONE - 1u; // (k_peel_shallow: a lane whose gate turned out to be a relay)
+static_assert((kHdrMask >> 29) & 1u, "inc_unless_bit<29> tells a relay by its original id");
 constexpr u32 kRelayOrig = kHdrMask;        // a relay's "original id" (word 2 of its first static record): above every gate id, so it is never its own DFS root — and how a step knows a relay
 static_assert(kRelayFan >= 8 && kRelayFan <= 32 && kHubMin >= kRelayFan && kHubMin <= 32, "a relay's consumers and a hub's top-level relays fit the prefetched half list (32 lanes)");
 __host__ __device__ constexpr u32 relay_ceil(u32 a) { return (a + kRelayFan - 1u) / kRelayFan; }
@@ -346,7 +347,8 @@ __device__ __attribute__((noinline)) bool deep_less(const u64* node_base, u32 ep
 // The relays above relay `idx` of level `lvl_off` (HUBS AND RELAYS): written by ONE thread — the one that holds the first edge
 // of the bottom relay's segment goes on upwards while the relay it just wrote is the first of ITS parent's segment.
 // Hub h: N consumers at clist[off_h ...), relays n + b ...; xbase: where entry i = relay i starts in clist.
-__device__ __forceinline__ void write_relays(u32 n, u32 h, u32 N, u32 off_h, u32 b, u32 j, u32 xbase, uint4* gstat, u32* fill, uint2* child) {
+__device__ __attribute__((noinline)) void write_relays(u32 n, u32 h, u32 N, u32 off_h, u32 j, uint4* gstat, u32* fill, uint2* child) {
+    const u32 xbase = 2u * n + 64u, b = relay_base(off_h);
     u32 cnt_lvl = relay_ceil(N), lvl_off = 0, idx = j;
     u32 list_off = off_h + j * kRelayFan, list_cnt = N - j * kRelayFan < kRelayFan ? N - j * kRelayFan : kRelayFan;
     for (;;) {
@@ -364,81 +366,74 @@ __device__ __forceinline__ void write_relays(u32 n, u32 h, u32 N, u32 off_h, u32
         list_off = p_off; list_cnt = p_cnt; lvl_off += cnt_lvl; idx = pj; cnt_lvl = relay_ceil(cnt_lvl);
     }
 }
-__global__ void k_gstat(u32 n, const u32* __restrict__ dep0, const u32* __restrict__ dep1, const u32* __restrict__ cons_off,
-                        const u32* __restrict__ eslot, const u32* __restrict__ orig, uint4* gstat, u32* clist, u32* fill, uint2* child, u32* has_hubs) {
+// the edge (consumer, slot `slot` of the list at off, cnt) of a HUB goes to the relay that owns the slot: {relay id, where that relay's list starts, its length}
+struct RelayEdge { u32 id, off, cnt; };
+__device__ __forceinline__ RelayEdge relay_edge(u32 n, u32 off, u32 cnt, u32 slot) {
+    const u32 j = slot / kRelayFan;
+    return RelayEdge{n + relay_base(off) + j, off + j * kRelayFan, cnt - j * kRelayFan < kRelayFan ? cnt - j * kRelayFan : kRelayFan};
+}
+__global__ void __launch_bounds__(256) k_gstat(u32 n, const u32* __restrict__ dep0, const u32* __restrict__ dep1, const u32* __restrict__ cons_off,
+                        const uint2* __restrict__ eslot, const u32* __restrict__ orig, uint4* gstat, u32* clist, u32* fill, uint2* child, u32* relay_total) {
     // (the consumer count of a gate is the difference of two neighbouring offsets — cons_off has n + 1 entries —: ONE
     // 8-byte access per producer instead of two 4-byte ones in two arrays.  Word 2 of a gate's first record is its ORIGINAL
     // id — what the DFS roots are compared by, topological_sort.rs:11-13; the launch works in rank space, c2a_kernels.h
     // RELABELLING —; the offset of its own consumer list is only wanted off the hot path: own_list_off.
     // A producer with more than kHubMin consumers is a HUB: the edge goes to the relay that owns its slot of the hub's list, the
-    // hub's own list are its top-level relays (relay_base: which relays a hub gets follows from where its list lies))
+    // hub's own list are its top-level relays (relay_base: which relays a hub gets follows from where its list lies); the
+    // thread that holds the first edge of a relay's segment writes the relay's static records.  Everything of a gate is
+    // LOADED before any of it is looked at — one memory round trip per gate, as without hubs —, the hubs are ONE unlikely branch.
+    // *relay_total: relays of all hubs (the launch has run n + that many steps when nothing is left behind): summed per
+    // workgroup — one atomic per hub on that word would be 0.6 ms of same-address atomics for 50 000 hubs)
+    __shared__ u32 s_relays;
+    if (threadIdx.x == 0) s_relays = 0u;
+    __syncthreads();
+    u32 my_relays = 0;
     const XcdSweep R = xcd_sweep(n);
-    const u32 xbase = 2u * n + 64u;
     for (u64 g = R.i; g < R.end; g += R.step) {
         u32 d0 = dep0[g], d1 = dep1[g];
+        const uint2 es = eslot[g];
         const u32 o = cons_off[g];
         u32 own_cnt = cons_off[g + 1] - o;
-        if (own_cnt > kHubMin) own_cnt = relay_top(own_cnt).cnt;
         uint4 g2 = make_uint4(0, 0, 0, 0);
-        if (d0 != C2A_NONE) {
-            const u32 off = cons_off[d0], cnt = cons_off[(u64)d0 + 1] - off, slot = eslot[2 * g];
-            clist[off + slot] = (u32)g;
-            g2.x = off; g2.y = cnt;
-            if (cnt > kHubMin) {
-                const u32 b = relay_base(off), j = slot / kRelayFan;
-                if (slot % kRelayFan == 0u) { write_relays(n, d0, cnt, off, b, j, xbase, gstat, fill, child); if (slot == 0u) *has_hubs = 1u; }
-                d0 = n + b + j; g2.x = off + j * kRelayFan; g2.y = cnt - j * kRelayFan < kRelayFan ? cnt - j * kRelayFan : kRelayFan;
+        if (d0 != C2A_NONE) { g2.x = cons_off[d0]; g2.y = cons_off[(u64)d0 + 1] - g2.x; }
+        if (d1 != C2A_NONE) { g2.z = cons_off[d1]; g2.w = cons_off[(u64)d1 + 1] - g2.z; }
+        if (d0 != C2A_NONE) clist[g2.x + es.x] = (u32)g;
+        if (d1 != C2A_NONE) clist[g2.z + es.y] = (u32)g | 0x80000000u;
+        if (C2A_UNLIKELY(own_cnt > kHubMin || g2.y > kHubMin || g2.w > kHubMin)) {
+            if (own_cnt > kHubMin) { my_relays += relay_count(own_cnt); own_cnt = relay_top(own_cnt).cnt; }
+            if (g2.y > kHubMin) {
+                if (es.x % kRelayFan == 0u) write_relays(n, d0, g2.y, g2.x, es.x / kRelayFan, gstat, fill, child);
+                const RelayEdge E = relay_edge(n, g2.x, g2.y, es.x);
+                d0 = E.id; g2.x = E.off; g2.y = E.cnt;
             }
-        }
-        if (d1 != C2A_NONE) {
-            const u32 off = cons_off[d1], cnt = cons_off[(u64)d1 + 1] - off, slot = eslot[2 * g + 1];
-            clist[off + slot] = (u32)g | 0x80000000u;
-            g2.z = off; g2.w = cnt;
-            if (cnt > kHubMin) {
-                const u32 b = relay_base(off), j = slot / kRelayFan;
-                if (slot % kRelayFan == 0u) { write_relays(n, d1, cnt, off, b, j, xbase, gstat, fill, child); if (slot == 0u) *has_hubs = 1u; }
-                d1 = n + b + j; g2.z = off + j * kRelayFan; g2.w = cnt - j * kRelayFan < kRelayFan ? cnt - j * kRelayFan : kRelayFan;
+            if (g2.w > kHubMin) {
+                if (es.y % kRelayFan == 0u) write_relays(n, d1, g2.w, g2.z, es.y / kRelayFan, gstat, fill, child);
+                const RelayEdge E = relay_edge(n, g2.z, g2.w, es.y);
+                d1 = E.id; g2.z = E.off; g2.w = E.cnt;
             }
         }
         gstat[2 * g] = make_uint4(d0, d1, orig[g], own_cnt);
         gstat[2 * g + 1] = g2;
     }
+    if (my_relays) atomicAdd(&s_relays, my_relays);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_relays) atomicAdd(relay_total, s_relays);
 }
 // entry i of the relay part of clist = relay i, edge label 0 (the consumer lists of relays' parents are runs of it): once per loaded graph
 __global__ void k_relay_list(u32 n, u32 cap, u32* clist) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (u64)gridDim.x * blockDim.x) clist[2ull * n + 64ull + i] = n + (u32)i;
 }
-// the tree entries of the relay range say "no relay here" (parent NONE - 1: a relay that ran has a parent, and a relay is never a DFS
-// root): once per loaded graph — every build of it writes the same relays
-constexpr u32 kNoRelay = C2A_NONE - 1u;
-__global__ void k_relay_clear(u32 n, u32 cap, uint4* meta) {
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (u64)gridDim.x * blockDim.x) meta[(u64)n + i] = make_uint4(kNoRelay, 0u, 0u, 0u);
+// The relays leave the DFS tree where it is READ (k_euler_next, behind the launch): what hangs below (c, l) is the hub at the top
+// of the relay chain that chose that edge — if every relay above chose the one below it —, and a hub's parent is the consumer its
+// bottom relay chose, over that relay's edge label.
+__device__ __forceinline__ u32 tree_child(u32 n, const u32* __restrict__ child, u32 c) {
+    while (C2A_UNLIKELY(c != C2A_NONE && c >= n)) c = child[2 * (u64)c];      // (a relay's one child hangs at label 0)
+    return c;
 }
-// Behind the launch: the relays leave the DFS tree.  A BOTTOM relay (its champion is a real gate c, over an edge labelled l)
-// stands for the hub iff the chain of relays above it chose it all the way up: then the hub's parent is c and its label l;
-// else nobody hangs below (c, l).  (ok: the launch ended cleanly; has_hubs: k_gstat wrote a relay in this build — without hubs
-// this launch is a look at two words; *count: relays that ran, a statistic)
-__global__ void __launch_bounds__(256) k_relay_fix(u32 n, u32 cap, const u32* __restrict__ ok, const u32* __restrict__ has_hubs, uint4* meta, u32* child, u32* count) {
-    __shared__ u32 s_cnt[4];
-    if (!*ok || !*has_hubs) return;
-    u32 mine = 0;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (u64)gridDim.x * blockDim.x) {
-        const u64 r = (u64)n + i;
-        const uint4 m = meta[r];
-        if (m.x == kNoRelay) continue;
-        ++mine;
-        if (m.x >= n) continue;                      // (a relay of a higher level: its champion is a relay)
-        const u32 l = m.w & 1u;
-        u32 x = child[2 * r];
-        while (x != C2A_NONE && x >= n) x = child[2 * (u64)x];
-        child[2 * (u64)m.x + l] = x;
-        if (x != C2A_NONE) { uint4 mx = meta[x]; mx.x = m.x; mx.w = (mx.w & ~1u) | l; meta[x] = mx; }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
-    if ((threadIdx.x & 63u) == 0) s_cnt[threadIdx.x >> 6] = mine;
-    __syncthreads();
-    if (threadIdx.x == 0) { const u32 t = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]; if (t) atomicAdd(count, t); }
+struct TreeParent { u32 p, label; };
+__device__ __forceinline__ TreeParent tree_parent(u32 n, const uint4* __restrict__ meta, uint4 m) {
+    while (C2A_UNLIKELY(m.x != C2A_NONE && m.x >= n)) m = meta[m.x];
+    return TreeParent{m.x, m.w & 1u};
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -686,7 +681,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
     u32 demand_seen = 0;                     // (reserve waves) the demand count this wave has answered
     u32 held = 0;                            // this wave holds a consumer ticket that has not been served yet ...
     u64 held_slot = 0;                       // ... for this slot
-    u32 processed = 0, beats = 0, max_level = 0, iters = 0;
+    u32 processed = 0, max_level = 0, iters = 0;
     u32 st_pops = 0, st_polls = 0, st_push = 0, st_seeds = 0;
     ull st_busy = 0, st_idle = 0, st_t0 = STATS ? c2a_now() : 0;
     ull ph_w1 = 0, ph_w2 = 0, ph_w3 = 0;
@@ -1157,9 +1152,9 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             }
             // the tree entry and the child link: wave-uniform data, read by later launches only — SCALAR stores (no exec
             // shuffle, no moves into vector registers; written back at the end of the wave: sstore_flush)
-            // (a relay's level does not count — the reverse Kahn levels of the real gates stay exact —, nor is it a gate done: HUBS AND RELAYS)
-            const u32 real = g_orig != kRelayOrig ? 1u : 0u;
-            const u32 level = (lraw & kHdrMask) + real;
+            // (a relay's level does not count — the reverse Kahn levels of the real gates stay exact —: HUBS AND RELAYS)
+            // (ids — original ones too — are below 2^29; a relay's "original id" has bit 29 set)
+            const u32 level = inc_unless_bit<29>(lraw & kHdrMask, g_orig);
             sstore_x4(&A.meta[gc], ch, depth, ch_root, my_label | (level << 1));
             if (C2A_LIKELY(ch_e != C2A_NONE)) sstore_x1_at(A.child, (2u * ch + my_label) * 4u, gc);      // (gate ids are below 2^29: the byte offset fits 32 bits)
             // (the three header words go into lanes 0..2 with v_writelane: a lane == k ladder is masked code)
@@ -1170,8 +1165,8 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             w_hi = wrlane_c<2>(my_pos | tag_hi, w_hi);      // (lane 2's low half is the root key already: str carries it)
             const u64 my_w = (u64)w_lo | ((u64)w_hi << 32);
             st_nw(&A.node[(u64)gc * kNodeWords + lane], my_w);
-            processed += real;
-            if (C2A_UNLIKELY((++beats & 63u) == 0) && lane == 0) atomicAdd(&A.ctl[CTL_HEARTBEAT], 1u);
+            ++processed;
+            if (C2A_UNLIKELY((processed & 63u) == 0) && lane == 0) atomicAdd(&A.ctl[CTL_HEARTBEAT], 1u);
             if (STATS) {
                 const ull ph4 = c2a_now();
                 if (dt_trace && lane == 0) {

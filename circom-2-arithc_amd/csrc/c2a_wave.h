@@ -55,6 +55,17 @@ __device__ __forceinline__ u32 select_uniform(u32 j, u32 a, u32 b) {
     return r;
 #endif
 }
+// x + 1 unless bit B of the wave-uniform f is set (s_bitcmp0 + s_addc: two scalar instructions; as `x + (cond ? 1 : 0)` the compiler
+// makes a 64-bit select and a second compare of it: four)
+template <int B> __device__ __forceinline__ u32 inc_unless_bit(u32 x, u32 f) {
+#ifdef C2A_EMULATE
+    return x + (((f >> B) & 1u) ? 0u : 1u);
+#else
+    u32 r;
+    asm("s_bitcmp0_b32 %2, %3\n\ts_addc_u32 %0, %1, 0" : "=s"(r) : "s"(x), "s"(f), "n"(B) : "scc");
+    return r;
+#endif
+}
 __device__ __forceinline__ u32 uniform(u32 v) {
 #ifdef C2A_EMULATE
     return v;
