@@ -228,13 +228,13 @@ def hub_dag(layers: int, layer_width: int, n_in: int = 4096, n_const: int = 64, 
     if n_big and H:
         is_big[(splitmix64(seed, 10, n_big) % np.uint64(H)).astype(np.int64)] = True
         w = np.where(is_big, big_lo * (big_hi / big_lo) ** u(11, H), w)
-    cumw = np.cumsum(w)
-    r_sel, r_pick = u(12, n), u(13, n)
-    cnt = np.searchsorted(hub_idx, k * Wd, side="left")                     # hubs in strictly earlier layers
-    take = (r_sel < p_hub) & (cnt > 0)
-    tot = np.where(cnt > 0, cumw[np.maximum(cnt, 1) - 1], 1.0)
-    pick = np.minimum(np.searchsorted(cumw, r_pick * tot, side="right"), np.maximum(cnt, 1) - 1)
     if H:
+        cumw = np.cumsum(w)
+        r_sel, r_pick = u(12, n), u(13, n)
+        cnt = np.searchsorted(hub_idx, k * Wd, side="left")                 # hubs in strictly earlier layers
+        take = (r_sel < p_hub) & (cnt > 0)
+        tot = np.where(cnt > 0, cumw[np.maximum(cnt, 1) - 1], 1.0)
+        pick = np.minimum(np.searchsorted(cumw, r_pick * tot, side="right"), np.maximum(cnt, 1) - 1)
         rh_log = np.where(take, out_of[hub_idx[pick]], rh_log)
     # ---- the mega hubs: one gate each in the first layers, read by a fraction f of the gates of every later layer
     r_m = u(14, n)
@@ -268,8 +268,11 @@ def reduction_forest(n: int, width: int = 2000, n_in: int = 4096, n_const: int =
         pool = pool[rng.permutation(P)]
         a = min(int(p_merge * P) // 2 * 2, 2 * (n - g))
         merges = a // 2
-        b = min(int(p_chain * P), n - g - merges)
+        b = min(int(p_chain * P), P - a, n - g - merges)
         leaves = min(max(width - (P - merges), 1 if P == 0 else 0), n - g - merges - b)
+        if merges + b + leaves == 0:                                      # (a pool too small for the fractions: extend one chain, so that every round makes a gate)
+            b = 1 if P > a else 0
+            leaves = 1 - b
         m_l, m_r = pool[:merges], pool[merges:a]
         c_p = pool[a:a + b]
         ext = rng.integers(0, n_in + n_const, size=b + 2 * leaves)

@@ -270,3 +270,14 @@ def test_families_1m(name, walk, orc, c2a):
                 assert be.checksum(nm) == bm.checksum_host(arr), (nm, rep)
     finally:
         be.close()
+
+
+@pytest.mark.gpu
+def test_fuzz_slice_on_the_hardware(hip_backend):
+    """a minute of tools/fuzz_gpu.py (random graphs of every family, random shapes and hub populations, up to 1 M gates, every
+    result array of the fused call against the oracle, the staged calls on every seventh) as part of the suite"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    fuzz = importlib.import_module("tools.fuzz_gpu")
+    n, per = fuzz.run(minutes=1.0, seed=20241008, max_gates=1_000_000, be=hip_backend)
+    assert n >= 20 and len(per) >= 4, (n, per)

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""usage (on the GPU box): python tools/fuzz_gpu.py [minutes] — random layered graphs of random shapes / op mixes / constant and
-output densities (incl. duplicate-free adversarial sizes around the tile boundaries) through c2a_build_circuit on the MI355X, every
-result array against the oracle; both numbering paths by turns; a fresh graph per iteration on ONE context (buffers reused)."""
+"""usage (on the GPU box): python tools/fuzz_gpu.py [minutes] [seed] [max_gates] — random graphs of random FAMILIES (layered_dag of random
+shapes / op mixes / constant and output densities incl. adversarial sizes around the tile boundaries; hub_dag with random hub
+populations; reduction forests; all-layer windows; tilings of the real SHA-256 block) through c2a_build_circuit on the MI355X,
+every result array against the oracle; a fresh graph per iteration on ONE context (buffers reused); every seventh graph the staged
+calls element-wise as well.  Prints one summary line per family; exit code 1 on any difference."""
 import importlib, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,32 +11,70 @@ sys.path.insert(0, ROOT)
 c2a = importlib.import_module("circom-2-arithc_amd")
 bm = importlib.import_module("circom-2-arithc_amd.backend")
 from oracle import oracle as orc
-minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-be = c2a.Backend(0)
-t_end = time.time() + 60 * minutes
-it = 0
-while time.time() < t_end:
-    layers = int(rng.choice([1, 2, 3, 7, 40, 200, 1000, 6000]))
-    width = int(rng.choice([1, 2, 5, 63, 64, 65, 300, 2048, 4097, 20000]))
-    if layers * width > 3_000_000:
-        continue
-    cf, of = float(rng.choice([0, 0, 0.05, 0.3])), float(rng.choice([0, 0, 0.05, 0.5]))
-    mix = [c2a.synth.MIX_BITWISE, c2a.synth.MIX_ALL, c2a.synth.MIX_SHA][int(rng.integers(3))]
-    fg = c2a.synth.layered_dag(layers, width, n_in=int(rng.integers(1, 50)), n_const=int(rng.integers(0, 9)), window=int(rng.integers(1, 70)),
-                               mix=mix, seed=int(rng.integers(1 << 30)), const_frac=cf, out_frac=of, permute=bool(rng.integers(2)))
-    args = (fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes)
-    exp = orc.build_circuit(*args, mode=1)
-    be.load_gates(*args)
-    for rep in range(2):
-        assert be.build_circuit() == exp.wire_count, (layers, width)
-        for nm, arr in (("sorted", exp.sorted), ("in0", exp.in0), ("in1", exp.in1), ("out", exp.out), ("op", exp.op)):
-            assert be.checksum(nm) == bm.checksum_host(arr), (nm, layers, width, cf, of, rep)
-        nw1 = ((exp.node_wire.astype(np.uint64) + 1) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-        assert be.checksum("node_wire1") == bm.checksum_host(nw1), ("node_wire", layers, width, cf, of, rep)
-    if it % 7 == 0:
-        np.testing.assert_array_equal(be.topo_sort(), exp.sorted)
-        nw, wc = be.assign_wires()
-        np.testing.assert_array_equal(nw, exp.node_wire)
-    it += 1
-print(f"{it} graphs == oracle ({minutes} min)")
+
+
+def draw(rng, max_gates, sha_blk):
+    S = c2a.synth
+    fam = str(rng.choice(["layered", "layered", "hub", "hub", "forest", "window_all", "sha"]))
+    seed = int(rng.integers(1 << 30))
+    while True:
+        layers = int(rng.choice([1, 2, 3, 7, 40, 200, 1000, 6000]))
+        width = int(rng.choice([1, 2, 5, 63, 64, 65, 300, 2048, 4097, 20000]))
+        if layers * width <= max_gates:
+            break
+    mix = [S.MIX_BITWISE, S.MIX_ALL, S.MIX_SHA][int(rng.integers(3))]
+    if fam == "layered":
+        cf, of = float(rng.choice([0, 0, 0.05, 0.3])), float(rng.choice([0, 0, 0.05, 0.5]))
+        return fam, S.layered_dag(layers, width, n_in=int(rng.integers(1, 50)), n_const=int(rng.integers(0, 9)), window=int(rng.integers(1, 70)),
+                                  mix=mix, seed=seed, const_frac=cf, out_frac=of, permute=bool(rng.integers(2)))
+    if fam == "hub":
+        mega = tuple(float(x) for x in rng.choice([0.3, 0.1, 0.03, 0.01, 0.002], size=int(rng.integers(0, 4)), replace=False))
+        return fam, S.hub_dag(max(2, layers), width, n_in=int(rng.integers(1, 50)), n_const=int(rng.integers(0, 9)), window=int(rng.integers(1, 70)), mix=mix,
+                              seed=seed, small_frac=float(rng.choice([0.0, 0.01, 0.05])), small_lo=float(rng.choice([9.0, 17.0, 40.0])),
+                              big=int(rng.choice([0, 300, 3000])), big_lo=float(rng.choice([100.0, 1000.0])), mega=mega,
+                              p_hub=float(rng.choice([0.1, 0.45, 0.9])), permute=bool(rng.integers(2)))
+    if fam == "forest":
+        return fam, S.reduction_forest(max(1, layers * width), width=max(1, width), n_in=int(rng.integers(1, 50)), n_const=int(rng.integers(0, 9)), mix=mix, seed=seed,
+                                       p_merge=float(rng.choice([0.1, 0.4, 0.8])), p_chain=float(rng.choice([0.0, 0.15, 0.3])), permute=bool(rng.integers(2)))
+    if fam == "window_all":
+        return fam, S.layered_dag(layers, width, n_in=int(rng.integers(1, 50)), n_const=int(rng.integers(0, 9)), window=layers, mix=mix, seed=seed)
+    copies = int(rng.integers(1, max(2, min(40, max_gates // 3448))))
+    return fam, S.tile_block(*sha_blk, copies=copies, shape=str(rng.choice(["chain", "tree"])), seed=seed, permute=bool(rng.integers(2)))
+
+
+def run(minutes=2.0, seed=1, max_gates=3_000_000, be=None, log=print):
+    from tools.family_check import sha_block
+    rng = np.random.default_rng(seed)
+    own = be is None
+    be = be or c2a.Backend(0)
+    blk = sha_block()
+    t_end = time.time() + 60 * minutes
+    it, per, relays = 0, {}, 0
+    try:
+        while time.time() < t_end:
+            fam, fg = draw(rng, max_gates, blk)
+            args = (fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes)
+            exp = orc.build_circuit(*args, mode=1)
+            be.load_gates(*args)
+            for rep in range(2):
+                assert be.build_circuit() == exp.wire_count, (fam, fg.n, "wire_count")
+                for nm, arr in (("sorted", exp.sorted), ("in0", exp.in0), ("in1", exp.in1), ("out", exp.out), ("op", exp.op)):
+                    assert be.checksum(nm) == bm.checksum_host(arr), (fam, nm, fg.n, fg.layers, fg.layer_width, rep)
+                nw1 = ((exp.node_wire.astype(np.uint64) + 1) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+                assert be.checksum("node_wire1") == bm.checksum_host(nw1), (fam, "node_wire", fg.n, rep)
+            relays += be.stats()["n_relays"]
+            if it % 7 == 0:
+                np.testing.assert_array_equal(be.topo_sort(), exp.sorted)
+                nw, wc = be.assign_wires()
+                np.testing.assert_array_equal(nw, exp.node_wire)
+            it += 1
+            per[fam] = per.get(fam, 0) + 1
+    finally:
+        if own:
+            be.close()
+    log(f"{it} graphs == oracle in {minutes} min (seed {seed}, up to {max_gates} gates): " + ", ".join(f"{k} {v}" for k, v in sorted(per.items())) + f"; {relays} relays ran")
+    return it, per
+
+
+if __name__ == "__main__":
+    run(float(sys.argv[1]) if len(sys.argv) > 1 else 2.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1, int(sys.argv[3]) if len(sys.argv) > 3 else 3_000_000)
