@@ -167,6 +167,85 @@ def cpu_baseline(fg, width, chunk_gates, circ, handle, t_flat):
             "variants_agree": same, "boolean_gates": n_bool, "host_cores_available": os.cpu_count()}
 
 
+def small_configs(c2a, new_backend, reps=10):
+    """BASELINE.json configs[0..3] as REAL circuits, the way the reference runs them — build_circuit + boolify ONCE per process
+    (src/main.rs:28-32) on 10^1 .. 10^5 gates —: the shipped input/circuit.circom (ArgMax(2); its flat list is the committed
+    fixture tests/golden/argmax2.json), a Poseidon-shaped permutation over Z/2^32, SHA-256 over nine blocks (width 32) and the
+    SHA3-256 sponge over 29 blocks (width 64), the last three unrolled here from tests/golden/circuits/*.circom.  Per circuit: the
+    GPU step with the circuit resident (steady, mean of `reps`), the first load + build + boolify on a fresh context (cold; the
+    context's creation apart), the CPU oracle on one core (structure-faithful build_circuit + bit-blast), and the GPU's arrays —
+    sorted ids, emitted gates, every boolean gate — against the oracle's.  Where the GPU path starts to pay is read off this
+    table (INTEGRATION.md, "When to dispatch")."""
+    from oracle import oracle as orc
+    comp = importlib.import_module("circom-2-arithc_amd.compiler")
+    gold = os.path.join(ROOT, "tests", "golden")
+    out = []
+
+    def payload_of(name):
+        if name == "argmax2":
+            fx = json.load(open(os.path.join(gold, "argmax2.json")))
+            g = fx["gates"]
+            return (np.array([x[1] for x in g], np.uint32), np.array([x[2] for x in g], np.uint32), np.array([x[3] for x in g], np.uint32),
+                    np.array([orc.OP[x[0]] for x in g], np.uint8), fx["n_nodes"], np.array(fx["input_nodes"], np.uint32),
+                    np.array(fx["output_nodes"], np.uint32)), 0.0
+        t0 = time.perf_counter()
+        C = comp.Compiler.from_circom(open(os.path.join(gold, "circuits", name + ".circom")).read(), backend=None)
+        inputs, outputs, _ = C._io_maps()
+        lh, rh, o, op = C._flat()
+        return (lh, rh, o, op, C.node_count + 1, np.array([nd for _, nd in inputs], np.uint32), np.array([nd for _, nd in outputs], np.uint32)), time.perf_counter() - t0
+
+    for name, label, width in (("argmax2", "configs[0]: input/circuit.circom = ArgMax(2)", 32), ("poseidonLike", "configs[1]: Poseidon-shaped permutation over Z/2^32", 32),
+                               ("sha256", "configs[2]: SHA-256 over 9 blocks", 32), ("sha3_256", "configs[3]: SHA3-256 sponge over 29 rate blocks", 64)):
+        args, t_unroll = payload_of(name)
+        n = len(args[0])
+        # CPU: the oracle's faithful variant + the whole bit-blast, best of 3
+        cpu = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            circ, h = orc.build_circuit(*args, mode=0, keep_handle=True)
+            t1 = time.perf_counter()
+            eb = orc.boolify(circ, width)
+            t2 = time.perf_counter()
+            cpu.append((t2 - t0, t1 - t0))
+            orc.free_circuit(h)
+        cpu_ms, cpu_build_ms = min(cpu)[0] * 1e3, min(cpu)[1] * 1e3
+        # GPU cold: a fresh context
+        t0 = time.perf_counter()
+        be = new_backend()
+        t1 = time.perf_counter()
+        be.load_gates(*args)
+        be.build_circuit()
+        be.boolify(width)
+        t2 = time.perf_counter()
+        # steady
+        for _ in range(2):
+            be.build_circuit(); be.boolify(width)
+        t3 = time.perf_counter()
+        acc = {}
+        for _ in range(reps):
+            be.build_circuit()
+            bi = be.boolify(width)
+            for k, v in be.timings().items():
+                acc[k] = acc.get(k, 0.0) + v / reps
+        steady_ms = (time.perf_counter() - t3) * 1e3 / reps
+        # check: every array
+        ok = bool(np.array_equal(be.topo_sort(), circ.sorted))
+        be.build_circuit(); be.boolify(width)
+        in0, in1, o_, op_ = be.emit_gates()
+        ok = ok and all(np.array_equal(a, b) for a, b in zip((in0, in1, o_, op_), (circ.in0, circ.in1, circ.out, circ.op)))
+        ok = ok and bi.n_gates == len(eb.in0) and all(np.array_equal(a, b) for a, b in zip(be.bool_read(), (eb.in0, eb.in1, eb.out, eb.op)))
+        st = be.stats()
+        be.close()
+        out.append({"name": label, "n_gates": n, "width": width, "boolean_gates": int(bi.n_gates), "levels": st["levels"],
+                    "gpu_ms_steady": steady_ms, "gpu_stages_ms": {k: round(v, 4) for k, v in acc.items()},
+                    "gpu_ms_cold": (t2 - t1) * 1e3, "gpu_context_create_ms": (t1 - t0) * 1e3,
+                    "cpu_ms": cpu_ms, "cpu_build_circuit_ms": cpu_build_ms, "cpu_cores": 1,
+                    "gpu_over_cpu_steady": cpu_ms / steady_ms, "gpu_over_cpu_cold": cpu_ms / ((t2 - t1) * 1e3),
+                    "unroll_s": t_unroll, "checked": ok})
+        assert ok, f"{label}: the GPU's arrays differ from the oracle's"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,6 +264,7 @@ def main():
     ap.add_argument("--no-cold", action="store_true", help="skip the cold single-shot measurement")
     ap.add_argument("--no-prune", action="store_true", help="skip the optional prune pass report")
     ap.add_argument("--no-reference-shaped", action="store_true", help="skip the step on the reference-shaped graph (constants at a tenth of the gates)")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE's configs[0..3] as real circuits (GPU steady / cold vs CPU per circuit; ~1.5 min, most of it unrolling the 148 K-gate sponge)")
     ap.add_argument("--mode", choices=["both", "shard", "replicas"], default="both",
                     help="N>1: 'shard' = ONE graph, sort replicated on every rank, boolify sharded by sorted-position range (strong "
                          "scaling, BASELINE's metric: the line's `value`); 'replicas' = N independent graphs, one per GPU (throughput, "
@@ -276,6 +356,7 @@ def main():
 
     steps = max(1, args.steps)
     stages = {k: v / steps for k, v in stage_acc.items()}
+    stats = be.stats()                                  # (of the timed region's own graph: the replicas region below loads another)
     # ---- check (every rank: its own results against the oracle) — BASELINE.md §2: "outputs compared bit-for-bit"
     backend_mod = importlib.import_module("circom-2-arithc_amd.backend")
     want_oracle = args.check or not args.no_cpu_baseline
@@ -326,7 +407,6 @@ def main():
 
     ms_per_step = elapsed * 1e3 / steps
     value = whole_job_rate(world if replicas else 1, n, steps, elapsed)
-    stats = be.stats()
     # ---- roofline of the whole step: 30 B per gate for sort + numbering + emission, 13 B read per
     # arithmetic gate + 13 B written per boolean gate for the map
     sort_bytes = 30.0 * n
@@ -468,6 +548,10 @@ def main():
                       "boolean_gates": ri.n_gates, "stages_ms": {k: v / steps for k, v in acc.items()},
                       "numbering_path": rst["numbering_path"], "numbering_events": rst["numbering_events"], "checked": rchecked}
 
+    configs = None
+    if world == 1 and not args.no_configs and not test_lib:
+        configs = small_configs(c2a, new_backend)
+
     sort_ms = stages.get("build_total", 0.0)
     bool_ms = stages.get("boolify_total", 0.0) if not shard else ms_per_step - sort_ms
     # what strong scaling can reach at all: the sort is replicated, only the boolify part B divides by N (Amdahl)
@@ -500,6 +584,7 @@ def main():
         "cpu_baseline": cpu,
         "width64": width64,
         "reference_shaped": ref_shaped,
+        "configs": configs,
         "artefacts": artefacts,
         "stages_ms": stages,
         "per_rank": per_rank,

@@ -88,6 +88,125 @@ def _keccak_case(msgs):
 CASES = [("sha256Block", 32, 55, _sha_case, 3448, 16, 8), ("keccakF1600", 64, 135, _keccak_case, 5112, 50, 25)]
 
 
+# ---- BASELINE.json configs[1..3] at their STATED sizes: the same templates with a block-count parameter
+def _sha_multi_case(msgs, n_blocks):
+    ins, outs = [], []
+    for m in msgs:
+        padded = m + b"\x80" + b"\0" * ((55 - len(m)) % 64) + struct.pack(">Q", 8 * len(m))
+        assert len(padded) == 64 * n_blocks, (len(m), len(padded))
+        ins.append({f"0.in[{i}]": w for i, w in enumerate(struct.unpack(f">{16 * n_blocks}I", padded))})
+        outs.append({f"0.out[{i}]": w for i, w in enumerate(struct.unpack(">8I", hashlib.sha256(m).digest()))})
+    return ins, outs
+
+
+def _sha3_multi_case(msgs, n_blocks):
+    ins, outs = [], []
+    for m in msgs:
+        blk = bytearray(m) + bytearray(136 * n_blocks - len(m))
+        assert 136 * (n_blocks - 1) <= len(m) < 136 * n_blocks
+        blk[len(m)] ^= 0x06
+        blk[-1] ^= 0x80
+        d = {f"0.in[{i}]": w for i, w in enumerate(struct.unpack(f"<{17 * n_blocks}Q", bytes(blk)))}
+        d.update({f"0.rc[{i}]": w for i, w in enumerate(KECCAK_RC)})
+        d["0.ones"] = (1 << 64) - 1
+        ins.append(d)
+        outs.append({f"0.out[{i}]": w for i, w in enumerate(struct.unpack("<4Q", hashlib.sha3_256(m).digest()))})
+    return ins, outs
+
+
+def poseidon_like_numpy(a, b):
+    """tests/golden/circuits/poseidonLike.circom in plain integers mod 2^32 (the constants recomputed, not read from the text)"""
+    M = 0xFFFFFFFF
+    rc, x = [], 20241008
+    for _ in range(36):
+        x = (x * 1664525 + 1013904223) & M
+        rc.append(x)
+    mds = [[5, 7, 3], [3, 5, 7], [7, 3, 5]]
+    st = [0, a & M, b & M]
+    p5 = lambda v: (pow(v, 5, 1 << 32))
+    for r in range(12):
+        st = [(st[j] + rc[3 * r + j]) & M for j in range(3)]
+        st = [p5(v) for v in st] if (r < 4 or r >= 8) else [p5(st[0]), st[1], st[2]]
+        st = [sum(mds[i][j] * st[j] for j in range(3)) & M for i in range(3)]
+    return st[0]
+
+
+def _poseidon_case(msgs, _n):
+    rng = np.random.default_rng(5)
+    pairs = [(0, 0), (1, 2), (0xFFFFFFFF, 0xFFFFFFFF)] + [tuple(int(v) for v in rng.integers(0, 1 << 32, 2)) for _ in range(5)]
+    return ([{"0.in[0]": a, "0.in[1]": b} for a, b in pairs], [{"0.out": poseidon_like_numpy(a, b)} for a, b in pairs])
+
+
+def _lens(lo, hi):
+    rng = np.random.default_rng(20241008)
+    return [bytes(rng.integers(0, 256, int(L), dtype=np.uint8)) for L in [lo, hi] + list(rng.integers(lo, hi + 1, 6))]
+
+
+# name, main as written, (blocks under the emulation, blocks on the GPU), width, messages(n_blocks), case maker, gates per block + fixed, n_in(n_blocks), n_out
+SIZED = [
+    ("poseidonLike", None, (1, 1), 32, lambda nb: [None] * 8, _poseidon_case, lambda nb: 301, lambda nb: 2, 1),
+    ("sha256", "Sha256(9)", (2, 9), 32, lambda nb: _lens(64 * (nb - 1), 64 * nb - 9), _sha_multi_case, lambda nb: 3448 * nb, lambda nb: 16 * nb, 8),
+    ("sha3_256", "Sha3_256(29)", (2, 29), 64, lambda nb: _lens(136 * (nb - 1), 136 * nb - 1), _sha3_multi_case, lambda nb: 5112 * nb + 8 + 17 * (nb - 1), lambda nb: 17 * nb + 25, 4),
+]
+
+
+@pytest.mark.parametrize("name,main,blocks,width,msgs_of,make,n_gates_of,n_in_of,n_out", SIZED, ids=[c[0] for c in SIZED])
+def test_configs_at_their_stated_sizes(name, main, blocks, width, msgs_of, make, n_gates_of, n_in_of, n_out, backend, orc):
+    """BASELINE.json configs[1] (Poseidon-shaped, 301 gates, AMul chains), configs[2] (SHA-256 over NINE blocks, 31 032 gates, width
+    32) and configs[3] (the SHA3-256 sponge over 29 rate blocks, 148 732 gates, width 64) as real circuits from Circom text: sort /
+    numbering / emission against the oracle's hash-map faithful build_circuit, and the ARITHMETIC circuit, its BOOLEAN image and the
+    PRUNED image evaluated (c2a_eval) against hashlib / numpy on eight inputs.  Under the host emulation the block count is 2 (the
+    same text with a smaller loop bound) and only the arithmetic circuit is evaluated; the stated sizes run on the hardware."""
+    on_gpu = "hip" in backend.version
+    nb = blocks[1] if on_gpu else blocks[0]
+    comp_mod = importlib.import_module("circom-2-arithc_amd.compiler")
+    text = open(os.path.join(CIRCUITS, f"{name}.circom")).read()
+    if main is not None:
+        assert text.count(main) == 1
+        text = text.replace(main, main.split("(")[0] + f"({nb})")
+    C = comp_mod.Compiler.from_circom(text, backend=backend)
+    assert len(C.gates) == n_gates_of(nb)
+    circ = C.build_circuit()
+    inputs, outputs, _ = C._io_maps()
+    lh, rh, out, op = C._flat()
+    exp = orc.build_circuit(lh, rh, out, op, C.node_count + 1, np.array([nd for _, nd in inputs], np.uint32),
+                            np.array([nd for _, nd in outputs], np.uint32), mode=0)
+    assert circ.wire_count == exp.wire_count
+    np.testing.assert_array_equal(circ.sorted_gate_ids, exp.sorted)
+    assert int((exp.sorted != np.arange(len(lh))).sum()) > len(lh) // 10              # NOT the identity
+    for a, b in zip((circ.in0, circ.in1, circ.out, circ.op), (exp.in0, exp.in1, exp.out, exp.op)):
+        np.testing.assert_array_equal(a, b)
+    iw, ow = circ.info.input_name_to_wire_index, circ.info.output_name_to_wire_index
+    assert len(iw) == n_in_of(nb) and len(ow) == n_out
+    ins_by_name, outs_by_name = make(msgs_of(nb), nb)
+    T = len(ins_by_name)
+    ins = np.zeros((len(iw), T), np.uint64)
+    want = np.zeros((n_out, T), np.uint64)
+    for t, (i_, o_) in enumerate(zip(ins_by_name, outs_by_name)):
+        for k, v in i_.items():
+            ins[iw[k], t] = v
+        for k, v in o_.items():
+            want[ow[k] - (circ.wire_count - n_out), t] = v
+    cst = {c.wire_index: int(c.value) for c in circ.info.constants.values()}
+    np.testing.assert_array_equal(backend.eval(ins, cst, width=width), want)
+    if not on_gpu and name != "poseidonLike":
+        return
+    bi = backend.boolify(width)
+    Tsz = np.array([orc.template_size(o, width)[0] for o in range(20)], dtype=np.int64)
+    assert bi.n_gates == int(Tsz[exp.op].sum())
+    np.testing.assert_array_equal(backend.eval(ins, cst, width=width, boolean=True), want)
+    sl, g0 = orc.boolify_range(exp, width, len(lh) // 2, 100)
+    for a, b in zip(backend.bool_read(g0, len(sl.in0)), (sl.in0, sl.in1, sl.out, sl.op)):
+        np.testing.assert_array_equal(a, b)
+    if not on_gpu:
+        return
+    checked, bad = backend.verify_boolify(seed=5)
+    assert checked == circ.wire_count * 64 and bad == 0
+    pi = backend.boolify_prune()
+    assert 0 < pi["n_gates"] <= bi.n_gates + 2
+    np.testing.assert_array_equal(backend.eval(ins, cst, width=width, pruned=True), want)
+
+
 @pytest.mark.parametrize("name,width,max_len,make,n_gates,n_in,n_out", CASES, ids=[c[0] for c in CASES])
 def test_hash_circuit_known_answers(name, width, max_len, make, n_gates, n_in, n_out, backend, orc):
     comp_mod = importlib.import_module("circom-2-arithc_amd.compiler")
