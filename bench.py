@@ -230,16 +230,28 @@ def small_configs(c2a, new_backend, reps=10):
         steady_ms = (time.perf_counter() - t3) * 1e3 / reps
         # check: every array
         ok = bool(np.array_equal(be.topo_sort(), circ.sorted))
-        be.build_circuit(); be.boolify(width)
+        be.build_circuit()
         in0, in1, o_, op_ = be.emit_gates()
         ok = ok and all(np.array_equal(a, b) for a, b in zip((in0, in1, o_, op_), (circ.in0, circ.in1, circ.out, circ.op)))
+        bi = be.boolify(width)
         ok = ok and bi.n_gates == len(eb.in0) and all(np.array_equal(a, b) for a, b in zip(be.bool_read(), (eb.in0, eb.in1, eb.out, eb.op)))
         st = be.stats()
+        # the HYBRID a maintainer can choose for a deep and narrow circuit (c2a_load_circuit): the reference's own build_circuit on
+        # the CPU, only boolify(&circuit, w) on the GPU — the emitted circuit's way over PCIe included
+        hyb = []
+        for _ in range(3):
+            t4 = time.perf_counter()
+            be.load_circuit(circ.in0, circ.in1, circ.out, circ.op, circ.wire_count, circ.n_in, circ.n_out)
+            bh = be.boolify(width)
+            hyb.append((time.perf_counter() - t4) * 1e3)
+        ok = ok and bh.n_gates == len(eb.in0) and all(np.array_equal(a, b) for a, b in zip(be.bool_read(), (eb.in0, eb.in1, eb.out, eb.op)))
         be.close()
         out.append({"name": label, "n_gates": n, "width": width, "boolean_gates": int(bi.n_gates), "levels": st["levels"],
                     "gpu_ms_steady": steady_ms, "gpu_stages_ms": {k: round(v, 4) for k, v in acc.items()},
                     "gpu_ms_cold": (t2 - t1) * 1e3, "gpu_context_create_ms": (t1 - t0) * 1e3,
                     "cpu_ms": cpu_ms, "cpu_build_circuit_ms": cpu_build_ms, "cpu_cores": 1,
+                    "hybrid_ms": cpu_build_ms + min(hyb), "hybrid_gpu_load_circuit_and_boolify_ms": min(hyb),
+                    "gates_per_level": n / max(1, st["levels"]),
                     "gpu_over_cpu_steady": cpu_ms / steady_ms, "gpu_over_cpu_cold": cpu_ms / ((t2 - t1) * 1e3),
                     "unroll_s": t_unroll, "checked": ok})
         assert ok, f"{label}: the GPU's arrays differ from the oracle's"

@@ -94,7 +94,7 @@ class BoolInfo:
 
 ABI_VERSION = 7          # == C2A_ABI_VERSION of include/c2a.h this binding was written against
 
-_EXPORTS = ["c2a_abi_version", "c2a_visible_devices", "c2a_create", "c2a_device_count", "c2a_format_bristol", "c2a_destroy", "c2a_last_error", "c2a_version", "c2a_load_gates", "c2a_topo_sort",
+_EXPORTS = ["c2a_abi_version", "c2a_visible_devices", "c2a_create", "c2a_device_count", "c2a_format_bristol", "c2a_destroy", "c2a_last_error", "c2a_version", "c2a_load_gates", "c2a_load_circuit", "c2a_topo_sort",
             "c2a_topo_sort_serial", "c2a_assign_wires", "c2a_emit_gates", "c2a_build_circuit", "c2a_boolify",
             "c2a_bool_read", "c2a_template_size", "c2a_checksum", "c2a_get_timings", "c2a_get_stats", "c2a_verify_boolify",
             "c2a_debug_patch_bool_op", "c2a_debug_peel_abort", "c2a_debug_set_build_no", "c2a_debug_hot_every", "c2a_boolify_plan", "c2a_boolify_chunk", "c2a_boolify_shard_range", "c2a_eval", "c2a_boolify_prune", "c2a_pruned_read"]
@@ -134,6 +134,8 @@ def load_library(lib_path: Optional[str] = None):
     L.c2a_last_error.restype = ctypes.c_char_p
     L.c2a_last_error.argtypes = [vp]
     L.c2a_version.restype = ctypes.c_char_p
+    L.c2a_load_circuit.restype = ctypes.c_int
+    L.c2a_load_circuit.argtypes = [vp, ctypes.c_uint64, u32p, u32p, u32p, u8p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
     L.c2a_load_gates.restype = ctypes.c_int
     L.c2a_load_gates.argtypes = [vp, ctypes.c_uint64, u32p, u32p, u32p, u8p, ctypes.c_uint32, ctypes.c_uint32, u32p,
                                  ctypes.c_uint32, u32p]
@@ -268,6 +270,17 @@ class Backend:
         self.n, self.n_nodes = len(lh), int(n_nodes)
         self._n_in, self._n_out = len(inn), len(outn)
         self.wire_count = None
+
+    def load_circuit(self, in0, in1, out, op, wire_count: int, n_in: int, n_out: int):
+        """an arithmetic circuit the host built itself (the reference's own build_circuit), for boolify alone: main.rs:30-32"""
+        in0, in1, out, op = _c(in0, np.uint32), _c(in1, np.uint32), _c(out, np.uint32), _c(op, np.uint8)
+        if not (len(in0) == len(in1) == len(out) == len(op)):
+            raise ValueError("gate arrays must have equal length")
+        self._check(self._lib.c2a_load_circuit(self._ctx, len(in0), _p(in0, ctypes.c_uint32), _p(in1, ctypes.c_uint32), _p(out, ctypes.c_uint32),
+                                               _p(op, ctypes.c_uint8), int(wire_count), int(n_in), int(n_out)))
+        self.n, self.n_nodes = len(in0), 0
+        self._n_in, self._n_out = int(n_in), int(n_out)
+        self.wire_count = int(wire_count)
 
     def topo_sort(self, fetch: bool = True, serial: bool = False) -> Optional[np.ndarray]:
         """sorted_gate_ids == topological_sort (src/topological_sort.rs:3-21)."""

@@ -72,6 +72,7 @@ struct c2a_ctx {
     u32 build_no = 0;              // number of the last producer map on this context (tag of its node-table records: k_producer)
     u32 peel_run = 0;              // number of the last dataflow run on this context (tag of its hand-off entries)
     u32 peel_epoch = 0;            // tag of the node words written by the last run (1 / 2 take turns; 0 after a clear)
+    bool circuit_only = false;     // c2a_load_circuit: the context holds an EMITTED circuit the host built itself (no gate graph: nothing to sort or number)
     bool io_clash = false;         // a node is both an input and an output (compiler.rs:363-383), found at load time
     bool peel_meta_valid = false;  // meta[] / stats.levels describe the circuit now loaded (c2a_verify_boolify schedules by them)
     bool node_clear = true;        // node records must be zeroed before the next run (new graph, or a run that failed)
@@ -649,7 +650,7 @@ int after_serial_sort(c2a_ctx* c, bool with_levels) {
 }
 
 int do_topo_sort(c2a_ctx* c, u64* cycle_at, bool defer_sorted = false) {
-    if (c->stage < ST_LOADED) return fail(c, C2A_ERR_STATE, "c2a_topo_sort: no gates loaded");
+    if (c->stage < ST_LOADED || c->circuit_only) return fail(c, C2A_ERR_STATE, "c2a_topo_sort: no gates loaded");
     c->stage = ST_LOADED;
     c->bool_planned = false; c->fmt_chunk_valid = false; c->pruned = false; c->gathered = false;
     c->peel_meta_valid = false;
@@ -745,7 +746,7 @@ int finish_wires(c2a_ctx* c) {
 }
 
 int do_assign_wires(c2a_ctx* c, bool defer_readback = false) {
-    if (c->stage < ST_SORTED) return fail(c, C2A_ERR_STATE, "c2a_assign_wires: call c2a_topo_sort first");
+    if (c->stage < ST_SORTED || c->circuit_only) return fail(c, C2A_ERR_STATE, "c2a_assign_wires: call c2a_topo_sort first");
     const u32 n = c->n;
     hipStream_t s = c->stream;
     const u64 m = (u64)n * 3;
@@ -981,6 +982,7 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     c->n = n; c->n_nodes = n_nodes; c->n_in = n_in; c->n_out = n_out;
     c->bool_planned = false; c->fmt_chunk_valid = false; c->pruned = false; c->gathered = false; c->peel_meta_valid = false; c->stats = c2a_stats{}; c->binfo = c2a_bool_info{};
     c->io_clash = false;
+    c->circuit_only = false;
     c->peel_deep = false;
     const size_t n4 = (size_t)n * 4, nn4 = (size_t)n_nodes * 4;
     ENSURE(c->lh, n4); ENSURE(c->rh, n4); ENSURE(c->out, n4); ENSURE(c->op, n); ENSURE(c->gate4, (size_t)n * 16);
@@ -1049,6 +1051,51 @@ int c2a_load_gates(c2a_ctx* c, uint64_t n64, const uint32_t* lh, const uint32_t*
     return C2A_OK;
 }
 
+int c2a_load_circuit(c2a_ctx* c, uint64_t n64, const uint32_t* in0, const uint32_t* in1, const uint32_t* out, const uint8_t* op,
+                     uint32_t wire_count, uint32_t n_in, uint32_t n_out) {
+    if (!c) return C2A_ERR_ARG;
+    c->stage = ST_EMPTY;
+    if (n64 >= (1ull << 31)) return fail(c, C2A_ERR_ARG, "c2a_load_circuit: n must be < 2^31");
+    if (n64 && (!in0 || !in1 || !out || !op)) return fail(c, C2A_ERR_ARG, "c2a_load_circuit: null gate arrays");
+    if ((u64)n_in + n_out > wire_count) return fail(c, C2A_ERR_ARG, "c2a_load_circuit: more input + output wires than wires");
+    const u32 n = (u32)n64;
+    HIP_TRY(hipSetDevice(c->device));
+    c->n = n; c->n_nodes = 0; c->n_in = n_in; c->n_out = n_out;
+    c->bool_planned = false; c->fmt_chunk_valid = false; c->pruned = false; c->gathered = false; c->peel_meta_valid = false; c->stats = c2a_stats{}; c->binfo = c2a_bool_info{};
+    c->stats.n_gates = n;
+    c->io_clash = false; c->has_dup = false; c->positional = false; c->serial_fallback = false;
+    std::memset(c->ev_valid, 0, sizeof(c->ev_valid));
+    const size_t n4 = (size_t)n * 4;
+    ENSURE(c->e_in0, n4); ENSURE(c->e_in1, n4); ENSURE(c->e_out, n4); ENSURE(c->e_op, n); ENSURE(c->scalars, SC_WORDS * 4);
+    hipStream_t s = c->stream;
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(c->e_in0.p, in0, n4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->e_in1.p, in1, n4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->e_out.p, out, n4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->e_op.p, op, n, hipMemcpyHostToDevice, s));
+    }
+    // behind the copies: wire ids must address the wires, op must be an AGateType; the gates per type (the totals of a boolify plan)
+    enum { LD_HIST = 0, LD_BAD = 32, LD_WORDS = 33 };
+    u32 ld[LD_WORDS];
+    HIP_TRY(hipMemsetAsync(c->scalars.p, 0, SC_WORDS * 4, s));
+    HIP_TRY(hipMemsetAsync(c->scalars.as<u32>() + LD_BAD, 0xFF, 4, s));
+    if (n) C2A_LAUNCH(k_validate, grid_for(n, 2048), kThreads, s, n, (const u32*)c->e_in0.as<u32>(), (const u32*)c->e_in1.as<u32>(), (const u32*)c->e_out.as<u32>(), (const u8*)c->e_op.as<u8>(), wire_count,
+                      (u32)C2A_NUM_GATE_TYPES, c->scalars.as<u32>() + LD_BAD, c->scalars.as<u32>() + LD_HIST);
+    HIP_TRY(hipMemcpyAsync(ld, c->scalars.p, sizeof(ld), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (ld[LD_BAD] != 0xFFFFFFFFu) {
+        const u64 g = ld[LD_BAD];
+        if (in0[g] >= wire_count || in1[g] >= wire_count || out[g] >= wire_count)
+            return fail(c, C2A_ERR_ARG, "c2a_load_circuit: wire id >= wire_count at gate " + std::to_string(g));
+        return fail(c, C2A_ERR_ARG, "c2a_load_circuit: unknown gate type at gate " + std::to_string(g));
+    }
+    for (u32 t = 0; t < C2A_NUM_GATE_TYPES; ++t) c->op_hist[t] = ld[LD_HIST + t];
+    c->wire_count = wire_count; c->n_mid = wire_count - n_in - n_out;
+    c->circuit_only = true; c->emitted_with_wires = true; c->sorted_ready = false;
+    c->stage = ST_EMITTED;
+    return C2A_OK;
+}
+
 int c2a_topo_sort(c2a_ctx* c, uint32_t* sorted, uint64_t* cycle_at) {
     if (!c) return C2A_ERR_ARG;
     HIP_TRY(hipSetDevice(c->device));
@@ -1062,7 +1109,7 @@ int c2a_topo_sort(c2a_ctx* c, uint32_t* sorted, uint64_t* cycle_at) {
 
 int c2a_topo_sort_serial(c2a_ctx* c, uint32_t* sorted, uint64_t* cycle_at) {
     if (!c) return C2A_ERR_ARG;
-    if (c->stage < ST_LOADED) return fail(c, C2A_ERR_STATE, "c2a_topo_sort_serial: no gates loaded");
+    if (c->stage < ST_LOADED || c->circuit_only) return fail(c, C2A_ERR_STATE, "c2a_topo_sort_serial: no gates loaded");
     HIP_TRY(hipSetDevice(c->device));
     c->stage = ST_LOADED;
     c->bool_planned = false; c->fmt_chunk_valid = false; c->pruned = false; c->gathered = false; c->peel_meta_valid = false;
@@ -1127,7 +1174,7 @@ int c2a_emit_gates(c2a_ctx* c, uint32_t* in0, uint32_t* in1, uint32_t* out, uint
 int c2a_build_circuit(c2a_ctx* c, uint64_t* cycle_at, uint32_t* wire_count) {
     if (!c) return C2A_ERR_ARG;
     HIP_TRY(hipSetDevice(c->device));
-    if (c->stage < ST_LOADED) return fail(c, C2A_ERR_STATE, "c2a_build_circuit: no gates loaded");
+    if (c->stage < ST_LOADED || c->circuit_only) return fail(c, C2A_ERR_STATE, "c2a_build_circuit: no gates loaded");
     if (c->io_clash) return fail(c, C2A_ERR_INCONSISTENCY, "Inconsistency: a node is used for both input and output");
     hipEvent_t b0 = c->ev[EV_BUILD0];
     HIP_TRY(hipEventRecord(b0, c->stream));

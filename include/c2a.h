@@ -127,6 +127,20 @@ int c2a_load_gates(c2a_ctx* ctx, uint64_t n, const uint32_t* lh, const uint32_t*
                    const uint32_t* output_nodes);
 
 /*
+ * The SECOND half of the path alone: marshal an arithmetic BristolCircuit the host built itself (the reference's own
+ * Compiler::build_circuit, src/compiler.rs:321-494: `gates` in their emitted order as SoA of wire ids + AGateType, `wire_count`,
+ * and how many of the first / last wires are inputs / outputs) — what `boolify(&circuit, width)` takes (src/main.rs:30-32).
+ * Behind it: c2a_boolify / c2a_boolify_plan + _chunk / c2a_bool_read / c2a_format_bristol / c2a_checksum; the calls that sort,
+ * number or need the sort's level data (c2a_topo_sort, c2a_assign_wires, c2a_build_circuit, c2a_eval, c2a_verify_boolify on a
+ * single device, c2a_boolify_prune) answer C2A_ERR_STATE.  For circuits that are DEEP AND NARROW — a chain of hash blocks: a few
+ * gates per dependency level — the sort is bound by its ~1.3 us per level on the GPU and a CPU core's DFS is faster, while the
+ * bit-blast is 10^2-10^4 x faster here: INTEGRATION.md "When to dispatch".
+ * C2A_ERR_ARG: a wire id >= wire_count, an unknown gate type, n_in + n_out > wire_count.
+ */
+int c2a_load_circuit(c2a_ctx* ctx, uint64_t n, const uint32_t* in0, const uint32_t* in1, const uint32_t* out, const uint8_t* op,
+                     uint32_t wire_count, uint32_t n_in, uint32_t n_out);
+
+/*
  * == topological_sort(len, get_deps) (src/topological_sort.rs:3-21) with the deps closure of
  * src/compiler.rs:408-421.  sorted_gate_ids (host, n entries) may be NULL (result stays in HBM).
  * On C2A_ERR_CYCLIC *cycle_at is the gate index of the reference's message.

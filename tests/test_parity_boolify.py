@@ -157,6 +157,46 @@ def test_prune_pass(backend, orc, c2a, width):
         backend.pruned_read(0, 1)
 
 
+@pytest.mark.parametrize("width", [8, 32, 64])
+def test_boolify_of_a_circuit_the_host_built(backend, orc, c2a, width):
+    """c2a_load_circuit: the second half of the path alone — `boolify(&circuit, width)` (src/main.rs:30-32) on a BristolCircuit the
+    host built itself (here: the oracle's build_circuit, standing in for the reference's own src/compiler.rs:321-494).  Same boolean
+    circuit as after c2a_build_circuit on the gate graph, bit for bit; the calls that need the gate graph refuse."""
+    mix = tuple(m for m in c2a.synth.MIX_ALL if m[0] != "APow")
+    fg = c2a.synth.layered_dag(14, 30, n_in=16, n_const=4, window=4, mix=mix, seed=300 + width)
+    circ = _oracle(orc, fg)
+    backend.load_circuit(circ.in0, circ.in1, circ.out, circ.op, circ.wire_count, circ.n_in, circ.n_out)
+    info = backend.boolify(width)
+    exp = orc.boolify(circ, width)
+    assert info.n_gates == len(exp.in0) and info.wire_count == exp.wire_count
+    assert (info.n_in, info.n_out, info.m_wires) == (circ.n_in, circ.n_out, circ.wire_count - circ.n_out)
+    for a, b in zip(backend.bool_read(), (exp.in0, exp.in1, exp.out, exp.op)):
+        np.testing.assert_array_equal(a, b)
+    # in chunks too, and as text
+    info2 = backend.boolify_plan(width)
+    assert info2.n_gates == info.n_gates
+    q0, chunk = backend.boolify_chunk(5, 40)
+    sl, g0 = orc.boolify_range(circ, width, 5, 40)
+    assert q0 == g0
+    for a, b in zip(chunk, (sl.in0, sl.in1, sl.out, sl.op)):
+        np.testing.assert_array_equal(a, b)
+    e_in0, e_in1, e_out, e_op = backend.emit_gates()                       # (the circuit as it was handed over)
+    np.testing.assert_array_equal(e_out, circ.out)
+    for call in (backend.topo_sort, backend.build_circuit, backend.assign_wires, lambda: backend.topo_sort(serial=True)):
+        with pytest.raises(c2a.BackendError):
+            call()
+    # argument errors: a wire beyond wire_count, an unknown gate type
+    bad = circ.in1.copy(); bad[7] = circ.wire_count
+    with pytest.raises(c2a.BackendError, match="wire id >= wire_count at gate 7"):
+        backend.load_circuit(circ.in0, bad, circ.out, circ.op, circ.wire_count, circ.n_in, circ.n_out)
+    bop = circ.op.copy(); bop[3] = 20
+    with pytest.raises(c2a.BackendError, match="unknown gate type at gate 3"):
+        backend.load_circuit(circ.in0, circ.in1, circ.out, bop, circ.wire_count, circ.n_in, circ.n_out)
+    # ... and the gate graph can be loaded into the same context afterwards
+    _load(backend, fg)
+    assert backend.boolify(width).n_gates == info.n_gates
+
+
 def test_boolify_empty_circuit(backend):
     e = np.empty(0, np.uint32)
     backend.load_gates(e, e, e, np.empty(0, np.uint8), 4, [1], [2])
