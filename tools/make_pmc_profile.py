@@ -4,8 +4,11 @@ into the profile bench.py quotes: HBM bytes per launch of every kernel of one st
 
     tools/make_pmc_profile.py <tag> <n_gates> <width> > profiles/r02_pmc_hbm_bytes.json
 
-FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads
-(MI355X_MICROARCH.md, HBM section: FETCH_SIZE = TCC_EA0_RDREQ x 64 B, requests are 128 B) and is doubled here."""
+FETCH_SIZE / WRITE_SIZE are in KiB.  The byte model is CALIBRATED (profiles/r06_pmc_calibration.txt: tools/ubench/gather.hip, known
+access counts per pattern under the same counters): on gfx950 every read request to the fabric is a 128-byte line — streaming,
+scattered 4 / 8 / 16-byte loads and 512-byte records alike (TCC_EA0_RDREQ_128B = TCC_EA0_RDREQ) — and FETCH_SIZE tallies 64 B per
+request, so it is doubled here for EVERY kernel (= 128 x TCC_EA0_RDREQ); WRITE_SIZE is exact as reported (64 B per full request, 32 B
+per scattered store); an atomic shows as a 32-byte write and its read half is not counted (`atomics` x 32 B more than reported)."""
 import json
 import os
 import re
@@ -65,7 +68,8 @@ def main(tag, n_gates, width):
         e["launches_per_step"] = e["launches_in_pass"] / base
     json.dump({"workload": {"n_gates": n_gates, "width": width},
                "source": f"rocprofv3 --kernel-trace --pmc <counter> -- python bench.py --steps 2 --warmup 1 (tools/pmc_pass.sh {tag} ...), "
-                         "one pass per counter group; FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md",
+                         "one pass per counter group; byte model calibrated in profiles/r06_pmc_calibration.txt (reads = FETCH_SIZE x 2 = 128 B x TCC_EA0_RDREQ in every "
+                         "pattern; WRITE_SIZE exact; an atomic = 32 B written, its read half uncounted)",
                "kernels": kernels}, sys.stdout, indent=1)
     print()
 
