@@ -73,6 +73,7 @@ struct c2a_ctx {
     u32 peel_run = 0;              // number of the last dataflow run on this context (tag of its hand-off entries)
     u32 peel_epoch = 0;            // tag of the node words written by the last run (1 / 2 take turns; 0 after a clear)
     bool circuit_only = false;     // c2a_load_circuit: the context holds an EMITTED circuit the host built itself (no gate graph: nothing to sort or number)
+    bool node_init_valid = false;  // node_wire1[] / first[] are as k_relabel left them (no wire, not seen): the wire numbering may start (else: k_node_init)
     bool io_clash = false;         // a node is both an input and an output (compiler.rs:363-383), found at load time
     bool peel_meta_valid = false;  // meta[] / stats.levels describe the circuit now loaded (c2a_verify_boolify schedules by them)
     bool node_clear = true;        // node records must be zeroed before the next run (new graph, or a run that failed)
@@ -100,6 +101,7 @@ struct c2a_ctx {
     // device buffers
     DevBuf lh, rh, out, op, gate4, nrec, orig, in_nodes, out_nodes;
     DevBuf prod1, dep0, dep1, cons_cnt, cons_off, eslot, aq_items, aq_pc, aq_seeds, aq_seeds1, aq_seed_flat, aq_seed_cnt, fill, meta, node, child, gstat, clist, pctl, pcold;
+    DevBuf rflag;                  // root bits by rank (k_root_bits), one u64 per 64 ranks
     DevBuf rbits, rpre, ridx, rlist, next, owner, local, slist, sjump, sjump2, sorted, sorted_r;
     DevBuf first, nflag, wflag, widx, node_wire1, node_wire, e_in0, e_in1, e_out, e_op;
     DevBuf pos_r, wire_r, erec, pblk, dpre, epre, gflag;      // positional numbering (c2a_kernels.h POSITIONAL NUMBERING)
@@ -128,7 +130,7 @@ struct c2a_ctx {
     std::vector<DevBuf*> all;
 
     c2a_ctx() {
-        all = {&lh, &rh, &out, &op, &gate4, &nrec, &orig, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &aq_items, &aq_pc, &aq_seeds, &aq_seeds1, &aq_seed_flat, &aq_seed_cnt, &fill,
+        all = {&rflag, &lh, &rh, &out, &op, &gate4, &nrec, &orig, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &aq_items, &aq_pc, &aq_seeds, &aq_seeds1, &aq_seed_flat, &aq_seed_cnt, &fill,
                &gstat, &clist, &pctl, &pcold, &meta, &node, &child, &rbits, &rpre, &ridx, &rlist, &next,
                &owner, &local, &slist, &sjump, &sjump2, &sorted, &sorted_r, &first, &nflag, &wflag, &widx, &node_wire1,
                &node_wire, &e_in0, &e_in1, &e_out, &e_op, &pos_r, &wire_r, &erec, &pblk, &dpre, &epre, &gflag, &scan_tmp, &scan_desc, &scalars, &dfs_state, &dfs_stack, &peel_prof, &peel_trace, &tsz, &asz, &goff,
@@ -315,7 +317,8 @@ int do_prep(c2a_ctx* c, bool for_peel = true) {
     {
         const u64 tiles = ((u64)c->n_nodes + kRelTile - 1) / kRelTile;
         C2A_LAUNCH(k_relabel, (u32)tiles, kRelThreads, s, c->n_nodes, n, c->build_no, c->prod1.as<u32>(), (const uint4*)c->nrec.as<uint4>(), dup, c->orig.as<u32>(),
-                   c->gate4.as<uint4>(), reinterpret_cast<u64*>(desc + R.relabel) + 8, reinterpret_cast<u32*>(desc + R.relabel));
+                   c->gate4.as<uint4>(), reinterpret_cast<u64*>(desc + R.relabel) + 8, reinterpret_cast<u32*>(desc + R.relabel), c->node_wire1.as<u32>(), c->first.as<u32>());
+        c->node_init_valid = true;
     }
     // (two gates wrote one node — never, for a circuit the reference's front-end built: these two leave at once)
     C2A_LAUNCH_NOSYNC(k_dup_clear, 512, kThreads, s, c->n_nodes, (const u32*)dup, c->prod1.as<u32>());
@@ -433,9 +436,8 @@ int peel_launch(c2a_ctx* c) {
     // what only the edges of the launch touch travels as one small block in HBM (keeps the kernel's scalar registers free)
     // (written by a one-thread launch that takes it by value: a copy from this stack object would need a host round trip)
     ENSURE(c->pcold, sizeof(PeelCold));
-    C2A_LAUNCH_NOSYNC(k_set_cold, 1, 1, s, c->pcold.as<PeelCold>(), cold);
     A.cold = c->pcold.as<PeelCold>();
-    C2A_LAUNCH(k_peel_sinks, sink_blocks, kThreads, s, A);
+    C2A_LAUNCH(k_peel_sinks, sink_blocks, kThreads, s, A, c->pcold.as<PeelCold>(), cold);
     // (the passes take turns on two region buffers; the sinks pass wrote the first with regions of sink_cap words)
     for (u32 lvl = 1; lvl <= shallow; ++lvl) {
         u32* cnts = c->aq_seed_cnt.as<u32>();
@@ -452,9 +454,7 @@ int peel_launch(c2a_ctx* c) {
     else if (c->peel_deep) C2A_LAUNCH_CONCURRENT((k_peel<false, true>), waves, 64, s, A);
     else C2A_LAUNCH_CONCURRENT((k_peel<false, false>), waves, 64, s, A);
     rec(c, EV_KPEEL1);
-    static_assert(CTL_PROCESSED == 0 && CTL_MAXLEVEL == 1 && CTL_ABORT == 2 && CTL_REREADS == 3, "the order k_post_peel writes them in");
-    C2A_LAUNCH(k_post_peel, 1, 64, s, c->hrb_dev, (const u32*)c->pctl.as<u32>(), (const u32*)(c->cons_off.as<u32>() + n), (const u32*)(c->scalars.as<u32>() + SC_DUP), n,
-               (const u32*)(c->scalars.as<u32>() + SC_RELAYS), c->scalars.as<u32>() + SC_PEELOK);
+    static_assert(CTL_PROCESSED == 0 && CTL_MAXLEVEL == 1 && CTL_ABORT == 2 && CTL_REREADS == 3, "the order k_root_bits posts them in");
     c->peel_slots = slots; c->peel_waves_used = waves; c->peel_want_stats = want_stats;
     return C2A_OK;
 }
@@ -551,14 +551,18 @@ int order_launch(c2a_ctx* c) {
     const u32* ok = c->scalars.as<u32>() + SC_PEELOK;
     // DFS roots (tree nodes without a parent) in ascending ORIGINAL gate id: a bit per id, a scan over the bitmap's words, the list
     const u32 W = (n + 31u) / 32u;
-    C2A_LAUNCH_NOSYNC(k_root_bits, G, kThreads, s, n, ok, (const uint4*)c->meta.as<uint4>(), (const u32*)c->orig.as<u32>(), c->rbits.as<u32>());
+    // (the first launch of the stage also posts the dataflow launch's numbers to the host and raises *ok for the launches behind it)
+    ENSURE(c->rflag, ((size_t)n / 64 + 2) * 8);
+    C2A_LAUNCH(k_root_bits, G, kThreads, s, n, (const u32*)c->pctl.as<u32>(), (const u32*)(c->cons_off.as<u32>() + n), (const u32*)(c->scalars.as<u32>() + SC_DUP),
+               (const u32*)(c->scalars.as<u32>() + SC_RELAYS), c->hrb_dev, c->scalars.as<u32>() + SC_PEELOK, (const uint4*)c->meta.as<uint4>(), (const u32*)c->orig.as<u32>(),
+               c->rbits.as<u32>(), c->rflag.as<u64>(), c->scalars.as<u32>() + SC_MAXDEPTH);
     int r = scan_1pass<1>(c, s, c->scan_tmp, W, ScanPopc{c->rbits.as<u32>()}, c->rpre.as<u32>(), (u32*)nullptr, c->scan_desc.as<char>() + R.roots);
     if (r) return r;
     const u32* n_roots_p = c->rpre.as<u32>() + W;
-    C2A_LAUNCH_NOSYNC(k_root_list, G, kThreads, s, n, ok, (const uint4*)c->meta.as<uint4>(), (const u32*)c->orig.as<u32>(), (const u32*)c->rbits.as<u32>(),
+    C2A_LAUNCH_NOSYNC(k_root_list, G, kThreads, s, n, ok, (const u64*)c->rflag.as<u64>(), (const u32*)c->orig.as<u32>(), (const u32*)c->rbits.as<u32>(),
                       (const u32*)c->rpre.as<u32>(), c->ridx.as<u32>(), c->rlist.as<u32>());
-    C2A_LAUNCH(k_euler_next, G, kThreads, s, n, ok, c->meta.as<uint4>(), c->child.as<u32>(),
-               c->ridx.as<u32>(), c->rlist.as<u32>(), n_roots_p, c->next.as<u32>(), c->scalars.as<u32>() + SC_MAXDEPTH);
+    C2A_LAUNCH_NOSYNC(k_euler_next, G, kThreads, s, n, ok, (const u64*)c->rflag.as<u64>(), (const u32*)c->child.as<u32>(),
+                      (const u32*)c->ridx.as<u32>(), (const u32*)c->rlist.as<u32>(), n_roots_p, c->next.as<u32>());
     const u32 m = 2 * n;
     u32* scount = c->scalars.as<u32>() + SC_SCOUNT;
     C2A_LAUNCH(k_rank_mark, std::max<u32>(1u, std::min<u32>(2048u, (m + kThreads * 8 - 1) / (kThreads * 8))), kThreads, s, m, ok, c->rlist.as<u32>(), scount, c->slist.as<u32>(),
@@ -753,8 +757,11 @@ int do_assign_wires(c2a_ctx* c, bool defer_readback = false) {
     rec(c, EV_WIRES0);
     c->emitted_with_wires = false;
     // (the IO flags of the nodes and the in / out clash word are do_prep's: they do not change between the sort and here)
-    C2A_LAUNCH_NOSYNC(k_node_init, grid_for(std::max<u32>(1u, c->n_nodes), 4096), kThreads, s, c->n_nodes, c->node_wire1.as<u32>(), c->first.as<u32>());
-    if (c->n_in) C2A_LAUNCH_NOSYNC(k_input_wires, grid_for(c->n_in, 1024), kThreads, s, c->n_in, c->in_nodes.as<u32>(), c->node_wire1.as<u32>());
+    // (k_relabel leaves node -> wire / first-seen as the numbering wants them; a second numbering of the same sorted circuit resets them itself)
+    if (!c->node_init_valid) C2A_LAUNCH_NOSYNC(k_node_init, grid_for(std::max<u32>(1u, c->n_nodes), 4096), kThreads, s, c->n_nodes, c->node_wire1.as<u32>(), c->first.as<u32>());
+    c->node_init_valid = false;
+    const bool inputs_ride = c->positional && c->n;      // (the positional numbering's first launch takes the input wires along)
+    if (c->n_in && !inputs_ride) C2A_LAUNCH_NOSYNC(k_input_wires, grid_for(c->n_in, 1024), kThreads, s, c->n_in, c->in_nodes.as<u32>(), c->node_wire1.as<u32>());
     const u32 G = grid_for(n, 4096);
     const u32* n_mid_p;
     int r;
@@ -767,9 +774,11 @@ int do_assign_wires(c2a_ctx* c, bool defer_readback = false) {
         HIP_TRY(hipMemsetAsync(c->pblk.p, 0, (size_t)PW * 16, s));
         if (c->sorted_ready) {                          // (the staged calls: positions = the inverse of the order the caller has been given)
             C2A_LAUNCH_NOSYNC(k_eval_inverse, G, kThreads, s, n, c->sorted_r.as<u32>(), c->pos_r.as<u32>());
-            C2A_LAUNCH_NOSYNC(k_pos_first<true>, G, kThreads, s, S, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), c->pos_r.as<u32>(), c->first.as<u32>());
+            C2A_LAUNCH_NOSYNC(k_pos_first<true>, G, kThreads, s, S, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), c->pos_r.as<u32>(), c->first.as<u32>(),
+                              c->n_in, (const u32*)c->in_nodes.as<u32>(), c->node_wire1.as<u32>());
         } else
-            C2A_LAUNCH_NOSYNC(k_pos_first<false>, G, kThreads, s, S, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), c->pos_r.as<u32>(), c->first.as<u32>());
+            C2A_LAUNCH_NOSYNC(k_pos_first<false>, G, kThreads, s, S, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), c->pos_r.as<u32>(), c->first.as<u32>(),
+                              c->n_in, (const u32*)c->in_nodes.as<u32>(), c->node_wire1.as<u32>());
         C2A_LAUNCH_NOSYNC(k_pos_bits, G, kThreads, s, n, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), (const u32*)c->pos_r.as<u32>(), (const u32*)c->first.as<u32>(),
                           c->pblk.as<u32>());
         r = scan_1pass<2>(c, s, c->scan_tmp, PW, ScanPosBits{c->pblk.as<uint4>()}, c->dpre.as<u32>(), c->epre.as<u32>());
@@ -860,8 +869,8 @@ void warm_functions() {
     hipFuncAttributes a;
 #define C2A_WARM(k) (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k))
     C2A_WARM(k_clear); C2A_WARM(k_validate); C2A_WARM(k_mark_inputs); C2A_WARM(k_mark_outputs); C2A_WARM(k_producer); C2A_WARM(k_relabel); C2A_WARM(k_dup_clear);
-    C2A_WARM(k_dup_producer); C2A_WARM(k_deps); C2A_WARM(k_gstat); C2A_WARM(k_set_cold); C2A_WARM(k_peel_sinks); C2A_WARM(k_peel_shallow);
-    C2A_WARM((k_peel<false, false>)); C2A_WARM(k_post_peel); C2A_WARM(k_root_bits); C2A_WARM(k_root_list); C2A_WARM(k_euler_next); C2A_WARM(k_rank_mark);
+    C2A_WARM(k_dup_producer); C2A_WARM(k_deps); C2A_WARM(k_gstat); C2A_WARM(k_peel_sinks); C2A_WARM(k_peel_shallow);
+    C2A_WARM((k_peel<false, false>)); C2A_WARM(k_root_bits); C2A_WARM(k_root_list); C2A_WARM(k_euler_next); C2A_WARM(k_rank_mark);
     C2A_WARM(k_post_words); C2A_WARM(k_rank_walk); C2A_WARM(k_rank_jump); C2A_WARM(k_rank_final); C2A_WARM(k_sorted_split); C2A_WARM(k_node_init);
     C2A_WARM(k_input_wires); C2A_WARM(k_pos_first<false>); C2A_WARM(k_pos_first<true>); C2A_WARM(k_pos_bits); C2A_WARM(k_assign_outputs); C2A_WARM(k_pos_rank);
     C2A_WARM(k_emit_rank); C2A_WARM(k_emit_split<true>); C2A_WARM(k_emit_split<false>); C2A_WARM(k_unbias);

@@ -271,7 +271,7 @@ __global__ void k_dup_producer(u32 n, const u32* __restrict__ dup, const u32* __
 // produced nodes have consecutive ranks).
 constexpr int kRelThreads = 256, kRelRounds = 16, kRelTile = kRelThreads * kRelRounds;
 __global__ void __launch_bounds__(kRelThreads) k_relabel(u32 n_nodes, u32 n, u32 build, u32* prod1, const uint4* __restrict__ nrec, u32* dup,
-                                                         u32* orig, uint4* gate4, u64* desc, u32* counter) {
+                                                         u32* orig, uint4* gate4, u64* desc, u32* counter, u32* node_wire1, u32* first_seen) {
     __shared__ u32 s_tile, s_wave[kRelThreads / 64];
     __shared__ u64 s_excl;
     const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
@@ -308,6 +308,9 @@ __global__ void __launch_bounds__(kRelThreads) k_relabel(u32 n_nodes, u32 n, u32
     for (int i = 0; i < kRelRounds; ++i) {
         const u64 v = base + (u64)i * 64;
         if (v >= n_nodes) continue;
+        // (what the wire numbering starts from, per node — no wire yet, not seen yet —: this pass streams over the node table anyway; a launch
+        // of its own, k_node_init, only when c2a_assign_wires is called again on a sorted circuit)
+        node_wire1[v] = 0u; first_seen[v] = 0xFFFFFFFFu;
         if ((rec[i].w >> 8) != build) { prod1[v] = 0u; continue; }
         const u32 rank = first + pre[i];
         if (rank < n) {                            // (always, unless two gates wrote one node: then all of this is redone)
@@ -413,17 +416,66 @@ __global__ void __launch_bounds__(kThreads) k_deps(u32 n, const u32* __restrict_
 // words, and every root finds its index by a look-up in the two small arrays.
 // (*ok: the dataflow launch in front ended cleanly and left no gate behind — k_post_peel —; the order stage is queued BEHIND it
 // without a host round trip, and does nothing when it did not: the tree entries it would read are not there)
-__global__ void k_root_bits(u32 n, const u32* __restrict__ ok, const uint4* __restrict__ meta, const u32* __restrict__ orig, u32* rbits) {
-    if (!*ok) return;
-    for (u64 r = gtid(); r < n; r += gstride())
-        if (meta[r].x == C2A_NONE) { const u32 o = orig[r]; atomicOr(&rbits[o >> 5], 1u << (o & 31u)); }
+// This launch also POSTS what the dataflow launch in front of it reported (block 0; a launch of its own, k_post_peel, in round 5):
+// every block works *ok out for itself from the launch's counters — gates done, summed over their kAcctShards parts, against n + the
+// relays of the hubs — so nothing has to sit between the two launches.
+// rflag: the root bits BY RANK, one u64 per wave of 64 ranks (a ballot): what k_root_list and k_euler_next ask instead of reading the
+// 16-byte tree entries again.  The depth of the DFS forest (a statistic) is taken here too: one atomic per workgroup.
+__global__ void __launch_bounds__(kThreads) k_root_bits(u32 n, const u32* __restrict__ ctl, const u32* __restrict__ edges, const u32* __restrict__ dup,
+                                                        const u32* __restrict__ relay_total, u32* post, u32* ok_out, const uint4* __restrict__ meta,
+                                                        const u32* __restrict__ orig, u32* rbits, u64* rflag, u32* maxdepth) {
+    __shared__ u32 s_ok, s_max[kThreads / 64];
+    const u32 lane = threadIdx.x & 63u;
+    if (threadIdx.x < 64) {
+        const u32 t = threadIdx.x;
+        u32 done = t < kAcctShards ? ctl[CTL_PROC + t * kAcctStride] : 0u, lvl = t < kAcctShards ? ctl[CTL_PROC + t * kAcctStride + 1] : 0u;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { done += __shfl_xor(done, off, 64); const u32 o = __shfl_xor(lvl, off, 64); lvl = o > lvl ? o : lvl; }
+        if (t == 0) {
+            // (the relays of the hubs are steps of the launch too: n + *relay_total when nothing is left behind; reported: gates done = steps
+            // minus relays — a relay that did not run has a gate above it that did not either)
+            const u32 relays = *relay_total;
+            const u32 ok = (ctl[CTL_ABORT] == 0u && done == n + relays) ? 1u : 0u;
+            s_ok = ok;
+            if (blockIdx.x == 0) {
+                post[0] = done - relays; post[1] = lvl; post[2] = ctl[CTL_ABORT]; post[3] = ctl[CTL_REREADS]; post[4] = *edges; post[5] = *dup; post[6] = ctl[CTL_NEEDDEEP]; post[7] = relays;
+                *ok_out = ok;                    // (what the rest of the order stage, queued right behind, goes by)
+            }
+        }
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    u32 md = 0;
+    for (u64 rb = gtid() - lane; rb < n; rb += gstride()) {       // (whole waves: the flags by rank are a ballot)
+        const u64 r = rb + lane;
+        bool root = false;
+        if (r < n) {
+            const uint4 m = meta[r];
+            md = m.y > md ? m.y : md;
+            root = m.x == C2A_NONE;
+            if (root) { const u32 o = orig[r]; atomicOr(&rbits[o >> 5], 1u << (o & 31u)); }
+        }
+        const u64 bal = __ballot(root);
+        if (lane == 0) rflag[rb >> 6] = bal;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const u32 o = __shfl_xor(md, off, 64); md = o > md ? o : md; }
+    if (lane == 0) s_max[threadIdx.x >> 6] = md;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 m = 0;
+        for (int w = 0; w < kThreads / 64; ++w) m = s_max[w] > m ? s_max[w] : m;
+        // (a look first: the maximum only grows, so a workgroup that sees a value >= its own has nothing to add — atomics on
+        // one word go one at a time, and there are thousands of workgroups)
+        if (m && m > __hip_atomic_load(maxdepth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxdepth, m);
+    }
 }
 struct ScanPopc { const u32* w; __device__ __forceinline__ void operator()(u64 i, u32* x) const { x[0] = (u32)__popc(w[i]); } };
-__global__ void k_root_list(u32 n, const u32* __restrict__ ok, const uint4* __restrict__ meta, const u32* __restrict__ orig, const u32* __restrict__ rbits,
+__global__ void k_root_list(u32 n, const u32* __restrict__ ok, const u64* __restrict__ rflag, const u32* __restrict__ orig, const u32* __restrict__ rbits,
                             const u32* __restrict__ rpre, u32* ridx, u32* rlist) {
     if (!*ok) return;
     for (u64 r = gtid(); r < n; r += gstride()) {
-        if (meta[r].x != C2A_NONE) continue;
+        if (!((rflag[r >> 6] >> (r & 63u)) & 1ull)) continue;
         const u32 o = orig[r];
         const u32 k = rpre[o >> 5] + (u32)__popc(rbits[o >> 5] & ((1u << (o & 31u)) - 1u));
         ridx[r] = k;
@@ -433,41 +485,29 @@ __global__ void k_root_list(u32 n, const u32* __restrict__ ok, const uint4* __re
 
 // element 2x = enter(x), 2x+1 = exit(x); the tour visits label-0 child, label-1 child, then exits.
 // child[2p + l] was written by the peel when the child picked (p, l) as its parent (NONE otherwise).
-// (also collects the depth of the DFS tree — a statistic — with one atomic per workgroup, never one per gate on a single word)
-__global__ void __launch_bounds__(kThreads) k_euler_next(u32 n, const u32* __restrict__ ok, const uint4* __restrict__ meta,
+// A node writes its own enter — and the EXITS OF ITS CHILDREN: behind the label-0 child comes the label-1 child if there is one, else
+// the node's own exit; behind the label-1 child the node's exit.  (Round 5 had every node look its sibling up at its parent's entry:
+// one scattered READ per node, a 128-byte line each — profiles/r06_pmc_calibration.txt —, 1.3 GB for 10 M gates; a scattered 4-byte
+// STORE is a 32-byte request.)  A root's exit leads to the next root (ascending original id: ridx / rlist); a root is told by the
+// root bits by rank (k_root_bits) — the tree entries themselves are not read here.
+// (tree_child: the relays of a hub — c2a_peel.h HUBS AND RELAYS — are skipped where the tree is read: what hangs below (p, l) is the
+// hub at the top of the relay chain that chose that edge)
+__global__ void __launch_bounds__(kThreads) k_euler_next(u32 n, const u32* __restrict__ ok, const u64* __restrict__ rflag,
                              const u32* __restrict__ child, const u32* __restrict__ ridx, const u32* __restrict__ rlist,
-                             const u32* __restrict__ n_roots_p, u32* next, u32* maxdepth) {
-    __shared__ u32 s_max[kThreads / 64];
+                             const u32* __restrict__ n_roots_p, u32* next) {
     if (!*ok) return;
     const u32 n_roots = *n_roots_p;
-    u32 md = 0;
     for (u64 i = gtid(); i < n; i += gstride()) {
         const u32 x = (u32)i;
-        md = meta[x].y > md ? meta[x].y : md;
-        // (tree_child / tree_parent: the relays of a hub — c2a_peel.h HUBS AND RELAYS — are skipped where the tree is read)
-        const u32 c0 = tree_child(n, child, child[2 * i]), c1 = tree_child(n, child, child[2 * i + 1]);
+        const uint2 cc = reinterpret_cast<const uint2*>(child)[i];
+        const u32 c0 = tree_child(n, child, cc.x), c1 = tree_child(n, child, cc.y);
         next[2 * i] = c0 != C2A_NONE ? 2 * c0 : (c1 != C2A_NONE ? 2 * c1 : 2 * x + 1);
-        const TreeParent P = tree_parent(n, meta, meta[x]);
-        u32 nx;
-        if (P.p == C2A_NONE) {
+        if (c0 != C2A_NONE) next[2 * (u64)c0 + 1] = c1 != C2A_NONE ? 2 * c1 : 2 * x + 1;
+        if (c1 != C2A_NONE) next[2 * (u64)c1 + 1] = 2 * x + 1;
+        if ((rflag[i >> 6] >> (i & 63u)) & 1ull) {
             const u32 k = ridx[x];
-            nx = k + 1 < n_roots ? 2 * rlist[k + 1] : C2A_NONE;
-        } else {
-            const u32 s1 = P.label == 0 ? tree_child(n, child, child[2 * (u64)P.p + 1]) : C2A_NONE;
-            nx = s1 != C2A_NONE ? 2 * s1 : 2 * P.p + 1;
+            next[2 * i + 1] = k + 1 < n_roots ? 2 * rlist[k + 1] : C2A_NONE;
         }
-        next[2 * i + 1] = nx;
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { const u32 o = __shfl_xor(md, off, 64); md = o > md ? o : md; }
-    if ((threadIdx.x & 63u) == 0) s_max[threadIdx.x >> 6] = md;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        u32 m = 0;
-        for (int w = 0; w < kThreads / 64; ++w) m = s_max[w] > m ? s_max[w] : m;
-        // (a look first: the maximum only grows, so a workgroup that sees a value >= its own has nothing to add — atomics on
-        // one word go one at a time, and there are thousands of workgroups)
-        if (m && m > __hip_atomic_load(maxdepth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxdepth, m);
     }
 }
 
@@ -792,7 +832,10 @@ __device__ __forceinline__ u32 pos_of(const PosSrc& S, u64 x) {
 constexpr u32 kFlagOutIO = kGateOutIO >> 8, kFlagLhConst = kGateLhConst >> 8, kFlagRhConst = kGateRhConst >> 8;      // (bits of gflag[])
 constexpr u32 kFlagEvent = kFlagOutIO | kFlagLhConst | kFlagRhConst;
 template <bool FROM_SORTED>
-__global__ void k_pos_first(PosSrc S, const u8* __restrict__ gflag, const uint4* __restrict__ gate4, u32* pos_r, u32* first) {
+__global__ void k_pos_first(PosSrc S, const u8* __restrict__ gflag, const uint4* __restrict__ gate4, u32* pos_r, u32* first, u32 n_in,
+                            const u32* __restrict__ in_nodes, u32* node_wire1) {
+    // (the input wires, compiler.rs:388-395, ride along: a launch of n_in threads of their own otherwise.  Duplicate node: the later insert wins)
+    for (u64 i = gtid(); i < n_in; i += gstride()) atomicMax(&node_wire1[in_nodes[i]], (u32)i + 1);
     for (u64 x = gtid(); x < S.n; x += gstride()) {
         const u32 p = pos_of<FROM_SORTED>(S, x);
         if (!FROM_SORTED) pos_r[x] = p;
@@ -1088,21 +1131,6 @@ __global__ void k_post_words(u32* dst, const u32* a, u32 na, const u32* b, u32 n
     for (u32 i = threadIdx.x; i < nb; i += blockDim.x) dst[na + i] = b[i];
     for (u32 i = threadIdx.x; i < nc; i += blockDim.x) dst[na + nb + i] = c3[i];
 }
-// the peel: gates done and the highest level (summed / maximised over their kAcctShards parts), gave up, re-reads, edges, duplicate writers
-__global__ void k_post_peel(u32* dst, const u32* ctl, const u32* edges, const u32* dup, u32 n, const u32* relay_total, u32* ok) {
-    const u32 t = threadIdx.x;            // (one wave)
-    u32 done = t < kAcctShards ? ctl[CTL_PROC + t * kAcctStride] : 0u, lvl = t < kAcctShards ? ctl[CTL_PROC + t * kAcctStride + 1] : 0u;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { done += __shfl_xor(done, off, 64); const u32 o = __shfl_xor(lvl, off, 64); lvl = o > lvl ? o : lvl; }
-    if (t == 0) {
-        // (the relays of the hubs are steps of the launch too: n + *relay_total when nothing is left behind; reported: gates done = steps minus relays —
-        // a relay that did not run has a gate above it that did not either)
-        const u32 relays = *relay_total;
-        dst[0] = done - relays; dst[1] = lvl; dst[2] = ctl[CTL_ABORT]; dst[3] = ctl[CTL_REREADS]; dst[4] = *edges; dst[5] = *dup; dst[6] = ctl[CTL_NEEDDEEP]; dst[7] = relays;
-        *ok = (ctl[CTL_ABORT] == 0u && done == n + relays) ? 1u : 0u;      // (what the order stage, queued right behind, goes by)
-    }
-}
-
 // order-sensitive 64-bit checksum of a u32 stream: sum over i of mix(i, v[i]) (commutative combine of
 // position-salted hashes => parallel, deterministic).  Used by the full-size parity tests.
 __device__ __forceinline__ u64 mix64(u64 x) {

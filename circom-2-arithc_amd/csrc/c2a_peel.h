@@ -441,8 +441,11 @@ __device__ __forceinline__ TreeParent tree_parent(u32 n, const uint4* __restrict
 // claim seed the dataflow launch.  No shared counter: workgroup b appends to its own region under its own counter.
 // A sink writes the three header words of its record only (its string is empty; readers treat depth 0 so).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_peel_sinks(PeelArgs A) {
+__global__ void __launch_bounds__(256) k_peel_sinks(PeelArgs A, PeelCold* cold_dst, PeelCold cold) {
     __shared__ u32 s_done[4];
+    // (what only the edges of the dataflow launch touch travels as one small block in HBM — it keeps that kernel's scalar registers free —,
+    // written here, two launches ahead of its first reader, from this launch's argument block: a launch of its own in round 5)
+    if (blockIdx.x == 0 && threadIdx.x == 0) *cold_dst = cold;
     const u32 lane = threadIdx.x & 63u;
     u32* out = A.seeds_w + (u64)blockIdx.x * A.region_cap;
     u32* counter = &A.seed_cnt_w[blockIdx.x];
@@ -632,7 +635,6 @@ __global__ void __launch_bounds__(256) k_peel_shallow(PeelArgs A, const u32* __r
     for (u32 i = threadIdx.x; i < s_cnt; i += 256) flat[s_base + i] = __hip_atomic_load(&dst[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-__global__ void k_set_cold(PeelCold* dst, PeelCold v) { *dst = v; }
 
 // everything issued for one gate at the top of its step; two of these swap roles (nothing is ever copied: a register
 // copy of a value still in flight is a use, and its wait would drain the step that was just issued)
