@@ -73,6 +73,7 @@ struct c2a_ctx {
     u32 peel_run = 0;              // number of the last dataflow run on this context (tag of its hand-off entries)
     u32 peel_epoch = 0;            // tag of the node words written by the last run (1 / 2 take turns; 0 after a clear)
     bool circuit_only = false;     // c2a_load_circuit: the context holds an EMITTED circuit the host built itself (no gate graph: nothing to sort or number)
+    bool wires_clear_valid = false; // the event bits (pblk) and the descriptors of their scan (scan_desc + R.bits) are as the build's ONE k_clear left them
     bool node_init_valid = false;  // node_wire1[] / first[] are as k_relabel left them (no wire, not seen): the wire numbering may start (else: k_node_init)
     bool io_clash = false;         // a node is both an input and an output (compiler.rs:363-383), found at load time
     bool peel_meta_valid = false;  // meta[] / stats.levels describe the circuit now loaded (c2a_verify_boolify schedules by them)
@@ -148,6 +149,10 @@ enum Scalar { SC_MAXDEPTH = 0, SC_SCOUNT = 1, SC_ERR = 2, SC_NMID = 3, SC_NROOTS
               SC_WORDS = 64 + 1 + 64 + 3 };
 static_assert(SC_WORDS >= SC_HOT + 1 + (int)kHotMax && SC_WORDS % 4 == 0, "the hot list lives behind the scalars (cleared with them by k_clear)");
 
+// internal status of peel_result (never crosses the ABI): the plain build of the dataflow launch met a DFS tree deeper than one chunk of
+// path string and ended itself — run the DEEP build
+constexpr int kRerunDeep = -1000;
+
 int fail(c2a_ctx* c, int code, const std::string& msg) {
     if (c) c->err = msg;
     return code;
@@ -165,7 +170,10 @@ int ensure(c2a_ctx* c, DevBuf& b, size_t bytes);
 int ensure_bool_out(c2a_ctx* c, u64 G) {
     const size_t w4 = (((size_t)G + 16) * 4 + 4095) & ~(size_t)4095, w1 = ((size_t)G + 16 + 4095) & ~(size_t)4095;
     int r = ensure(c, c->b_pool, 3 * w4 + w1);
-    if (r) return r;
+    if (r) {                                         // (the old pool is gone: its four views must not outlive it)
+        for (DevBuf* v : {&c->b_in0, &c->b_in1, &c->b_out, &c->b_op}) { v->p = nullptr; v->cap = 0; }
+        return r;
+    }
     char* p = c->b_pool.as<char>();
     c->b_in0.p = p; c->b_in0.cap = w4; c->b_in1.p = p + w4; c->b_in1.cap = w4; c->b_out.p = p + 2 * w4; c->b_out.cap = w4; c->b_op.p = p + 3 * w4; c->b_op.cap = w1;
     return C2A_OK;
@@ -268,6 +276,7 @@ int clear_for_build(c2a_ctx* c, bool peel_only = false) {
             add(c->scan_desc.p, R.total);
             add(c->rbits.p, ((size_t)n + 31) / 32 * 4);
             add(c->pblk.p, ((size_t)n + 31) / 32 * 16);
+            c->wires_clear_valid = true;
         }
     }
     if (n && peel_only) {                            // (a second attempt: what the first one's order stage has used)
@@ -519,7 +528,7 @@ int peel_result(c2a_ctx* c, u32* peeled_out) {
         if (st[2]) std::fprintf(stderr, "[c2a peel stats] per hand-off entry: %.0f ns waiting for its two tickets, %.0f ns writing it\n", st[19] * 10.0 / st[2], (st[17] - st[19]) * 10.0 / st[2]);
     }
     c->peel_gave_up = t4[CTL_ABORT] != 0;
-    if (need_deep) { c->peel_deep = true; c->err = "dataflow peel: the DFS tree is deeper than one chunk of path string"; return C2A_ERR_HIP; }      // (the caller runs the DEEP launch)
+    if (need_deep) { c->peel_deep = true; return kRerunDeep; }      // (not a failure: the caller runs the DEEP build of the launch on clean buffers)
     if (t4[CTL_ABORT]) return fail(c, C2A_ERR_HIP, "dataflow peel: watchdog tripped (" + std::to_string(t4[CTL_ABORT]) + " waves gave up waiting)");
     c->node_clear = false;
     *peeled_out = t4[CTL_PROCESSED];
@@ -676,20 +685,20 @@ int do_topo_sort(c2a_ctx* c, u64* cycle_at, bool defer_sorted = false) {
     rec(c, EV_PREP1);
     u32 peeled = 0;
     c->serial_fallback = false;
-    bool deep_before = c->peel_deep;
     for (int attempt = 0;; ++attempt) {
         if ((r = peel_launch(c))) return r;
         rec(c, EV_PEEL1);
         if ((r = order_launch(c))) return r;
         HIP_TRY(hipEventSynchronize(c->ev[EV_ORDER_RB]));       // (the walk and the jumps run meanwhile)
         r = peel_result(c, &peeled);
-        if (!(r == C2A_ERR_HIP && c->peel_gave_up)) break;
-        const bool deep_switch = c->peel_deep && !deep_before;
-        if (deep_switch) { deep_before = true; --attempt; }      // (not a failure: the plain launch found the tree deeper than one chunk)
+        const bool rerun_deep = r == kRerunDeep;
+        if (!rerun_deep && !(r == C2A_ERR_HIP && c->peel_gave_up)) break;
+        if (rerun_deep) --attempt;                              // (the plain launch found the tree deeper than one chunk: the DEEP one has not been tried yet)
         if (attempt <= 0) {
-            // the launch's watchdog tripped (a wave waited too long for a record or for global progress): once more on clean
-            // buffers — node records re-zeroed, tickets and child pointers reset — before the serial DFS takes over
-            if (!deep_switch) std::fprintf(stderr, "[c2a] the dataflow peel gave up (%s); retrying once on clean buffers\n", c->err.c_str());
+            // the launch's watchdog tripped (a wave waited too long for a record or for global progress) — or the plain build asked for
+            // the DEEP one —: once more on clean buffers (node records re-zeroed, tickets and child pointers reset) before the serial DFS
+            // takes over
+            if (!rerun_deep) std::fprintf(stderr, "[c2a] the dataflow peel gave up (%s); retrying once on clean buffers\n", c->err.c_str());
             HIP_TRY(hipMemsetAsync(c->fill.p, 0, (size_t)n_all_of(c->n) * 4, c->stream));
             HIP_TRY(hipMemsetAsync(c->child.p, 0xFF, (size_t)n_all_of(c->n) * 8, c->stream));
             HIP_TRY(hipMemsetAsync(c->scalars.as<u32>() + SC_MAXDEPTH, 0, 8, c->stream));
@@ -702,9 +711,9 @@ int do_topo_sort(c2a_ctx* c, u64* cycle_at, bool defer_sorted = false) {
         // terminates, slow), the order in rank space and the reverse Kahn levels for what comes behind.
         if (!c->fallback_logged) { std::fprintf(stderr, "[c2a] the dataflow peel gave up twice (%s): sorting with the serial DFS instead\n", c->err.c_str()); c->fallback_logged = true; }
         c->serial_fallback = true;
-        c->err.clear();
         break;
     }
+    if (r == C2A_OK || c->serial_fallback) c->err.clear();      // (a retry that succeeded leaves no message behind)
     if (r && !c->serial_fallback) return r;
     c->stats.n_edges = c->rb_edges;                  // (read back with the launch's own counters)
     c->has_dup = c->rb_dup != 0;
@@ -771,7 +780,10 @@ int do_assign_wires(c2a_ctx* c, bool defer_readback = false) {
     if (c->positional && n) {
         // POSITIONAL NUMBERING (c2a_kernels.h): positions, the event bits that shift the numbering, then wires AND gates by formula
         const PosSrc S{n, c->local.as<u64>(), c->rank_suffix, c->pos_r.as<u32>()};
-        HIP_TRY(hipMemsetAsync(c->pblk.p, 0, (size_t)PW * 16, s));
+        // (zeroed by the build's k_clear — a numbering that is run again on the same sorted circuit zeroes them itself)
+        const bool cleared = c->wires_clear_valid;
+        c->wires_clear_valid = false;
+        if (!cleared) HIP_TRY(hipMemsetAsync(c->pblk.p, 0, (size_t)PW * 16, s));
         if (c->sorted_ready) {                          // (the staged calls: positions = the inverse of the order the caller has been given)
             C2A_LAUNCH_NOSYNC(k_eval_inverse, G, kThreads, s, n, c->sorted_r.as<u32>(), c->pos_r.as<u32>());
             C2A_LAUNCH_NOSYNC(k_pos_first<true>, G, kThreads, s, S, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), c->pos_r.as<u32>(), c->first.as<u32>(),
@@ -781,7 +793,8 @@ int do_assign_wires(c2a_ctx* c, bool defer_readback = false) {
                               c->n_in, (const u32*)c->in_nodes.as<u32>(), c->node_wire1.as<u32>());
         C2A_LAUNCH_NOSYNC(k_pos_bits, G, kThreads, s, n, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), (const u32*)c->pos_r.as<u32>(), (const u32*)c->first.as<u32>(),
                           c->pblk.as<u32>());
-        r = scan_1pass<2>(c, s, c->scan_tmp, PW, ScanPosBits{c->pblk.as<uint4>()}, c->dpre.as<u32>(), c->epre.as<u32>());
+        r = scan_1pass<2>(c, s, c->scan_tmp, PW, ScanPosBits{c->pblk.as<uint4>()}, c->dpre.as<u32>(), c->epre.as<u32>(),
+                          cleared ? (void*)(c->scan_desc.as<char>() + build_regions(c).bits) : nullptr);
         if (r) return r;
         n_mid_p = c->dpre.as<u32>() + PW;               // (the net shift of all events: the walk hands out n + that many wires, compiler.rs:440-441)
         n_events_p = c->epre.as<u32>() + PW;
@@ -914,7 +927,6 @@ int c2a_create(int n_devices, const int* device_ids, c2a_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
         c->n_cu = prop.multiProcessorCount;
-    if (const char* e = std::getenv("C2A_BOOL_THREADS")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 256 || v == 512 || v == 1024) c->bool_threads = v; }
     if (const char* e = std::getenv("C2A_BOOL_CHUNK")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 128 || v == 256 || v == 512) c->bool_chunk = v; }
     if (const char* e = std::getenv("C2A_PEEL_SEED_CHUNK")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 4096) c->peel_seed_chunk = v; }
     if (const char* e = std::getenv("C2A_PEEL_SHALLOW")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 48) c->peel_shallow = v; }
@@ -942,7 +954,7 @@ int c2a_create(int n_devices, const int* device_ids, c2a_ctx** out) {
     }
     (void)hipSetDevice(device_id);
 #ifndef C2A_EMULATE
-    if (std::getenv("C2A_NO_WARM") == nullptr) warm_functions();
+    warm_functions();
 #endif
     *out = c;
     return C2A_OK;
