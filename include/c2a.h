@@ -149,8 +149,10 @@ int c2a_load_circuit(c2a_ctx* ctx, uint64_t n, const uint32_t* in0, const uint32
  */
 int c2a_topo_sort(c2a_ctx* ctx, uint32_t* sorted_gate_ids, uint64_t* cycle_at);
 
-/* Same contract, executed as the literal DFS on one GPU lane (diagnostics / cross-check; slow).  c2a_topo_sort falls back to
- * it by itself when its dataflow launch gives up twice (a watchdog, never seen on hardware): like the reference's sort
+/* Same contract, executed as the literal DFS on one GPU lane (diagnostics / cross-check; slow: measured on an MI355X 2.1-2.4 us per
+ * gate — 2.1 s for 1 M gates, 24 s for 10 M, tools/serial_time.py; a host core does the same DFS in 41 ms / 1.7 s).  c2a_topo_sort
+ * falls back to it by itself when its dataflow launch gives up twice (a watchdog, never seen on hardware outside the tests'
+ * c2a_debug_peel_abort: 2.7 s / 31 s then, the serial walk for the levels included): like the reference's sort
  * (src/topological_sort.rs:3-21) it cannot fail on an acyclic graph. */
 int c2a_topo_sort_serial(c2a_ctx* ctx, uint32_t* sorted_gate_ids, uint64_t* cycle_at);
 
@@ -264,7 +266,7 @@ int c2a_eval(c2a_ctx* ctx, int which, uint32_t width, uint32_t n_vectors, const 
 int c2a_debug_patch_bool_op(c2a_ctx* ctx, uint64_t index, uint8_t new_op);
 /* Fault injection for the tests of the sort that cannot fail (src/topological_sort.rs:3-21 always terminates on an acyclic graph):
  * the next `launches` dataflow launches are treated as if their watchdog had tripped — one: the retry on clean buffers; two: the
- * serial DFS takes over (c2a_topo_sort then costs what c2a_topo_sort_serial costs: one lane, ~0.7 us per gate and edge). */
+ * serial DFS takes over (c2a_topo_sort then costs what c2a_topo_sort_serial costs: one lane, 2.1-2.4 us per gate). */
 int c2a_debug_peel_abort(c2a_ctx* ctx, uint32_t launches);
 /* Tests: the number the next build's node-table records are tagged with follows `build_no` (24 bits; the table is cleared when the
  * numbers wrap).  After c2a_load_gates. */
