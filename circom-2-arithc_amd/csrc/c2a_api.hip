@@ -125,13 +125,15 @@ struct c2a_ctx {
     DevBuf g_in0, g_in1, g_out, g_op, pr_rep, pr_need, pr_tin0, pr_tin1, pr_top, pr_live, pr_goff, pr_counts, p_in0, p_in1, p_out, p_op;
     DevBuf ev_produced, ev_spos, ev_aval, ev_bval, ev_lcount, ev_lbase, ev_lorder, ev_bar, ev_io, cb_in0, cb_in1, cb_out, cb_op;
     bool bool_planned = false;
-    bool gathered = false;         // multi-device: g_* hold the whole boolean circuit of the last c2a_boolify on the primary device
+    bool peer_access = false;      // multi-device: the primary can read every peer's memory (hipDeviceEnablePeerAccess at c2a_create): the level-parallel passes read the pieces of the boolean circuit where they lie
+    DevBuf segs;                   // the BoolSegs of the last such pass
+    bool gathered = false;         // multi-device WITHOUT peer access: g_* hold the whole boolean circuit of the last c2a_boolify on the primary device
     bool pruned = false;           // p_* hold the pruned image of the boolean circuit now in b_*
     c2a_prune_info pinfo{};
     std::vector<DevBuf*> all;
 
     c2a_ctx() {
-        all = {&rflag, &lh, &rh, &out, &op, &gate4, &nrec, &orig, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &aq_items, &aq_pc, &aq_seeds, &aq_seeds1, &aq_seed_flat, &aq_seed_cnt, &fill,
+        all = {&segs, &rflag, &lh, &rh, &out, &op, &gate4, &nrec, &orig, &in_nodes, &out_nodes, &prod1, &dep0, &dep1, &cons_cnt, &cons_off, &eslot, &aq_items, &aq_pc, &aq_seeds, &aq_seeds1, &aq_seed_flat, &aq_seed_cnt, &fill,
                &gstat, &clist, &pctl, &pcold, &meta, &node, &child, &rbits, &rpre, &ridx, &rlist, &next,
                &owner, &local, &slist, &sjump, &sjump2, &sorted, &sorted_r, &first, &nflag, &wflag, &widx, &node_wire1,
                &node_wire, &e_in0, &e_in1, &e_out, &e_op, &pos_r, &wire_r, &erec, &pblk, &dpre, &epre, &gflag, &scan_tmp, &scan_desc, &scalars, &dfs_state, &dfs_stack, &peel_prof, &peel_trace, &tsz, &asz, &goff,
@@ -953,6 +955,16 @@ int c2a_create(int n_devices, const int* device_ids, c2a_ctx** out) {
         if (hipSetDevice(P.device) != hipSuccess || hipStreamCreate(&P.stream) != hipSuccess) { (void)hipSetDevice(device_id); c2a_destroy(c); return C2A_ERR_HIP; }
     }
     (void)hipSetDevice(device_id);
+    // the primary reads the peers' pieces of the boolean circuit in place (c2a_eval, c2a_boolify_prune): map them if the devices allow it
+    c->peer_access = !c->peers.empty();
+    for (PeerDev& P : c->peers) {
+        if (P.device == device_id) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, device_id, P.device) != hipSuccess || !can) { c->peer_access = false; break; }
+        const hipError_t e = hipDeviceEnablePeerAccess(P.device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { c->peer_access = false; break; }
+        (void)hipGetLastError();
+    }
 #ifndef C2A_EMULATE
     warm_functions();
 #endif
@@ -1557,32 +1569,58 @@ int c2a_checksum(c2a_ctx* c, int which, uint64_t* value) {
     return C2A_OK;
 }
 
-// The whole boolean circuit on the primary device: what c2a_boolify left there, or — on a multi-device context, where every
-// device keeps the gates of its own range — a gathered copy (peer copies, made once per c2a_boolify, on the first call of
-// something that needs all of it: the evaluator, the verifier, the prune pass, which = 1 of the text formatter).
-struct BoolView { const u32* in0; const u32* in1; const u32* out; const u8* op; };
-static int full_bool(c2a_ctx* c, BoolView* v) {
-    if (c->peers.empty()) { *v = BoolView{c->b_in0.as<u32>(), c->b_in1.as<u32>(), c->b_out.as<u32>(), c->b_op.as<u8>()}; return C2A_OK; }
+// The boolean circuit as the level-parallel passes see it (c2a_kernels.h BoolSegs): ONE piece on a single-device context; on a
+// multi-device one every device keeps the gates of its own range of sorted positions and the primary READS them where they lie —
+// peer access over xGMI, enabled at c2a_create — instead of gathering all of it (9.6 GB at the headline size) first.  Only where a
+// peer cannot be mapped (no peer access between the two devices) the pieces are gathered on the primary as before (peer copies, made
+// once per c2a_boolify).
+static int bool_segs(c2a_ctx* c, const BoolSegs** out) {
+    BoolSegs S{};
     const u64 G = c->binfo.n_gates;
-    if (!c->gathered) {
-        ENSURE(c->g_in0, G * 4 + 16); ENSURE(c->g_in1, G * 4 + 16); ENSURE(c->g_out, G * 4 + 16); ENSURE(c->g_op, G + 16);
-        const u64 g0 = c->shard0_qhi;
-        HIP_TRY(hipMemcpyAsync(c->g_in0.p, c->b_in0.p, g0 * 4, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->g_in1.p, c->b_in1.p, g0 * 4, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->g_out.p, c->b_out.p, g0 * 4, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->g_op.p, c->b_op.p, g0, hipMemcpyDeviceToDevice, c->stream));
-        for (PeerDev& P : c->peers) {
-            const u64 cntq = P.q_hi - P.q_lo, skip = P.q_lo - P.q_bias;
-            if (!cntq) continue;
-            HIP_TRY(hipMemcpyPeerAsync(c->g_in0.as<u32>() + P.q_lo, c->device, P.b_in0.as<u32>() + skip, P.device, cntq * 4, c->stream));
-            HIP_TRY(hipMemcpyPeerAsync(c->g_in1.as<u32>() + P.q_lo, c->device, P.b_in1.as<u32>() + skip, P.device, cntq * 4, c->stream));
-            HIP_TRY(hipMemcpyPeerAsync(c->g_out.as<u32>() + P.q_lo, c->device, P.b_out.as<u32>() + skip, P.device, cntq * 4, c->stream));
-            HIP_TRY(hipMemcpyPeerAsync(c->g_op.as<u8>() + P.q_lo, c->device, P.b_op.as<u8>() + skip, P.device, cntq, c->stream));
+    if (c->peers.empty()) {
+        S.n_seg = 1; S.p_hi[0] = c->n;
+        S.in0[0] = c->b_in0.as<u32>(); S.in1[0] = c->b_in1.as<u32>(); S.out[0] = c->b_out.as<u32>(); S.op[0] = c->b_op.as<u8>();
+    } else if (c->peer_access) {
+        S.n_seg = 1 + (u32)c->peers.size();
+        S.p_hi[0] = c->shard0_hi;
+        S.in0[0] = c->b_in0.as<u32>(); S.in1[0] = c->b_in1.as<u32>(); S.out[0] = c->b_out.as<u32>(); S.op[0] = c->b_op.as<u8>();
+        for (size_t k = 0; k < c->peers.size(); ++k) {
+            const PeerDev& P = c->peers[k];
+            S.p_hi[k + 1] = P.p_hi;
+            // (boolean gate q of the whole circuit is stored at index q - q_bias of the peer's arrays)
+            S.in0[k + 1] = P.b_in0.as<u32>() - P.q_bias; S.in1[k + 1] = P.b_in1.as<u32>() - P.q_bias;
+            S.out[k + 1] = P.b_out.as<u32>() - P.q_bias; S.op[k + 1] = P.b_op.as<u8>() - P.q_bias;
         }
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        c->gathered = true;
+    } else {
+        if (!c->gathered) {
+            ENSURE(c->g_in0, G * 4 + 16); ENSURE(c->g_in1, G * 4 + 16); ENSURE(c->g_out, G * 4 + 16); ENSURE(c->g_op, G + 16);
+            const u64 g0 = c->shard0_qhi;
+            HIP_TRY(hipMemcpyAsync(c->g_in0.p, c->b_in0.p, g0 * 4, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->g_in1.p, c->b_in1.p, g0 * 4, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->g_out.p, c->b_out.p, g0 * 4, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->g_op.p, c->b_op.p, g0, hipMemcpyDeviceToDevice, c->stream));
+            for (PeerDev& P : c->peers) {
+                const u64 cntq = P.q_hi - P.q_lo, skip = P.q_lo - P.q_bias;
+                if (!cntq) continue;
+                HIP_TRY(hipMemcpyPeerAsync(c->g_in0.as<u32>() + P.q_lo, c->device, P.b_in0.as<u32>() + skip, P.device, cntq * 4, c->stream));
+                HIP_TRY(hipMemcpyPeerAsync(c->g_in1.as<u32>() + P.q_lo, c->device, P.b_in1.as<u32>() + skip, P.device, cntq * 4, c->stream));
+                HIP_TRY(hipMemcpyPeerAsync(c->g_out.as<u32>() + P.q_lo, c->device, P.b_out.as<u32>() + skip, P.device, cntq * 4, c->stream));
+                HIP_TRY(hipMemcpyPeerAsync(c->g_op.as<u8>() + P.q_lo, c->device, P.b_op.as<u8>() + skip, P.device, cntq, c->stream));
+            }
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->gathered = true;
+        }
+        S.n_seg = 1; S.p_hi[0] = c->n;
+        S.in0[0] = c->g_in0.as<u32>(); S.in1[0] = c->g_in1.as<u32>(); S.out[0] = c->g_out.as<u32>(); S.op[0] = c->g_op.as<u8>();
     }
-    *v = BoolView{c->g_in0.as<u32>(), c->g_in1.as<u32>(), c->g_out.as<u32>(), c->g_op.as<u8>()};
+    // (the peers' kernels and copies must have landed before the primary reads their pieces)
+    DeviceGuard guard(c->device);
+    for (PeerDev& P : c->peers) { HIP_TRY(hipSetDevice(P.device)); HIP_TRY(hipStreamSynchronize(P.stream)); }
+    HIP_TRY(hipSetDevice(c->device));
+    ENSURE(c->segs, sizeof(BoolSegs));
+    HIP_TRY(hipMemcpyAsync(c->segs.p, &S, sizeof(S), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));        // (S is a stack object)
+    *out = c->segs.as<BoolSegs>();
     return C2A_OK;
 }
 
@@ -1620,9 +1658,9 @@ static int eval_run(c2a_ctx* c, u32 mode, u32 width) {
     R.levels = c->stats.levels; R.width = width; R.mode = mode;
     R.lbase = c->ev_lbase.as<u32>(); R.order = c->ev_lorder.as<u32>(); R.spos = c->ev_spos.as<u32>();
     R.e_in0 = c->e_in0.as<u32>(); R.e_in1 = c->e_in1.as<u32>(); R.e_out = c->e_out.as<u32>(); R.e_op = c->e_op.as<u8>();
-    BoolView bv{nullptr, nullptr, nullptr, nullptr};
-    if (mode & 2u) { int rv = full_bool(c, &bv); if (rv) return rv; }
-    R.goff = c->goff.as<u64>(); R.b_in0 = bv.in0; R.b_in1 = bv.in1; R.b_out = bv.out; R.b_op = bv.op;
+    R.segs = nullptr;
+    if (mode & 2u) { int rv = bool_segs(c, &R.segs); if (rv) return rv; }
+    R.goff = c->goff.as<u64>(); R.b_in0 = nullptr; R.b_in1 = nullptr; R.b_out = nullptr; R.b_op = nullptr;
     R.aval = c->ev_aval.as<u64>(); R.bval = c->ev_bval.as<u64>();
     ENSURE(c->ev_bar, 256);
     HIP_TRY(hipMemsetAsync(c->ev_bar.p, 0, 256, s));
@@ -1752,9 +1790,8 @@ int c2a_boolify_prune(c2a_ctx* c, c2a_prune_info* info) {
     R.out_base = (u64)c->binfo.m_wires * width + c->binfo.aux_total;
     R.zero_wire = (u32)wires; R.one_wire = (u32)wires + 1;
     R.lbase = c->ev_lbase.as<u32>(); R.order = c->ev_lorder.as<u32>(); R.spos = c->ev_spos.as<u32>();
-    BoolView bv;
-    if ((r = full_bool(c, &bv))) return r;
-    R.goff = c->goff.as<u64>(); R.b_in0 = bv.in0; R.b_in1 = bv.in1; R.b_out = bv.out; R.b_op = bv.op;
+    if ((r = bool_segs(c, &R.segs))) return r;
+    R.goff = c->goff.as<u64>();
     R.rep = c->pr_rep.as<u32>(); R.need = c->pr_need.as<u32>();
     R.t_in0 = c->pr_tin0.as<u32>(); R.t_in1 = c->pr_tin1.as<u32>(); R.t_op = c->pr_top.as<u8>();
     R.live_cnt = c->pr_live.as<u32>(); R.bar = c->ev_bar.as<u32>(); R.counts = c->pr_counts.as<ull>();
@@ -1785,7 +1822,7 @@ int c2a_boolify_prune(c2a_ctx* c, c2a_prune_info* info) {
     C2A_LAUNCH_NOSYNC(k_prune_consts, 1, 64, s, R.zero_wire, R.one_wire, c->p_in0.as<u32>(), c->p_in1.as<u32>(), c->p_out.as<u32>(), c->p_op.as<u8>());
     if (n)
         C2A_LAUNCH_NOSYNC(k_prune_compact, grid_for(n, 4096), kThreads, s, n, (const u64*)c->goff.as<u64>(), (const u32*)c->pr_goff.as<u32>(),
-                          (const u32*)c->pr_tin0.as<u32>(), (const u32*)c->pr_tin1.as<u32>(), bv.out, (const u8*)c->pr_top.as<u8>(),
+                          (const u32*)c->pr_tin0.as<u32>(), (const u32*)c->pr_tin1.as<u32>(), R.segs, (const u8*)c->pr_top.as<u8>(),
                           c->p_in0.as<u32>(), c->p_in1.as<u32>(), c->p_out.as<u32>(), c->p_op.as<u8>());
     HIP_TRY(hipStreamSynchronize(s));
     c->pinfo.n_gates = PG; c->pinfo.n_gates_before = G; c->pinfo.n_folded = cnts[0]; c->pinfo.n_dead = cnts[1];
@@ -1860,7 +1897,7 @@ int c2a_eval(c2a_ctx* c, int which, uint32_t width, uint32_t n_vectors, const ui
             R.levels = c->stats.levels; R.width = width; R.mode = 2;
             R.lbase = c->ev_lbase.as<u32>(); R.order = c->ev_lorder.as<u32>(); R.spos = c->ev_spos.as<u32>();
             R.e_in0 = c->e_in0.as<u32>(); R.e_in1 = c->e_in1.as<u32>(); R.e_out = c->e_out.as<u32>(); R.e_op = c->e_op.as<u8>();
-            R.goff = c->goff.as<u64>(); R.b_in0 = c->p_in0.as<u32>(); R.b_in1 = c->p_in1.as<u32>(); R.b_out = c->p_out.as<u32>(); R.b_op = c->p_op.as<u8>();
+            R.goff = c->goff.as<u64>(); R.segs = nullptr; R.b_in0 = c->p_in0.as<u32>(); R.b_in1 = c->p_in1.as<u32>(); R.b_out = c->p_out.as<u32>(); R.b_op = c->p_op.as<u8>();
             R.aval = c->ev_aval.as<u64>(); R.bval = c->ev_bval.as<u64>();
             ENSURE(c->ev_bar, 256);
             HIP_TRY(hipMemsetAsync(c->ev_bar.p, 0, 256, s));

@@ -1224,11 +1224,25 @@ __global__ void k_level_scatter(u32 n, const uint4* __restrict__ meta, const u32
 // (10 000 launches for the 10 M-gate graph).  The values of a level are read by other workgroups — other XCDs, whose L2s
 // are not coherent with each other — in the next one, so values go through agent-scope accesses (the launch boundary used
 // to do that) and the barrier is a fence + a counter every workgroup bumps once per level.
+// The boolean circuit as the level-parallel passes see it: on a multi-device context every device keeps the boolean gates of its own
+// range of SORTED POSITIONS, an arithmetic gate's template lies in one piece, and the passes — which run on the primary
+// device — read a piece where it lies (peer access over xGMI) instead of gathering 9.6 GB on the primary first.  Segment s holds the
+// gates of sorted positions [p_hi[s - 1], p_hi[s]); the pointers are biased so that pointer[q] is boolean gate q of the WHOLE circuit.
+constexpr u32 kMaxSegs = 64;
+struct BoolSegs { u32 n_seg, pad; u32 p_hi[kMaxSegs]; const u32* in0[kMaxSegs]; const u32* in1[kMaxSegs]; const u32* out[kMaxSegs]; const u8* op[kMaxSegs]; };
+struct BoolPtrs { const u32* in0; const u32* in1; const u32* out; const u8* op; };
+__device__ __forceinline__ BoolPtrs seg_of(const BoolSegs* S, u32 p) {
+    u32 s = 0;
+    const u32 ns = S->n_seg;
+    while (s + 1 < ns && p >= S->p_hi[s]) ++s;
+    return BoolPtrs{S->in0[s], S->in1[s], S->out[s], S->op[s]};
+}
 struct EvalRun {
     u32 levels, width, mode;           // mode bit 0: the arithmetic circuit, bit 1: its boolean image
     const u32* lbase; const u32* order; const u32* spos;
     const u32* e_in0; const u32* e_in1; const u32* e_out; const u8* e_op;
-    const u64* goff; const u32* b_in0; const u32* b_in1; const u32* b_out; const u8* b_op;
+    const u64* goff; const BoolSegs* segs;        // the boolean image (k_eval_run)
+    const u32* b_in0; const u32* b_in1; const u32* b_out; const u8* b_op;      // k_eval_pruned: the pruned image (one piece, on the primary)
     u64* aval; u64* bval;
     u32* bar;                          // barrier counter (zeroed before the launch)
 };
@@ -1358,7 +1372,8 @@ __global__ void __launch_bounds__(kThreads) k_eval_run(EvalRun R) {
         if (R.mode & 2u)
             for (u64 i = wave; i < cnt; i += n_waves) {
                 const u32 p = R.spos[R.order[lo + (u32)i]];
-                eval_template_wave(R.goff[p], R.goff[p + 1], R.b_in0, R.b_in1, R.b_out, R.b_op, R.bval, lane);
+                const BoolPtrs B = seg_of(R.segs, p);
+                eval_template_wave(R.goff[p], R.goff[p + 1], B.in0, B.in1, B.out, B.op, R.bval, lane);
             }
         if (lv == 0) break;
         if (!grid_barrier(R.bar, target)) return;
@@ -1450,7 +1465,7 @@ struct PruneRun {
     u64 out_base;                      // first boolean wire of the circuit outputs (n_out arithmetic wires x width)
     u32 zero_wire, one_wire;           // the two constant wires (new: wire_count, wire_count + 1)
     const u32* lbase; const u32* order; const u32* spos;
-    const u64* goff; const u32* b_in0; const u32* b_in1; const u32* b_out; const u8* b_op;
+    const u64* goff; const BoolSegs* segs;
     u32* rep;                          // [wires + 2]
     u32* need;                         // [wires + 2]
     u32* t_in0; u32* t_in1; u8* t_op;  // [G] rewritten gates (t_op 0xFF: folded away; bit 7 set after `live`: dead)
@@ -1472,12 +1487,13 @@ __global__ void __launch_bounds__(kThreads) k_prune_fold(PruneRun R) {
         for (u64 i = wave; i < cnt; i += n_waves) {
             const u32 p = R.spos[R.order[lo + (u32)i]];
             const u64 k0 = R.goff[p], k1 = R.goff[p + 1];
+            const BoolPtrs B = seg_of(R.segs, p);
             for (u64 base = k0; base < k1; base += 64) {
                 const u32 nv = k1 - base < 64 ? (u32)(k1 - base) : 64u;
                 const bool valid = lane < nv;
                 const u64 k = base + lane;
                 u32 i0 = 0xFFFFFFFFu, i1 = 0xFFFFFFFFu, out = 0xFFFFFFFEu, op = 2;
-                if (valid) { i0 = R.b_in0[k]; i1 = R.b_in1[k]; out = R.b_out[k]; op = R.b_op[k]; }
+                if (valid) { i0 = B.in0[k]; i1 = B.in1[k]; out = B.out[k]; op = B.op[k]; }
                 ChunkDeps d = chunk_deps(i0, i1, out, nv, lane);
                 if (op == 2u) d.d1 = -1;
                 const u32 a_mem = valid && d.d0 < 0 ? ev_ld32(&R.rep[i0]) : 0u;
@@ -1536,13 +1552,14 @@ __global__ void __launch_bounds__(kThreads) k_prune_live(PruneRun R) {
         for (u64 i = wave; i < cnt; i += n_waves) {
             const u32 p = R.spos[R.order[lo + (u32)i]];
             const u64 k0 = R.goff[p], k1 = R.goff[p + 1];
+            const BoolPtrs B = seg_of(R.segs, p);
             u32 live_total = 0;
             // chunks from the last to the first; inside a chunk a gate is needed by the live gates behind it that read its wire
             for (u64 base = k0 + ((k1 - k0 - 1) & ~63ull); k1 > k0; base -= 64) {
                 const u32 nv = k1 - base < 64 ? (u32)(k1 - base) : 64u;
                 const u64 k = base + lane;
                 u32 op = 0xFFu, out = 0xFFFFFFFEu, t0 = 0xFFFFFFFFu, t1 = 0xFFFFFFFFu;
-                if (lane < nv) { op = R.t_op[k]; out = R.b_out[k]; }
+                if (lane < nv) { op = R.t_op[k]; out = B.out[k]; }
                 const bool kept = op != 0xFFu;
                 if (kept) { t0 = R.t_in0[k]; t1 = op == 2u ? t0 : R.t_in1[k]; }
                 u64 readers = 0;
@@ -1581,10 +1598,11 @@ __global__ void k_prune_init(u64 n_wires, u32* rep, u32* need) {
 }
 // the live gates of every arithmetic gate, in order, from position 2 on (0, 1: the gates that make the constant wires)
 __global__ void k_prune_compact(u32 n, const u64* __restrict__ goff, const u32* __restrict__ pgoff, const u32* __restrict__ t_in0,
-                                const u32* __restrict__ t_in1, const u32* __restrict__ b_out, const u8* __restrict__ t_op,
+                                const u32* __restrict__ t_in1, const BoolSegs* __restrict__ segs, const u8* __restrict__ t_op,
                                 u32* p_in0, u32* p_in1, u32* p_out, u8* p_op) {
     for (u64 p = gtid(); p < n; p += gstride()) {
         u64 q = 2ull + pgoff[p];
+        const u32* b_out = seg_of(segs, (u32)p).out;
         for (u64 k = goff[p]; k < goff[p + 1]; ++k) {
             const u32 op = t_op[k];
             if (op & 0x80u) continue;                  // folded (0xFF) or dead (bit 7)

@@ -269,12 +269,15 @@ typedef int hipError_t;
 typedef int hipStream_t;
 struct hipEventImpl { std::chrono::steady_clock::time_point t; };
 typedef hipEventImpl* hipEvent_t;
-enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErrorPeerAccessAlreadyEnabled = 704 };
 enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 struct hipDeviceProp_t { int multiProcessorCount; char name[64]; char gcnArchName[64]; size_t totalGlobalMem; };
 
 inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hip_emul error"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
+// the two "devices" are one address space; HIPEMU_NO_PEER=1 (tests) says they cannot map each other: the library then gathers
+inline hipError_t hipDeviceCanAccessPeer(int* can, int, int) { *can = std::getenv("HIPEMU_NO_PEER") ? 0 : 1; return hipSuccess; }
+inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 2; return hipSuccess; }      // two "devices" so that the multi-device path can run

@@ -308,6 +308,7 @@ def test_chunked_boolify_equals_the_full_result(backend, orc, c2a, width):
 
 
 MULTI = [pytest.param(("emul", [0, 1]), id="emul-2dev"), pytest.param(("emul", [0, 1, 1]), id="emul-3shards"),
+         pytest.param(("emul-nopeer", [0, 1, 1]), id="emul-3shards-no-peer-access"),      # (the devices cannot map each other: the pieces are gathered)
          pytest.param(("hip", [0, 0]), id="hip-2shards", marks=pytest.mark.gpu),
          pytest.param(("hip", [0, 0, 0, 0, 0]), id="hip-5shards", marks=pytest.mark.gpu),
          # real peers (hipSetDevice switching, cross-device hipMemcpyPeerAsync, per-device allocation): run wherever the box
@@ -325,7 +326,12 @@ def multi_backend(request, c2a):
     kind, ids = request.param
     if kind == "hip" and max(ids) >= c2a.visible_devices():
         pytest.skip(f"needs {max(ids) + 1} GPUs, this box has {c2a.visible_devices()}")
-    be = c2a.Backend(ids, lib_path=request.getfixturevalue("emul_lib")) if kind == "emul" else c2a.Backend(ids)
+    if kind == "emul-nopeer":
+        from conftest import _Env
+        with _Env(HIPEMU_NO_PEER=1):
+            be = c2a.Backend(ids, lib_path=request.getfixturevalue("emul_lib"))
+    else:
+        be = c2a.Backend(ids, lib_path=request.getfixturevalue("emul_lib")) if kind == "emul" else c2a.Backend(ids)
     yield be
     be.close()
 
@@ -358,6 +364,7 @@ def test_multi_device_boolify_equals_the_single_device_result(multi_backend, orc
     # a flipped op anywhere — first gate, a gate of every shard, last gate — is caught where it lies
     checked, bad = be.verify_boolify(1)
     assert bad == 0 and checked == fg.n * 64
+    assert be.stats()["verifier"] == 2                        # (the per-device local check, not the whole-circuit simulation: c2a.h c2a_stats)
     if width <= 8 or multi_backend.version.find("emulation") < 0:      # (the emulator takes seconds per pass at width 32: once is enough there)
         ops = be.bool_read()[3]
         rng = np.random.default_rng(width)
@@ -373,9 +380,15 @@ def test_multi_device_boolify_equals_the_single_device_result(multi_backend, orc
         # test_gpu_verifier_agrees_and_detects_faults, which uses the linear-size templates for its detection rate)
         assert tried >= 4 and caught >= 1, (caught, tried)
         assert be.verify_boolify(1)[1] == 0
-    # the evaluator of the boolean image and the prune pass simulate the circuit level by level across all its gates: they
-    # gather it on the primary device once (peer copies) and give the single-device answers
+    # the evaluator of the boolean image and the prune pass simulate the circuit level by level across all its gates, on the primary
+    # device: they read every device's piece where it lies (peer access; gathered on the primary only where the devices cannot map
+    # each other) and give the single-device answers
+    rng = np.random.default_rng(11)
+    vec = rng.integers(0, 2 ** 63, (len(fg.input_nodes), 5), dtype=np.uint64) & np.uint64((1 << width) - 1)
+    want_vals = be.eval(vec, {}, width=width)
+    np.testing.assert_array_equal(be.eval(vec, {}, width=width, boolean=True), want_vals)
     pi = be.boolify_prune()
+    np.testing.assert_array_equal(be.eval(vec, {}, width=width, pruned=True), want_vals)
     want, wcnt = orc.prune_bool(exp, int(info.wire(_oracle(orc, fg).wire_count - len(fg.output_nodes))))
     assert {k: pi[k] for k in wcnt} == wcnt
     for g, e in zip(be.pruned_read(), want):
