@@ -40,7 +40,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (~6.3 TB/s achievable)
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r05_pmc_hbm_bytes.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r06_pmc_hbm_bytes.json")
 
 
 def timed_region(warm_step, step, steps, warmup, dist=None, torch=None, device=None):
@@ -589,7 +589,7 @@ def main():
         "roofline": {"bound": "hbm", "scope": "whole timed step (sort + numbering + emission + boolify)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_step": step_bytes, "traffic": total_traffic,
-                     "traffic_source": "profiles/r05_pmc_hbm_bytes.json — a QUOTED figure from the committed rocprofv3 --pmc passes of this command (TCC_EA0_RDREQ x 128 B + WRITE_SIZE), not counters of this run" if pmc else None,
+                     "traffic_source": "profiles/r06_pmc_hbm_bytes.json — a QUOTED figure from the committed rocprofv3 --pmc passes of this command under the byte model calibrated in profiles/r06_pmc_calibration.txt (reads = 128 B x TCC_EA0_RDREQ in every access pattern, WRITE_SIZE exact), not counters of this run" if pmc else None,
                      "kernels": kernels,
                      "note": "the step is bound by the dependent-step latency of the exact DFS order (k_peel), not by bytes: its algorithmic traffic is 0.3 GB"},
         "aggregate_replicas": agg,
