@@ -418,5 +418,31 @@ inline BristolCircuit boolify(const Compiler& compiler, const BristolCircuit& ci
     return b;
 }
 
+// boolify(&circuit, width) (main.rs:30-32) of ANY arithmetic BristolCircuit — one the host built itself (the reference's own
+// Compiler::build_circuit, src/compiler.rs:321-494), not necessarily the last one built on this backend: the gates go over as SoA of
+// wire ids (c2a_load_circuit) and only the bit-blast runs on the GPU.  The choice for deep and narrow circuits.
+inline BristolCircuit boolify_circuit(Backend& be, const BristolCircuit& circuit, uint32_t width, bool fetch = true) {
+    const uint32_t n_in = (uint32_t)circuit.info.input_name_to_wire_index.size(), n_out = (uint32_t)circuit.info.output_name_to_wire_index.size();
+    be.check(c2a_load_circuit(be.get(), circuit.op.size(), circuit.in0.data(), circuit.in1.data(), circuit.out.data(), circuit.op.data(),
+                              (uint32_t)circuit.wire_count, n_in, n_out));
+    c2a_bool_info bi;
+    be.check(c2a_boolify(be.get(), width, &bi));
+    auto wire = [&](size_t W) -> size_t {
+        return W < bi.m_wires ? W * width : (size_t)bi.m_wires * width + bi.aux_total + (W - bi.m_wires) * width;
+    };
+    BristolCircuit b;
+    b.boolean = true;
+    b.wire_count = bi.wire_count;
+    for (auto& kv : circuit.info.input_name_to_wire_index) b.info.input_name_to_wire_index[kv.first] = wire(kv.second);
+    for (auto& kv : circuit.info.output_name_to_wire_index) b.info.output_name_to_wire_index[kv.first] = wire(kv.second);
+    for (auto& kv : circuit.info.constants) b.info.constants[kv.first] = ConstantInfo{kv.second.value, wire(kv.second.wire_index)};
+    b.io_widths = std::make_pair(std::vector<size_t>(bi.n_in, width), std::vector<size_t>(bi.n_out, width));
+    if (fetch) {
+        b.in0.resize(bi.n_gates); b.in1.resize(bi.n_gates); b.out.resize(bi.n_gates); b.op.resize(bi.n_gates);
+        be.check(c2a_bool_read(be.get(), 0, bi.n_gates, b.in0.data(), b.in1.data(), b.out.data(), b.op.data()));
+    } else b.gates_on_device = bi.n_gates;
+    return b;
+}
+
 }  // namespace host
 }  // namespace c2a

@@ -199,6 +199,11 @@ int main() {
         uint32_t got = 0;
         for (int i = 0; i < 8; ++i) got |= (uint32_t)w[b.info.output_name_to_wire_index.at("0.out") + i] << i;
         CHECK(got == ((av + bv) & 0xFF));
+        // boolify(&circuit, width) of a circuit handed over as it is (c2a_load_circuit): the same boolean circuit, gate for gate
+        std::printf("test_boolify_of_a_host_built_circuit\n");
+        const BristolCircuit b2 = boolify_circuit(be, circuit, 8);
+        CHECK(b2.wire_count == b.wire_count && b2.in0 == b.in0 && b2.in1 == b.in1 && b2.out == b.out && b2.op == b.op);
+        CHECK(b2.info.input_name_to_wire_index == b.info.input_name_to_wire_index && b2.info.output_name_to_wire_index == b.info.output_name_to_wire_index);
     }
     std::printf(failures ? "%d check(s) FAILED\n" : "all checks passed\n", failures);
     return failures ? 1 : 0;
