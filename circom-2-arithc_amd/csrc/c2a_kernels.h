@@ -1357,6 +1357,9 @@ __device__ __forceinline__ void eval_template_wave(u64 k0, u64 k1, const u32* __
     }
 }
 __global__ void __launch_bounds__(kThreads) k_eval_run(EvalRun R) {
+    // (one piece — every single-device context —: its pointers are read once per wave, not once per gate)
+    const bool one_seg = !R.segs || R.segs->n_seg == 1u;
+    const BoolPtrs B_all = R.segs ? seg_of(R.segs, 0u) : BoolPtrs{nullptr, nullptr, nullptr, nullptr};
     const u64 mk = R.width >= 64 ? ~0ull : ((1ull << R.width) - 1ull);
     const u32 lane = threadIdx.x & 63u;
     const u64 wave = gtid() >> 6, n_waves = gstride() >> 6;
@@ -1372,7 +1375,7 @@ __global__ void __launch_bounds__(kThreads) k_eval_run(EvalRun R) {
         if (R.mode & 2u)
             for (u64 i = wave; i < cnt; i += n_waves) {
                 const u32 p = R.spos[R.order[lo + (u32)i]];
-                const BoolPtrs B = seg_of(R.segs, p);
+                const BoolPtrs B = one_seg ? B_all : seg_of(R.segs, p);
                 eval_template_wave(R.goff[p], R.goff[p + 1], B.in0, B.in1, B.out, B.op, R.bval, lane);
             }
         if (lv == 0) break;
@@ -1477,6 +1480,8 @@ __device__ __forceinline__ u32 ev_ld32(const u32* p) { return __hip_atomic_load(
 __device__ __forceinline__ void ev_st32(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // (both passes: a wave per arithmetic gate, its template 64 gates at a time like eval_template_wave)
 __global__ void __launch_bounds__(kThreads) k_prune_fold(PruneRun R) {
+    const bool one_seg = R.segs->n_seg == 1u;      // (one piece: its pointers are read once per wave, not once per gate)
+    const BoolPtrs B_all = seg_of(R.segs, 0u);
     const u32 lane = threadIdx.x & 63u;
     const u64 wave = gtid() >> 6, n_waves = gstride() >> 6;
     u32 target = 0;
@@ -1487,7 +1492,7 @@ __global__ void __launch_bounds__(kThreads) k_prune_fold(PruneRun R) {
         for (u64 i = wave; i < cnt; i += n_waves) {
             const u32 p = R.spos[R.order[lo + (u32)i]];
             const u64 k0 = R.goff[p], k1 = R.goff[p + 1];
-            const BoolPtrs B = seg_of(R.segs, p);
+            const BoolPtrs B = one_seg ? B_all : seg_of(R.segs, p);
             for (u64 base = k0; base < k1; base += 64) {
                 const u32 nv = k1 - base < 64 ? (u32)(k1 - base) : 64u;
                 const bool valid = lane < nv;
@@ -1542,6 +1547,8 @@ __global__ void __launch_bounds__(kThreads) k_prune_fold(PruneRun R) {
     if (folded) atomicAdd(&R.counts[0], (ull)folded);
 }
 __global__ void __launch_bounds__(kThreads) k_prune_live(PruneRun R) {
+    const bool one_seg = R.segs->n_seg == 1u;      // (one piece: its pointers are read once per wave, not once per gate)
+    const BoolPtrs B_all = seg_of(R.segs, 0u);
     const u32 lane = threadIdx.x & 63u;
     const u64 wave = gtid() >> 6, n_waves = gstride() >> 6;
     u32 target = 0;
@@ -1552,7 +1559,7 @@ __global__ void __launch_bounds__(kThreads) k_prune_live(PruneRun R) {
         for (u64 i = wave; i < cnt; i += n_waves) {
             const u32 p = R.spos[R.order[lo + (u32)i]];
             const u64 k0 = R.goff[p], k1 = R.goff[p + 1];
-            const BoolPtrs B = seg_of(R.segs, p);
+            const BoolPtrs B = one_seg ? B_all : seg_of(R.segs, p);
             u32 live_total = 0;
             // chunks from the last to the first; inside a chunk a gate is needed by the live gates behind it that read its wire
             for (u64 base = k0 + ((k1 - k0 - 1) & ~63ull); k1 > k0; base -= 64) {

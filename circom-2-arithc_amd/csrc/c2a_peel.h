@@ -827,9 +827,16 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             gi = make_uint4(rdlane(pv, 0), rdlane(pv, 1), rdlane(pv, 2), rdlane(pv, 3));
             gi2 = make_uint4(rdlane(pv, 4), rdlane(pv, 5), rdlane(pv, 6), rdlane(pv, 7));
             g = rdlane(pv, 15);
-            // its consumers came along (lanes 8..14) unless it has more than seven: then none is taken from the entry and
-            // the cold loop of the step reads the list itself
+            // its consumers came along (lanes 8..14) unless it has more than seven — a relay with all its eight, a hub's top level:
+            // then the list itself is loaded HERE, one round trip before the step is issued (a relay's entry even carries where its
+            // list starts: word 2 of its second static record), instead of leaving all of it to the list loop of the step
             cl0 = pv; cl0_base = 8; cl0_cap = kSlotCons;
+            if (C2A_UNLIKELY(gi.w > kSlotCons)) {
+                const u32 l_off = gi.z == kRelayOrig ? gi2.z : uniform(own_list_off(uniform(A.cold->n), A.cold->cons_off, A.gstat, g));
+                cl0 = A.clist[l_off + lane];                                 // (clist is padded by 64 entries)
+                C2A_PIN(cl0);
+                cl0_base = 0; cl0_cap = 64;
+            }
         }
         // (wave-uniform by construction — say so: one value the compiler takes for divergent here, and every value of the
         // chain loop that depends on the gate id moves to vector registers and is handled as divergent code)

@@ -332,6 +332,7 @@ def multi_backend(request, c2a):
             be = c2a.Backend(ids, lib_path=request.getfixturevalue("emul_lib"))
     else:
         be = c2a.Backend(ids, lib_path=request.getfixturevalue("emul_lib")) if kind == "emul" else c2a.Backend(ids)
+    be._test_shards = len(ids)
     yield be
     be.close()
 
@@ -341,6 +342,8 @@ def test_multi_device_boolify_equals_the_single_device_result(multi_backend, orc
     """boolify cut by sorted-position range over the devices of the context: the gathered SoA, ranged reads across shard
     boundaries and the (additive) checksums are those of the whole circuit."""
     be = multi_backend
+    if width == 32 and "emulation" in be.version and be._test_shards > 2:
+        pytest.skip("the emulator takes 45 s for this circuit at width 32: the two-device context covers it there, every shard count runs on the hardware")
     mix = tuple(m for m in c2a.synth.MIX_ALL if m[0] != "APow")
     fg = c2a.synth.layered_dag(14, 23, n_in=16, n_const=4, window=4, mix=mix, seed=7 + width)
     for rerun in range(2):                                  # same buffers twice
