@@ -259,6 +259,9 @@ int c2a_pruned_read(c2a_ctx* ctx, uint64_t first, uint64_t count, uint32_t* in0,
  * C2A_ERR_STATE for a circuit in which two gates write one node (the reference keeps the last, src/compiler.rs:403-406): a
  * writer that is not the producer carries no dependency edge, the level-parallel passes (this one, c2a_verify_boolify,
  * c2a_boolify_prune) would race it against the wire's readers — evaluate the emitted gate list sequentially instead.
+ * On a MULTI-DEVICE context which = 1 and c2a_boolify_prune run on the primary device and read every device's piece of the
+ * boolean circuit where it lies (peer access, enabled at c2a_create; gathered on the primary only where two devices cannot map
+ * each other's memory).
  */
 int c2a_eval(c2a_ctx* ctx, int which, uint32_t width, uint32_t n_vectors, const uint64_t* inputs, uint32_t n_const,
              const uint32_t* const_wires, const uint64_t* const_values, uint64_t* outputs);
