@@ -95,6 +95,13 @@
 #include "c2a_platform.h"
 #include "c2a_wave.h"
 
+#ifndef C2A_POLL_CAP
+// longest back-off of a wave that waits for a hand-off entry, in units of 64 clocks.  Round 5 backed off to 64 units (~1.8 us): on a wide graph
+// the launch does not wait for hand-offs, but a DEEP AND NARROW circuit — a chain of hash blocks, a few gates per level, four gates in ten handed
+// off — waits for every one of them: SHA-256 over 8 blocks 6.10 -> 5.06 ms with 4 units, a Merkle tree of 290 blocks 6.5 -> 5.85, the headline
+// 5.88 -> 5.86 (its tail: the end of the launch is seen sooner); 1 unit: no better, 16: half the gain (tools/ab_configs.sh)
+#define C2A_POLL_CAP 4
+#endif
 #ifndef C2A_PRIO_TOUR
 #define C2A_PRIO_TOUR 1      /* wave priority from the issue of the next step to the end of the step (3 in front of it) */
 #endif
@@ -125,7 +132,10 @@ constexpr u32 kPollLimit = 1u << 16;        // (the emulation runs every wave of
 #else
 constexpr u32 kPollLimit = 1u << 21;        // ~1 s of polling for a record: give up (reported as an error) instead of hanging
 #endif
-constexpr u32 kWatchdogChecks = 1u << 15;   // idle-side checks (one per 32 polls, ~100 us apart) without global progress
+// The watchdog of a waiting wave: no GLOBAL progress (the heartbeat) for ~3 s.  By the clock on the device — a waiting wave looks at its
+// slot every 256 clocks (C2A_POLL_CAP) and at the launch's state every 32 looks —, by the number of looks under the emulation (no clock there).
+constexpr u32 kWatchdogChecks = 1u << 15;
+constexpr ull kWatchdogTicks = 300000000ull;      // of the constant 100 MHz clock
 // control block (u32 words; every hot word on its own 128-byte line)
 enum PeelCtl { CTL_PROCESSED = 0, CTL_MAXLEVEL = 1, CTL_ABORT = 2, CTL_REREADS = 3, CTL_DONE = 4, CTL_NEEDDEEP = 5, CTL_HEARTBEAT = 32, CTL_SEEDNEXT = 64,
                CTL_BEGIN = 128, CTL_END = CTL_BEGIN + 64 * 32, CTL_DEMAND = CTL_END + 64 * 32,
@@ -761,6 +771,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             }
             u64 slot_i = held_slot;          // the slot this wave watches: its own, or (see below) one that is served already
             u32 polls = 0, hb_seen = 0, hb_checks = 0;
+            ull hb_t0 = c2a_now(); (void)hb_t0;
             u64 v = 0;
             bool got = false;
             for (;;) {
@@ -773,8 +784,16 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                     if (lane < 3) c3 = ld_a32(&A.ctl[lane == 0 ? CTL_ABORT : (lane == 1 ? CTL_DONE : CTL_HEARTBEAT)]); wave_join();
                     const u32 aborted = rdlane(c3, 0), done = rdlane(c3, 1), hb = rdlane(c3, 2);
                     if (aborted || done) break;
+                    bool starved;
+#ifdef C2A_EMULATE
+                    starved = hb == hb_seen && ++hb_checks > kWatchdogChecks;
+#else
+                    const ull t_now = c2a_now();
+                    starved = hb == hb_seen && t_now - hb_t0 > kWatchdogTicks;
+                    if (hb != hb_seen) hb_t0 = t_now;
+#endif
                     if (hb != hb_seen) { hb_seen = hb; hb_checks = 0; }
-                    else if (++hb_checks > kWatchdogChecks) { if (lane == 0) atomicAdd(&A.ctl[CTL_ABORT], 1u); wave_join(); break; }
+                    else if (starved) { if (lane == 0) atomicAdd(&A.ctl[CTL_ABORT], 1u); wave_join(); break; }
                     // The full look at the counters (192 lines that every pusher writes) is for one wave in 64 at this rate —
                     // with every waiting wave doing it, those reads alone were 0.4-1.5 TB/s on the lines the tickets live
                     // on — and for every wave once in 1024 polls, so that ending (and picking up a stranded entry) never
@@ -816,7 +835,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                     }
                 }
                 // back off: the longer nothing turns up, the less often this wave asks (64 clocks per unit)
-                peel_sleep(polls < 16 ? 4 : (polls < 64 ? 16 : 64));
+                peel_sleep(polls < 16 ? 4 : (polls < 64 || C2A_POLL_CAP <= 16 ? (C2A_POLL_CAP < 16 ? C2A_POLL_CAP : 16) : C2A_POLL_CAP));
             }
             if (STATS) st_polls += polls;
             if (STATS) { const ull tt = c2a_now(); st_idle += tt - st_t0; st_t0 = tt; }
