@@ -102,6 +102,13 @@
 // 5.88 -> 5.86 (its tail: the end of the launch is seen sooner); 1 unit: no better, 16: half the gain (tools/ab_configs.sh)
 #define C2A_POLL_CAP 4
 #endif
+#ifndef C2A_SCAN_MASK
+// one waiting wave in 64 reads the launch's 192 counter lines (is it over?  is an entry stranded?) every (mask + 1) looks at its slot = ~14 us;
+// every wave does once in 16 384 looks (~1.8 ms: ending never depends on a particular wave being resident).  Per 32 / 128 / 512 looks: SHA-256 x 8
+// blocks 4.94 / 4.95 / 4.95 ms, the headline's k_peel 5.80 / 5.80 / 5.90 (a longer tail); every wave once in 1 024 looks (with the 256-clock look
+// that is every 0.11 ms, 450 GB/s of reads on the lines the tickets live on when most waves wait): 5.06-5.12 ms for the SHA-256 chain
+#define C2A_SCAN_MASK 127u
+#endif
 #ifndef C2A_PRIO_TOUR
 #define C2A_PRIO_TOUR 1      /* wave priority from the issue of the next step to the end of the step (3 in front of it) */
 #endif
@@ -798,7 +805,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                     // with every waiting wave doing it, those reads alone were 0.4-1.5 TB/s on the lines the tickets live
                     // on — and for every wave once in 1024 polls, so that ending (and picking up a stranded entry) never
                     // depends on a particular wave being resident
-                    if ((me & 63u) == 0 || (polls & 1023u) == 0) {
+                    if (((me & 63u) == 0 && (polls & C2A_SCAN_MASK) == 0) || (polls & 16383u) == 0) {
                         // every END, then every BEGIN: each read waits for the one before
                         u32 n_end = lane < kAcctShards ? ld_a32(&A.ctl[CTL_END + lane * kAcctStride]) : 0u;
 #pragma unroll
