@@ -281,3 +281,18 @@ def test_fuzz_slice_on_the_hardware(hip_backend):
     fuzz = importlib.import_module("tools.fuzz_gpu")
     n, per = fuzz.run(minutes=1.0, seed=20241008, max_gates=1_000_000, be=hip_backend)
     assert n >= 20 and len(per) >= 4, (n, per)
+
+
+def test_hub_with_duplicate_writers(backend, orc):
+    """two gates write the hub's node (the reference keeps the LAST writer as its producer, src/compiler.rs:403-406): the general
+    numbering path, the identity relabelling — and the relay tree hangs under the later gate"""
+    rng = np.random.default_rng(21)
+    p = _star(rng, 120, chain=12, hub_gate_first=False)
+    n = len(p["lh"])
+    extra = dict(lh=np.array([1, 2], np.uint32), rh=np.array([2, 1], np.uint32), out=np.array([10, 10 + 1 + 5], np.uint32),
+                 op=np.array([0, 10], np.uint8))                    # a second writer of the hub's node, and one of a consumer's node
+    for k in ("lh", "rh", "out", "op"):
+        p[k] = np.concatenate([p[k], extra[k]])
+    assert _compare(backend, orc, p, check_serial=True) == "ok"
+    st = backend.stats()
+    assert st["numbering_path"] == 0 and st["n_relays"] == expected_relays(p["lh"], p["rh"], p["out"]) > 0
