@@ -146,7 +146,7 @@ int c2a_load_circuit(c2a_ctx* ctx, uint64_t n, const uint32_t* in0, const uint32
  * On C2A_ERR_CYCLIC *cycle_at is the gate index of the reference's message.
  * n + 4 n / 9 + 64 < 2^29, i.e. n < 371 M (C2A_ERR_ARG beyond: the sort's ticket words — one per gate and per relay of a hub, the
  * virtual gates a producer with more than 8 consumers gets — are addressed by 32-bit byte offsets; its workspace of
- * ~1 KB per gate runs out of a 288 GB device before that).
+ * ~1.4 KB per gate runs out of a 288 GB device before that).
  */
 int c2a_topo_sort(c2a_ctx* ctx, uint32_t* sorted_gate_ids, uint64_t* cycle_at);
 
