@@ -95,6 +95,55 @@ def load_pmc(n, width):
     return {}
 
 
+def live_pmc(args, timeout_s=240):
+    """HBM traffic of THIS command on THIS box: two child runs of the same step under `rocprofv3 --kernel-trace --pmc` (FETCH_SIZE, then
+    WRITE_SIZE: the TCC block cannot hold both in one pass), summarised per kernel under the byte model calibrated in
+    profiles/r06_pmc_calibration.txt (every read request is a 128-byte line: read bytes = 2 x FETCH_SIZE; WRITE_SIZE exact).  Returns the
+    same {kernel: {...}} table as profiles/r06_pmc_hbm_bytes.json, or None (no rocprofv3 on this box, a pass failed or timed out) — the
+    line then quotes the committed profile and says so."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    import csv
+    import glob
+    child_steps = 2
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="c2a_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+               "--pmc-child", "--steps", str(child_steps), "--warmup", "1", "--layers", str(args.layers), "--layer-width", str(args.layer_width), "--width", str(args.width)]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+        except (subprocess.TimeoutExpired, OSError):
+            shutil.rmtree(d, ignore_errors=True)
+            return None
+        agg, launches = {}, {}
+        for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    if row["Counter_Name"] != counter:
+                        continue
+                    k = re.sub(r"<.*$", "", re.sub(r"^void ", "", row["Kernel_Name"].split("(")[0]))
+                    agg[k] = agg.get(k, 0.0) + float(row["Counter_Value"])
+                    launches.setdefault(k, set()).add(row["Dispatch_Id"])
+        shutil.rmtree(d, ignore_errors=True)
+        if r.returncode != 0 or "c2a::k_boolify" not in agg:
+            return None
+        for k in agg:
+            if k.startswith("c2a::"):
+                vals.setdefault(k, {})[counter] = agg[k] / len(launches[k])
+                vals[k]["launches"] = len(launches[k])
+    base = vals["c2a::k_boolify"]["launches"] or 1              # one k_boolify per step
+    out = {}
+    for k, v in vals.items():
+        f, w = v.get("FETCH_SIZE", 0.0) * 1024.0 * 2.0, v.get("WRITE_SIZE", 0.0) * 1024.0
+        out[k] = {"fetch_bytes": f, "write_bytes": w, "hbm_bytes_per_launch": f + w, "launches_per_step": v["launches"] / base}
+    return out
+
+
 def oracle_circuit(fg):
     """The CPU oracle's build_circuit of the benchmark input (flat-array variant): the checker of `checked`, and the first
     half of `cpu_baseline`.  Returns (circuit, handle, seconds)."""
@@ -276,6 +325,8 @@ def main():
     ap.add_argument("--no-cold", action="store_true", help="skip the cold single-shot measurement")
     ap.add_argument("--no-prune", action="store_true", help="skip the optional prune pass report")
     ap.add_argument("--no-reference-shaped", action="store_true", help="skip the step on the reference-shaped graph (constants at a tenth of the gates)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not measure the step's HBM traffic in two child runs under rocprofv3 --pmc (~1 min); quote profiles/ instead")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # (the child of live_pmc: load, warm-up + steps, nothing printed)
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE's configs[0..3] as real circuits (GPU steady / cold vs CPU per circuit; ~1.5 min, most of it unrolling the 148 K-gate sponge)")
     ap.add_argument("--mode", choices=["both", "shard", "replicas"], default="both",
                     help="N>1: 'shard' = ONE graph, sort replicated on every rank, boolify sharded by sorted-position range (strong "
@@ -324,7 +375,7 @@ def main():
     # ---- cold single shot: what one call of the reference's main.rs:28-32 costs from nothing — a fresh context, workspace
     # allocation, the 130 MB payload over PCIe, the node-record clear (overlapped with the copy), ONE build_circuit + boolify
     cold = None
-    if world == 1 and not args.no_cold:        # (first thing on the device: nothing of this process is resident yet)
+    if world == 1 and not args.no_cold and not args.pmc_child:        # (first thing on the device: nothing of this process is resident yet)
         t0 = time.perf_counter()
         be2 = new_backend()
         t1 = time.perf_counter()
@@ -348,6 +399,12 @@ def main():
 
     n = fg.n
     last = {}
+    if args.pmc_child:
+        for _ in range(args.warmup + args.steps):
+            be.build_circuit()
+            be.boolify(args.width)
+        be.close()
+        return
 
     def step():
         if shard:      # every rank holds the whole sorted circuit, so it can place its own range without any exchange
@@ -425,7 +482,10 @@ def main():
     bool_bytes = 13.0 * n + 13.0 * info.n_gates
     step_bytes = sort_bytes + bool_bytes
     achieved = step_bytes / (ms_per_step * 1e-3) / 1e9
-    pmc = load_pmc(n, args.width)
+    pmc_live = None
+    if world == 1 and not args.no_live_pmc and not test_lib:
+        pmc_live = live_pmc(args)
+    pmc = pmc_live or load_pmc(n, args.width)
 
     def kernel_entry(name, pmc_key, algo_bytes, ms):
         e = {"kernel": name, "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": ms,
@@ -589,7 +649,7 @@ def main():
         "roofline": {"bound": "hbm", "scope": "whole timed step (sort + numbering + emission + boolify)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_step": step_bytes, "traffic": total_traffic,
-                     "traffic_source": "profiles/r06_pmc_hbm_bytes.json — a QUOTED figure from the committed rocprofv3 --pmc passes of this command under the byte model calibrated in profiles/r06_pmc_calibration.txt (reads = 128 B x TCC_EA0_RDREQ in every access pattern, WRITE_SIZE exact), not counters of this run" if pmc else None,
+                     "traffic_source": "MEASURED in this run: two child runs of the same step under rocprofv3 --kernel-trace --pmc (FETCH_SIZE; WRITE_SIZE), byte model calibrated in profiles/r06_pmc_calibration.txt (reads = 2 x FETCH_SIZE = 128 B per request in every access pattern, WRITE_SIZE exact)" if pmc_live else "profiles/r06_pmc_hbm_bytes.json — a QUOTED figure from the committed rocprofv3 --pmc passes of this command under the byte model calibrated in profiles/r06_pmc_calibration.txt (reads = 128 B x TCC_EA0_RDREQ in every access pattern, WRITE_SIZE exact), not counters of this run" if pmc else None,
                      "kernels": kernels,
                      "note": "the step is bound by the dependent-step latency of the exact DFS order (k_peel), not by bytes: its algorithmic traffic is 0.3 GB"},
         "aggregate_replicas": agg,

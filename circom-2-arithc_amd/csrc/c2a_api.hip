@@ -144,7 +144,7 @@ struct c2a_ctx {
 namespace {
 
 // scalars block layout (u32 words unless noted)
-enum Scalar { SC_MAXDEPTH = 0, SC_SCOUNT = 1, SC_ERR = 2, SC_NMID = 3, SC_NROOTS = 4, SC_LEVELS = 5, SC_PEELOK = 6 /* the dataflow launch ended cleanly and left no gate behind (k_post_peel) */,
+enum Scalar { SC_MAXDEPTH = 0, SC_SCOUNT = 1, SC_ERR = 2, SC_NMID = 3, SC_NROOTS = 4, SC_LEVELS = 5, SC_PEELOK = 6 /* the dataflow launch ended cleanly and left no gate behind (k_root_bits) */,
               SC_RELAYS = 7 /* relays of all hubs of this build (k_gstat) */,
               SC_DFS = 8 /*3 words*/, SC_DUP = 52,
               SC_TOTAL64 = 16 /* u64 slots from here: 16..31 */, SC_HOT = 64 /* 1 + kHotMax words: the hot producers k_deps found (c2a_kernels.h HOT PRODUCERS) */,
@@ -470,7 +470,7 @@ int peel_launch(c2a_ctx* c) {
     return C2A_OK;
 }
 
-// what the launch reported (hrb[0..5], posted by k_post_peel; the host has waited for an event behind it)
+// what the launch reported (hrb[0..5], posted by k_root_bits; the host has waited for an event behind it)
 int peel_result(c2a_ctx* c, u32* peeled_out) {
     const u32 n = c->n;
     const size_t slots = c->peel_slots;
@@ -549,7 +549,7 @@ inline u32 jump_rounds(u64 S) {
     return rounds;
 }
 
-// The order stage, QUEUED behind the peel without a host round trip: its first kernels go by SC_PEELOK (k_post_peel) and do
+// The order stage, QUEUED behind the peel without a host round trip: its first kernels go by SC_PEELOK (raised by the first of them, k_root_bits) and do
 // nothing when the launch gave up or left gates behind; the walk and the jumps then find no splitter.  The number of jump
 // launches comes from an upper bound on the splitter count (a hash of the element number picks one element in 64: the mean
 // + 8 standard deviations; order_result checks the real count and queues what is missing — surplus launches only copy).

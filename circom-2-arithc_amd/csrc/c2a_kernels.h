@@ -414,7 +414,7 @@ __global__ void __launch_bounds__(kThreads) k_deps(u32 n, const u32* __restrict_
 // DFS roots = tree nodes without a parent, in ascending ORIGINAL gate id (topological_sort.rs:11-13) — the tree lives in
 // rank space, so: a bit per original id (1.25 MB for 10 M gates: the scattered atomics stay on chip), a scan over the bitmap's
 // words, and every root finds its index by a look-up in the two small arrays.
-// (*ok: the dataflow launch in front ended cleanly and left no gate behind — k_post_peel —; the order stage is queued BEHIND it
+// (*ok: the dataflow launch in front ended cleanly and left no gate behind — k_root_bits works that out —; the order stage is queued BEHIND it
 // without a host round trip, and does nothing when it did not: the tree entries it would read are not there)
 // This launch also POSTS what the dataflow launch in front of it reported (block 0; a launch of its own, k_post_peel, in round 5):
 // every block works *ok out for itself from the launch's counters — gates done, summed over their kAcctShards parts, against n + the

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for i in 1 2 3; do
   for cold in "--no-cold" ""; do
-    python $R/bench.py --steps 10 --warmup 3 --no-width64 --no-artefacts --no-prune --no-configs --no-cpu-baseline $cold 2>/dev/null | python3 -c "
+    python $R/bench.py --steps 10 --warmup 3 --no-width64 --no-artefacts --no-prune --no-configs --no-live-pmc --no-cpu-baseline $cold 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

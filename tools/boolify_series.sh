@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; steps=${1:-60}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/bs
-timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/bs -- python $R/bench.py --steps $steps --warmup 3 --no-width64 --no-artefacts --no-prune --no-configs --no-cpu-baseline > /tmp/bs.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/bs -- python $R/bench.py --steps $steps --warmup 3 --no-width64 --no-artefacts --no-prune --no-configs --no-live-pmc --no-cpu-baseline > /tmp/bs.log 2>&1
 f=$(find /tmp/bs -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys

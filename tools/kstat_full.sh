@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kf_$tag
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kf_$tag -o $tag -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-width64 --no-artefacts --no-prune --no-configs --no-cold --no-reference-shaped "$@" > /tmp/kf_$tag.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kf_$tag -o $tag -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-width64 --no-artefacts --no-prune --no-configs --no-live-pmc --no-cold --no-reference-shaped "$@" > /tmp/kf_$tag.log 2>&1
 db=$(find /tmp/kf_$tag -name "*_results.db" | head -1)
 mkdir -p $R/gpurun_out
 python3 $R/tools/rocpd_summary.py $db > $R/gpurun_out/kfull_$tag.txt

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 for sh in "$@"; do
   w=${sh#*@}; s=${sh%@*}; [ "$w" = "$sh" ] && w=8
   L=${s%x*}; W=${s#*x}
-  C2A_PEEL_WAVES=$w timeout 600 python $R/bench.py --steps 2 --warmup 1 --layers $L --layer-width $W --width 8 --no-cpu-baseline --no-width64 --no-artefacts --no-prune --no-configs --no-cold --check 2>&1 | python3 -c "
+  C2A_PEEL_WAVES=$w timeout 600 python $R/bench.py --steps 2 --warmup 1 --layers $L --layer-width $W --width 8 --no-cpu-baseline --no-width64 --no-artefacts --no-prune --no-configs --no-live-pmc --no-cold --check 2>&1 | python3 -c "
 import json,sys
 for l in sys.stdin:
     l=l.strip()

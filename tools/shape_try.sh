@@ -5,7 +5,7 @@ shapes=()
 for a in "$@"; do case $a in *=*) export "$a";; *) shapes+=($a);; esac; done
 for sh in "${shapes[@]}"; do
   L=${sh%x*}; W=${sh#*x}
-  timeout 300 python $R/bench.py --steps 3 --warmup 1 --layers $L --layer-width $W --no-cpu-baseline --no-width64 --no-artefacts --no-prune --no-configs --no-cold 2>&1 | python3 -c "
+  timeout 300 python $R/bench.py --steps 3 --warmup 1 --layers $L --layer-width $W --no-cpu-baseline --no-width64 --no-artefacts --no-prune --no-configs --no-live-pmc --no-cold 2>&1 | python3 -c "
 import json,sys
 for l in sys.stdin:
     l=l.strip()
