@@ -723,6 +723,13 @@ __global__ void k_mark_outputs(u32 n_out, const u32* __restrict__ out_nodes, u8*
 // Every node has one writer (*dup == 0, the normal case): the sorted order is topological, so a produced node is first
 // seen as its producer's `out` — nothing to compute — and only references to un-produced nodes (inputs, constants) need
 // the atomicMin.  Otherwise: atomicMin over all 3n references.
+// first[node] = min(first[node], i) — with a LOOK first: a named constant that a whole template context reads (the reference's
+// unroller makes one node per literal and context, process.rs:558-579: `0`, `1`) is ONE word for all its readers, atomics on one
+// word go one at a time (~11 ns), and nearly all of them would lose anyway.  A constant read by 10^6 of 10 M gates: the numbering
+// stage 12.5 ms without the look, 0.1 with it.  (A stale look only costs an atomic that loses: the atomic stays the arbiter.)
+__device__ __forceinline__ void first_min(u32* first, u32 node, u32 i) {
+    if (__hip_atomic_load(&first[node], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > i) atomicMin(&first[node], i);
+}
 __global__ void k_first_seen(u32 n, const u32* __restrict__ sorted, const uint4* __restrict__ gate4, const u32* __restrict__ prod1,
                              const u32* __restrict__ dup, u32* first) {
     const bool general = *dup != 0;
@@ -730,12 +737,12 @@ __global__ void k_first_seen(u32 n, const u32* __restrict__ sorted, const uint4*
         const uint4 g = gate4[sorted[pos]];
         const u32 i = 3u * (u32)pos;
         if (general) {
-            atomicMin(&first[g.x], i);
-            atomicMin(&first[g.y], i + 1);
-            atomicMin(&first[g.z], i + 2);
+            first_min(first, g.x, i);
+            first_min(first, g.y, i + 1);
+            first_min(first, g.z, i + 2);
         } else {
-            if (prod1[g.x] == 0) atomicMin(&first[g.x], i);
-            if (prod1[g.y] == 0) atomicMin(&first[g.y], i + 1);
+            if (prod1[g.x] == 0) first_min(first, g.x, i);
+            if (prod1[g.y] == 0) first_min(first, g.y, i + 1);
         }
     }
 }
@@ -842,8 +849,8 @@ __global__ void k_pos_first(PosSrc S, const u8* __restrict__ gflag, const uint4*
         const u32 f = gflag[x];
         if (!(f & (kFlagLhConst | kFlagRhConst))) continue;
         const uint4 g = gate4[x];
-        if (f & kFlagLhConst) atomicMin(&first[g.x], 3u * p);
-        if (f & kFlagRhConst) atomicMin(&first[g.y], 3u * p + 1u);
+        if (f & kFlagLhConst) first_min(first, g.x, 3u * p);
+        if (f & kFlagRhConst) first_min(first, g.y, 3u * p + 1u);
     }
 }
 __global__ void k_pos_bits(u32 n, const u8* __restrict__ gflag, const uint4* __restrict__ gate4, const u32* __restrict__ pos_r,

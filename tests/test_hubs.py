@@ -296,3 +296,32 @@ def test_hub_with_duplicate_writers(backend, orc):
     assert _compare(backend, orc, p, check_serial=True) == "ok"
     st = backend.stats()
     assert st["numbering_path"] == 0 and st["n_relays"] == expected_relays(p["lh"], p["rh"], p["out"]) > 0
+
+
+def test_constant_read_by_many_gates(backend, orc, c2a):
+    """A NAMED CONSTANT that a whole template context reads — the reference's unroller makes one node per literal and context
+    (src/process.rs:558-579; keys at src/compiler.rs:354-359): `0`, `1` — is one un-produced node with 10^4-10^6 readers: it gets
+    its wire where the walk first sees it (src/compiler.rs:431-441), and "first" is a minimum over all its readers on ONE word.
+    Both numbering paths against the oracle; on the hardware the numbering must not take the 12 ms it took before the look-before-
+    atomic (tools/const_hub_check.py: 10 M gates, 10^6 readers)."""
+    from conftest import _Env
+    on_gpu = "hip" in backend.version
+    n = 1_000_000 if on_gpu else 24_000
+    fg = c2a.synth.layered_dag(n // 2000, 2000, seed=c2a.synth.SEED + 9)
+    rng = np.random.default_rng(2)
+    rh, lh = fg.rh.copy(), fg.lh.copy()
+    rh[rng.random(fg.n) < 0.2] = fg.const_nodes[0]
+    lh[rng.random(fg.n) < 0.02] = fg.const_nodes[1]
+    p = dict(lh=lh, rh=rh, out=fg.out, op=fg.op, n_nodes=fg.n_nodes, input_nodes=fg.input_nodes, output_nodes=fg.output_nodes)
+    assert _compare(backend, orc, p, check_serial=False) == "ok"
+    assert backend.stats()["numbering_path"] == 1
+    if on_gpu:
+        backend.build_circuit()
+        assert backend.timings()["wires"] < 1.0, backend.timings()           # ms
+    with _Env(C2A_NUMBERING_WALK=1):
+        be = c2a.Backend(0) if on_gpu else c2a.Backend(0, lib_path=os.path.join(os.path.dirname(os.path.abspath(__file__)), "emul", "libc2a_emul.so"))
+    try:
+        assert _compare(be, orc, p, check_serial=False) == "ok"
+        assert be.stats()["numbering_path"] == 0
+    finally:
+        be.close()
