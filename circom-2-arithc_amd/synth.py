@@ -364,4 +364,17 @@ def family(name: str, n_target: int = 1_000_000, seed: int = SEED) -> FlatGates:
         return layered_dag(L, Wd, window=L, seed=seed)
     if name == "forest":
         return reduction_forest(L * Wd, width=Wd, seed=seed)
+    if name == "const_hub":           # two named constants that a tenth / a hundredth of ALL gates read (one node per literal and template context: process.rs:558-579)
+        return shared_constants(layered_dag(L, Wd, seed=seed), (0.1, 0.01), seed)
     raise KeyError(name)
+
+
+def shared_constants(fg: FlatGates, fracs: Sequence[float], seed: int = SEED) -> FlatGates:
+    """fg with the rh (every second time: lh) operand of a fraction fracs[k] of its gates replaced by its k-th constant node: un-produced
+    nodes with 10^3-10^6 readers, as a literal used all over a template context is"""
+    lh, rh = fg.lh.copy(), fg.rh.copy()
+    for k, f in enumerate(fracs):
+        hit = (splitmix64(seed, 40 + k, fg.n) >> np.uint64(11)).astype(np.float64) / float(1 << 53) < f
+        (rh if k % 2 == 0 else lh)[hit] = fg.const_nodes[k % len(fg.const_nodes)]
+    return FlatGates(lh=lh, rh=rh, out=fg.out, op=fg.op, n_nodes=fg.n_nodes, input_nodes=fg.input_nodes, output_nodes=fg.output_nodes,
+                     const_nodes=fg.const_nodes, layers=fg.layers, layer_width=fg.layer_width)

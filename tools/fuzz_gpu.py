@@ -25,8 +25,11 @@ def draw(rng, max_gates, sha_blk):
     mix = [S.MIX_BITWISE, S.MIX_ALL, S.MIX_SHA][int(rng.integers(3))]
     if fam == "layered":
         cf, of = float(rng.choice([0, 0, 0.05, 0.3])), float(rng.choice([0, 0, 0.05, 0.5]))
-        return fam, S.layered_dag(layers, width, n_in=int(rng.integers(1, 50)), n_const=int(rng.integers(0, 9)), window=int(rng.integers(1, 70)),
-                                  mix=mix, seed=seed, const_frac=cf, out_frac=of, permute=bool(rng.integers(2)))
+        fg = S.layered_dag(layers, width, n_in=int(rng.integers(1, 50)), n_const=int(rng.integers(1, 9)), window=int(rng.integers(1, 70)),
+                           mix=mix, seed=seed, const_frac=cf, out_frac=of, permute=bool(rng.integers(2)))
+        if rng.integers(3) == 0:      # (named constants that many gates read)
+            fg = S.shared_constants(fg, tuple(float(x) for x in rng.choice([0.3, 0.1, 0.01], size=int(rng.integers(1, 4)))), seed)
+        return fam, fg
     if fam == "hub":
         mega = tuple(float(x) for x in rng.choice([0.3, 0.1, 0.03, 0.01, 0.002], size=int(rng.integers(0, 4)), replace=False))
         return fam, S.hub_dag(max(2, layers), width, n_in=int(rng.integers(1, 50)), n_const=int(rng.integers(0, 9)), window=int(rng.integers(1, 70)), mix=mix,
