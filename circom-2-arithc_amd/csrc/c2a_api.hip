@@ -1634,12 +1634,14 @@ static int eval_levels(c2a_ctx* c) {
     if (!n) return C2A_OK;
     C2A_LAUNCH_NOSYNC(k_eval_inverse, grid_for(n, 4096), kThreads, s, n, c->sorted_r.as<u32>(), c->ev_spos.as<u32>());
     HIP_TRY(hipMemsetAsync(c->ev_lcount.p, 0, ((size_t)L + 1) * 4, s));
-    C2A_LAUNCH_NOSYNC(k_level_hist, grid_for(n, 4096), kThreads, s, n, (const uint4*)c->meta.as<uint4>(), c->ev_lcount.as<u32>());
+    u32 lbits = 1;
+    while (lbits < 32 && (1ull << lbits) <= (u64)L) ++lbits;      // (bits that tell two levels apart: the wave's lanes are matched by them)
+    C2A_LAUNCH(k_level_hist, grid_for(n, 4096), kThreads, s, n, (const uint4*)c->meta.as<uint4>(), c->ev_lcount.as<u32>(), lbits);
     int r = scan_exclusive<u32>(c, c->ev_lcount.as<u32>(), c->ev_lbase.as<u32>(), L);
     if (r) return r;
     HIP_TRY(hipMemsetAsync(c->ev_lcount.p, 0, ((size_t)L + 1) * 4, s));
-    C2A_LAUNCH_NOSYNC(k_level_scatter, grid_for(n, 4096), kThreads, s, n, (const uint4*)c->meta.as<uint4>(),
-                      (const u32*)c->ev_lbase.as<u32>(), c->ev_lcount.as<u32>(), c->ev_lorder.as<u32>());
+    C2A_LAUNCH(k_level_scatter, grid_for(n, 4096), kThreads, s, n, (const uint4*)c->meta.as<uint4>(),
+               (const u32*)c->ev_lbase.as<u32>(), c->ev_lcount.as<u32>(), c->ev_lorder.as<u32>(), lbits);
     return C2A_OK;
 }
 

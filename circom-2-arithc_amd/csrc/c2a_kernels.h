@@ -1216,14 +1216,44 @@ __global__ void k_eval_init(u32 wire_count, u32 width, u32 M, u64 out_base, u64 
 
 // one level: lane per (gate, vector) for the arithmetic side, lane per gate for its boolean template
 // level lists for the level-parallel evaluation: counting sort of the tree nodes by reverse Kahn level (meta.w >> 1)
-__global__ void k_level_hist(u32 n, const uint4* __restrict__ meta, u32* lcount) {
-    for (u64 i = gtid(); i < n; i += gstride()) atomicAdd(&lcount[meta[i].w >> 1], 1u);
+// ONE ticket per lane on cnt[key] — the lanes of a wave that name the SAME key take one range together: the gates of a level of a wide
+// and shallow circuit (10 M gates in ten levels) are a million tickets on one word, and atomics on one word go one at a time (~11 ns).
+// The lanes' keys are matched bit by bit (a ballot per bit, stopping as soon as every lane is alone); every group's first lane draws
+// for its group, all of them in the same instruction.  All lanes of the wave call this together (valid: this lane wants a ticket).
+// (Off the metric's path — the level lists of the evaluator, the verifier and the prune pass — where 300 instructions per wave and round
+// do not matter; k_deps finds its hot producers another way: c2a_kernels.h HOT PRODUCERS.)
+__device__ __forceinline__ u32 wave_ticket(u32* cnt, u32 key, bool valid, u32 lane, u32 nbits) {
+    u64 peers = __ballot(valid);
+    for (u32 b = 0; b < nbits; ++b) {
+        const bool bit = (key >> b) & 1u;
+        const u64 m = __ballot(valid && bit);
+        peers &= bit ? m : ~m;
+        if ((b & 3u) == 3u && __ballot(valid && __popcll(peers) > 1) == 0ull) break;
+    }
+    const u64 lt_mask = (1ull << lane) - 1ull;
+    const u32 leader = valid ? (u32)__builtin_ctzll(peers) : lane;
+    u32 base = 0;
+    if (valid && leader == lane) base = atomicAdd(&cnt[key], (u32)__popcll(peers));
+    base = (u32)__shfl((int)base, (int)leader, 64);
+    return base + (u32)__popcll(peers & lt_mask);
 }
-__global__ void k_level_scatter(u32 n, const uint4* __restrict__ meta, const u32* __restrict__ lbase,
-                                u32* cursor, u32* lorder) {
-    for (u64 i = gtid(); i < n; i += gstride()) {
-        const u32 lv = meta[i].w >> 1;
-        lorder[lbase[lv] + atomicAdd(&cursor[lv], 1u)] = (u32)i;
+__global__ void __launch_bounds__(kThreads) k_level_hist(u32 n, const uint4* __restrict__ meta, u32* lcount, u32 nbits) {
+    const u32 lane = threadIdx.x & 63u;
+    for (u64 ib = gtid() - lane; ib < n; ib += gstride()) {
+        const u64 i = ib + lane;
+        const bool live = i < n;
+        (void)wave_ticket(lcount, live ? meta[i].w >> 1 : 0u, live, lane, nbits);
+    }
+}
+__global__ void __launch_bounds__(kThreads) k_level_scatter(u32 n, const uint4* __restrict__ meta, const u32* __restrict__ lbase,
+                                u32* cursor, u32* lorder, u32 nbits) {
+    const u32 lane = threadIdx.x & 63u;
+    for (u64 ib = gtid() - lane; ib < n; ib += gstride()) {
+        const u64 i = ib + lane;
+        const bool live = i < n;
+        const u32 lv = live ? meta[i].w >> 1 : 0u;
+        const u32 slot = wave_ticket(cursor, lv, live, lane, nbits);
+        if (live) lorder[lbase[lv] + slot] = (u32)i;
     }
 }
 
