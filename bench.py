@@ -95,7 +95,7 @@ def load_pmc(n, width):
     return {}
 
 
-def live_pmc(args, timeout_s=240):
+def live_pmc(args, timeout_s=150):
     """HBM traffic of THIS command on THIS box: two child runs of the same step under `rocprofv3 --kernel-trace --pmc` (FETCH_SIZE, then
     WRITE_SIZE: the TCC block cannot hold both in one pass), summarised per kernel under the byte model calibrated in
     profiles/r06_pmc_calibration.txt (every read request is a 128-byte line: read bytes = 2 x FETCH_SIZE; WRITE_SIZE exact).  Returns the
@@ -106,6 +106,9 @@ def live_pmc(args, timeout_s=240):
     import subprocess
     import tempfile
     if not shutil.which("rocprofv3"):
+        return None
+    # (this run may itself be a child of rocprofv3 — the driver profiling the bench, tools/kstat.sh —: no profiler inside a profiler)
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None
     import csv
     import glob
