@@ -84,6 +84,7 @@ struct c2a_ctx {
     bool fallback_logged = false;
     bool numbering_walk = false;   // C2A_NUMBERING_WALK=1: never the positional numbering (tests and A/B runs: the walk in sorted order on any circuit)
     u32 debug_peel_abort = 0;      // tests only (c2a_debug_peel_abort): this many dataflow launches are treated as given up
+    bool hot_every_forced = false; // (c2a_debug_hot_every was called: the tests' threshold, whatever the gate count)
     u32 hot_every = kHotEvery;     // k_deps: the consumer ticket that makes a producer "hot" (c2a_debug_hot_every lowers it for the tests)
 
     // problem
@@ -335,8 +336,15 @@ int do_prep(c2a_ctx* c, bool for_peel = true) {
     C2A_LAUNCH_NOSYNC(k_dup_clear, 512, kThreads, s, c->n_nodes, (const u32*)dup, c->prod1.as<u32>());
     C2A_LAUNCH_NOSYNC(k_dup_producer, 512, kThreads, s, n, (const u32*)dup, (const u32*)c->out.as<u32>(), c->prod1.as<u32>());
     int r;
-    C2A_LAUNCH(k_deps, G, kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->out.as<u32>(), c->op.as<u8>(), dup, c->prod1.as<u32>(), (const u8*)c->nflag.as<u8>(), c->orig.as<u32>(),
-                      c->gate4.as<uint4>(), c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>(), c->gflag.as<u8>(), c->scalars.as<u32>() + SC_HOT, c->hot_every);
+    // k_deps finds its HOT producers on the way (c2a_kernels.h): a wave must go round several times for what one round finds to serve the
+    // next — at least eight rounds per thread (a 1 M-gate graph in one round of a million threads took every ticket one by one: a node
+    // read by a tenth of its gates was 1.1 ms) —, and a producer counts as hot from a 64th of the gates on (at most from its 16 384th
+    // consumer, at least from its 1 024th)
+    u32 hot_every = c->hot_every;
+    if (!c->hot_every_forced) { hot_every = 1024; while (hot_every < kHotEvery && (u64)hot_every * 128 <= n) hot_every *= 2; }
+    const u32 G_deps = std::min<u32>(G, grid_for(((u64)n + 7) / 8, 4096));
+    C2A_LAUNCH(k_deps, G_deps, kThreads, s, n, c->lh.as<u32>(), c->rh.as<u32>(), c->out.as<u32>(), c->op.as<u8>(), dup, c->prod1.as<u32>(), (const u8*)c->nflag.as<u8>(), c->orig.as<u32>(),
+                      c->gate4.as<uint4>(), c->dep0.as<u32>(), c->dep1.as<u32>(), c->cons_cnt.as<u32>(), c->eslot.as<u32>(), c->gflag.as<u8>(), c->scalars.as<u32>() + SC_HOT, hot_every);
     if (!for_peel) return C2A_OK;
     r = scan_exclusive<u32>(c, c->cons_cnt.as<u32>(), c->cons_off.as<u32>(), n, desc + R.cons);
     if (r) return r;
@@ -774,6 +782,10 @@ int do_assign_wires(c2a_ctx* c, bool defer_readback = false) {
     const bool inputs_ride = c->positional && c->n;      // (the positional numbering's first launch takes the input wires along)
     if (c->n_in && !inputs_ride) C2A_LAUNCH_NOSYNC(k_input_wires, grid_for(c->n_in, 1024), kThreads, s, c->n_in, c->in_nodes.as<u32>(), c->node_wire1.as<u32>());
     const u32 G = grid_for(n, 4096);
+    // (the first-seen minimum looks before it draws: a thread must go round several times for the look to find something — eight rounds;
+    // in ONE round every reader of a shared constant looks at the same time, sees nothing and draws: 123 000 readers in a 410 000-gate
+    // circuit were 0.85 ms)
+    const u32 G8 = std::min<u32>(G, grid_for(((u64)n + 7) / 8, 4096));
     const u32* n_mid_p;
     int r;
     const u32 PW = (n + 31u) / 32u;                 // 32-position blocks of the event bits
@@ -788,10 +800,10 @@ int do_assign_wires(c2a_ctx* c, bool defer_readback = false) {
         if (!cleared) HIP_TRY(hipMemsetAsync(c->pblk.p, 0, (size_t)PW * 16, s));
         if (c->sorted_ready) {                          // (the staged calls: positions = the inverse of the order the caller has been given)
             C2A_LAUNCH_NOSYNC(k_eval_inverse, G, kThreads, s, n, c->sorted_r.as<u32>(), c->pos_r.as<u32>());
-            C2A_LAUNCH_NOSYNC(k_pos_first<true>, G, kThreads, s, S, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), c->pos_r.as<u32>(), c->first.as<u32>(),
+            C2A_LAUNCH_NOSYNC(k_pos_first<true>, G8, kThreads, s, S, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), c->pos_r.as<u32>(), c->first.as<u32>(),
                               c->n_in, (const u32*)c->in_nodes.as<u32>(), c->node_wire1.as<u32>());
         } else
-            C2A_LAUNCH_NOSYNC(k_pos_first<false>, G, kThreads, s, S, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), c->pos_r.as<u32>(), c->first.as<u32>(),
+            C2A_LAUNCH_NOSYNC(k_pos_first<false>, G8, kThreads, s, S, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), c->pos_r.as<u32>(), c->first.as<u32>(),
                               c->n_in, (const u32*)c->in_nodes.as<u32>(), c->node_wire1.as<u32>());
         C2A_LAUNCH_NOSYNC(k_pos_bits, G, kThreads, s, n, (const u8*)c->gflag.as<u8>(), (const uint4*)c->gate4.as<uint4>(), (const u32*)c->pos_r.as<u32>(), (const u32*)c->first.as<u32>(),
                           c->pblk.as<u32>());
@@ -803,7 +815,7 @@ int do_assign_wires(c2a_ctx* c, bool defer_readback = false) {
         c->nmid_add = n;
     } else {
         if (n) {
-            C2A_LAUNCH_NOSYNC(k_first_seen, G, kThreads, s, n, c->sorted_r.as<u32>(), (const uint4*)c->gate4.as<uint4>(),
+            C2A_LAUNCH_NOSYNC(k_first_seen, G8, kThreads, s, n, c->sorted_r.as<u32>(), (const uint4*)c->gate4.as<uint4>(),
                               (const u32*)c->prod1.as<u32>(), (const u32*)(c->scalars.as<u32>() + SC_DUP), c->first.as<u32>());
             C2A_LAUNCH_NOSYNC(k_new_wire_flags, G, kThreads, s, n, c->sorted_r.as<u32>(), (const uint4*)c->gate4.as<uint4>(),
                               c->first.as<u32>(), c->nflag.as<u8>(), (const u32*)c->prod1.as<u32>(),
@@ -2046,7 +2058,7 @@ int c2a_debug_set_build_no(c2a_ctx* c, uint32_t build_no) {
 
 int c2a_debug_hot_every(c2a_ctx* c, uint32_t ticket) {
     if (!c || ticket < 2 || (ticket & (ticket - 1)) != 0) return C2A_ERR_ARG;
-    c->hot_every = ticket;
+    c->hot_every = ticket; c->hot_every_forced = true;
     return C2A_OK;
 }
 

@@ -52,7 +52,7 @@ def run(minutes=2.0, seed=1, max_gates=3_000_000, be=None, log=print):
     be = be or c2a.Backend(0)
     blk = sha_block()
     t_end = time.time() + 60 * minutes
-    it, per, relays = 0, {}, 0
+    it, per, relays, slow = 0, {}, 0, []
     try:
         while time.time() < t_end:
             fam, fg = draw(rng, max_gates, blk)
@@ -65,7 +65,14 @@ def run(minutes=2.0, seed=1, max_gates=3_000_000, be=None, log=print):
                     assert be.checksum(nm) == bm.checksum_host(arr), (fam, nm, fg.n, fg.layers, fg.layer_width, rep)
                 nw1 = ((exp.node_wire.astype(np.uint64) + 1) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
                 assert be.checksum("node_wire1") == bm.checksum_host(nw1), (fam, "node_wire", fg.n, rep)
-            relays += be.stats()["n_relays"]
+            st = be.stats()
+            relays += st["n_relays"]
+            # TIMING against a model of what a build should cost — launches + the depth bound + throughput —: a
+            # ratio far above 1 is a performance cliff of the kind round 6 found by hand (a hub, a shared constant, a shallow level)
+            t = be.timings()
+            model = 0.45 + st["levels"] * 0.0016 + fg.n * 1.2e-6
+            slow.append((t["build_total"] / model, fam, fg.n, st["levels"], fg.layers, fg.layer_width, round(t["build_total"], 3),
+                         {k: round(t[k], 3) for k in ("prep", "peel", "order", "wires", "emit")}, st["n_relays"], st["path_chunks"]))
             if it % 7 == 0:
                 np.testing.assert_array_equal(be.topo_sort(), exp.sorted)
                 nw, wc = be.assign_wires()
@@ -76,6 +83,10 @@ def run(minutes=2.0, seed=1, max_gates=3_000_000, be=None, log=print):
         if own:
             be.close()
     log(f"{it} graphs == oracle in {minutes} min (seed {seed}, up to {max_gates} gates): " + ", ".join(f"{k} {v}" for k, v in sorted(per.items())) + f"; {relays} relays ran")
+    slow.sort(key=lambda r: r[0], reverse=True)
+    log("slowest builds against the model 0.45 ms + 1.6 us x levels + 1.2 ns x gates (ratio, family, gates, levels, layers, width, build ms, stages, relays, chunks):")
+    for row in slow[:8]:
+        log("   %.2f %s" % (row[0], row[1:]))
     return it, per
 
 
