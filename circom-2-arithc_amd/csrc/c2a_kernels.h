@@ -429,8 +429,9 @@ __global__ void __launch_bounds__(kThreads) k_root_bits(u32 n, const u32* __rest
     if (threadIdx.x < 64) {
         const u32 t = threadIdx.x;
         u32 done = t < kAcctShards ? ctl[CTL_PROC + t * kAcctStride] : 0u, lvl = t < kAcctShards ? ctl[CTL_PROC + t * kAcctStride + 1] : 0u;
+        u32 rereads = (blockIdx.x == 0 && t < kAcctShards) ? ctl[CTL_PROC + t * kAcctStride + 2] : 0u;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { done += __shfl_xor(done, off, 64); const u32 o = __shfl_xor(lvl, off, 64); lvl = o > lvl ? o : lvl; }
+        for (int off = 32; off >= 1; off >>= 1) { done += __shfl_xor(done, off, 64); rereads += __shfl_xor(rereads, off, 64); const u32 o = __shfl_xor(lvl, off, 64); lvl = o > lvl ? o : lvl; }
         if (t == 0) {
             // (the relays of the hubs are steps of the launch too: n + *relay_total when nothing is left behind; reported: gates done = steps
             // minus relays — a relay that did not run has a gate above it that did not either)
@@ -438,7 +439,7 @@ __global__ void __launch_bounds__(kThreads) k_root_bits(u32 n, const u32* __rest
             const u32 ok = (ctl[CTL_ABORT] == 0u && done == n + relays) ? 1u : 0u;
             s_ok = ok;
             if (blockIdx.x == 0) {
-                post[0] = done - relays; post[1] = lvl; post[2] = ctl[CTL_ABORT]; post[3] = ctl[CTL_REREADS]; post[4] = *edges; post[5] = *dup; post[6] = ctl[CTL_NEEDDEEP]; post[7] = relays;
+                post[0] = done - relays; post[1] = lvl; post[2] = ctl[CTL_ABORT]; post[3] = rereads; post[4] = *edges; post[5] = *dup; post[6] = ctl[CTL_NEEDDEEP]; post[7] = relays;
                 *ok_out = ok;                    // (what the rest of the order stage, queued right behind, goes by)
             }
         }

@@ -102,6 +102,16 @@
 // 5.88 -> 5.86 (its tail: the end of the launch is seen sooner); 1 unit: no better, 16: half the gain (tools/ab_configs.sh)
 #define C2A_POLL_CAP 4
 #endif
+#ifndef C2A_HB_MASK
+// a wave tells the watchdog that the launch is alive once in (mask + 1) steps: an atomic on the ONE line every waiting wave looks at (a waiting
+// wave gives up after 3 s without one; a step is ~1 us).  Once in 64 steps -> once in 512: SHA-256 Merkle tree of 290 blocks 5.73 -> 5.55 ms, of
+// 2 900 blocks 12.7 -> 12.5, the headline's k_peel 5.89 -> 5.84 (tools/ab_family.sh, ab_configs.sh).  (The emulation counts looks, not time.)
+#ifdef C2A_EMULATE
+#define C2A_HB_MASK 63u
+#else
+#define C2A_HB_MASK 511u
+#endif
+#endif
 #ifndef C2A_SCAN_MASK
 // one waiting wave in 64 reads the launch's 192 counter lines (is it over?  is an entry stranded?) every (mask + 1) looks at its slot = ~14 us;
 // every wave does once in 16 384 looks (~1.8 ms: ending never depends on a particular wave being resident).  Per 32 / 128 / 512 looks: SHA-256 x 8
@@ -315,11 +325,17 @@ __device__ __attribute__((noinline)) u64 peel_reread(const u64* node_base, u32 e
         u64 badm = __ballot(tag_stale_or_never(epoch, w));
         if ((badm & 1ull) == 0) badm &= needed_lanes((u32)rdlane64(w, 0));          // (word 0 is there: its depth says what else must be)
         if (badm == 0 || ++polls > kPollLimit) break;
-        if ((polls & 63u) == 1u && __ballot(ld_a32(&ctl[CTL_ABORT]) != 0u) != 0ull) break;       // the launch is being given up: nobody waits any more
+        // (the look at ABORT travels WITH the next read of the record, not in front of it: one round trip, not two)
+        u32 ab = 0;
+        if ((polls & 63u) == 1u) ab = ld_a32(&ctl[CTL_ABORT]);
         peel_sleep(polls < 8 ? 4 : 16);
         w = ld_nw(p);
+        if (__ballot(ab != 0u) != 0ull) break;       // the launch is being given up: nobody waits any more
     }
-    if (polls && lane == 0) atomicAdd(&ctl[CTL_REREADS], polls);
+    // (counted in the workgroup's own part of the accounts, word 2: ONE word for all of them sat on the line ABORT and DONE live on,
+    // which every waiting wave reads — in a graph where the waves wait for one another's records (strictly layered: STRICT LAYERS in
+    // DESIGN.md) that was an atomic per re-read on the line everybody polls)
+    if (polls && lane == 0) atomicAdd(&ctl[CTL_PROC + (blockIdx.x & (kAcctShards - 1u)) * kAcctStride + 2], polls);
     return w;
 }
 // the plain launch has met a node that fills its chunk: tell the host (which runs the DEEP build) and end the launch
@@ -1201,7 +1217,7 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             const u64 my_w = (u64)w_lo | ((u64)w_hi << 32);
             st_nw(&A.node[(u64)gc * kNodeWords + lane], my_w);
             ++processed;
-            if (C2A_UNLIKELY((processed & 63u) == 0) && lane == 0) atomicAdd(&A.ctl[CTL_HEARTBEAT], 1u);
+            if (C2A_UNLIKELY((processed & C2A_HB_MASK) == 0) && lane == 0) atomicAdd(&A.ctl[CTL_HEARTBEAT], 1u);
             if (STATS) {
                 const ull ph4 = c2a_now();
                 if (dt_trace && lane == 0) {

@@ -364,6 +364,8 @@ def family(name: str, n_target: int = 1_000_000, seed: int = SEED) -> FlatGates:
         return layered_dag(L, Wd, window=L, seed=seed)
     if name == "forest":
         return reduction_forest(L * Wd, width=Wd, seed=seed)
+    if name == "strict":              # STRICT LAYERS: both operands out of the layer right above (20 inputs, 4 constants: ~1 % of the rh), so every
+        return layered_dag(L, Wd, n_in=20, n_const=4, window=1, seed=seed)      # layer waits for ALL of the one below it — a wave per gate, all in step
     if name == "const_hub":           # two named constants that a tenth / a hundredth of ALL gates read (one node per literal and template context: process.rs:558-579)
         return shared_constants(layered_dag(L, Wd, seed=seed), (0.1, 0.01), seed)
     raise KeyError(name)

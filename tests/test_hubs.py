@@ -205,7 +205,7 @@ def test_random_graphs_with_hubs(backend, orc):
     assert relays > 50
 
 
-FAMILIES = ["hub", "hub_mild", "window_all", "forest", "const_hub"]
+FAMILIES = ["hub", "hub_mild", "window_all", "forest", "const_hub", "strict"]
 
 
 @pytest.mark.parametrize("name", FAMILIES)

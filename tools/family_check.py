@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """usage: python tools/family_check.py [--n GATES] [--reps R] [--emul] [--walk] [--sha-tiles] FAMILY ...
 
-The graph families beyond layered_dag (synth.family: hub, hub_mild, window_all, forest; sha_chain / sha_tree = tilings of the
+The graph families beyond layered_dag (synth.family: hub, hub_mild, window_all, forest, const_hub, strict; sha_chain / sha_tree = tilings of the
 REAL SHA-256 block's flat list) through c2a_build_circuit, every result array against the oracle (checksums of sorted ids, the
 emitted circuit and node -> wire), and what the build's stages took: one line per family.  --emul: the host-emulation build of
 the library (CPU boxes, small sizes); --walk: the general wire numbering as well."""

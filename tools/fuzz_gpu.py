@@ -15,7 +15,7 @@ from oracle import oracle as orc
 
 def draw(rng, max_gates, sha_blk):
     S = c2a.synth
-    fam = str(rng.choice(["layered", "layered", "hub", "hub", "forest", "window_all", "sha"]))
+    fam = str(rng.choice(["layered", "layered", "hub", "hub", "forest", "window_all", "strict", "sha"]))
     seed = int(rng.integers(1 << 30))
     while True:
         layers = int(rng.choice([1, 2, 3, 7, 40, 200, 1000, 6000]))
@@ -39,6 +39,9 @@ def draw(rng, max_gates, sha_blk):
     if fam == "forest":
         return fam, S.reduction_forest(max(1, layers * width), width=max(1, width), n_in=int(rng.integers(1, 50)), n_const=int(rng.integers(0, 9)), mix=mix, seed=seed,
                                        p_merge=float(rng.choice([0.1, 0.4, 0.8])), p_chain=float(rng.choice([0.0, 0.15, 0.3])), permute=bool(rng.integers(2)))
+    if fam == "strict":       # (both operands out of the layer right above, or nearly: every layer waits for all of the one below)
+        return fam, S.layered_dag(layers, width, n_in=int(rng.integers(1, 30)), n_const=int(rng.integers(0, 5)), window=int(rng.integers(1, 3)), mix=mix, seed=seed,
+                                  permute=bool(rng.integers(2)))
     if fam == "window_all":
         return fam, S.layered_dag(layers, width, n_in=int(rng.integers(1, 50)), n_const=int(rng.integers(0, 9)), window=layers, mix=mix, seed=seed)
     copies = int(rng.integers(1, max(2, min(40, max_gates // 3448))))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""usage (on the GPU box): python tools/peel_trace.py [layers width] — where the dataflow launch spends its critical path.
+"""usage (on the GPU box): python tools/peel_trace.py [layers width [window [n_in]]] — where the dataflow launch spends its critical path.
 Runs the statistics build once with C2A_PEEL_TRACE (every gate notes when its step started, how it came to its wave — chain step,
 popped from a hand-off array, seed — and when its record was stored), then walks the dependency graph: for every gate the consumer
 whose record was stored LAST is its critical consumer; from the gate that finished last back to a sink along critical consumers =
@@ -14,11 +14,13 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 layers = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 width = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+window = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+n_in = int(sys.argv[4]) if len(sys.argv) > 4 else 4096      # (few inputs: nearly every rh is a gate of the window)
 d = tempfile.mkdtemp()
 os.environ["C2A_PEEL_STATS"] = "1"
 os.environ["C2A_PEEL_TRACE"] = d
 c2a = importlib.import_module("circom-2-arithc_amd")
-fg = c2a.synth.layered_dag(layers, width, seed=c2a.synth.SEED)
+fg = c2a.synth.layered_dag(layers, width, window=window, n_in=n_in, n_const=64 if n_in >= 64 else 4, seed=c2a.synth.SEED)
 be = c2a.Backend(0)
 be.load_gates(fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes)
 be.topo_sort(fetch=False)

@@ -12,7 +12,7 @@ for r in $(seq $rounds); do
 done
 # the families beyond layered_dag at 10 M gates (synth.family; tools/family_check.py: every result array against the oracle, k_peel ms per shape)
 for r in $(seq $rounds); do
-  out=$(timeout 900 python $R/tools/family_check.py --n 10000000 --reps 2 hub_mild hub window_all forest sha_tree const_hub 2>&1)
+  out=$(timeout 900 python $R/tools/family_check.py --n 10000000 --reps 2 hub_mild hub window_all forest sha_tree const_hub strict 2>&1)
   echo "$out" | sed "s/^/$r /" | cut -c1-330
   case "$out" in *"failures: 0"*) ;; *) fail=$((fail+1));; esac
 done
