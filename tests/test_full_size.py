@@ -193,3 +193,21 @@ def test_hub_10m(orc, c2a):
         in0, in1, out, op = be.emit_gates()
         np.testing.assert_array_equal(sorted_ids, exp.sorted)
         _check_properties(fg, sorted_ids, in0, in1, out, node_wire, wire_count)
+
+
+def test_strict_layers_10m(orc, c2a):
+    """10 M gates in STRICT layers (synth.family("strict"): both operands out of the layer right above, so every layer waits for all of
+    the one below and a gate's other consumers are being worked on at the same time — 1.6 M record re-reads): the fused build against
+    the oracle by checksums, the levels exact, and the sort within four times the headline's per level (it was 10 us per level — 50 ms —
+    while every re-read did an atomic on the line all waiting waves poll: DESIGN.md 4.2, STRICT LAYERS; measured now: 11.3 ms)."""
+    fg = c2a.synth.family("strict", 10_000_000)
+    args = (fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes)
+    exp = orc.build_circuit(*args, mode=1)
+    with c2a.Backend(0) as be:
+        be.load_gates(*args)
+        for rep in range(2):
+            assert be.build_circuit() == exp.wire_count
+            _check_checksums(be, exp)
+        st, t = be.stats(), be.timings()
+        assert st["levels"] == 5000 and st["numbering_path"] == 1 and st["peel_rereads"] > 100_000, st
+        assert t["k_peel"] < 25.0, t          # ms

@@ -55,7 +55,7 @@ def run(minutes=2.0, seed=1, max_gates=3_000_000, be=None, log=print):
     be = be or c2a.Backend(0)
     blk = sha_block()
     t_end = time.time() + 60 * minutes
-    it, per, relays, slow = 0, {}, 0, []
+    it, per, relays, slow, hiccups = 0, {}, 0, [], []
     try:
         while time.time() < t_end:
             fam, fg = draw(rng, max_gates, blk)
@@ -74,6 +74,15 @@ def run(minutes=2.0, seed=1, max_gates=3_000_000, be=None, log=print):
             # ratio far above 1 is a performance cliff of the kind round 6 found by hand (a hub, a shared constant, a shallow level)
             t = be.timings()
             model = 0.45 + st["levels"] * 0.0016 + fg.n * 1.2e-6
+            first = t["build_total"]
+            if first > 2.0 * model:       # (a cliff shows every time; a hiccup of the box — the order stage has a host round trip in it — does not: build again)
+                for _ in range(3):
+                    be.build_circuit()
+                    t2 = be.timings()
+                    if t2["build_total"] < t["build_total"]:
+                        t = t2
+                if t["build_total"] <= 2.0 * model:
+                    hiccups.append((round(first, 3), round(t["build_total"], 3), fam, fg.n))
             slow.append((t["build_total"] / model, fam, fg.n, st["levels"], fg.layers, fg.layer_width, round(t["build_total"], 3),
                          {k: round(t[k], 3) for k in ("prep", "peel", "order", "wires", "emit")}, st["n_relays"], st["path_chunks"]))
             if it % 7 == 0:
@@ -90,6 +99,7 @@ def run(minutes=2.0, seed=1, max_gates=3_000_000, be=None, log=print):
     log("slowest builds against the model 0.45 ms + 1.6 us x levels + 1.2 ns x gates (ratio, family, gates, levels, layers, width, build ms, stages, relays, chunks):")
     for row in slow[:8]:
         log("   %.2f %s" % (row[0], row[1:]))
+    log(f"builds above twice the model that were not when built again (first ms, best of three more, family, gates): {hiccups}")
     return it, per
 
 
