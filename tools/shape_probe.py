@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""usage (on the GPU box): python tools/shape_probe.py — which property of a layered graph the sort's time follows: gate ids permuted or not, window 1 or 64,
+fresh constants, extra outputs (1000 x 2048 gates each), k_peel / peel / build ms of the third build."""
 import importlib, sys, itertools
 sys.path.insert(0, "/root/repo")
 c2a = importlib.import_module("circom-2-arithc_amd")

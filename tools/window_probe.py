@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""usage (on the GPU box): python tools/window_probe.py [window [layers [width]]] — layered_dag with 20 inputs and the rh operand out of the last
+`window` layers (1 = strict layers: DESIGN.md 4.2) through c2a_build_circuit twice: k_peel / peel / build ms and the record re-reads of the warm run.
+Knobs of the launch come from the environment (C2A_PEEL_WAVES, C2A_PEEL_FIFOS, C2A_PEEL_RESERVE, C2A_PEEL_STATS)."""
 import importlib, sys
 sys.path.insert(0, "/root/repo")
 c2a = importlib.import_module("circom-2-arithc_amd")
