@@ -251,7 +251,9 @@ def test_gpu_verifier_agrees_and_detects_faults(backend, c2a, width):
     arithmetic wire x 64 vectors against its boolean wires.  It must report 0 on the real circuit and > 0 as soon
     as one boolean gate is corrupted."""
     mix = c2a.synth.MIX_ALL if width <= 8 else tuple(m for m in c2a.synth.MIX_ALL if m[0] != "APow")
-    fg = c2a.synth.layered_dag(14, 18, n_in=8, n_const=3, window=3, mix=mix, seed=900 + width)
+    # (under the emulation a divider at width 64 is 33 000 boolean gates walked by fibres: a third of the gates there, all of them on the hardware)
+    layers = 5 if width >= 32 and "emulation" in backend.version else 14
+    fg = c2a.synth.layered_dag(layers, 18, n_in=8, n_const=3, window=3, mix=mix, seed=900 + width)
     _load(backend, fg)
     backend.boolify(width)
     checked, bad = backend.verify_boolify(seed=42)
@@ -345,7 +347,9 @@ def test_multi_device_boolify_equals_the_single_device_result(multi_backend, orc
     if width == 32 and "emulation" in be.version and be._test_shards > 2:
         pytest.skip("the emulator takes 45 s for this circuit at width 32: the two-device context covers it there, every shard count runs on the hardware")
     mix = tuple(m for m in c2a.synth.MIX_ALL if m[0] != "APow")
-    fg = c2a.synth.layered_dag(14, 23, n_in=16, n_const=4, window=4, mix=mix, seed=7 + width)
+    # (the emulator walks a width-32 divider's 8 193 gates by fibres: a smaller circuit there, this one on the hardware)
+    layers, wd = (6, 14) if width == 32 and "emulation" in be.version else (14, 23)
+    fg = c2a.synth.layered_dag(layers, wd, n_in=16, n_const=4, window=4, mix=mix, seed=7 + width)
     for rerun in range(2):                                  # same buffers twice
         _load(be, fg)
         info = be.boolify(width)

@@ -78,11 +78,15 @@ def main():
                 t = be.timings()
                 if best is None or t["build_total"] < best["build_total"]:
                     best = t
+            t0 = time.perf_counter()
+            info = be.boolify(32)
+            wall_first = (time.perf_counter() - t0) * 1e3
+            tb_first = be.timings()
             info = be.boolify(32)
             tb = be.timings()
             st = be.stats()
             print(f"{name:26s} n {fg.n:9d} == oracle x3 | build {best['build_total']:9.3f} ms: prep {best['prep']:.3f} peel {best['peel']:.3f} (k_peel {best['k_peel']:.3f}) "
-                  f"order {best['order']:.3f} wires {best['wires']:.3f} emit {best['emit']:.3f} | boolify {tb['boolify_total']:.3f} ms ({info.n_gates} gates) | levels {st['levels']} "
+                  f"order {best['order']:.3f} wires {best['wires']:.3f} emit {best['emit']:.3f} | boolify {tb['boolify_total']:.3f} ms = prep {tb['bool_prep']:.3f} + map {tb['bool_map']:.3f} (first call on this graph: {tb_first['boolify_total']:.1f} ms of GPU time, {wall_first:.1f} ms on the host's clock; {info.n_gates} gates) | levels {st['levels']} "
                   f"depth {st['max_depth']} chunks {st['path_chunks']} roots {st['n_roots']} rereads {st['peel_rereads']} relays {st['n_relays']} path {st['numbering_path']} | "
                   f"cpu oracle {t_cpu:.0f} ms", flush=True)
         except Exception as e:  # noqa: BLE001
