@@ -20,7 +20,12 @@ d = tempfile.mkdtemp()
 os.environ["C2A_PEEL_STATS"] = "1"
 os.environ["C2A_PEEL_TRACE"] = d
 c2a = importlib.import_module("circom-2-arithc_amd")
-fg = c2a.synth.layered_dag(layers, width, window=window, n_in=n_in, n_const=64 if n_in >= 64 else 4, seed=c2a.synth.SEED)
+if os.environ.get("PEEL_TRACE_SHA"):       # PEEL_TRACE_SHA=chain:8 / tree:290 — a tiling of the real SHA-256 block instead (tools/family_check.py)
+    from tools.family_check import sha_block
+    shape, copies = os.environ["PEEL_TRACE_SHA"].split(":")
+    fg = c2a.synth.tile_block(*sha_block(), copies=int(copies), shape=shape, seed=c2a.synth.SEED, permute=False)
+else:
+    fg = c2a.synth.layered_dag(layers, width, window=window, n_in=n_in, n_const=64 if n_in >= 64 else 4, seed=c2a.synth.SEED)
 be = c2a.Backend(0)
 be.load_gates(fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes)
 be.topo_sort(fetch=False)
