@@ -353,15 +353,20 @@ __device__ __attribute__((noinline)) bool deep_less(const u64* node_base, u32 ep
     u32 below_a = C2A_NONE, below_b = C2A_NONE;
     bool a_own = true, b_own = true;
     u32 pa = (u32)rdlane64(wa_in, 1), pb = (u32)rdlane64(wb_in, 1);      // cprev of the node currently held in a / b
-    while (ia > ib) { below_a = a; a = pa; --ia; lena = kChunkBits; a_own = false; if (ia) pa = C2A_CPREV(a); }
-    while (ib > ia) { below_b = b; b = pb; --ib; lenb = kChunkBits; b_own = false; if (ib) pb = C2A_CPREV(b); }
+    // (a hop is a dependent memory round trip, and a tree 10^7 deep has 2 600 chunk levels: a long climb is work too — the watchdog goes by this)
+    u32 hops = 0;
+#define C2A_HOP() do { if (C2A_UNLIKELY((++hops & 255u) == 0)) { if (lane == 0) atomicAdd(&ctl[CTL_HEARTBEAT], 1u); wave_join(); } } while (0)
+    while (ia > ib) { below_a = a; a = pa; --ia; lena = kChunkBits; a_own = false; if (ia) pa = C2A_CPREV(a); C2A_HOP(); }
+    while (ib > ia) { below_b = b; b = pb; --ib; lenb = kChunkBits; b_own = false; if (ib) pb = C2A_CPREV(b); C2A_HOP(); }
     while (ia > 0 && a != b) {
         if (pa == pb) break;
         below_a = a; below_b = b;
         a = pa; b = pb; --ia;
         lena = lenb = kChunkBits; a_own = b_own = false;
         if (ia) { pa = C2A_CPREV(a); pb = C2A_CPREV(b); }
+        C2A_HOP();
     }
+#undef C2A_HOP
     if (a == b) {      // one node is the chunk-boundary ancestor of the other: the other's next label decides
         if (below_a != C2A_NONE) return C2A_BIT0(below_a) < lb;
         return la < C2A_BIT0(below_b);
