@@ -66,8 +66,11 @@ struct c2a_ctx {
     u32 peel_sinks_blocks = 4096;  // grid cap of the sinks pass (latency-bound per thread: two dependent round trips per sink)
     u32 peel_waves = 8;            // dataflow launch: single-wave workgroups per CU (clamped by the occupancy query)
     u32 peel_fifos = 64;           // dataflow launch: hand-off arrays (a power of two <= 64)
-    u32 peel_reserve = 0;          // dataflow launch: reserve waves per CU (join the hand-off lines on demand only).  Measured with 8:
-                                   // 2 000 gates per level 14.0 -> 14.5 ms, 4 000: 12.0 -> 9.3, 8 000: 12.8 -> 7.8, 50 000: 10.9 -> 7.3
+    u32 peel_reserve = 8;          // dataflow launch: reserve waves per CU, parked until entries pile up in the hand-off arrays with nobody in line for them
+    u32 peel_release = 0;          // ... this many of them (0: twice the primary waves = 4 096.  10 M gates, k_peel ms without a reserve / with: a matrix
+                                   // product's 29 000 reduction chains 7.35 / 4.96, a butterfly 20 x 2^19 7.66 / 5.52, ten layers of 10^6 4.28 / 3.54, a Merkle tree of
+                                   // 2 900 SHA-256 blocks 12.5 / 11.0; the headline 5.85 / 5.88 (its backlog peaks at 2-4 000: at 2 048 the reserve comes in, 5.97),
+                                   // strict layers 11.2 / 11.3, hubs 5.9 / 6.05 (comes in), SHA-256 x 8 4.95 / 4.98; at 6 144 the Merkle tree stays at 12.7)
     size_t peel_slots = 0; u32 peel_waves_used = 0; bool peel_want_stats = false;      // of the launch now queued (peel_launch -> peel_result)
     u32 build_no = 0;              // number of the last producer map on this context (tag of its node-table records: k_producer)
     u32 peel_run = 0;              // number of the last dataflow run on this context (tag of its hand-off entries)
@@ -354,7 +357,7 @@ int do_prep(c2a_ctx* c, bool for_peel = true) {
 }
 
 // The grid of the dataflow launch: `peel_waves` single-wave workgroups per CU that take part from the start, plus
-// `peel_reserve` per CU that stay out of the hand-off lines until a pusher finds a line empty (c2a_peel.h), clamped to what
+// `peel_reserve` per CU that stay out of the hand-off lines until a backlog builds up in them (c2a_peel.h, THE RESERVE), clamped to what
 // fits the device at once (the launch is CORRECT with any grid — termination counts units of work, not waves — but
 // waves beyond residency only queue up behind it).
 u32 peel_grid(c2a_ctx* c, bool stats, u32* n_primary) {
@@ -420,8 +423,7 @@ int peel_launch(c2a_ctx* c) {
     }
     A.run = ++c->peel_run;
     A.n_primary = n_primary;
-    A.reserve_min = 4;
-    if (waves <= n_primary) A.reserve_min = 0;       // no reserve waves: pushers need not count the entries nobody was in line for
+    A.reserve_min = c->peel_release ? c->peel_release : 2u * n_primary;      // entries waiting with nobody in line for them that call the parked waves in (c2a_peel.h, THE RESERVE)
     A.fifo = c->aq_items.as<u64>(); A.q_pc = c->aq_pc.as<u64>(); A.ctl = c->pctl.as<u32>();
     cold.stats = nullptr; cold.q_time = nullptr; cold.p_time = nullptr; cold.t_trace = nullptr;
     const char* trace_dir = want_stats ? std::getenv("C2A_PEEL_TRACE") : nullptr;
@@ -946,6 +948,7 @@ int c2a_create(int n_devices, const int* device_ids, c2a_ctx** out) {
     if (const char* e = std::getenv("C2A_PEEL_SHALLOW")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 48) c->peel_shallow = v; }
     if (const char* e = std::getenv("C2A_PEEL_WAVES")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 32) c->peel_waves = v; }
     if (const char* e = std::getenv("C2A_PEEL_RESERVE")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v <= 32) c->peel_reserve = v; }
+    if (const char* e = std::getenv("C2A_PEEL_RELEASE")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1) c->peel_release = v; }
     if (const char* e = std::getenv("C2A_NUMBERING_WALK")) c->numbering_walk = e[0] == '1';
     if (const char* e = std::getenv("C2A_PEEL_FIFOS")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->peel_fifos = v; }
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return C2A_ERR_HIP; }

@@ -102,6 +102,9 @@
 // 5.88 -> 5.86 (its tail: the end of the launch is seen sooner); 1 unit: no better, 16: half the gain (tools/ab_configs.sh)
 #define C2A_POLL_CAP 4
 #endif
+#ifndef C2A_PARK_MONITORS
+#define C2A_PARK_MONITORS 512u      /* one parked wave in this many watches the hand-off arrays' backlog (a power of two) */
+#endif
 #ifndef C2A_HB_MASK
 // a wave tells the watchdog that the launch is alive once in (mask + 1) steps: an atomic on the ONE line every waiting wave looks at (a waiting
 // wave gives up after 3 s without one; a step is ~1 us).  Once in 64 steps -> once in 512: SHA-256 Merkle tree of 290 blocks 5.73 -> 5.55 ms, of
@@ -155,11 +158,11 @@ constexpr u32 kWatchdogChecks = 1u << 15;
 constexpr ull kWatchdogTicks = 300000000ull;      // of the constant 100 MHz clock
 // control block (u32 words; every hot word on its own 128-byte line)
 enum PeelCtl { CTL_PROCESSED = 0, CTL_MAXLEVEL = 1, CTL_ABORT = 2, CTL_REREADS = 3, CTL_DONE = 4, CTL_NEEDDEEP = 5, CTL_HEARTBEAT = 32, CTL_SEEDNEXT = 64,
-               CTL_BEGIN = 128, CTL_END = CTL_BEGIN + 64 * 32, CTL_DEMAND = CTL_END + 64 * 32,
+               CTL_BEGIN = 128, CTL_END = CTL_BEGIN + 64 * 32, CTL_PARK = CTL_END + 64 * 32,
                // gates done (word 0) and the highest level seen (word 1), in kAcctShards parts like BEGIN / END: thousands of
                // workgroups (sinks pass, level-1 pass) and every wave of the launch report here as they leave, and atomics on
                // ONE word go one at a time, ~10 ns each (measured: 4 096 workgroups x 3 such atomics were 120 us of the level-1 pass)
-               CTL_PROC = CTL_DEMAND + 64 * 32, CTL_WORDS = CTL_PROC + 64 * 32 };
+               CTL_PROC = CTL_PARK + 64 * 32, CTL_WORDS = CTL_PROC + 64 * 32 };
 constexpr u32 kPcStride = 16;               // u64 words between two hand-off arrays' ticket words (128 bytes)
 constexpr u32 kSlotWords = 16;              // a hand-off entry: words 0..7 gstat[2g], gstat[2g + 1]; 8..14 first consumers; 15 gate id
 constexpr u32 kSlotCons = 7;
@@ -235,8 +238,8 @@ struct PeelArgs {
     u64* fifo;                 // [n_fifos][q_cap][kSlotWords] slots (used once per run, no wrap-around: a wave spreads its pushes
                                // round robin and holds at most one unserved consumer ticket; never cleared: the tag says which run)
     u32 run;                   // tag of this run's hand-off entries (never zero)
-    u32 n_primary;             // waves beyond this many are a RESERVE: they join the hand-off lines only on demand
-    u32 reserve_min;           // ... of this many pushes (per 64th of the pushers) that found nobody in line
+    u32 n_primary;             // waves beyond this many are a RESERVE: parked — out of the hand-off lines — until the launch is short of waves,
+    u32 reserve_min;           // i.e. until this many pushed entries are waiting with nobody in line for them (THE RESERVE, below)
     u32* ctl;                  // [CTL_WORDS]
     const PeelCold* cold;
     // the sinks pass only
@@ -713,12 +716,11 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
     // byte offset of the word of a hand-off entry that this lane writes: lanes 8..15 words 0..7 (the pushed gate's static
     // records), lanes 32..39 words 8..15 (its first consumers, its id)
     const u32 ent_off = (lane >= 8u && lane < 16u) ? (lane - 8u) * 8u : ((lane >= 32u && lane < 40u) ? (lane - 24u) * 8u : C2A_NONE);
-    const u32 no_demand = A.reserve_min ? 0u : C2A_NONE;      // (one compare at the pusher: all ones = never tell anybody)
+    bool parked = me >= A.n_primary;         // THE RESERVE (below): this wave stays out — of the seeds too — until the launch is short of waves
     const u32 dummy_idx = ((A.n_all + 3u) & ~3u) + me * kFillDummyStride; (void)dummy_idx;      // this wave's dummy ticket word (a line of its own behind fill[n_all], from a 16-byte boundary on)
-    bool seeds_left = true;
+    bool seeds_left = !parked;
     u32 region = 0, idx = 0, region_cnt = 0;
     u32 push_rr = me, pop_rr = me * 7u;      // round-robin cursors over the hand-off arrays
-    u32 demand_seen = 0;                     // (reserve waves) the demand count this wave has answered
     u32 held = 0;                            // this wave holds a consumer ticket that has not been served yet ...
     u64 held_slot = 0;                       // ... for this slot
     u32 processed = 0, max_level = 0, iters = 0;
@@ -769,25 +771,40 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
             // those were returning atomics, waited for)
             if (lane == 0) atomicAdd(&A.ctl[CTL_END + (me & (kAcctShards - 1u)) * kAcctStride], 1u); wave_join();
             // ---- a consumer ticket — kept until it is served, whatever else this wave does meanwhile — and the slot it names
-            if (C2A_UNLIKELY(!held && me >= A.n_primary)) {
-                // A RESERVE wave (C2A_PEEL_RESERVE per CU, off by default) stays out of the lines — every wave in line makes
-                // the others' polls and the ticket lines slower, and 8 waves per CU are enough for a graph 2 000 gates wide —
-                // until enough pushers have found a line EMPTY: then the launch is short of waves, not of work
+            if (C2A_UNLIKELY(parked)) {
+                // THE RESERVE.  Eight waves per CU are what a graph a few thousand gates wide can use: every further wave in the lines
+                // makes the others' looks and the ticket lines slower (headline + 1.6 %, strict layers + 9 % with sixteen).  A graph
+                // tens of thousands of gates wide — a matrix product's reduction chains, a butterfly, the leaves of a Merkle tree — is
+                // short of WAVES, not of latency (2 048 waves x a gate per microsecond): there sixteen per CU are worth 20-35 %.  Which
+                // of the two a launch is shows in the hand-off arrays: entries pushed and nobody in line for them.  A parked wave looks
+                // at a flag every ~7 us (one of 64 copies: 2 048 waves on ONE line cost the headline 2 %); one in C2A_PARK_MONITORS adds
+                // up the arrays' backlog every ~7 us — 64 lines that every push and pop hits with an atomic: with one monitor in 32 the
+                // headline's launch took 8.5 ms instead of 5.9 — and raises the flag at reserve_min entries; a wave that has seen the
+                // flag is an ordinary wave from then on.  Ending, and picking up a stranded entry, never depends
+                // on a parked wave: those are the waiting waves' scans.
                 bool leave = false;
-                for (u32 sb = 1; sb < 128; ++sb) {
-                    u32 dm = 0;
-                    if (lane == 0) dm = ld_a32(&A.ctl[CTL_DEMAND + (me & (kAcctShards - 1u)) * kAcctStride]); wave_join();
-                    dm = rdlane(dm, 0);
-                    if (dm - demand_seen >= A.reserve_min) { demand_seen = dm; break; }
-                    if ((sb & 7u) == 0) {
-                        u32 c2 = 0;
-                        if (lane < 2) c2 = ld_a32(&A.ctl[lane == 0 ? CTL_ABORT : CTL_DONE]); wave_join();
-                        if (rdlane(c2, 0) | rdlane(c2, 1)) { leave = true; break; }
+                const bool monitor = ((me - A.n_primary) & (C2A_PARK_MONITORS - 1u)) == 0;
+                for (u32 sb = 0;; ++sb) {
+                    // (the word this wave looks at is one of kAcctShards copies, each on a line of its own: 1 = come in, 2 = the launch
+                    // is over; whoever raises either writes all copies with one store.  ABORT — an atomic — is looked at now and then)
+                    u32 c3 = 0;
+                    if (lane == 0 || (lane < 3 && (sb & 7u) == 0)) c3 = ld_a32(&A.ctl[lane == 0 ? CTL_PARK + (me & (kAcctShards - 1u)) * kAcctStride : (lane == 1 ? CTL_ABORT : CTL_DONE)]);
+                    wave_join();
+                    if (rdlane(c3, 0) == 2u || rdlane(c3, 1) | rdlane(c3, 2)) { leave = true; break; }
+                    if (rdlane(c3, 0)) break;
+                    if (monitor) {
+                        const u64 pcw = lane < A.n_fifos ? ld_nw(&A.q_pc[(u64)lane * kPcStride]) : 0ull;
+                        u32 back = (u32)pcw - (u32)(pcw >> 32);                  // pushed - taken (tickets of waves in line count as taken)
+                        back = (back & 0x80000000u) ? 0u : back;
+#pragma unroll
+                        for (int off = 32; off >= 1; off >>= 1) back += __shfl_xor(back, off, 64);
+                        if (uniform(back) >= A.reserve_min) { st_a32(&A.ctl[CTL_PARK + lane * kAcctStride], 1u); wave_join(); break; }
                     }
-                    peel_sleep(127);
+                    peel_sleep(127); peel_sleep(127);
                 }
                 if (leave) break;
-                // (after 128 looks it joins a line anyway: ending, and picking up a stranded entry, never depends on others)
+                // (into a line first: an entry it receives is a unit of work that BEGIN has counted; the seed pool after that, as part of it)
+                parked = false; seeds_left = true;
             }
             if (C2A_LIKELY(!held)) {
                 const u32 f = (pop_rr++) & (A.n_fifos - 1u);
@@ -841,7 +858,9 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                         for (int off = 32; off >= 1; off >>= 1) n_begin += __shfl_xor(n_begin, off, 64);
                         n_begin = uniform(n_begin);
                         if (n_end == n_begin) {      // nothing active, nothing in flight: the peel is over — tell everybody
-                            if (lane == 0) st_a32(&A.ctl[CTL_DONE], 1u); wave_join();
+                            if (lane == 0) st_a32(&A.ctl[CTL_DONE], 1u);
+                            st_a32(&A.ctl[CTL_PARK + lane * kAcctStride], 2u);      // (the parked waves' copies: THE RESERVE)
+                            wave_join();
                             break;
                         }
                         // An entry in an array where nobody waits (every wave is committed to a slot elsewhere) would sit
@@ -1171,8 +1190,6 @@ __global__ void __launch_bounds__(64) C2A_PEEL_KERNEL_ATTR k_peel(PeelArgs A_in)
                 push_t = sreg_get<kSregPush>(sr); push_c = sreg_get<kSregPush + 1>(sr);
                 if (STATS) ph_pwait += c2a_now() - ph2a;
                 const u32 t = push_f * A.q_cap + push_t;            // (all slots together stay below 2^32: the host checks)
-                // nobody was in line for this entry: tell the reserve (reserve_min is 0 when the launch has none)
-                if (C2A_UNLIKELY((push_c | no_demand) <= push_t)) { if (lane == 0) atomicAdd(&A.ctl[CTL_DEMAND + (me & (kAcctShards - 1u)) * kAcctStride], 1u); wave_join(); }
                 if (STATS && lane == 0) dq_time[t] = ph0;
                 // ONE masked store: a lane knows which word of the entry is its own (ent_off, set up once per wave)
                 // (the two lane masks are made HERE, a compare each: as loop invariants they would live in scalar register pairs,

@@ -353,6 +353,55 @@ def tile_block(lh, rh, out, op, n_nodes, in_nodes, out_nodes, copies: int, shape
 
 
 # the new families at the sizes the GPU suite (1 M) and tools/stress.sh (10 M) run them at: name -> callable(scale)
+# ---- shapes at the edges of what layered_dag makes (tools/extreme_probe.py, tests/test_hubs.py: wide and shallow graphs are short of waves, not of latency)
+def butterfly(log_w, layers, seed=3):
+    """layer k, gate j: lh = (k-1, j), rh = (k-1, j ^ 2^((k-1) % log_w)): strict layers with structure (an FFT's data flow)"""
+    W = 1 << log_w
+    n = layers * W
+    n_in = W
+    out = (1 + n_in + np.arange(n, dtype=np.int64)).astype(np.uint32)
+    k = np.repeat(np.arange(layers, dtype=np.int64), W)
+    j = np.tile(np.arange(W, dtype=np.int64), layers)
+    prev = lambda jj: np.where(k == 0, 1 + jj, 1 + n_in + (k - 1) * W + jj)
+    lh = prev(j).astype(np.uint32)
+    rh = prev(j ^ (1 << ((np.maximum(k, 1) - 1) % log_w))).astype(np.uint32)
+    op = np.full(n, OP["AAdd"], dtype=np.uint8)
+    perm = np.argsort(splitmix64(seed, 5, n), kind="stable")
+    outs = out[(layers - 1) * W:]
+    return FlatGates(lh=lh[perm], rh=rh[perm], out=out[perm], op=op, n_nodes=int(1 + n_in + n), input_nodes=(1 + np.arange(n_in)).astype(np.uint32),
+                       output_nodes=outs, const_nodes=np.zeros(0, np.uint32), layers=layers, layer_width=W)
+
+
+def matmul(m, seed=3):
+    """C = A x B for m x m matrices as the reference's unroller would emit it: m^3 AMul gates (A[i,k] and B[k,j] are INPUT nodes with m readers each)
+    and, per output, a chain of m - 1 AAdd gates — m^2 reduction chains of equal length, every chain step with a leaf beside it"""
+    n_in = 2 * m * m
+    a = lambda i, k: 1 + i * m + k
+    b = lambda k, j: 1 + m * m + k * m + j
+    i, j, k = np.meshgrid(np.arange(m), np.arange(m), np.arange(m), indexing="ij")
+    i, j, k = i.reshape(-1), j.reshape(-1), k.reshape(-1)
+    n_mul = m ** 3
+    mul_out = 1 + n_in + np.arange(n_mul, dtype=np.int64)                   # product (i, j, k)
+    add_out = 1 + n_in + n_mul + np.arange(m * m * (m - 1), dtype=np.int64)   # partial sum (i, j, k), k = 1 .. m-1
+    ai, aj, ak = np.meshgrid(np.arange(m), np.arange(m), np.arange(1, m), indexing="ij")
+    ai, aj, ak = ai.reshape(-1), aj.reshape(-1), ak.reshape(-1)
+    prod_of = lambda ii, jj, kk: mul_out[(ii * m + jj) * m + kk]
+    sum_of = lambda ii, jj, kk: add_out[(ii * m + jj) * (m - 1) + kk - 1]
+    add_lh = np.where(ak == 1, prod_of(ai, aj, 0), sum_of(ai, aj, np.maximum(ak - 1, 1)))
+    add_rh = prod_of(ai, aj, ak)
+    lh = np.concatenate([a(i, k), add_lh]).astype(np.uint32)
+    rh = np.concatenate([b(k, j), add_rh]).astype(np.uint32)
+    out = np.concatenate([mul_out, add_out]).astype(np.uint32)
+    op = np.concatenate([np.full(n_mul, OP["AMul"]), np.full(len(add_out), OP["AAdd"])]).astype(np.uint8)
+    n = len(out)
+    perm = np.argsort(splitmix64(seed, 5, n), kind="stable")
+    oi, oj = np.meshgrid(np.arange(m), np.arange(m), indexing="ij")
+    outs = sum_of(oi.reshape(-1), oj.reshape(-1), m - 1).astype(np.uint32)
+    return FlatGates(lh=lh[perm], rh=rh[perm], out=out[perm], op=op[perm], n_nodes=int(1 + n_in + n), input_nodes=(1 + np.arange(n_in)).astype(np.uint32),
+                       output_nodes=outs, const_nodes=np.zeros(0, np.uint32), layers=m, layer_width=m * m)
+
+
+
 def family(name: str, n_target: int = 1_000_000, seed: int = SEED) -> FlatGates:
     Wd = 2000
     L = max(8, n_target // Wd)

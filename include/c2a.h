@@ -81,7 +81,7 @@ typedef struct c2a_stats {
     uint32_t n_roots;            /* DFS roots (children of the virtual root) */
     uint32_t n_splitters;        /* list-ranking sublists */
     uint32_t level_launches;     /* peel kernel launches: 2 (the sinks pass + the one dataflow launch) */
-    uint32_t peel_waves;         /* single-wave workgroups of the dataflow launch (CUs x min(knob, occupancy query)) */
+    uint32_t peel_waves;         /* single-wave workgroups of the dataflow launch (CUs x min(knobs, occupancy query): eight per CU + eight parked in reserve) */
     uint32_t path_chunks;        /* path-string chunks (61 words of 62 bits: 3782 bits) the deepest DFS path spans (1 = every tournament is one round trip) */
     uint32_t peel_rereads;       /* times a wave read a candidate record again because a word of it had not arrived yet */
     uint32_t numbering_events;   /* what shifts the wire numbering away from "sorted position q gets wire n_in + q": gates whose out node

@@ -240,6 +240,34 @@ def test_tiled_sha256_small(backend, orc, c2a, shape, permute):
     assert exp_levels > (2000 if shape == "chain" else 1000)     # the chain is five blocks deep, the tree three
 
 
+@pytest.mark.parametrize("shape", ["matmul", "butterfly"])
+def test_wide_and_shallow_small(backend, orc, c2a, shape):
+    """wide and shallow graphs — a matrix product's reduction chains, a butterfly — pile entries up in the hand-off arrays with nobody in
+    line for them: what calls the launch's parked waves in (c2a_peel.h, THE RESERVE; under the emulation four waves are parked and 24
+    waiting entries are the mark): every array against the oracle"""
+    fg = c2a.synth.matmul(9) if shape == "matmul" else c2a.synth.butterfly(6, 9)
+    assert _compare(backend, orc, _payload(fg), check_serial=False) == "ok"
+    assert backend.stats()["levels"] == (9 if shape == "matmul" else 9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["matmul", "butterfly", "one_layer"])
+def test_wide_and_shallow_1m(shape, orc, c2a):
+    """the same at size: a 100 x 100 matrix product (1.99 M gates, 10 000 reduction chains), a butterfly of 16 x 2^16, ONE layer of 2 M gates —
+    short of waves, not of latency: the reserve comes in (matmul 170^3: 7.4 -> 5.0 ms).  Every array against the oracle, twice."""
+    fg = {"matmul": lambda: c2a.synth.matmul(100), "butterfly": lambda: c2a.synth.butterfly(16, 16),
+          "one_layer": lambda: c2a.synth.layered_dag(1, 2_000_000)}[shape]()
+    with c2a.Backend(0) as be:
+        assert _compare(be, orc, _payload(fg), check_serial=False) == "ok"
+        bm = importlib.import_module("circom-2-arithc_amd.backend")
+        exp = orc.build_circuit(fg.lh, fg.rh, fg.out, fg.op, fg.n_nodes, fg.input_nodes, fg.output_nodes, mode=1)
+        for rep in range(2):
+            assert be.build_circuit() == exp.wire_count
+            for nm, arr in (("sorted", exp.sorted), ("in0", exp.in0), ("in1", exp.in1), ("out", exp.out), ("op", exp.op)):
+                assert be.checksum(nm) == bm.checksum_host(arr), (nm, rep)
+        assert be.stats()["peel_waves"] >= 2 * 8      # (eight per CU and the reserve)
+
+
 # ---- at size, on the hardware: every family at >= 1 M gates, both numbering paths, every array element-wise
 @pytest.mark.gpu
 @pytest.mark.parametrize("walk", [False, True], ids=["positional", "walk"])
