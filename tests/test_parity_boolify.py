@@ -157,6 +157,19 @@ def test_prune_pass(backend, orc, c2a, width):
         backend.pruned_read(0, 1)
 
 
+def test_boolify_refuses_a_circuit_whose_boolean_wire_ids_do_not_fit_u32(backend, c2a):
+    """c2a_boolify knows the boolean circuit's size from the gate types alone (no allocation, no kernel): 10 000 APow gates at width 64
+    need more than 2^32 boolean wires — the Bristol fashion's wire ids, like the `boolify` crate's usize on a 32-bit id space, stop there:
+    C2A_ERR_OVERFLOW with its message, and the context stays usable (measured on the hardware with a 130 x 130 matrix product at
+    width 32: 6.5 G boolean gates refused; 100 x 100 — 2.98 G gates, 39 GB — bit-blast in 9.1 ms and verified: tools/big_boolify_check.py)"""
+    fg = c2a.synth.layered_dag(10, 1000, n_in=8, n_const=2, window=3, mix=(("APow", 1),), seed=77)
+    _load(backend, fg)
+    with pytest.raises(OverflowError, match="exceed u32"):
+        backend.boolify(64)
+    info = backend.boolify(1)                 # (the same context, a width that fits)
+    assert info.n_gates > 0 and info.width == 1
+
+
 @pytest.mark.parametrize("width", [8, 32, 64])
 def test_boolify_of_a_circuit_the_host_built(backend, orc, c2a, width):
     """c2a_load_circuit: the second half of the path alone — `boolify(&circuit, width)` (src/main.rs:30-32) on a BristolCircuit the
