@@ -61,6 +61,7 @@ struct c2a_ctx {
                                    // credit stalls x 3 in the slow ones, translation misses the same); 1 024 threads — a quarter of the workgroups in flight,
                                    // each done four times sooner: the window of memory being written is a quarter as wide — 1.7 - 1.95
     u32 bool_chunk = 256;          // arithmetic gates per k_boolify workgroup: 128, 256 (measured best) or 512
+    u32 bool_slices = 0;           // workgroups per chunk (0: chosen per launch — bool_map; C2A_BOOL_SLICES forces it: tests)
     u32 peel_seed_chunk = 4;       // dataflow launch: seeds a wave takes at a time (1: the one counter they all hit cost 1.4 ms with 175 000 seeds; with the 33 000 the shallow passes leave: 2 / 4 / 8 / 16 = 7.72 / 7.70 / 7.78 / 7.85 ms)
     u32 peel_shallow = 4;          // levels behind the sinks done a whole level at once before the dataflow launch (>= 1, <= 48)
     u32 peel_sinks_blocks = 4096;  // grid cap of the sinks pass (latency-bound per thread: two dependent round trips per sink)
@@ -943,6 +944,7 @@ int c2a_create(int n_devices, const int* device_ids, c2a_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
         c->n_cu = prop.multiProcessorCount;
+    if (const char* e = std::getenv("C2A_BOOL_SLICES")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 1024) c->bool_slices = v; }
     if (const char* e = std::getenv("C2A_BOOL_CHUNK")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 128 || v == 256 || v == 512) c->bool_chunk = v; }
     if (const char* e = std::getenv("C2A_PEEL_SEED_CHUNK")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 4096) c->peel_seed_chunk = v; }
     if (const char* e = std::getenv("C2A_PEEL_SHALLOW")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 48) c->peel_shallow = v; }
@@ -1335,8 +1337,20 @@ int bool_map(c2a_ctx* c, const BoolSrc& S, u32 p_first, u32 p_end, u64 q_bias, u
     A.b_in0 = o_in0; A.b_in1 = o_in1; A.b_out = o_out; A.b_op = o_op;
     A.p_first = p_first; A.p_end = p_end; A.q_bias = q_bias;
     const u32 ch = c->bool_chunk;
-    const u32 blocks = (p_end - p_first + ch - 1) / ch;
+    const u32 chunks = (p_end - p_first + ch - 1) / ch;
     const u32 th = c->bool_threads;
+    // fewer chunks than four per CU: several workgroups per chunk (c2a_kernels.h, SLICES), as long as a workgroup keeps >= 8 192 boolean
+    // gates — two rounds of its 1 024 lanes x 4 — (the boolean gates of this range are known from the plan: binfo, or the shard's share)
+    u32 slices = 1;
+    const u32 want = 4u * (u32)c->n_cu;
+    if (chunks < want) {
+        const u64 per_chunk = c->binfo.n_gates * (u64)(p_end - p_first) / std::max<u32>(1u, c->n) / chunks;      // (an average: shares are by arithmetic gate)
+        const u64 by_work = per_chunk / 8192u;
+        slices = (u32)std::min<u64>(std::min<u64>((want + chunks - 1) / chunks, std::max<u64>(1u, by_work)), 1024u);
+    }
+    if (c->bool_slices) slices = c->bool_slices;
+    A.slices = slices;
+    const dim3 blocks(chunks, slices);
 #define C2A_BOOL_CASE(CH, TH) if (ch == CH && th == TH) C2A_LAUNCH((k_boolify<CH, TH>), blocks, TH, S.stream, A, S.tables); else
     C2A_BOOL_CASE(128, 256) C2A_BOOL_CASE(256, 256) C2A_BOOL_CASE(512, 256) C2A_BOOL_CASE(256, 512) C2A_BOOL_CASE(512, 1024)
         C2A_LAUNCH((k_boolify<256, 1024>), blocks, 1024, S.stream, A, S.tables);

@@ -991,6 +991,7 @@ struct BoolArgs {
     u32 p_first;      // first arithmetic gate (sorted position) of this launch
     u32 p_end;        // one past the last
     u64 q_bias;       // boolean gate q is stored at index q - q_bias (multiple of 4: keeps the 16-byte alignment)
+    u32 slices;       // workgroups per CHUNK arithmetic gates (gridDim.y): each takes a share of the chunk's boolean gates
 };
 
 
@@ -1014,6 +1015,11 @@ __device__ __forceinline__ u32 bool_owner(u32 r, const u32* s_goff, u32 cnt) {
 // consecutive boolean gates per iteration — owner by binary search over the block's <= CHUNK offsets in LDS —
 // and stores them as one 16-byte vector per SoA stream (4-byte-per-lane stores are issue-bound on gfx950, not
 // bandwidth-bound); the <= 3 unaligned gates at each end of the workgroup's range go out as scalars.
+// SLICES (round 6): a chunk of 256 multipliers is 723 000 boolean gates, of 256 dividers 2.1 M — with one workgroup per chunk a circuit of a
+// few hundred such gates keeps two or three CUs busy (the Poseidon-shaped config: 0.20 ms for 559 000 boolean gates), and one of 10^5
+// dividers 391 workgroups on 256 CUs (two rounds for 1.5 rounds' work: 4.0 TB/s against 5.2 for the small templates).  When the
+// chunks are fewer than four per CU the host asks for several workgroups per chunk (gridDim.y): each repeats the chunk's prologue
+// and takes a share of the aligned body, in whole groups of 16 gates; the first also does the unaligned ends.
 // Measured alternatives that LOST in interleaved same-session A/B runs (kept out of the tree): a start-bit map
 // + popcount instead of the search, a "four gates, one owner" fast path, software-pipelined template loads,
 // persistent workgroups with LDS-staged packed templates, non-temporal stores (profiles/r01_boolify_ab.txt).
@@ -1047,9 +1053,15 @@ __global__ void __launch_bounds__(THREADS) k_boolify(BoolArgs A, const BoolTable
     const uint4* __restrict__ tmpl = A.tmpl;
     // ---- aligned body: groups of 4 (r = block-relative index).  r1 - r0 is a multiple of 16: the four lanes of a quad are in
     // here together (the emulation wants the whole wave at the exchange: the loop runs per wave, lanes past the end idle)
-    for (u32 rw = r0 + 4u * (tid & ~63u); rw < r1; rw += 4u * THREADS) {
+    // (this workgroup's share of the body: groups of 16 gates [nb y / S, nb (y + 1) / S) — all of it when the launch has one slice)
+    u32 ra = r0, rb = r1;
+    if (A.slices != 1u) {
+        const u32 nb = (r1 - r0) >> 4;
+        ra = r0 + 16u * (u32)((u64)nb * blockIdx.y / A.slices); rb = r0 + 16u * (u32)((u64)nb * (blockIdx.y + 1u) / A.slices);
+    }
+    for (u32 rw = ra + 4u * (tid & ~63u); rw < rb; rw += 4u * THREADS) {
         const u32 r = rw + 4u * (tid & 63u);
-        const bool act = r < r1;
+        const bool act = r < rb;
         u32 vop = 0;
         const u64 q = q0 + r - A.q_bias;
         if (act) {
@@ -1073,7 +1085,7 @@ __global__ void __launch_bounds__(THREADS) k_boolify(BoolArgs A, const BoolTable
         if (act && (tid & 3u) == 0u) *reinterpret_cast<u32x4*>(A.b_op + q) = u32x4{vop, o1, o2, o3};
     }
     // ---- head [0,r0) and tail [r1,total): at most 15 + 15 gates
-    {
+    if (blockIdx.y == 0) {
         const u32 nh = r0, nt = total - r1;
         if (tid < nh + nt) {
             const u32 r = tid < nh ? tid : r1 + (tid - nh);

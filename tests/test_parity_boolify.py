@@ -157,6 +157,29 @@ def test_prune_pass(backend, orc, c2a, width):
         backend.pruned_read(0, 1)
 
 
+@pytest.mark.parametrize("kind", ["emul", pytest.param("hip", marks=pytest.mark.gpu)])
+@pytest.mark.parametrize("slices", [1, 3, 7, 64])
+def test_boolify_slices(request, orc, c2a, kind, slices):
+    """k_boolify with several workgroups per chunk of 256 arithmetic gates (c2a_kernels.h, SLICES: what a circuit of a few hundred
+    multipliers gets — the Poseidon-shaped config went from 0.20 to 0.015 ms): any number of slices, the same boolean circuit — whole
+    groups of 16 gates per slice, the unaligned ends with the first; more slices than groups leaves some with nothing"""
+    from conftest import _Env
+    mix = tuple(m for m in c2a.synth.MIX_ALL if m[0] != "APow")
+    fg = c2a.synth.layered_dag(9, 37, n_in=8, n_const=3, window=3, mix=mix, seed=31 + slices)
+    with _Env(C2A_BOOL_SLICES=slices):
+        be = c2a.Backend(0, lib_path=request.getfixturevalue("emul_lib")) if kind == "emul" else c2a.Backend(0)
+    try:
+        for width in (5, 16):
+            _load(be, fg)
+            info = be.boolify(width)
+            exp = orc.boolify(_oracle(orc, fg), width)
+            assert info.n_gates == len(exp.in0) and info.wire_count == exp.wire_count
+            for g, e in zip(be.bool_read(), (exp.in0, exp.in1, exp.out, exp.op)):
+                np.testing.assert_array_equal(g, e)
+    finally:
+        be.close()
+
+
 def test_boolify_refuses_a_circuit_whose_boolean_wire_ids_do_not_fit_u32(backend, c2a):
     """c2a_boolify knows the boolean circuit's size from the gate types alone (no allocation, no kernel): 10 000 APow gates at width 64
     need more than 2^32 boolean wires — the Bristol fashion's wire ids, like the `boolify` crate's usize on a 32-bit id space, stop there:
