@@ -68,6 +68,7 @@ struct c2a_ctx {
     u32 peel_waves = 8;            // dataflow launch: single-wave workgroups per CU (clamped by the occupancy query)
     u32 peel_fifos = 64;           // dataflow launch: hand-off arrays (a power of two <= 64)
     u32 peel_reserve = 8;          // dataflow launch: reserve waves per CU, parked until entries pile up in the hand-off arrays with nobody in line for them
+    bool peel_waves_forced = false, peel_reserve_forced = false;      // (set by the environment: tests and tools/ sweeps get what they ask for at any size)
     u32 peel_release = 0;          // ... this many of them (0: twice the primary waves = 4 096.  10 M gates, k_peel ms without a reserve / with: a matrix
                                    // product's 29 000 reduction chains 7.35 / 4.96, a butterfly 20 x 2^19 7.66 / 5.52, ten layers of 10^6 4.28 / 3.54, a Merkle tree of
                                    // 2 900 SHA-256 blocks 12.5 / 11.0; the headline 5.85 / 5.88 (its backlog peaks at 2-4 000: at 2 048 the reserve comes in, 5.97),
@@ -371,8 +372,11 @@ u32 peel_grid(c2a_ctx* c, bool stats, u32* n_primary) {
     hipError_t e = stats ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_peel<true, true>, 64, 0)
                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_peel<false, true>, 64, 0);
     if (e != hipSuccess || per_cu < 1) per_cu = 1;
-    const u32 w = std::min<u32>(c->peel_waves, (u32)per_cu);
-    const u32 r = std::min<u32>(c->peel_reserve, (u32)per_cu - w);
+    // (a small graph cannot be short of waves: below 2^20 gates no reserve is launched — 2 048 workgroups that would only start and leave —,
+    // below 4 096 one wave per CU does: the launch of a 22-gate circuit is mostly its workgroups coming and going)
+    const u32 n_all = n_all_of(c->n);
+    const u32 w = std::min<u32>(n_all < 4096u && !c->peel_waves_forced ? 1u : c->peel_waves, (u32)per_cu);
+    const u32 r = std::min<u32>(n_all < (1u << 20) && !c->peel_reserve_forced ? 0u : c->peel_reserve, (u32)per_cu - w);
     *n_primary = std::max<u32>(1u, (u32)c->n_cu * w);
     return *n_primary + (u32)c->n_cu * r;
 #endif
@@ -948,8 +952,8 @@ int c2a_create(int n_devices, const int* device_ids, c2a_ctx** out) {
     if (const char* e = std::getenv("C2A_BOOL_CHUNK")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v == 128 || v == 256 || v == 512) c->bool_chunk = v; }
     if (const char* e = std::getenv("C2A_PEEL_SEED_CHUNK")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 4096) c->peel_seed_chunk = v; }
     if (const char* e = std::getenv("C2A_PEEL_SHALLOW")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 48) c->peel_shallow = v; }
-    if (const char* e = std::getenv("C2A_PEEL_WAVES")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 32) c->peel_waves = v; }
-    if (const char* e = std::getenv("C2A_PEEL_RESERVE")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v <= 32) c->peel_reserve = v; }
+    if (const char* e = std::getenv("C2A_PEEL_WAVES")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 32) { c->peel_waves = v; c->peel_waves_forced = true; } }
+    if (const char* e = std::getenv("C2A_PEEL_RESERVE")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v <= 32) { c->peel_reserve = v; c->peel_reserve_forced = true; } }
     if (const char* e = std::getenv("C2A_PEEL_RELEASE")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1) c->peel_release = v; }
     if (const char* e = std::getenv("C2A_NUMBERING_WALK")) c->numbering_walk = e[0] == '1';
     if (const char* e = std::getenv("C2A_PEEL_FIFOS")) { const u32 v = (u32)std::strtoul(e, nullptr, 10); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->peel_fifos = v; }
