@@ -97,7 +97,7 @@ WAVE_BACKENDS = [_variant("emul", "w8"), _variant("hip", "w8"), _variant("hip", 
 
 
 FIFO_BACKENDS = [_variant("emul", "f1"), _variant("emul", "f2"), _variant("emul", "f64"), _variant("hip", "f1"), _variant("hip", "f4"),
-                 _variant("hip", "r8")]       # (r8: 8 reserve waves per CU that join the hand-off lines on demand)
+                 _variant("hip", "r8")]       # (r8: 8 reserve waves per CU, parked until a backlog builds up in the hand-off arrays — whatever the size of the graph)
 
 
 @pytest.fixture(params=FIFO_BACKENDS)
